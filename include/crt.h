@@ -1,0 +1,217 @@
+/*
+ * crt.h — C ABI of the MI355X-native ray/BVH-traversal hot path.
+ *
+ * Drop-in boundary for the place where the reference dispatches its GLSL fragment
+ * shader (Caitlyn/Scene.h:1000-1156 upload, :1158-1231 per-frame dispatch,
+ * :1233-1246 camera uniforms).  Every entry point cites the reference interface it
+ * replaces.  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative crt_status otherwise;
+ *     crt_last_error() returns a thread-local description (the reference prints and
+ *     continues, Scene.h:510-511 / Shader.h:84-94; this ABI never throws).
+ *   - a crt_scene handle is NOT thread-safe: one caller thread (the reference is a
+ *     single thread owning the GL context, main.cpp:22).
+ *   - all calls are synchronous on return unless named *_async.
+ *   - functions marked [host] need no GPU; everything else fails with
+ *     CRT_ERR_NO_DEVICE when no gfx950 device is visible (there is no CPU fallback).
+ *   - image rows are bottom-row-first like GL (Quad.h:16-24).
+ */
+#ifndef CRT_H_
+#define CRT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_ABI_VERSION 1
+
+typedef enum crt_status {
+    CRT_OK = 0,
+    CRT_ERR_INVALID = -1,     /* bad argument / inconsistent buffers           */
+    CRT_ERR_NO_DEVICE = -2,   /* no HIP device: the product path refuses to run */
+    CRT_ERR_HIP = -3,         /* a HIP runtime call failed                      */
+    CRT_ERR_IO = -4,          /* file not found / parse failure                 */
+    CRT_ERR_LIMIT = -5,       /* a structural limit was exceeded (stack depth…) */
+    CRT_ERR_NOMEM = -6
+} crt_status;
+
+/* ---------------------------------------------------------------- layouts -- */
+
+/* Caitlyn/Triangle.h:19-27 — 48-byte index record, uploaded RGBA32I ×3
+ * (Scene.h:1036-1041).  v = (i0,i1,i2,material); vn = (n0,n1,n2,1) or the integer-
+ * truncated geometric normal with w=0 (Scene.h:849-852); vt = (t0,t1,t2,0). */
+typedef struct crt_triangle { int32_t v[4]; int32_t vn[4]; int32_t vt[4]; } crt_triangle;
+
+/* Caitlyn/FlatNode.h:34-40 — 32-byte BVH2 node, uploaded RGBA32F ×2
+ * (Scene.h:1057-1062).  Interior: bmin[3]=left child (right=left+1), bmax[3]=0.
+ * Leaf: bmin[3]=first triangle slot, bmax[3]=count (>=1).  Links are floats. */
+typedef struct crt_flatnode { float bmin[4]; float bmax[4]; } crt_flatnode;
+
+/* Caitlyn/cwbvh.h:11-25 == Shader/cwbvh.fs:355-362 — 80-byte compressed 8-wide
+ * node, five 16-byte rows exactly as the shader fetches them (cwbvh.fs:484-488). */
+typedef struct crt_node8 {
+    float    p[3];               /* quantisation origin                          */
+    uint8_t  e[3];               /* biased exponents, scale = 2^(e-127)          */
+    uint8_t  imask;              /* bit i <=> slot i is an inner child           */
+    uint32_t child_base_index;
+    uint32_t triangle_base_index;
+    uint8_t  meta[8];
+    uint8_t  qlo_x[8], qhi_x[8];
+    uint8_t  qlo_y[8], qhi_y[8];
+    uint8_t  qlo_z[8], qhi_z[8];
+} crt_node8;
+
+/* Caitlyn/Scene.h:75-85 — 64-byte material, RGBA32F ×4 (Scene.h:1043-1048). */
+typedef struct crt_material { float albedo[4]; float emission[4]; float specular[4]; float tex_ind[4]; } crt_material;
+
+/* Caitlyn/Scene.h:151-166 — 72-byte light, RGB32F ×6 (Scene.h:1050-1055):
+ * p,u,v,n,e,(area,pdf,0). */
+typedef struct crt_light { float p[3], u[3], v[3], n[3], e[3], area_pdf[3]; } crt_light;
+
+/* camera uniform block, Scene.h:1143-1149 / :1237-1243 (fov = vertical, radians). */
+typedef struct crt_camera {
+    float position[3]; float right[3]; float up[3]; float forward[3];
+    float fov; float focal_dist; float aperture;
+} crt_camera;
+
+/* explicit ray / hit records for crt_trace (no reference counterpart). */
+typedef struct crt_ray { float o[3]; float tmax; float d[3]; uint32_t pad; } crt_ray;          /* 32 B */
+typedef struct crt_hit { float t, u, v; int32_t tri; } crt_hit;   /* tri = original triangle id, -1 = miss */
+typedef struct crt_ray_stats { uint16_t nodes, tris; } crt_ray_stats;  /* per-ray visit counters (optional) */
+
+enum { CRT_TRACE_CLOSEST = 0, CRT_TRACE_ANY = 1 };
+
+/* Everything Scene::gpu_data uploads (Scene.h:1015-1078) plus the intended bvh8
+ * buffer.  All pointers are HOST memory and are COPIED (the reference frees its CPU
+ * vectors right after upload, Scene.h:503).  `triangles` are in BVH2 leaf order with
+ * spatial-split duplicates (sbvh.h:130-139).  Either `bvh` (BVH2; converted to CWBVH
+ * on the host) or `bvh8` + `bvh8_tri_slots` must be given; both may be. */
+typedef struct crt_scene_desc {
+    uint32_t abi_version;               /* CRT_ABI_VERSION */
+    const float*        vertices;   size_t n_vertices;   /* xyz, 12 B   Scene.h:1015-1020 */
+    const float*        normals;    size_t n_normals;    /* xyz         Scene.h:1022-1027 */
+    const float*        texcoords;  size_t n_texcoords;  /* uv          Scene.h:1029-1034 */
+    const crt_triangle* triangles;  size_t n_triangles;  /*             Scene.h:1036-1041 */
+    const int32_t*      tri_orig_ids;                    /* sbvh.h:136-137 triangle_indices; NULL -> slot id */
+    const crt_material* materials;  size_t n_materials;  /*             Scene.h:1043-1048 */
+    const crt_light*    lights;     size_t n_lights;     /*             Scene.h:1050-1055 */
+    const crt_flatnode* bvh;        size_t n_bvh;        /*             Scene.h:1057-1062 */
+    const crt_node8*    bvh8;       size_t n_bvh8;       /* intended bvh8 buffer (cwbvh.fs:484) */
+    const int32_t*      bvh8_tri_slots; size_t n_bvh8_tris; /* CWBVH triangle order -> slot in `triangles` */
+    const uint8_t*      albedo_textures; uint32_t tex_width, tex_height, n_textures; /* RGB8 array, Scene.h:1065-1078 */
+    uint32_t width, height;             /* screenResolution, Scene.h:1151 */
+    uint32_t max_depth;                 /* path segments; the shader hard-codes 3 (path_trace.fs:867) */
+} crt_scene_desc;
+
+typedef struct crt_scene crt_scene;
+
+/* ------------------------------------------------- device path (needs GPU) -- */
+
+/* replaces Scene::gpu_data, Scene.h:1000-1156 */
+int crt_scene_create(const crt_scene_desc* desc, crt_scene** out);
+/* replaces Scene::delete_gpu_data / delete_tex_data, Scene.h:978-998 */
+int crt_scene_destroy(crt_scene* s);
+/* replaces Scene::update, Scene.h:1233-1246 */
+int crt_set_camera(crt_scene* s, const crt_camera* cam);
+/* replaces the path_trace draw in Scene::Render, Scene.h:1208-1213: adds ONE sample
+ * per pixel to the device-resident RGB32F sum buffer; (rx,ry) = randomVector. */
+int crt_render_frame(crt_scene* s, float rx, float ry);
+/* replaces the camera-moved clear, Scene.h:1160-1172 */
+int crt_reset(crt_scene* s);
+/* path_trace_texture read-back: n_floats must be width*height*3 (bottom row first).
+ * With a shard set, returns this rank's pixels only (others 0). */
+int crt_read_sum(crt_scene* s, float* rgb, size_t n_floats);
+/* replaces the output pass, Shader/output.fs:9-20 + Scene.h:1226-1230:
+ * rgba8 = pow(tonemap(sum*inv_count), 1/2.2), alpha 255; n_bytes = width*height*4 */
+int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes);
+/* closest-/any-hit over an explicit HOST ray buffer (test/bench entry).
+ * stats may be NULL.  For CRT_TRACE_ANY, hit.tri >= 0 iff occluded (t,u,v = 0). */
+int crt_trace(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits, int mode, crt_ray_stats* stats);
+/* same with DEVICE pointers (rays/hits/stats already resident in HBM); asynchronous
+ * on the scene's stream unless sync != 0.  repeat >= 1 re-launches for timing. */
+int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, int mode, void* d_stats, int sync);
+
+/* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is
+ * cut into tile x tile squares dealt round-robin in Morton order to `world` ranks;
+ * this scene renders only rank's tiles.  Call before the first crt_render_frame. */
+int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile);
+/* packed tile-major sum buffer of this rank: n_local_tiles * tile*tile*3 floats. */
+int crt_packed_info(crt_scene* s, uint32_t* n_local_tiles, uint32_t* tile, size_t* n_floats);
+int crt_read_packed(crt_scene* s, float* dst_host, size_t n_floats);
+int crt_copy_packed_device(crt_scene* s, void* d_dst, size_t n_floats, int sync);
+
+/* Telemetry of the last crt_render_frame / crt_trace_device (hipEvent timings on the
+ * scene's own stream, ray counts).  SURVEY 8d. */
+typedef struct crt_frame_stats {
+    uint64_t closest_rays, any_rays;     /* traversals executed                  */
+    float ms_total;                      /* raygen..accumulate, device time      */
+    float ms_trace_closest, ms_trace_any;/* summed over bounces                  */
+    float ms_shade, ms_raygen;
+    uint32_t n_trace_launches;
+} crt_frame_stats;
+int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out);
+/* structural facts about the device-resident CWBVH */
+typedef struct crt_bvh_info { uint64_t n_nodes8, n_tris8, n_bvh2_nodes, max_depth8; } crt_bvh_info;
+int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out);
+int crt_device_count(void);
+
+/* --------------------------------------------------- host side ([host]) ----- */
+
+/* Caitlyn/Camera.h:7-19 Camera(pos, lookAt, fovDeg) + updateCamera :48-58 [host] */
+int crt_camera_look_at(const float pos[3], const float look_at[3], float fov_deg, crt_camera* out);
+
+/* Caitlyn/Rnd.h:21-40 PCG_Hash / randf2 (state starts at 1, Rnd.h:7) [host] */
+uint32_t crt_pcg_hash(uint32_t x);
+float    crt_randf2(uint32_t* state);
+
+/* SBVH builder, Caitlyn/sbvh.h:99-153 SBVH(trs, vertices) [host].
+ * Reorders into leaf order with spatial-split duplicates.  flags bit0: disable spatial
+ * splits (pure SAH sweep, "SAH BVH" of config 1). */
+typedef struct crt_sbvh crt_sbvh;
+int crt_sbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertices, size_t n_vertices,
+                   uint32_t flags, crt_sbvh** out);
+size_t crt_sbvh_num_nodes(const crt_sbvh*);            /* flat_nodes.size()        */
+size_t crt_sbvh_num_slots(const crt_sbvh*);            /* triangle_indices.size()  */
+const crt_flatnode* crt_sbvh_nodes(const crt_sbvh*);   /* sbvh.h:570-609 BFS order */
+const int32_t*      crt_sbvh_triangle_indices(const crt_sbvh*); /* slot -> original triangle */
+const crt_triangle* crt_sbvh_triangles(const crt_sbvh*);        /* reordered trs, sbvh.h:130-139 */
+void crt_sbvh_free(crt_sbvh*);
+
+/* CWBVH converter, Caitlyn/cwbvh.h:58-73 CWBVH::convert(SBVH&) with the defects of
+ * SURVEY 8a corrected (appendix C) [host]. */
+typedef struct crt_cwbvh crt_cwbvh;
+int crt_cwbvh_convert(const crt_flatnode* bvh2, size_t n_nodes, size_t n_slots, crt_cwbvh** out);
+size_t crt_cwbvh_num_nodes(const crt_cwbvh*);
+size_t crt_cwbvh_num_tris(const crt_cwbvh*);
+const crt_node8* crt_cwbvh_nodes(const crt_cwbvh*);
+const int32_t*   crt_cwbvh_tri_slots(const crt_cwbvh*);  /* CWBVH order -> BVH2 leaf slot */
+uint32_t crt_cwbvh_depth(const crt_cwbvh*);
+void crt_cwbvh_free(crt_cwbvh*);
+
+/* OBJ/MTL loader, Caitlyn/Scene.h:742-926 Read_Object (+ ReadMtl :507-596; textures
+ * not loaded) [host].  Applies the -vertex_min translation (:915-925) to vertices,
+ * light origins and *camera_position (may be NULL). */
+typedef struct crt_mesh crt_mesh;
+int crt_load_obj(const char* path, float camera_position[3], crt_mesh** out);
+size_t crt_mesh_counts(const crt_mesh*, size_t* n_vertices, size_t* n_normals, size_t* n_texcoords,
+                       size_t* n_triangles, size_t* n_materials, size_t* n_lights);
+const float*        crt_mesh_vertices(const crt_mesh*);
+const float*        crt_mesh_normals(const crt_mesh*);
+const float*        crt_mesh_texcoords(const crt_mesh*);
+const crt_triangle* crt_mesh_triangles(const crt_mesh*);
+const crt_material* crt_mesh_materials(const crt_mesh*);
+const crt_light*    crt_mesh_lights(const crt_mesh*);
+const float*        crt_mesh_vertex_min(const crt_mesh*);   /* pre-translation minimum */
+void crt_mesh_free(crt_mesh*);
+
+const char* crt_last_error(void);
+uint32_t    crt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_H_ */
