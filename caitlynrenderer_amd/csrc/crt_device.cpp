@@ -1,0 +1,630 @@
+// Device half of include/crt.h: scene upload, per-frame wavefront dispatch, read-back.
+// Replaces Scene::gpu_data / Render / update (Caitlyn/Scene.h:1000-1246).  Owns its own HIP
+// stream; every kernel of a frame is enqueued there, queue lengths stay on the device, and the
+// host synchronises once per call (never inside the frame).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/crt.h"
+#include "crt_error.hpp"
+#include "host/cwbvh.hpp"
+#include "rt_kernels.hpp"
+
+using crt::fail;
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+namespace {
+
+constexpr int kMaxEvents = 8 + 8 * 16;
+
+struct EventSpan { hipEvent_t a = nullptr, b = nullptr; int kind = 0; };   // kind: 0 raygen 1 closest 2 any 3 shade/other
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) return fail(CRT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return CRT_OK;
+}
+
+uint32_t morton2(uint32_t x, uint32_t y) {
+    auto spread = [](uint32_t v) {
+        v &= 0xffffu;
+        v = (v | (v << 8)) & 0x00ff00ffu;
+        v = (v | (v << 4)) & 0x0f0f0f0fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+
+}  // namespace
+
+struct crt_scene {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    uint32_t width = 0, height = 0, max_depth = 1, n_lights = 0;
+
+    // scene (replicated on every rank)
+    uint4* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    int4* d_triangles = nullptr;
+    float* d_normals = nullptr;
+    float4* d_materials = nullptr;
+    float* d_lights = nullptr;
+    crt_bvh_info info{};
+
+    // shard + frame buffers
+    uint32_t rank = 0, world = 1, tile = 64;
+    std::vector<uint2> tiles;            // local tiles
+    uint2* d_tile_xy = nullptr;
+    uint32_t n_local_tiles = 0, n_local_pixels = 0;
+    uint64_t n_local_in_frame = 0;
+    float* d_sum = nullptr;
+    float* d_linear = nullptr;
+    uint8_t* d_rgba = nullptr;
+    float4* d_rays[2] = {nullptr, nullptr};
+    float4* d_hits = nullptr;
+    float4* d_shadow = nullptr;
+    float4* d_shadow_hits = nullptr;
+    crt::PathBuffers pb{};
+    uint32_t* d_counts = nullptr;        // [2 * b] = rays into segment b, [2 * b + 1] = shadow rays of segment b
+    uint32_t* h_counts = nullptr;        // pinned
+    bool frame_buffers_ready = false;
+
+    crt_camera cam{};
+    bool have_camera = false;
+    uint32_t jitter = 1;
+
+    // scratch for crt_trace (host rays)
+    float4* d_t_rays = nullptr; float4* d_t_hits = nullptr; uint32_t* d_t_stats = nullptr; size_t t_cap = 0;
+
+    // telemetry
+    std::vector<EventSpan> spans;
+    int n_spans = 0;
+    crt_frame_stats stats{};
+    bool stats_pending = false;
+    bool stats_from_frame = false;
+    uint32_t trace_occupancy = 5;
+
+    ~crt_scene() {
+        hipSetDevice(device);
+        if (stream) hipStreamSynchronize(stream);
+        void* ptrs[] = {d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
+                        d_rays[0], d_rays[1], d_hits, d_shadow, d_shadow_hits, pb.L, pb.T, pb.seed, pb.C, d_counts,
+                        d_t_rays, d_t_hits, d_t_stats};
+        for (void* p : ptrs) if (p) hipFree(p);
+        if (h_counts) hipHostFree(h_counts);
+        for (EventSpan& s : spans) { if (s.a) hipEventDestroy(s.a); if (s.b) hipEventDestroy(s.b); }
+        if (stream) hipStreamDestroy(stream);
+    }
+
+    uint32_t trace_grid(uint64_t n) const {
+        uint64_t blocks = (n + CRT_TRACE_BLOCK - 1) / CRT_TRACE_BLOCK;
+        uint64_t cap = (uint64_t)n_cu * trace_occupancy;
+        return (uint32_t)std::max<uint64_t>(1, std::min(blocks, cap));
+    }
+    uint32_t flat_grid(uint64_t n) const {
+        uint64_t blocks = (n + 255) / 256;
+        return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)n_cu * 8));
+    }
+    EventSpan* begin_span(int kind) {
+        if (n_spans >= (int)spans.size()) return nullptr;
+        EventSpan* s = &spans[n_spans++];
+        s->kind = kind;
+        hipEventRecord(s->a, stream);
+        return s;
+    }
+    void end_span(EventSpan* s) { if (s) hipEventRecord(s->b, stream); }
+};
+
+namespace {
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(CRT_ERR_NO_DEVICE, "no HIP device visible: the traversal path has no CPU fallback");
+    return CRT_OK;
+}
+
+int build_shard(crt_scene* s) {
+    const uint32_t T = s->tile;
+    const uint32_t tx_n = (s->width + T - 1) / T, ty_n = (s->height + T - 1) / T;
+    struct Item { uint32_t code, x, y; };
+    std::vector<Item> all;
+    all.reserve((size_t)tx_n * ty_n);
+    for (uint32_t y = 0; y < ty_n; ++y)
+        for (uint32_t x = 0; x < tx_n; ++x) all.push_back({morton2(x, y), x, y});
+    std::sort(all.begin(), all.end(), [](const Item& a, const Item& b) { return a.code < b.code; });
+    s->tiles.clear();
+    s->n_local_in_frame = 0;
+    for (size_t k = s->rank; k < all.size(); k += s->world) {
+        s->tiles.push_back(make_uint2(all[k].x, all[k].y));
+        const uint32_t w = std::min(T, s->width - all[k].x * T), h = std::min(T, s->height - all[k].y * T);
+        s->n_local_in_frame += (uint64_t)w * h;
+    }
+    s->n_local_tiles = (uint32_t)s->tiles.size();
+    const uint64_t px = (uint64_t)s->n_local_tiles * T * T;
+    if (px >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "framebuffer shard too large for 32-bit pixel indices");
+    s->n_local_pixels = (uint32_t)px;
+    return CRT_OK;
+}
+
+void free_frame_buffers(crt_scene* s) {
+    void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
+                     (void**)&s->d_rays[1], (void**)&s->d_hits, (void**)&s->d_shadow, (void**)&s->d_shadow_hits,
+                     (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed, (void**)&s->pb.C};
+    for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
+    s->frame_buffers_ready = false;
+}
+
+int alloc_frame_buffers(crt_scene* s) {
+    free_frame_buffers(s);
+    int rc = build_shard(s);
+    if (rc) return rc;
+    const size_t P = s->n_local_pixels;
+    if ((rc = dev_alloc(&s->d_tile_xy, s->n_local_tiles))) return rc;
+    HIPCHK(hipMemcpy(s->d_tile_xy, s->tiles.data(), s->tiles.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(&s->d_sum, 3 * P))) return rc;
+    HIPCHK(hipMemset(s->d_sum, 0, 3 * std::max<size_t>(P, 1) * sizeof(float)));
+    if ((rc = dev_alloc(&s->d_rays[0], 2 * P))) return rc;
+    if ((rc = dev_alloc(&s->d_rays[1], 2 * P))) return rc;
+    if ((rc = dev_alloc(&s->d_hits, P))) return rc;
+    if ((rc = dev_alloc(&s->d_shadow, 2 * P))) return rc;
+    if ((rc = dev_alloc(&s->d_shadow_hits, P))) return rc;
+    if ((rc = dev_alloc(&s->pb.L, P))) return rc;
+    if ((rc = dev_alloc(&s->pb.T, P))) return rc;
+    if ((rc = dev_alloc(&s->pb.seed, P))) return rc;
+    if ((rc = dev_alloc(&s->pb.C, P))) return rc;
+    s->frame_buffers_ready = true;
+    return CRT_OK;
+}
+
+crt::FrameArgs frame_args(const crt_scene* s, float rx, float ry) {
+    crt::FrameArgs f{};
+    f.tile_xy = s->d_tile_xy;
+    f.n_local_pixels = s->n_local_pixels;
+    f.tile = s->tile; f.width = s->width; f.height = s->height;
+    f.jitter = s->jitter;
+    f.rv = rx * ry;
+    const float W = (float)s->width, H = (float)s->height;
+    f.tan_fov = std::tan(s->cam.fov * 0.5f);
+    f.aspect_tan = W / H * f.tan_fov;
+    for (int k = 0; k < 3; ++k) {
+        f.cam_pos[k] = s->cam.position[k]; f.cam_right[k] = s->cam.right[k];
+        f.cam_up[k] = s->cam.up[k]; f.cam_forward[k] = s->cam.forward[k];
+    }
+    return f;
+}
+
+int collect_stats(crt_scene* s) {
+    if (!s->stats_pending) return CRT_OK;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    crt_frame_stats st{};
+    for (int i = 0; i < s->n_spans; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->spans[i].a, s->spans[i].b) != hipSuccess) continue;
+        switch (s->spans[i].kind) {
+            case 0: st.ms_raygen += ms; break;
+            case 1: st.ms_trace_closest += ms; st.n_trace_launches++; break;
+            case 2: st.ms_trace_any += ms; st.n_trace_launches++; break;
+            default: st.ms_shade += ms; break;
+        }
+    }
+    if (s->n_spans > 0) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->spans[0].a, s->spans[s->n_spans - 1].b) == hipSuccess) st.ms_total = ms;
+    }
+    st.closest_rays = s->stats.closest_rays;
+    st.any_rays = s->stats.any_rays;
+    s->stats = st;
+    s->stats_pending = false;
+    return CRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
+    if (!out) return fail(CRT_ERR_INVALID, "crt_scene_create: null out");
+    *out = nullptr;
+    if (!d) return fail(CRT_ERR_INVALID, "crt_scene_create: null desc");
+    if (d->abi_version != CRT_ABI_VERSION) return fail(CRT_ERR_INVALID, "crt_scene_create: abi_version mismatch");
+    if (!d->vertices || !d->triangles || d->n_triangles == 0 || d->n_vertices == 0)
+        return fail(CRT_ERR_INVALID, "crt_scene_create: vertices/triangles missing");
+    if (!d->materials || d->n_materials == 0) return fail(CRT_ERR_INVALID, "crt_scene_create: materials missing");
+    if (d->n_lights && !d->lights) return fail(CRT_ERR_INVALID, "crt_scene_create: lights missing");
+    if (!d->bvh && !d->bvh8) return fail(CRT_ERR_INVALID, "crt_scene_create: neither bvh nor bvh8 given");
+    if (d->width == 0 || d->height == 0 || d->width > 65535u * 8u || d->height > 65535u * 8u)
+        return fail(CRT_ERR_INVALID, "crt_scene_create: bad resolution");
+    if (d->max_depth == 0 || d->max_depth > 16) return fail(CRT_ERR_INVALID, "crt_scene_create: max_depth must be 1..16");
+    if (d->n_triangles >= (1ull << 31) || d->n_vertices >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_scene_create: too many elements");
+
+    // index validation: a bad index would be an out-of-bounds device access
+    for (size_t i = 0; i < d->n_triangles; ++i) {
+        const crt_triangle& t = d->triangles[i];
+        for (int j = 0; j < 3; ++j)
+            if (t.v[j] < 0 || (size_t)t.v[j] >= d->n_vertices) return fail(CRT_ERR_INVALID, "crt_scene_create: vertex index out of range");
+        if (t.v[3] < 0 || (size_t)t.v[3] >= d->n_materials) return fail(CRT_ERR_INVALID, "crt_scene_create: material index out of range");
+        if (t.vn[3] != 0)
+            for (int j = 0; j < 3; ++j)
+                if (t.vn[j] < 0 || (size_t)t.vn[j] >= d->n_normals || !d->normals)
+                    return fail(CRT_ERR_INVALID, "crt_scene_create: normal index out of range");
+    }
+    for (size_t m = 0; m < d->n_materials; ++m) {
+        const float ew = d->materials[m].emission[3];
+        if (ew != -1.0f && !(ew >= 0.0f && (size_t)ew < d->n_lights))
+            return fail(CRT_ERR_INVALID, "crt_scene_create: emissive material refers to a light that does not exist");
+    }
+    int rc = require_device();
+    if (rc) return rc;
+
+    // CWBVH: take the caller's, or convert the BVH2 (cwbvh.h:58)
+    crt::CWBVH conv;
+    const crt_node8* nodes8 = d->bvh8;
+    size_t n_nodes8 = d->n_bvh8;
+    const int32_t* tri_slots = d->bvh8_tri_slots;
+    size_t n_tris8 = d->n_bvh8_tris;
+    uint32_t depth8 = 0;
+    if (!nodes8) {
+        if (!conv.convert(d->bvh, d->n_bvh, d->n_triangles, d->tri_orig_ids))
+            return fail(CRT_ERR_INVALID, "crt_scene_create: BVH2 -> CWBVH failed: " + conv.error);
+        nodes8 = conv.nodes.data(); n_nodes8 = conv.nodes.size();
+        tri_slots = conv.tri_slots.data(); n_tris8 = conv.tri_slots.size();
+    } else if (!tri_slots) {
+        return fail(CRT_ERR_INVALID, "crt_scene_create: bvh8 given without bvh8_tri_slots");
+    }
+    {
+        std::string why = crt::validate_cwbvh(nodes8, n_nodes8, n_tris8, CRT_STACK_ENTRIES, &depth8);
+        if (!why.empty()) return fail(why.find("deeper") != std::string::npos ? CRT_ERR_LIMIT : CRT_ERR_INVALID,
+                                      "crt_scene_create: CWBVH rejected: " + why);
+        for (size_t i = 0; i < n_tris8; ++i)
+            if (tri_slots[i] < 0 || (size_t)tri_slots[i] >= d->n_triangles)
+                return fail(CRT_ERR_INVALID, "crt_scene_create: bvh8_tri_slots entry out of range");
+    }
+
+    crt_scene* s = new (std::nothrow) crt_scene;
+    if (!s) return fail(CRT_ERR_NOMEM, "crt_scene_create: out of memory");
+    auto bail = [&](int code) { delete s; return code; };
+    if (hipGetDevice(&s->device) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipGetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
+    s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
+    s->info.n_nodes8 = n_nodes8; s->info.n_tris8 = n_tris8; s->info.n_bvh2_nodes = d->n_bvh; s->info.max_depth8 = depth8;
+
+    // pre-gathered intersection records in CWBVH triangle order: (v0|orig id) (e1|slot) (e2|material).
+    // e1 = v1 - v0, e2 = v2 - v0 are the subtractions of path_trace.fs:337-338, done once here.
+    std::vector<float4> recs(3 * n_tris8);
+    for (size_t i = 0; i < n_tris8; ++i) {
+        const int32_t slot = tri_slots[i];
+        const crt_triangle& t = d->triangles[slot];
+        const float* v0 = d->vertices + 3 * (size_t)t.v[0];
+        const float* v1 = d->vertices + 3 * (size_t)t.v[1];
+        const float* v2 = d->vertices + 3 * (size_t)t.v[2];
+        const int32_t id = d->tri_orig_ids ? d->tri_orig_ids[slot] : slot;
+        float4 a, b, c;
+        a.x = v0[0]; a.y = v0[1]; a.z = v0[2]; std::memcpy(&a.w, &id, 4);
+        b.x = v1[0] - v0[0]; b.y = v1[1] - v0[1]; b.z = v1[2] - v0[2]; std::memcpy(&b.w, &slot, 4);
+        c.x = v2[0] - v0[0]; c.y = v2[1] - v0[1]; c.z = v2[2] - v0[2]; std::memcpy(&c.w, &t.v[3], 4);
+        recs[3 * i] = a; recs[3 * i + 1] = b; recs[3 * i + 2] = c;
+    }
+
+#define UP(dst, src, count, T)                                                                             \
+    do {                                                                                                   \
+        if ((rc = dev_alloc(&(dst), (count)))) return bail(rc);                                            \
+        if ((count) && hipMemcpy((dst), (src), (count) * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)  \
+            return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));                                        \
+    } while (0)
+    static_assert(sizeof(crt_node8) == 80, "node8 must be 80 bytes (cwbvh.h:11-25)");
+    static_assert(sizeof(crt_triangle) == 48 && sizeof(crt_flatnode) == 32 && sizeof(crt_material) == 64 && sizeof(crt_light) == 72, "layout");
+    UP(s->d_nodes, reinterpret_cast<const uint4*>(nodes8), n_nodes8 * 5, uint4);
+    UP(s->d_tris, recs.data(), recs.size(), float4);
+    UP(s->d_triangles, reinterpret_cast<const int4*>(d->triangles), d->n_triangles * 3, int4);
+    UP(s->d_normals, d->normals, d->n_normals * 3, float);
+    UP(s->d_materials, reinterpret_cast<const float4*>(d->materials), d->n_materials * 4, float4);
+    UP(s->d_lights, reinterpret_cast<const float*>(d->lights), d->n_lights * 18, float);
+#undef UP
+    if ((rc = dev_alloc(&s->d_counts, 2 * 17))) return bail(rc);
+    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), 2 * 17 * sizeof(uint32_t)) != hipSuccess)
+        return bail(fail(CRT_ERR_NOMEM, "hipHostMalloc failed"));
+    s->spans.resize(kMaxEvents);
+    for (EventSpan& sp : s->spans)
+        if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)
+            return bail(fail(CRT_ERR_HIP, "hipEventCreate failed"));
+    *out = s;
+    return CRT_OK;
+}
+
+int crt_scene_destroy(crt_scene* s) {
+    delete s;
+    return CRT_OK;
+}
+
+int crt_set_camera(crt_scene* s, const crt_camera* cam) {
+    if (!s || !cam) return fail(CRT_ERR_INVALID, "crt_set_camera: null argument");
+    s->cam = *cam;
+    s->have_camera = true;
+    return CRT_OK;
+}
+
+int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_set_shard: null scene");
+    if (world == 0 || rank >= world) return fail(CRT_ERR_INVALID, "crt_set_shard: rank/world");
+    if (tile < 8 || (tile & 7u) || tile > 1024) return fail(CRT_ERR_INVALID, "crt_set_shard: tile must be a multiple of 8 in 8..1024");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->rank = rank; s->world = world; s->tile = tile;
+    return alloc_frame_buffers(s);
+}
+
+static int ensure_frame(crt_scene* s) {
+    if (!s->frame_buffers_ready) return alloc_frame_buffers(s);
+    return CRT_OK;
+}
+
+int crt_reset(crt_scene* s) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_reset: null scene");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(s->d_sum, 0, 3 * (size_t)std::max<uint32_t>(s->n_local_pixels, 1) * sizeof(float), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CRT_OK;
+}
+
+int crt_set_option(crt_scene* s, const char* name, int value) {
+    if (!s || !name) return fail(CRT_ERR_INVALID, "crt_set_option: null argument");
+    if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
+    else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
+    else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
+    return CRT_OK;
+}
+
+// One sample per pixel: raygen -> [closest, shade, any, resolve] x max_depth -> accumulate.
+int crt_render_frame_async(crt_scene* s, float rx, float ry) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_render_frame: null scene");
+    if (!s->have_camera) return fail(CRT_ERR_INVALID, "crt_render_frame: crt_set_camera was never called");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if (s->n_local_pixels == 0) return CRT_OK;
+    const uint32_t P = s->n_local_pixels;
+    const crt::FrameArgs f = frame_args(s, rx, ry);
+    s->n_spans = 0;
+    HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * 17 * sizeof(uint32_t), s->stream));
+    HIPCHK(hipMemcpyAsync(s->d_counts, &s->n_local_pixels, sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+
+    EventSpan* sp = s->begin_span(0);
+    crt::launch_raygen(f, s->pb, s->d_rays[0], s->flat_grid(P), s->stream);
+    s->end_span(sp);
+
+    for (uint32_t b = 0; b < s->max_depth; ++b) {
+        float4* rin = s->d_rays[b & 1];
+        float4* rnext = s->d_rays[(b + 1) & 1];
+        uint32_t* c_in = s->d_counts + 2 * b;
+        uint32_t* c_shadow = s->d_counts + 2 * b + 1;
+        uint32_t* c_next = s->d_counts + 2 * (b + 1);
+
+        crt::TraceArgs ta{};
+        ta.nodes = s->d_nodes; ta.tris = s->d_tris; ta.rays = rin; ta.hits = s->d_hits; ta.stats = nullptr;
+        ta.count_ptr = c_in; ta.n = P; ta.out_orig_id = 0;
+        sp = s->begin_span(1);
+        crt::launch_trace(ta, CRT_TRACE_CLOSEST, false, s->trace_grid(P), s->stream);
+        s->end_span(sp);
+
+        crt::ShadeArgs sa{};
+        sa.rays_in = rin; sa.hits = s->d_hits; sa.count_in = c_in;
+        sa.rays_next = rnext; sa.count_next = c_next;
+        sa.rays_shadow = s->d_shadow; sa.count_shadow = c_shadow;
+        sa.tris = s->d_tris; sa.triangles = s->d_triangles; sa.normals = s->d_normals;
+        sa.materials = s->d_materials; sa.lights = s->d_lights; sa.n_lights = (int32_t)s->n_lights;
+        sa.rv = f.rv; sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
+        sp = s->begin_span(3);
+        crt::launch_shade(sa, s->pb, s->flat_grid(P), s->stream);
+        s->end_span(sp);
+
+        crt::TraceArgs tb = ta;
+        tb.rays = s->d_shadow; tb.hits = s->d_shadow_hits; tb.count_ptr = c_shadow;
+        sp = s->begin_span(2);
+        crt::launch_trace(tb, CRT_TRACE_ANY, false, s->trace_grid(P), s->stream);
+        s->end_span(sp);
+
+        sp = s->begin_span(3);
+        crt::launch_shadow_resolve(s->d_shadow, s->d_shadow_hits, c_shadow, s->pb, s->flat_grid(P), s->stream);
+        s->end_span(sp);
+    }
+    sp = s->begin_span(3);
+    crt::launch_accumulate(s->d_sum, s->pb, P, s->flat_grid(P), s->stream);
+    s->end_span(sp);
+    HIPCHK(hipMemcpyAsync(s->h_counts, s->d_counts, 2 * 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipGetLastError());
+    s->stats_pending = true;
+    s->stats_from_frame = true;   // ray counts come from h_counts at the next sync
+    return CRT_OK;
+}
+
+int crt_sync(crt_scene* s) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_sync: null scene");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    return CRT_OK;
+}
+
+int crt_render_frame(crt_scene* s, float rx, float ry) {
+    int rc = crt_render_frame_async(s, rx, ry);
+    if (rc) return rc;
+    return crt_sync(s);
+}
+
+int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
+    if (!s || !out) return fail(CRT_ERR_INVALID, "crt_get_frame_stats: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    if (s->stats_pending) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (s->stats_from_frame) {
+            uint64_t closest = 0, any = 0;
+            for (uint32_t b = 0; b < s->max_depth; ++b) { closest += s->h_counts[2 * b]; any += s->h_counts[2 * b + 1]; }
+            // segment 0 walks the padded tile grid; padding pixels are immediate misses, not rays
+            if (closest >= s->n_local_pixels) closest -= (s->n_local_pixels - s->n_local_in_frame);
+            s->stats.closest_rays = closest; s->stats.any_rays = any;
+        }
+        int rc = collect_stats(s);
+        if (rc) return rc;
+    }
+    *out = s->stats;
+    return CRT_OK;
+}
+
+int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out) {
+    if (!s || !out) return fail(CRT_ERR_INVALID, "crt_get_bvh_info: null argument");
+    *out = s->info;
+    return CRT_OK;
+}
+
+int crt_packed_info(crt_scene* s, uint32_t* n_local_tiles, uint32_t* tile, size_t* n_floats) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_packed_info: null scene");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if (n_local_tiles) *n_local_tiles = s->n_local_tiles;
+    if (tile) *tile = s->tile;
+    if (n_floats) *n_floats = 3 * (size_t)s->n_local_pixels;
+    return CRT_OK;
+}
+
+int crt_read_packed(crt_scene* s, float* dst, size_t n_floats) {
+    if (!s || !dst) return fail(CRT_ERR_INVALID, "crt_read_packed: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if (n_floats != 3 * (size_t)s->n_local_pixels) return fail(CRT_ERR_INVALID, "crt_read_packed: size mismatch");
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(dst, s->d_sum, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_copy_packed_device(crt_scene* s, void* d_dst, size_t n_floats, int sync) {
+    if (!s || !d_dst) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if (n_floats != 3 * (size_t)s->n_local_pixels) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: size mismatch");
+    HIPCHK(hipMemcpyAsync(d_dst, s->d_sum, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    if (sync) HIPCHK(hipStreamSynchronize(s->stream));
+    return CRT_OK;
+}
+
+static int untile_to_linear(crt_scene* s) {
+    const size_t n = 3 * (size_t)s->width * s->height;
+    if (!s->d_linear) { int rc = dev_alloc(&s->d_linear, n); if (rc) return rc; }
+    HIPCHK(hipMemsetAsync(s->d_linear, 0, n * sizeof(float), s->stream));
+    if (s->n_local_pixels) {
+        const crt::FrameArgs f = frame_args(s, 0.f, 0.f);
+        crt::launch_untile(f, s->d_sum, s->d_linear, s->flat_grid(s->n_local_pixels), s->stream);
+    }
+    return CRT_OK;
+}
+
+int crt_read_sum(crt_scene* s, float* rgb, size_t n_floats) {
+    if (!s || !rgb) return fail(CRT_ERR_INVALID, "crt_read_sum: null argument");
+    if (n_floats != 3 * (size_t)s->width * s->height) return fail(CRT_ERR_INVALID, "crt_read_sum: n_floats must be width*height*3");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if ((rc = untile_to_linear(s))) return rc;
+    HIPCHK(hipMemcpyAsync(rgb, s->d_linear, n_floats * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CRT_OK;
+}
+
+int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
+    if (!s || !rgba) return fail(CRT_ERR_INVALID, "crt_resolve: null argument");
+    const size_t npx = (size_t)s->width * s->height;
+    if (n_bytes != 4 * npx) return fail(CRT_ERR_INVALID, "crt_resolve: n_bytes must be width*height*4");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if ((rc = untile_to_linear(s))) return rc;
+    if (!s->d_rgba) { if ((rc = dev_alloc(&s->d_rgba, 4 * npx))) return rc; }
+    crt::launch_resolve(s->d_linear, (uint32_t)npx, inv_count, s->d_rgba, s->flat_grid(npx), s->stream);
+    HIPCHK(hipMemcpyAsync(rgba, s->d_rgba, n_bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CRT_OK;
+}
+
+int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, int mode, void* d_stats, int sync) {
+    if (!s || !d_rays || !d_hits) return fail(CRT_ERR_INVALID, "crt_trace_device: null argument");
+    if (mode != CRT_TRACE_CLOSEST && mode != CRT_TRACE_ANY) return fail(CRT_ERR_INVALID, "crt_trace_device: bad mode");
+    if (n >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_trace_device: too many rays for one launch");
+    HIPCHK(hipSetDevice(s->device));
+    if (n == 0) return CRT_OK;
+    crt::TraceArgs ta{};
+    ta.nodes = s->d_nodes; ta.tris = s->d_tris;
+    ta.rays = static_cast<const float4*>(d_rays); ta.hits = static_cast<float4*>(d_hits);
+    ta.stats = static_cast<uint32_t*>(d_stats); ta.count_ptr = nullptr; ta.n = (uint32_t)n; ta.out_orig_id = 1;
+    s->n_spans = 0;
+    EventSpan* sp = s->begin_span(mode == CRT_TRACE_ANY ? 2 : 1);
+    crt::launch_trace(ta, mode, d_stats != nullptr, s->trace_grid(n), s->stream);
+    s->end_span(sp);
+    HIPCHK(hipGetLastError());
+    s->stats_pending = true;
+    s->stats_from_frame = false;
+    s->stats.closest_rays = mode == CRT_TRACE_CLOSEST ? n : 0;
+    s->stats.any_rays = mode == CRT_TRACE_ANY ? n : 0;
+    if (sync) HIPCHK(hipStreamSynchronize(s->stream));
+    return CRT_OK;
+}
+
+int crt_trace(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits, int mode, crt_ray_stats* stats) {
+    if (!s || (n && (!rays || !hits))) return fail(CRT_ERR_INVALID, "crt_trace: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    if (n == 0) return CRT_OK;
+    if (n > s->t_cap) {
+        if (s->d_t_rays) hipFree(s->d_t_rays);
+        if (s->d_t_hits) hipFree(s->d_t_hits);
+        if (s->d_t_stats) hipFree(s->d_t_stats);
+        s->d_t_rays = nullptr; s->d_t_hits = nullptr; s->d_t_stats = nullptr; s->t_cap = 0;
+        int rc;
+        if ((rc = dev_alloc(&s->d_t_rays, 2 * n))) return rc;
+        if ((rc = dev_alloc(&s->d_t_hits, n))) return rc;
+        if ((rc = dev_alloc(&s->d_t_stats, n))) return rc;
+        s->t_cap = n;
+    }
+    static_assert(sizeof(crt_ray) == 32 && sizeof(crt_hit) == 16 && sizeof(crt_ray_stats) == 4, "ray/hit layout");
+    HIPCHK(hipMemcpyAsync(s->d_t_rays, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, s->stream));
+    int rc = crt_trace_device(s, s->d_t_rays, n, s->d_t_hits, mode, stats ? s->d_t_stats : nullptr, 0);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(hits, s->d_t_hits, n * sizeof(crt_hit), hipMemcpyDeviceToHost, s->stream));
+    if (stats) HIPCHK(hipMemcpyAsync(stats, s->d_t_stats, n * sizeof(crt_ray_stats), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CRT_OK;
+}
+
+}  // extern "C"

@@ -95,6 +95,7 @@ size_t crt_cwbvh_num_nodes(const crt_cwbvh* h) { return h ? h->bvh.nodes.size() 
 size_t crt_cwbvh_num_tris(const crt_cwbvh* h) { return h ? h->bvh.tri_slots.size() : 0; }
 const crt_node8* crt_cwbvh_nodes(const crt_cwbvh* h) { return h ? h->bvh.nodes.data() : nullptr; }
 const int32_t* crt_cwbvh_tri_slots(const crt_cwbvh* h) { return h ? h->bvh.tri_slots.data() : nullptr; }
+const int32_t* crt_cwbvh_child_bvh2(const crt_cwbvh* h) { return h ? h->bvh.child_bvh2.data() : nullptr; }
 uint32_t crt_cwbvh_depth(const crt_cwbvh* h) { return h ? h->bvh.depth : 0; }
 void crt_cwbvh_free(crt_cwbvh* h) { delete h; }
 

@@ -219,6 +219,8 @@ struct Converter {
         }
         out->nodes[n8idx] = node;
         out->nodes.resize(out->nodes.size() + n_inner);
+        out->child_bvh2.resize(out->nodes.size() * 8, -1);
+        for (int slot = 0; slot < 8; ++slot) out->child_bvh2[(size_t)n8idx * 8 + slot] = children[slot];
         uint32_t offset = 0;
         for (int slot = 0; slot < 8; ++slot)
             if (node.imask & (1u << slot)) collapse(children[slot], node.child_base_index + offset++, level + 1);
@@ -231,6 +233,7 @@ bool CWBVH::convert(const crt_flatnode* bvh2, size_t n_nodes, size_t n_slots, co
     nodes.clear();
     triangle_indices.clear();
     tri_slots.clear();
+    child_bvh2.clear();
     depth = 0;
     error.clear();
     if (!bvh2 || n_nodes == 0) { error = "empty BVH2"; return false; }

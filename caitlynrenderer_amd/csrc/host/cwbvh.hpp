@@ -18,6 +18,7 @@ struct CWBVH {
     std::vector<crt_node8> nodes;             // cwbvh.h:53
     std::vector<int32_t> triangle_indices;    // cwbvh.h:54: CWBVH triangle order -> original triangle id
     std::vector<int32_t> tri_slots;           // CWBVH triangle order -> BVH2 leaf slot
+    std::vector<int32_t> child_bvh2;          // 8 per node8: the BVH2 node each slot stands for, -1 = empty
     uint32_t depth = 0;                       // levels of node8 (root alone = 1)
     std::string error;                        // non-empty when convert() refused the input
 

@@ -1,0 +1,490 @@
+// HIP kernels for gfx950 (CDNA4): CWBVH traversal (closest / any hit) and the thin wavefront
+// shell around it (ray generation, shading + NEE ray emission, shadow resolve, accumulate).
+//
+// Reference behaviour restated here (never its code): Shader/cwbvh.fs:348-616 (traversal, with the
+// SURVEY.md §8a defects corrected), Shader/path_trace.fs:322-374 (Moller-Trumbore), :414-489 (hit
+// attributes), :843-1024 (integrator), :1026-1060 (ray generation, accumulate), Shader/output.fs
+// (resolve).  One ray per lane, 64-lane wavefronts; traversal stack in LDS; queue compaction with
+// wave ballots.  No MFMA: this is pointer chasing, bounded by memory latency/bandwidth.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_kernels.hpp"
+#include "rt_math.hpp"
+
+namespace crt {
+
+#define CRT_INF 1e9f        // path_trace.fs:35
+#define CRT_EPS 1e-4f       // path_trace.fs:36
+#define CRT_PI 3.1415926f   // path_trace.fs:16
+#define CRT_PI2 6.2831853f  // path_trace.fs:17
+
+// ------------------------------------------------------------------ traversal --------
+
+__device__ __forceinline__ uint32_t sign_extend_s8x4(uint32_t x) { return ((x >> 7) & 0x01010101u) * 0xffu; }   // cwbvh.fs:369-372
+
+__device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }          // v_cvt_f32_ubyteN
+
+// 8-wide quantised child-box test (cwbvh.fs:376-446, corrected: far = min(min()), tmin clamped to 0,
+// tmax clamped to max_t, hit iff tmin <= tmax).  Returns the hit mask: inner children in the top
+// byte at bit (24+slot)^oct, leaf triangles as unary-count bits in the low 24.
+__device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3,
+                                                    const uint4 n4, vec3 o, vec3 inv, bool negx, bool negy, bool negz,
+                                                    uint32_t oct4, float max_t) {
+    const vec3 p = V3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
+    const uint32_t e_imask = n0.w;
+    const vec3 adj_inv = V3(__uint_as_float((e_imask & 0xffu) << 23) * inv.x,
+                            __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * inv.y,
+                            __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * inv.z);
+    const vec3 adj_o = (p - o) * inv;
+    uint32_t hit_mask = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t meta4 = i == 0 ? n1.z : n1.w;
+        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
+        const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1F1F1F1Fu;
+        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+        const uint32_t qlox = i == 0 ? n2.x : n2.y, qhix = i == 0 ? n2.z : n2.w;
+        const uint32_t qloy = i == 0 ? n3.x : n3.y, qhiy = i == 0 ? n3.z : n3.w;
+        const uint32_t qloz = i == 0 ? n4.x : n4.y, qhiz = i == 0 ? n4.z : n4.w;
+        const uint32_t xmin = negx ? qhix : qlox, xmax = negx ? qlox : qhix;
+        const uint32_t ymin = negy ? qhiy : qloy, ymax = negy ? qloy : qhiy;
+        const uint32_t zmin = negz ? qhiz : qloz, zmax = negz ? qloz : qhiz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float tminx = __builtin_fmaf(ubyte_f(xmin, j), adj_inv.x, adj_o.x);
+            const float tminy = __builtin_fmaf(ubyte_f(ymin, j), adj_inv.y, adj_o.y);
+            const float tminz = __builtin_fmaf(ubyte_f(zmin, j), adj_inv.z, adj_o.z);
+            const float tmaxx = __builtin_fmaf(ubyte_f(xmax, j), adj_inv.x, adj_o.x);
+            const float tmaxy = __builtin_fmaf(ubyte_f(ymax, j), adj_inv.y, adj_o.y);
+            const float tmaxz = __builtin_fmaf(ubyte_f(zmax, j), adj_inv.z, adj_o.z);
+            const float tmin = __builtin_fmaxf(__builtin_fmaxf(tminx, tminy), __builtin_fmaxf(tminz, 0.0f));
+            const float tmax = __builtin_fminf(__builtin_fminf(tmaxx, tmaxy), __builtin_fminf(tmaxz, max_t));
+            if (tmin <= tmax) {
+                const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
+                const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
+                hit_mask |= child_bits << bit_index;
+            }
+        }
+    }
+    return hit_mask;
+}
+
+struct HitState {
+    float t, u, v;
+    int tri;   // index into the CWBVH-ordered triangle array, -1 = none
+    int id;    // original triangle id of `tri`
+};
+
+// Moller-Trumbore, operation order of path_trace.fs:337-360, on the pre-gathered record
+// (v0, e1 = v1 - v0, e2 = v2 - v0): the two subtractions are the same fp32 operations the shader
+// performs per test, done once at upload.
+__device__ __forceinline__ bool mt_test(const float4 a, const float4 b, const float4 c, vec3 o, vec3 d, float& u,
+                                        float& v, float& t) {
+    const vec3 v0 = V3(a.x, a.y, a.z), e1 = V3(b.x, b.y, b.z), e2 = V3(c.x, c.y, c.z);
+    const vec3 pv = cross(d, e2);
+    const vec3 tv = o - v0;
+    const vec3 qv = cross(tv, e1);
+    float uu = dot(tv, pv);
+    float vv = dot(d, qv);
+    float tt = dot(e2, qv);
+    const float inv_det = rcp_ieee(dot(e1, pv));
+    uu = uu * inv_det;
+    vv = vv * inv_det;
+    tt = tt * inv_det;
+    const float w = 1.0f - uu - vv;
+    u = uu; v = vv; t = tt;
+    return (uu >= 0.0f) & (vv >= 0.0f) & (tt >= 0.0f) & (w >= 0.0f);
+}
+
+// One ray through the CWBVH (cwbvh.fs:448-536 closest, :538-616 any).  `stk` is this lane's column
+// of the wave's LDS stack: stk[level * 64].
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o,
+                                         vec3 d, float tmax_in, uint2* stk, HitState& best, uint32_t& n_nodes,
+                                         uint32_t& n_tris) {
+    const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
+    const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);   // cwbvh.fs:348-353
+    const vec3 inv = V3(rcp_ieee(d.x), rcp_ieee(d.y), rcp_ieee(d.z));
+    float max_t = tmax_in;
+    best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
+    int sp = 0;
+    uint2 cur = make_uint2(0u, 0x80000000u);
+    for (;;) {
+        uint2 tg;
+        if (cur.y & 0xff000000u) {
+            const uint32_t hits_imask = cur.y;
+            const int off = 31 - __builtin_clz(hits_imask);
+            const uint32_t base = cur.x;
+            cur.y &= ~(1u << off);
+            if (cur.y & 0xff000000u) {
+                if (sp < CRT_STACK_ENTRIES) { stk[sp * 64] = cur; ++sp; }
+            }
+            const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+            const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+            const uint4* np = nodes + (size_t)(base + rel) * 5;
+            const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+            if (STATS) ++n_nodes;
+            const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
+            cur.x = n1.x;
+            tg.x = n1.y;
+            cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+            tg.y = hitmask & 0x00ffffffu;
+        } else {
+            tg = cur;
+            cur = make_uint2(0u, 0u);
+        }
+        while (tg.y) {
+            const int b = 31 - __builtin_clz(tg.y);
+            tg.y &= ~(1u << b);
+            const uint32_t ti = tg.x + (uint32_t)b;
+            const float4* tp = tris + (size_t)ti * 3;
+            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            if (STATS) ++n_tris;
+            float u, v, t;
+            if (mt_test(ta, tb, tc, o, d, u, v, t)) {
+                if (ANY) {
+                    if (t < max_t) { best.tri = (int)ti; return true; }
+                } else {
+                    const int id = __float_as_int(ta.w);
+                    // SURVEY appendix C tie rule: nearer wins, equal t -> lower original id
+                    if (t < best.t || (t == best.t && best.tri >= 0 && id < best.id)) {
+                        best.t = t; best.u = u; best.v = v; best.tri = (int)ti; best.id = id;
+                        max_t = t;
+                    }
+                }
+            }
+        }
+        if (!(cur.y & 0xff000000u)) {
+            if (sp == 0) break;
+            --sp;
+            cur = stk[sp * 64];
+        }
+    }
+    return best.tri >= 0;
+}
+
+// Persistent-threads trace kernel: every wave walks the ray queue in 64-ray batches,
+// batch b -> wave (b mod total_waves).  count_ptr (device) overrides n when non-null so that
+// queue lengths produced on the device never round-trip through the host.
+template <bool ANY, bool STATS>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
+    __shared__ uint2 s_stack[CRT_TRACE_BLOCK / 64][CRT_STACK_ENTRIES][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2* stk = &s_stack[wave][0][lane];
+    const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
+    const uint32_t waves_total = gridDim.x * (CRT_TRACE_BLOCK / 64);
+    const uint32_t wave_id = blockIdx.x * (CRT_TRACE_BLOCK / 64) + wave;
+    for (uint32_t base = wave_id * 64u; base < n; base += waves_total * 64u) {
+        const uint32_t i = base + lane;
+        if (i >= n) continue;
+        const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
+        HitState best;
+        uint32_t nn = 0, nt = 0;
+        traverse<ANY, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk, best, nn, nt);
+        float4 h;
+        h.x = ANY ? 0.f : (best.tri >= 0 ? best.t : 0.f);
+        h.y = ANY ? 0.f : best.u;
+        h.z = ANY ? 0.f : best.v;
+        int out = best.tri;
+        if (ANY) out = best.tri >= 0 ? 0 : -1;
+        else if (a.out_orig_id) out = best.tri >= 0 ? best.id : -1;
+        h.w = __int_as_float(out);
+        a.hits[i] = h;
+        if (STATS) {
+            a.stats[i] = ((nt > 65535u ? 65535u : nt) << 16) | (nn > 65535u ? 65535u : nn);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ queue helpers ----
+
+// Wave-aggregated append: one atomic per wave, lanes get consecutive slots in lane order.
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __builtin_ctzll(m);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+
+// local pixel index -> frame pixel.  Pixels are laid out tile-major; inside a tile, 8x8 blocks
+// row-major, so one 64-lane wave covers an 8x8 pixel block (coherent primary rays).
+__device__ __forceinline__ bool pixel_of(const FrameArgs& f, uint32_t i, uint32_t& px, uint32_t& py) {
+    const uint32_t tile_px = f.tile * f.tile;
+    const uint32_t t = i / tile_px, j = i % tile_px;
+    const uint32_t blocks_per_row = f.tile >> 3;
+    const uint32_t blk = j >> 6, k = j & 63u;
+    const uint2 txy = f.tile_xy[t];
+    px = txy.x * f.tile + (blk % blocks_per_row) * 8u + (k & 7u);
+    py = txy.y * f.tile + (blk / blocks_per_row) * 8u + (k >> 3);
+    return px < f.width && py < f.height;
+}
+
+// ------------------------------------------------------------------ ray generation ---
+
+// path_trace.fs:1026-1047.  Writes the dense primary-ray queue (index == local pixel index) and
+// the initial path state.  Out-of-frame padding pixels get tmax = -1 (an immediate miss).
+__global__ void __launch_bounds__(256) k_raygen(FrameArgs f, PathBuffers pb, float4* __restrict__ rays) {
+    const uint32_t n = f.n_local_pixels;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t px, py;
+        const bool in_frame = pixel_of(f, i, px, py);
+        float sx = (float)px + 0.5f, sy = (float)py + 0.5f;
+        const float W = (float)f.width, H = (float)f.height;
+        float jx = 0.f, jy = 0.f;
+        if (f.jitter) {
+            const float r1 = 2.0f * shader_rand(sx, sy, f.rv);
+            const float r2 = 2.0f * shader_rand(sx, sy, f.rv);
+            jx = r1 < 1.0f ? __fsqrt_rn(r1) - 1.0f : 1.0f - __fsqrt_rn(2.0f - r1);
+            jy = r2 < 1.0f ? __fsqrt_rn(r2) - 1.0f : 1.0f - __fsqrt_rn(2.0f - r2);
+            jx = __fdiv_rn(jx, W * 0.5f);
+            jy = __fdiv_rn(jy, H * 0.5f);
+        }
+        const float tx = __fdiv_rn((float)px + 0.5f, W), ty = __fdiv_rn((float)py + 0.5f, H);
+        float dx = (2.0f * tx - 1.0f) + jx;
+        float dy = (2.0f * ty - 1.0f) + jy;
+        dx = dx * f.aspect_tan;   // (W / H * tan(fov/2)), formed on the host like the oracle does
+        dy = dy * f.tan_fov;
+        const vec3 right = V3(f.cam_right[0], f.cam_right[1], f.cam_right[2]);
+        const vec3 up = V3(f.cam_up[0], f.cam_up[1], f.cam_up[2]);
+        const vec3 fwd = V3(f.cam_forward[0], f.cam_forward[1], f.cam_forward[2]);
+        const vec3 dir = normalize((right * dx + up * dy) + fwd);
+        rays[2 * (size_t)i] = make_float4(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2], in_frame ? CRT_INF : -1.0f);
+        rays[2 * (size_t)i + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i));
+        pb.L[i] = make_float4(0.f, 0.f, 0.f, 1.0f);                       // L, prev_pdf
+        pb.T[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));        // T, is_specular
+        pb.seed[i] = make_float2(sx, sy);
+    }
+}
+
+// ------------------------------------------------------------------ shading ----------
+
+// One path segment after its closest-hit traversal: path_trace.fs:872-1018 for the hit case.
+// Emits at most one shadow ray (NEE, :940-998) and, unless this was the last segment, the next
+// path ray (:1004-1018), both appended with wave ballots.
+__global__ void __launch_bounds__(256) k_shade(ShadeArgs a, PathBuffers pb) {
+    const uint32_t n = *a.count_in;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // keep whole waves in the loop so the ballots in wave_append see every lane
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_round; e += stride) {
+        bool emit_shadow = false, emit_next = false;
+        float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, nx0 = sh0, nx1 = sh0;
+        if (e < n) {
+            const float4 r0 = a.rays_in[2 * (size_t)e], r1 = a.rays_in[2 * (size_t)e + 1];
+            const float4 h = a.hits[e];
+            const uint32_t pix = __float_as_uint(r1.w);
+            const int tri = __float_as_int(h.w);
+            if (tri >= 0) {
+                const vec3 o = V3(r0.x, r0.y, r0.z), d = V3(r1.x, r1.y, r1.z);
+                const float t = h.x, bu = h.y, bv = h.z;
+                const float4 tb = a.tris[3 * (size_t)tri + 1], tc = a.tris[3 * (size_t)tri + 2];
+                const int slot = __float_as_int(tb.w), mtl = __float_as_int(tc.w);
+                // path_trace.fs:440-454
+                const int4 vn = a.triangles[3 * (size_t)slot + 1];
+                vec3 n;
+                if (vn.w == 0) n = V3((float)vn.x, (float)vn.y, (float)vn.z);
+                else {
+                    const float* N = a.normals;
+                    const vec3 na = V3(N[3 * (size_t)vn.x], N[3 * (size_t)vn.x + 1], N[3 * (size_t)vn.x + 2]);
+                    const vec3 nb = V3(N[3 * (size_t)vn.y], N[3 * (size_t)vn.y + 1], N[3 * (size_t)vn.y + 2]);
+                    const vec3 nc = V3(N[3 * (size_t)vn.z], N[3 * (size_t)vn.z + 1], N[3 * (size_t)vn.z + 2]);
+                    const float w = 1.0f - bu - bv;
+                    n = (na * w + nb * bu) + nc * bv;
+                }
+                const float4 m_albedo = a.materials[4 * (size_t)mtl], m_emission = a.materials[4 * (size_t)mtl + 1],
+                             m_specular = a.materials[4 * (size_t)mtl + 2];
+                float4 Lp = pb.L[pix];
+                float4 Tp = pb.T[pix];
+                float2 seed = pb.seed[pix];
+                vec3 L = V3(Lp.x, Lp.y, Lp.z), T = V3(Tp.x, Tp.y, Tp.z);
+                const float prev_pdf = Lp.w;
+                const bool is_specular = __float_as_uint(Tp.w) != 0u;
+
+                const float cos_incident = dot(d, n);
+                const vec3 original_n = n;
+                if (cos_incident > 0) n = -n;
+                if (m_emission.w != -1.0f) {                                   // path_trace.fs:894-928
+                    const vec3 em = V3(m_emission.x, m_emission.y, m_emission.z);
+                    if (is_specular) L = L + T * em;
+                    else {
+                        vec3 ld = d * t;
+                        const float len = length(ld);
+                        ld = normalize(ld);
+                        const float cos_light = -1.0f * dot(ld, n);
+                        const float len2 = len * len;
+                        const int li = (int)m_emission.w;
+                        const float* ap = a.lights + 18 * (size_t)li + 15;
+                        const float pdf_light = __fdiv_rn(len2, ap[0] * cos_light) * ap[1];
+                        const float tt = prev_pdf * prev_pdf;                  // power_heuristic :214-218
+                        const float w = __fdiv_rn(tt, pdf_light * pdf_light + tt);
+                        L = L + (T * em) * w;
+                    }
+                    pb.L[pix] = make_float4(L.x, L.y, L.z, prev_pdf);
+                } else {
+                    const vec3 hit_point = (o + d * t) + n * 0.0002f;          // path_trace.fs:930
+                    const vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
+                    if (m_specular.w == 0.0f) {
+                        if (a.n_lights <= 0) {
+                            shader_rand(seed.x, seed.y, a.rv); shader_rand(seed.x, seed.y, a.rv); shader_rand(seed.x, seed.y, a.rv);
+                        } else {
+                            int li = (int)(shader_rand(seed.x, seed.y, a.rv) * (float)a.n_lights);
+                            if (li > a.n_lights - 1) li = a.n_lights - 1;
+                            const float* Lt = a.lights + 18 * (size_t)li;
+                            const float sq = __fsqrt_rn(shader_rand(seed.x, seed.y, a.rv));   // :843-855
+                            const float b0 = 1.0f - sq;
+                            const float b1 = shader_rand(seed.x, seed.y, a.rv) * sq;
+                            const vec3 lp = (V3(Lt[0], Lt[1], Lt[2]) + V3(Lt[3], Lt[4], Lt[5]) * b0) + V3(Lt[6], Lt[7], Lt[8]) * b1;
+                            vec3 ldir = lp - hit_point;
+                            const float len = length(ldir);
+                            const float ilen = rcp_ieee(len);
+                            ldir = ldir * ilen;
+                            const float cos_mtl = dot(ldir, original_n);
+                            const float cos_light = dot(ldir, V3(Lt[9], Lt[10], Lt[11]));
+                            if (cos_mtl > 0.0f && cos_light < 0.0f) {           // :968 (shadow test happens in k_trace<ANY>)
+                                const vec3 le = V3(Lt[12], Lt[13], Lt[14]);
+                                const float pdf_light = __fdiv_rn(len * len, Lt[15] * -cos_light) * Lt[16];
+                                const float bsdf_pdf = __fdiv_rn(dot(ldir, n) * 1.0f, CRT_PI);
+                                const float tt = pdf_light * pdf_light;
+                                const float w = __fdiv_rn(tt, bsdf_pdf * bsdf_pdf + tt);
+                                vec3 c = ((T * le) * albedo) * w;
+                                c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
+                                pb.C[pix] = make_float4(c.x, c.y, c.z, 0.f);
+                                emit_shadow = true;
+                                sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
+                                sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix));
+                            }
+                        }
+                    }
+                    if (!a.last_segment) {
+                        vec3 ou, ov;                                            // path_trace.fs:44-60
+                        if (n.z < -0.9999999f) { ou = V3(0.f, -1.f, 0.f); ov = V3(-1.f, 0.f, 0.f); }
+                        else {
+                            const float aa = rcp_ieee(1.0f + n.z);
+                            const float bb = -n.x * n.y * aa;
+                            ou = V3(1.0f + bb, bb, -n.x);
+                            ov = V3(bb, 1.0f + bb, -n.y);
+                        }
+                        const float u1 = shader_rand(seed.x, seed.y, a.rv);    // :257-270
+                        const float u2 = shader_rand(seed.x, seed.y, a.rv);
+                        const float r = __fsqrt_rn(u1);
+                        const float phi = CRT_PI2 * u2;
+                        const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), __fsqrt_rn(1.0f - u1));
+                        const vec3 sdir = (ou * dl.x + ov * dl.y) + n * dl.z;
+                        const float bsdf_pdf = __fdiv_rn(dot(sdir, n) * 1.0f, CRT_PI);
+                        T = T * albedo;
+                        pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
+                        pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(0u));
+                        pb.seed[pix] = seed;
+                        emit_next = true;
+                        nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
+                        nx1 = make_float4(sdir.x, sdir.y, sdir.z, __uint_as_float(pix));
+                    }
+                }
+            }
+        }
+        const uint32_t si = wave_append(emit_shadow, a.count_shadow);
+        if (emit_shadow) { a.rays_shadow[2 * (size_t)si] = sh0; a.rays_shadow[2 * (size_t)si + 1] = sh1; }
+        const uint32_t ni = wave_append(emit_next, a.count_next);
+        if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
+    }
+}
+
+// L += C for every unoccluded shadow ray (path_trace.fs:968-998).
+__global__ void __launch_bounds__(256) k_shadow_resolve(const float4* __restrict__ rays_shadow, const float4* __restrict__ hits,
+                                                        const uint32_t* __restrict__ count, PathBuffers pb) {
+    const uint32_t n = *count;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        if (__float_as_int(hits[e].w) >= 0) continue;
+        const uint32_t pix = __float_as_uint(rays_shadow[2 * (size_t)e + 1].w);
+        const float4 c = pb.C[pix];
+        float4 L = pb.L[pix];
+        L.x += c.x; L.y += c.y; L.z += c.z;
+        pb.L[pix] = L;
+    }
+}
+
+// sum += L (path_trace.fs:1055-1059); sum is the packed tile-major RGB32F buffer.
+__global__ void __launch_bounds__(256) k_accumulate(float* __restrict__ sum, PathBuffers pb, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 L = pb.L[i];
+        float* s = sum + 3 * (size_t)i;
+        s[0] = L.x + s[0];
+        s[1] = L.y + s[1];
+        s[2] = L.z + s[2];
+    }
+}
+
+// packed tile-major -> linear frame (bottom row first); pixels of other ranks stay untouched.
+__global__ void __launch_bounds__(256) k_untile(FrameArgs f, const float* __restrict__ packed, float* __restrict__ linear) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < f.n_local_pixels; i += gridDim.x * blockDim.x) {
+        uint32_t px, py;
+        if (!pixel_of(f, i, px, py)) continue;
+        const size_t o = 3 * ((size_t)py * f.width + px);
+        linear[o] = packed[3 * (size_t)i];
+        linear[o + 1] = packed[3 * (size_t)i + 1];
+        linear[o + 2] = packed[3 * (size_t)i + 2];
+    }
+}
+
+// Shader/output.fs:9-20 on the linear sum buffer.
+__global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linear, uint32_t n_pixels, float inv_count,
+                                                 uint8_t* __restrict__ rgba) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x) {
+        const float c0 = linear[3 * (size_t)i] * inv_count, c1 = linear[3 * (size_t)i + 1] * inv_count,
+                    c2 = linear[3 * (size_t)i + 2] * inv_count;
+        const float lum = 0.3f * c0 + 0.6f * c1 + 0.1f * c2;
+        const float k = __fdiv_rn(1.0f, 1.0f + __fdiv_rn(lum, 2.0f));
+        const float cc[3] = {c0, c1, c2};
+        uchar4 out;
+        uint8_t* o8 = reinterpret_cast<uint8_t*>(&out);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = powf(cc[ch] * 1.0f * k, 1.0f / 2.2f);
+            v = v < 0.f ? 0.f : v > 1.f ? 1.f : v;
+            if (v != v) v = 0.f;
+            o8[ch] = (uint8_t)(v * 255.0f + 0.5f);
+        }
+        o8[3] = 255;
+        reinterpret_cast<uchar4*>(rgba)[i] = out;
+    }
+}
+
+// ------------------------------------------------------------------ launchers --------
+
+void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream) {
+    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    if (mode == 1) {
+        if (stats) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, stream, a);
+        else       hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, stream, a);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, stream, a);
+        else       hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, stream, a);
+    }
+}
+void launch_raygen(const FrameArgs& f, const PathBuffers& pb, float4* rays, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(256), 0, stream, f, pb, rays);
+}
+void launch_shade(const ShadeArgs& a, const PathBuffers& pb, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, stream, a, pb);
+}
+void launch_shadow_resolve(const float4* rays_shadow, const float4* hits, const uint32_t* count, const PathBuffers& pb,
+                           uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(256), 0, stream, rays_shadow, hits, count, pb);
+}
+void launch_accumulate(float* sum, const PathBuffers& pb, uint32_t n, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, stream, sum, pb, n);
+}
+void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_untile, dim3(grid), dim3(256), 0, stream, f, packed, linear);
+}
+void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, stream, linear, n_pixels, inv_count, rgba);
+}
+
+}  // namespace crt

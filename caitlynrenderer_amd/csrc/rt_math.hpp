@@ -1,0 +1,91 @@
+// Device-side arithmetic shared by every kernel.  The operation ORDER of each helper is part
+// of the parity contract with the CPU oracle (DESIGN.md "floating-point rules"); the library is
+// built with -ffp-contract=off so nothing here is fused unless fmaf is written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crt {
+
+struct vec3 { float x, y, z; };
+
+__device__ __forceinline__ vec3 V3(float x, float y, float z) { return vec3{x, y, z}; }
+__device__ __forceinline__ vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ vec3 operator-(vec3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ vec3 cross(vec3 a, vec3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float length(vec3 a) { return __fsqrt_rn(dot(a, a)); }
+// v * (1/sqrt(dot)): two correctly rounded operations then three multiplies (glm::normalize).
+__device__ __forceinline__ vec3 normalize(vec3 a) {
+    float inv = __fdiv_rn(1.0f, __fsqrt_rn(dot(a, a)));
+    return a * inv;
+}
+__device__ __forceinline__ float rcp_ieee(float x) { return __fdiv_rn(1.0f, x); }
+
+// ---- pinned sin/cos: Cody-Waite by pi in double, Taylor polynomial, one rounding to float.
+// Same constants and the same sequence of +,-,* as oracle/oracle.c orc_sin / orc_cos.
+__device__ __forceinline__ double reduce_pi(double x, double& k) {
+    k = __builtin_rint(x * 0x1.45f306dc9c883p-2);
+    return ((x - k * 0x1.921fb544p+1) - k * 0x1.0b4611a6p-33) - k * 0x1.3198a2ep-68;
+}
+__device__ __forceinline__ double sin_poly(double r) {
+    double z = r * r;
+    double p = 1.0 / 51090942171709440000.0;
+    p = p * z + (-1.0 / 121645100408832000.0);
+    p = p * z + (1.0 / 355687428096000.0);
+    p = p * z + (-1.0 / 1307674368000.0);
+    p = p * z + (1.0 / 6227020800.0);
+    p = p * z + (-1.0 / 39916800.0);
+    p = p * z + (1.0 / 362880.0);
+    p = p * z + (-1.0 / 5040.0);
+    p = p * z + (1.0 / 120.0);
+    p = p * z + (-1.0 / 6.0);
+    return r + (r * z) * p;
+}
+__device__ __forceinline__ double cos_poly(double r) {
+    double z = r * r;
+    double p = 1.0 / 1124000727777607680000.0;
+    p = p * z + (-1.0 / 2432902008176640000.0);
+    p = p * z + (1.0 / 6402373705728000.0);
+    p = p * z + (-1.0 / 20922789888000.0);
+    p = p * z + (1.0 / 87178291200.0);
+    p = p * z + (-1.0 / 479001600.0);
+    p = p * z + (1.0 / 3628800.0);
+    p = p * z + (-1.0 / 40320.0);
+    p = p * z + (1.0 / 720.0);
+    p = p * z + (-1.0 / 24.0);
+    p = p * z + 0.5;
+    return 1.0 - z * p;
+}
+__device__ __forceinline__ float pinned_sin(float xf) {
+    double x = (double)xf;
+    if (!(__builtin_fabs(x) < 1e9)) return 0.0f;
+    double k, r = reduce_pi(x, k);
+    double s = sin_poly(r);
+    if (((long long)k) & 1) s = -s;
+    return (float)s;
+}
+__device__ __forceinline__ float pinned_cos(float xf) {
+    double x = (double)xf;
+    if (!(__builtin_fabs(x) < 1e9)) return 1.0f;
+    double k, r = reduce_pi(x, k);
+    double c = cos_poly(r);
+    if (((long long)k) & 1) c = -c;
+    return (float)c;
+}
+
+// Shader/path_trace.fs:38-42
+__device__ __forceinline__ float shader_rand(float& sx, float& sy, float rv) {
+    sx -= rv;
+    sy -= rv;
+    float d = sx * 12.9898f + sy * 78.233f;
+    float v = pinned_sin(d) * 43758.5453f;
+    return v - __builtin_floorf(v);
+}
+
+}  // namespace crt

@@ -1,0 +1,67 @@
+"""Deterministic procedural meshes for the bench/test configs.
+
+`tessellated_cornell(base, n)` takes the 16 Cornell quads (already translated by -vertex_min),
+cuts each of the 15 non-light quads into n x n cells of two triangles (v00,v10,v11),(v00,v11,v01),
+keeps the light quad as 2 triangles, displaces interior grid vertices along the quad normal by
+0.02*(pcg_hash(vertex_index ^ 0x1234)/2^32 - 0.5), and gives every vertex the quad normal
+(vn.w = 1).  n = 183 gives 1,004,672 triangles / 507,844 vertices; n = 8 gives 1,922 triangles.
+"""
+import numpy as np
+
+from .host import Mesh
+
+
+def pcg_hash_np(x):
+    """Vectorised Caitlyn/Rnd.h:21-26 on uint32 arrays."""
+    x = np.asarray(x, dtype=np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    state = (x * np.uint64(747796405) + np.uint64(2891336453)) & m
+    word = (((state >> ((state >> np.uint64(28)) + np.uint64(4))) ^ state) * np.uint64(277803737)) & m
+    return (((word >> np.uint64(22)) ^ word) & m).astype(np.uint32)
+
+
+def tessellated_cornell(base, n):
+    tris = base.triangles
+    assert tris.shape[0] % 2 == 0, "base mesh must be fan-triangulated quads"
+    verts64 = base.vertices.astype(np.float64)
+    out_v, out_t = [], []
+    n_vertices = 0
+    for q in range(tris.shape[0] // 2):
+        t0, t1 = tris[2 * q], tris[2 * q + 1]
+        a, b, c, d = int(t0[0]), int(t0[1]), int(t0[2]), int(t1[2])   # fan (a,b,c),(a,c,d)
+        mtl = int(t0[3])
+        vn = t0[4:8].copy()
+        emissive = base.materials[mtl, 7] != -1.0
+        P00, P10, P11, P01 = verts64[a], verts64[b], verts64[c], verts64[d]
+        if emissive:
+            out_v.append(np.stack([P00, P10, P11, P01]).astype(np.float32))
+            base_i = n_vertices
+            for (i0, i1, i2) in ((0, 1, 2), (0, 2, 3)):
+                out_t.append(np.array([[base_i + i0, base_i + i1, base_i + i2, mtl, vn[0], vn[1], vn[2], vn[3], -1, -1, -1, 0]], np.int32))
+            n_vertices += 4
+            continue
+        s = (np.arange(n + 1, dtype=np.float64) / n)
+        S, T = np.meshgrid(s, s, indexing="ij")           # S: i (P00->P10), T: j (P00->P01)
+        S, T = S[..., None], T[..., None]
+        P = (1 - S) * (1 - T) * P00 + S * (1 - T) * P10 + S * T * P11 + (1 - S) * T * P01
+        idx = n_vertices + np.arange((n + 1) * (n + 1), dtype=np.int64).reshape(n + 1, n + 1)
+        h = pcg_hash_np((idx.astype(np.uint64) ^ np.uint64(0x1234)) & np.uint64(0xFFFFFFFF)).astype(np.float64)
+        disp = 0.02 * (h / 4294967296.0 - 0.5)
+        interior = np.zeros((n + 1, n + 1), bool)
+        interior[1:n, 1:n] = True
+        N = base.normals[int(vn[0])].astype(np.float64) if vn[3] == 1 else np.cross(P10 - P00, P01 - P00)
+        P = P + (disp * interior)[..., None] * N
+        out_v.append(P.reshape(-1, 3).astype(np.float32))
+        i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        v00, v10, v11, v01 = idx[i, j], idx[i + 1, j], idx[i + 1, j + 1], idx[i, j + 1]
+        cells = np.empty((n, n, 2, 12), np.int32)
+        cells[..., 0, 0], cells[..., 0, 1], cells[..., 0, 2] = v00, v10, v11
+        cells[..., 1, 0], cells[..., 1, 1], cells[..., 1, 2] = v00, v11, v01
+        cells[..., 3] = mtl
+        cells[..., 4:8] = vn
+        cells[..., 8:11] = -1
+        cells[..., 11] = 0
+        out_t.append(cells.reshape(-1, 12))
+        n_vertices += (n + 1) * (n + 1)
+    return Mesh(np.concatenate(out_v), base.normals, base.texcoords, np.concatenate(out_t), base.materials,
+                base.lights, base.vertex_min)

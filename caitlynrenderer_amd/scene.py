@@ -1,0 +1,172 @@
+"""Device-side scene: the drop-in for Scene::gpu_data / update / Render (Caitlyn/Scene.h:1000-1246).
+
+`SceneData` is the bundle of host arrays the reference uploads; `Scene` owns the device copy and
+dispatches the HIP path through the C ABI.  There is no CPU fallback: constructing a `Scene`
+without a GPU raises CrtError(CRT_ERR_NO_DEVICE).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import (CRT_ABI_VERSION, CRT_TRACE_ANY, CRT_TRACE_CLOSEST, check, crt_bvh_info, crt_frame_stats,
+                   crt_scene_desc, lib)
+from .host import CWBVH, SBVH, Camera, Mesh, Rnd, _ptr
+
+RAY_DT = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("d", "<f4", 3), ("pad", "<u4")])
+HIT_DT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri", "<i4")])
+STATS_DT = np.dtype([("nodes", "<u2"), ("tris", "<u2")])
+
+
+class SceneData:
+    """Host arrays in upload order (Scene.h:1015-1062) + the CWBVH the shader was meant to get."""
+
+    def __init__(self, mesh, sbvh, cwbvh, camera):
+        self.vertices, self.normals, self.texcoords = mesh.vertices, mesh.normals, mesh.texcoords
+        self.materials, self.lights = mesh.materials, mesh.lights
+        self.triangles = sbvh.triangles                 # leaf order with duplicates (sbvh.h:130-139)
+        self.tri_orig_ids = sbvh.triangle_indices
+        self.bvh = sbvh.flat_nodes
+        self.bvh8 = cwbvh.nodes if cwbvh is not None else None
+        self.bvh8_tri_slots = cwbvh.tri_slots if cwbvh is not None else None
+        self.camera = camera
+        self.n_source_triangles = int(mesh.triangles.shape[0])
+
+    @staticmethod
+    def build(mesh, camera, sbvh_flags=0, with_cwbvh=True):
+        """Scene::build_bvh (Scene.h:929-959) followed by the intended CWBVH::convert."""
+        sbvh = SBVH(mesh.triangles, mesh.vertices, sbvh_flags)
+        cw = CWBVH().convert(sbvh) if with_cwbvh else None
+        return SceneData(mesh, sbvh, cw, camera)
+
+    @staticmethod
+    def from_obj(path, camera):
+        """Scene(file_name, …) up to gpu_data (Scene.h:447-495): load, translate, build."""
+        mesh = Mesh.read_object(path, camera)
+        return SceneData.build(mesh, camera)
+
+
+class Scene:
+    def __init__(self, data, width, height, max_depth=3):
+        self._h = C.c_void_p()
+        self.width, self.height, self.max_depth = int(width), int(height), int(max_depth)
+        self.frame_count = 0                       # Scene.h:384
+        self.rnd = Rnd()                           # Rnd.h:7
+        d = crt_scene_desc()
+        d.abi_version = CRT_ABI_VERSION
+        keep = []
+
+        def arr(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(a)
+            return a
+
+        v = arr(data.vertices, np.float32); d.vertices, d.n_vertices = _ptr(v), v.shape[0]
+        n = arr(data.normals, np.float32); d.normals, d.n_normals = _ptr(n), n.shape[0]
+        t = arr(data.texcoords, np.float32); d.texcoords, d.n_texcoords = _ptr(t), t.shape[0]
+        tr = arr(data.triangles, np.int32); d.triangles, d.n_triangles = _ptr(tr), tr.shape[0]
+        if data.tri_orig_ids is not None:
+            ids = arr(data.tri_orig_ids, np.int32); d.tri_orig_ids = _ptr(ids)
+        m = arr(data.materials, np.float32); d.materials, d.n_materials = _ptr(m), m.shape[0]
+        l = arr(data.lights, np.float32); d.lights, d.n_lights = _ptr(l), l.shape[0]
+        if data.bvh is not None:
+            b = arr(data.bvh, np.float32); d.bvh, d.n_bvh = _ptr(b), b.shape[0]
+        if data.bvh8 is not None:
+            b8 = arr(data.bvh8, np.uint8); d.bvh8, d.n_bvh8 = _ptr(b8), b8.shape[0]
+            sl = arr(data.bvh8_tri_slots, np.int32); d.bvh8_tri_slots, d.n_bvh8_tris = _ptr(sl), sl.shape[0]
+        d.width, d.height, d.max_depth = self.width, self.height, self.max_depth
+        check(lib().crt_scene_create(C.byref(d), C.byref(self._h)))
+        if data.camera is not None:
+            self.update(data.camera)
+
+    # -- reference-shaped API ------------------------------------------------------------
+    def update(self, camera):
+        """Scene::update (Scene.h:1233-1246)."""
+        check(lib().crt_set_camera(self._h, C.byref(camera.c)))
+
+    def Render(self):
+        """Scene::Render (Scene.h:1158-1231) minus the present pass: draw one sample, ++frame_count."""
+        r1, r2 = self.rnd.randf2(), self.rnd.randf2()          # Scene.h:1208
+        self.render_frame(r1, r2)
+        self.frame_count += 1
+        return r1, r2
+
+    def reset(self):
+        """camera.isMoving branch (Scene.h:1160-1172)."""
+        check(lib().crt_reset(self._h))
+        self.frame_count = 0
+
+    # -- explicit API ----------------------------------------------------------------------
+    def render_frame(self, rx, ry, sync=True):
+        fn = lib().crt_render_frame if sync else lib().crt_render_frame_async
+        check(fn(self._h, float(np.float32(rx)), float(np.float32(ry))))
+
+    def sync(self):
+        check(lib().crt_sync(self._h))
+
+    def set_option(self, name, value):
+        check(lib().crt_set_option(self._h, name.encode(), int(value)))
+
+    def read_sum(self):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        check(lib().crt_read_sum(self._h, _ptr(out), out.size))
+        return out
+
+    def resolve(self, inv_count=None):
+        if inv_count is None:
+            inv_count = 1.0 / max(self.frame_count, 1)
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        check(lib().crt_resolve(self._h, float(np.float32(inv_count)), _ptr(out), out.size))
+        return out
+
+    def trace(self, rays, mode=CRT_TRACE_CLOSEST, stats=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        hits = np.empty(rays.shape[0], HIT_DT)
+        st = np.zeros(rays.shape[0], STATS_DT) if stats else None
+        check(lib().crt_trace(self._h, _ptr(rays), rays.shape[0], _ptr(hits), int(mode), _ptr(st) if stats else None))
+        return (hits, st) if stats else hits
+
+    def trace_device(self, d_rays, n, d_hits, mode=CRT_TRACE_CLOSEST, d_stats=None, sync=True):
+        check(lib().crt_trace_device(self._h, C.c_void_p(d_rays), int(n), C.c_void_p(d_hits), int(mode),
+                                     C.c_void_p(d_stats) if d_stats else None, 1 if sync else 0))
+
+    def set_shard(self, rank, world, tile=64):
+        check(lib().crt_set_shard(self._h, int(rank), int(world), int(tile)))
+
+    def packed_info(self):
+        nt, tile, nf = C.c_uint32(), C.c_uint32(), C.c_size_t()
+        check(lib().crt_packed_info(self._h, C.byref(nt), C.byref(tile), C.byref(nf)))
+        return nt.value, tile.value, nf.value
+
+    def read_packed(self):
+        _, _, nf = self.packed_info()
+        out = np.empty(nf, np.float32)
+        check(lib().crt_read_packed(self._h, _ptr(out), nf))
+        return out
+
+    def copy_packed_device(self, d_dst, n_floats, sync=True):
+        check(lib().crt_copy_packed_device(self._h, C.c_void_p(d_dst), int(n_floats), 1 if sync else 0))
+
+    def frame_stats(self):
+        st = crt_frame_stats()
+        check(lib().crt_get_frame_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def bvh_info(self):
+        st = crt_bvh_info()
+        check(lib().crt_get_bvh_info(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def close(self):
+        if self._h:
+            lib().crt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["Scene", "SceneData", "Camera", "Mesh", "SBVH", "CWBVH", "RAY_DT", "HIT_DT", "STATS_DT",
+           "CRT_TRACE_CLOSEST", "CRT_TRACE_ANY"]

@@ -1,0 +1,77 @@
+"""Framebuffer tile sharding across GPUs and the read-back gather.
+
+No reference counterpart: the reference is one OpenGL context.  Pixels are independent, so the
+frame is cut into tile x tile squares, dealt round-robin in Morton order to the ranks (the Cornell
+view misses 44 % of a 16:9 frame, so contiguous bands would be unbalanced), every rank accumulates
+its own tiles locally, and the only communication is one all-gather of the packed RGB32F tile
+buffers at read-back (RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests).
+`tile_order` must stay identical to build_shard() in csrc/crt_device.cpp.
+"""
+import numpy as np
+
+
+def _spread(v):
+    v = v & 0xFFFF
+    v = (v | (v << 8)) & 0x00FF00FF
+    v = (v | (v << 4)) & 0x0F0F0F0F
+    v = (v | (v << 2)) & 0x33333333
+    v = (v | (v << 1)) & 0x55555555
+    return v
+
+
+def tile_order(width, height, tile):
+    """All tiles of the frame as (tx, ty), sorted by Morton code."""
+    nx, ny = (width + tile - 1) // tile, (height + tile - 1) // tile
+    items = sorted((_spread(x) | (_spread(y) << 1), x, y) for y in range(ny) for x in range(nx))
+    return [(x, y) for _, x, y in items]
+
+
+def local_tiles(width, height, tile, rank, world):
+    return tile_order(width, height, tile)[rank::world]
+
+
+def max_local_tiles(width, height, tile, world):
+    n = len(tile_order(width, height, tile))
+    return (n + world - 1) // world
+
+
+def pixel_grid(tile):
+    """(dy, dx) of the in-tile pixel order: 8x8 blocks row-major, pixels row-major inside a block."""
+    j = np.arange(tile * tile)
+    blk, k = j >> 6, j & 63
+    bpr = tile >> 3
+    dx = (blk % bpr) * 8 + (k & 7)
+    dy = (blk // bpr) * 8 + (k >> 3)
+    return dy, dx
+
+
+def untile_into(frame, packed, tiles, tile):
+    """Scatter one rank's packed (n_tiles, tile*tile, 3) buffer into frame (H, W, 3)."""
+    H, W = frame.shape[0], frame.shape[1]
+    dy, dx = pixel_grid(tile)
+    packed = np.asarray(packed).reshape(-1, tile * tile, 3)
+    for t, (tx, ty) in enumerate(tiles):
+        py, px = ty * tile + dy, tx * tile + dx
+        ok = (py < H) & (px < W)
+        frame[py[ok], px[ok]] = packed[t][ok]
+    return frame
+
+
+def gather_frame(local_packed, width, height, tile, rank, world, group=None):
+    """All-gather the packed tile buffers and un-tile; returns the full (H, W, 3) frame on every rank.
+
+    local_packed: torch tensor (n_local_tiles*tile*tile*3,) on the device the process group uses.
+    """
+    import torch
+    import torch.distributed as dist
+    cap = max_local_tiles(width, height, tile, world) * tile * tile * 3
+    send = local_packed.new_zeros(cap)
+    send[: local_packed.numel()] = local_packed
+    recv = local_packed.new_empty(world * cap)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    frame = np.zeros((height, width, 3), np.float32)
+    host = recv.cpu().numpy().reshape(world, cap)
+    for r in range(world):
+        tl = local_tiles(width, height, tile, r, world)
+        untile_into(frame, host[r][: len(tl) * tile * tile * 3], tl, tile)
+    return frame

@@ -120,6 +120,13 @@ int crt_set_camera(crt_scene* s, const crt_camera* cam);
 /* replaces the path_trace draw in Scene::Render, Scene.h:1208-1213: adds ONE sample
  * per pixel to the device-resident RGB32F sum buffer; (rx,ry) = randomVector. */
 int crt_render_frame(crt_scene* s, float rx, float ry);
+/* same, without the final stream synchronise: frames queue back to back on the scene's
+ * stream; crt_sync (or any read-back call) waits for them. */
+int crt_render_frame_async(crt_scene* s, float rx, float ry);
+int crt_sync(crt_scene* s);
+/* knobs: "jitter" (0/1, tent-filter jitter of path_trace.fs:1030-1037; default 1),
+ * "trace_occupancy" (persistent workgroups per CU for the traversal kernels). */
+int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);
 /* path_trace_texture read-back: n_floats must be width*height*3 (bottom row first).
@@ -132,7 +139,7 @@ int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes);
  * stats may be NULL.  For CRT_TRACE_ANY, hit.tri >= 0 iff occluded (t,u,v = 0). */
 int crt_trace(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits, int mode, crt_ray_stats* stats);
 /* same with DEVICE pointers (rays/hits/stats already resident in HBM); asynchronous
- * on the scene's stream unless sync != 0.  repeat >= 1 re-launches for timing. */
+ * on the scene's stream unless sync != 0. */
 int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, int mode, void* d_stats, int sync);
 
 /* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is
@@ -189,6 +196,8 @@ size_t crt_cwbvh_num_nodes(const crt_cwbvh*);
 size_t crt_cwbvh_num_tris(const crt_cwbvh*);
 const crt_node8* crt_cwbvh_nodes(const crt_cwbvh*);
 const int32_t*   crt_cwbvh_tri_slots(const crt_cwbvh*);  /* CWBVH order -> BVH2 leaf slot */
+/* 8 entries per node8: the BVH2 node each child slot stands for (-1 = empty); for validators */
+const int32_t*   crt_cwbvh_child_bvh2(const crt_cwbvh*);
 uint32_t crt_cwbvh_depth(const crt_cwbvh*);
 void crt_cwbvh_free(crt_cwbvh*);
 

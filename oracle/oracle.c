@@ -1,0 +1,706 @@
+/*
+ * oracle.c — scalar CPU restatement of CaitlynRenderer's per-ray hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product path (caitlynrenderer_amd/) never
+ * calls, links or imports anything under oracle/.
+ *
+ * What it follows (all paths relative to /root/reference):
+ *   rand                       Shader/path_trace.fs:38-42
+ *   slab test                  Shader/path_trace.fs:84-109
+ *   Moller-Trumbore            Shader/path_trace.fs:322-374 (record), :376-412 (no record)
+ *   hit attributes             Shader/path_trace.fs:414-489
+ *   BVH2 closest / any hit     Shader/path_trace.fs:511-667 / :669-819
+ *   CWBVH node test + walks    Shader/cwbvh.fs:348-446, :448-536, :538-616 with the defects
+ *                              listed in SURVEY.md §8a corrected as in SURVEY.md appendix C
+ *   light sampling, integrator Shader/path_trace.fs:843-855, :857-1024
+ *   ray generation, accumulate Shader/path_trace.fs:1026-1060
+ *   resolve                    Shader/output.fs:9-20
+ *   host RNG                   Caitlyn/Rnd.h:21-40
+ *
+ * How it is pinned.  The reference ships NO tests, golden images or fixtures for this path
+ * (SURVEY.md §4), its GLSL cannot execute in this environment, and its only compilable host
+ * header (sbvh.h) needs glm, which the image lacks, so no oracle/_ref build exists.  The
+ * oracle is therefore pinned by the known-answer values the survey captured from the
+ * reference's own sbvh.h and data files (committed under tests/golden/):
+ * Cornell BVH2 leaf order and node boxes, host RNG sequence, camera after load, and the BVH2
+ * primary-ray census (hit count, centre-pixel hit id and t, node/triangle visits per ray).
+ * Bit-parity with a real GLSL run is UNPINNED: GLSL leaves sin/normalize/min/max precision
+ * to the implementation, so the floating-point rules below are this project's definition.
+ *
+ * Floating-point rules (shared bit-for-bit with the HIP kernels):
+ *   - compiled with -ffp-contract=off: no fused multiply-add except where fmaf() is written;
+ *   - dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z; cross as usual; a*s then + left to right;
+ *   - normalize(v) = v * (1.0f / sqrtf(dot(v,v))); length = sqrtf(dot); '/' and sqrtf are the
+ *     IEEE correctly rounded operations;
+ *   - min/max = fminf/fmaxf (IEEE minNum/maxNum: a NaN operand is ignored), which is also
+ *     what v_min_f32/v_max_f32 do on gfx950;
+ *   - sin/cos are evaluated in double by a fixed sequence of +,-,* (orc_sin/orc_cos) and
+ *     rounded once to float; tan(fov/2) is computed once per frame on the host with tanf.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#define ORC_INF 1e9f           /* path_trace.fs:35 */
+#define ORC_EPS 1e-4f          /* path_trace.fs:36 */
+#define ORC_PI 3.1415926f      /* path_trace.fs:16 */
+#define ORC_PI2 6.2831853f     /* path_trace.fs:17 */
+#define BVH2_STACK 128         /* reference: 12 / 16 ints (path_trace.fs:513, :671); too shallow at 2k tris */
+#define BVH8_STACK 32          /* reference LOCAL_STACK_SIZE 16 (cwbvh.fs:374) */
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 scl(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline float len3(v3 a) { return sqrtf(dot3(a, a)); }
+static inline v3 norm3(v3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return scl(a, inv); }
+
+/* ------------------------------------------------------------ pinned sin/cos -- */
+
+/* Cody-Waite reduction by pi in three 33-bit pieces (the fdlibm pio2 constants doubled),
+ * exact for |k| < 2^20, then a Taylor polynomial in double; error << 1 float ulp. */
+static const double PI_1 = 0x1.921fb544p+1, PI_2 = 0x1.0b4611a6p-33, PI_3 = 0x1.3198a2ep-68;
+static const double INV_PI = 0x1.45f306dc9c883p-2;
+
+static inline double reduce_pi(double x, double* k_out) {
+    double k = rint(x * INV_PI);
+    double r = ((x - k * PI_1) - k * PI_2) - k * PI_3;
+    *k_out = k;
+    return r;
+}
+static inline double sin_poly(double r) {
+    double z = r * r;
+    double p = 1.0 / 51090942171709440000.0;          /*  1/21! */
+    p = p * z + (-1.0 / 121645100408832000.0);        /* -1/19! */
+    p = p * z + (1.0 / 355687428096000.0);            /*  1/17! */
+    p = p * z + (-1.0 / 1307674368000.0);             /* -1/15! */
+    p = p * z + (1.0 / 6227020800.0);                 /*  1/13! */
+    p = p * z + (-1.0 / 39916800.0);                  /* -1/11! */
+    p = p * z + (1.0 / 362880.0);                     /*  1/9!  */
+    p = p * z + (-1.0 / 5040.0);                      /* -1/7!  */
+    p = p * z + (1.0 / 120.0);                        /*  1/5!  */
+    p = p * z + (-1.0 / 6.0);                         /* -1/3!  */
+    return r + (r * z) * p;
+}
+static inline double cos_poly(double r) {
+    double z = r * r;
+    double p = 1.0 / 1124000727777607680000.0;        /*  1/22! */
+    p = p * z + (-1.0 / 2432902008176640000.0);       /* -1/20! */
+    p = p * z + (1.0 / 6402373705728000.0);           /*  1/18! */
+    p = p * z + (-1.0 / 20922789888000.0);            /* -1/16! */
+    p = p * z + (1.0 / 87178291200.0);                /*  1/14! */
+    p = p * z + (-1.0 / 479001600.0);                 /* -1/12! */
+    p = p * z + (1.0 / 3628800.0);                    /*  1/10! */
+    p = p * z + (-1.0 / 40320.0);                     /* -1/8!  */
+    p = p * z + (1.0 / 720.0);                        /*  1/6!  */
+    p = p * z + (-1.0 / 24.0);                        /* -1/4!  */
+    p = p * z + 0.5;                                  /*  1/2!  */
+    return 1.0 - z * p;
+}
+float orc_sin(float xf) {
+    double x = (double)xf;
+    if (!(fabs(x) < 1e9)) return 0.0f;                /* outside the domain the shaders reach */
+    double k, r = reduce_pi(x, &k);
+    double s = sin_poly(r);
+    if (((long long)k) & 1) s = -s;
+    return (float)s;
+}
+float orc_cos(float xf) {
+    double x = (double)xf;
+    if (!(fabs(x) < 1e9)) return 1.0f;
+    double k, r = reduce_pi(x, &k);
+    double c = cos_poly(r);
+    if (((long long)k) & 1) c = -c;
+    return (float)c;
+}
+
+/* path_trace.fs:38-42 */
+float orc_rand(float seed[2], float rx, float ry) {
+    float rv = rx * ry;
+    seed[0] -= rv;
+    seed[1] -= rv;
+    float d = seed[0] * 12.9898f + seed[1] * 78.233f;
+    float v = orc_sin(d) * 43758.5453f;
+    return v - floorf(v);
+}
+
+/* Rnd.h:21-26 */
+uint32_t orc_pcg_hash(uint32_t input) {
+    uint32_t state = input * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+/* Rnd.h:36-40, imax = 1.0f / UINT32_MAX (Rnd.h:8) */
+float orc_randf2(uint32_t* state) {
+    *state = orc_pcg_hash(*state);
+    return (float)(*state) * (1.0f / (float)UINT32_MAX);
+}
+
+/* -------------------------------------------------------------- primitives -- */
+
+typedef struct {
+    float t, u, v;
+    int slot;      /* index into s->triangles (BVH2 leaf order) */
+    int id;        /* original triangle id */
+    int mtl;
+} rec_t;
+
+typedef struct { uint32_t nodes, tris; } cnt_t;
+
+static inline int orig_id(const orc_scene* s, int slot) { return s->tri_orig_ids ? s->tri_orig_ids[slot] : slot; }
+
+/* path_trace.fs:322-374 (exact operation order). */
+static inline int mt_test(const orc_scene* s, v3 o, v3 d, int slot, float* u, float* v, float* t) {
+    const int32_t* ti = s->triangles + 12 * (size_t)slot;
+    v3 v0 = ld3(s->vertices + 3 * (size_t)ti[0]);
+    v3 v1 = ld3(s->vertices + 3 * (size_t)ti[1]);
+    v3 v2 = ld3(s->vertices + 3 * (size_t)ti[2]);
+    v1 = sub(v1, v0);
+    v2 = sub(v2, v0);
+    v3 pv = cross3(d, v2);
+    v3 tv = sub(o, v0);
+    v3 qv = cross3(tv, v1);
+    float uu = dot3(tv, pv);
+    float vv = dot3(d, qv);
+    float tt = dot3(v2, qv);
+    float inv_det = 1.0f / dot3(v1, pv);
+    uu = uu * inv_det;
+    vv = vv * inv_det;
+    tt = tt * inv_det;
+    float w = 1.0f - uu - vv;
+    *u = uu; *v = vv; *t = tt;
+    return (uu >= 0.0f) && (vv >= 0.0f) && (tt >= 0.0f) && (w >= 0.0f);
+}
+
+static inline void closest_update(const orc_scene* s, v3 o, v3 d, int slot, rec_t* rec, int tie, cnt_t* c) {
+    float u, v, t;
+    c->tris++;
+    if (!mt_test(s, o, d, slot, &u, &v, &t)) return;
+    int id = orig_id(s, slot);
+    int better = t < rec->t;
+    if (tie == ORC_TIE_LOWEST_ID && t == rec->t && rec->slot >= 0 && id < rec->id) better = 1;
+    if (better) {
+        rec->t = t; rec->u = u; rec->v = v; rec->slot = slot; rec->id = id;
+        rec->mtl = s->triangles[12 * (size_t)slot + 3];
+    }
+}
+/* path_trace.fs:376-412 */
+static inline int any_test(const orc_scene* s, v3 o, v3 d, int slot, float max_t, cnt_t* c) {
+    float u, v, t;
+    c->tris++;
+    return mt_test(s, o, d, slot, &u, &v, &t) && t < max_t;
+}
+
+/* path_trace.fs:84-109 */
+static inline float hit_bbox(v3 o, v3 bmin, v3 bmax, v3 invdir, float* tl) {
+    bmin = mul(sub(bmin, o), invdir);
+    bmax = mul(sub(bmax, o), invdir);
+    v3 tmax = V(fmaxf(bmax.x, bmin.x), fmaxf(bmax.y, bmin.y), fmaxf(bmax.z, bmin.z));
+    v3 tmin = V(fminf(bmax.x, bmin.x), fminf(bmax.y, bmin.y), fminf(bmax.z, bmin.z));
+    float th = fminf(tmax.x, fminf(tmax.y, tmax.z));
+    *tl = fmaxf(tmin.x, fmaxf(tmin.y, tmin.z));
+    return th;
+}
+
+/* ------------------------------------------------------------------- brute -- */
+
+static void brute_closest(const orc_scene* s, v3 o, v3 d, float tmax, rec_t* rec, int tie, cnt_t* c) {
+    rec->t = tmax; rec->slot = -1; rec->id = -1;
+    for (int i = 0; i < s->n_triangles; ++i) closest_update(s, o, d, i, rec, tie, c);
+}
+static int brute_any(const orc_scene* s, v3 o, v3 d, float max_t, cnt_t* c) {
+    for (int i = 0; i < s->n_triangles; ++i)
+        if (any_test(s, o, d, i, max_t, c)) return 1;
+    return 0;
+}
+
+/* -------------------------------------------------------------------- BVH2 -- */
+
+/* path_trace.fs:511-652 */
+static void bvh2_closest(const orc_scene* s, v3 o, v3 d, float tmax, rec_t* rec, int tie, cnt_t* c) {
+    int stk[BVH2_STACK];
+    int ptr = 0;
+    stk[ptr++] = -1;
+    rec->t = tmax; rec->slot = -1; rec->id = -1;
+    const v3 invdir = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int ind = 0;
+    while (ind > -1) {
+        const float* nd = s->bvh2 + 8 * (size_t)ind;
+        c->nodes++;
+        int left = (int)nd[3];
+        if (nd[7] == 0.0f) {
+            int right = left + 1;
+            const float* a = s->bvh2 + 8 * (size_t)left;
+            const float* b = s->bvh2 + 8 * (size_t)right;
+            float tl1, tl2;
+            float th1 = hit_bbox(o, ld3(a), ld3(a + 4), invdir, &tl1);
+            float th2 = hit_bbox(o, ld3(b), ld3(b + 4), invdir, &tl2);
+            /* path_trace.fs:562-563 test `tl < t`; the lowest-id tie rule needs `<=` so that a
+             * box holding an equal-t triangle is still entered */
+            int l = th1 > 0 && th1 >= tl1 && (tie == ORC_TIE_LOWEST_ID ? tl1 <= rec->t : tl1 < rec->t);
+            int r = th2 > 0 && th2 >= tl2 && (tie == ORC_TIE_LOWEST_ID ? tl2 <= rec->t : tl2 < rec->t);
+            if (l) {
+                ind = left;
+                if (r) {
+                    int off = tl1 > tl2 ? 1 : 0;
+                    if (ptr < BVH2_STACK) stk[ptr++] = ind + 1 - off;
+                    ind += off;
+                }
+                continue;
+            } else if (r) {
+                ind = right;
+                continue;
+            }
+        } else {
+            int range = (int)nd[7];
+            for (int i = left; i < left + range; ++i) closest_update(s, o, d, i, rec, tie, c);
+        }
+        ind = stk[--ptr];
+    }
+}
+
+/* path_trace.fs:669-819 */
+static int bvh2_any(const orc_scene* s, v3 o, v3 d, float max_t, cnt_t* c) {
+    int stk[BVH2_STACK];
+    int ptr = 0;
+    stk[ptr++] = -1;
+    const v3 invdir = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int ind = 0;
+    while (ind > -1) {
+        const float* nd = s->bvh2 + 8 * (size_t)ind;
+        c->nodes++;
+        int left = (int)nd[3];
+        if (nd[7] != 0.0f) {
+            int range = (int)nd[7];
+            for (int i = left; i < left + range; ++i)
+                if (any_test(s, o, d, i, max_t, c)) return 1;
+        } else {
+            int right = left + 1;
+            const float* a = s->bvh2 + 8 * (size_t)left;
+            const float* b = s->bvh2 + 8 * (size_t)right;
+            float tl1, tl2;
+            float th1 = hit_bbox(o, ld3(a), ld3(a + 4), invdir, &tl1);
+            float th2 = hit_bbox(o, ld3(b), ld3(b + 4), invdir, &tl2);
+            int l = th1 >= 0 && th1 >= tl1 && tl1 <= max_t;
+            int r = th2 >= 0 && th2 >= tl2 && tl2 <= max_t;
+            if (l) {
+                ind = left;
+                if (r) {
+                    int off = tl1 > tl2 ? 1 : 0;
+                    if (ptr < BVH2_STACK) stk[ptr++] = ind + 1 - off;
+                    ind += off;
+                }
+                continue;
+            } else if (r) {
+                ind = right;
+                continue;
+            }
+        }
+        ind = stk[--ptr];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------- CWBVH -- */
+
+static inline uint32_t ld_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline float ld_f32(const uint8_t* p) { float v; memcpy(&v, p, 4); return v; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int msb(uint32_t x) { return 31 - __builtin_clz(x); }   /* findMSB, x != 0 */
+
+/* cwbvh.fs:348-353 */
+static inline uint32_t oct_inv4(v3 d) {
+    return (d.x < 0.0f ? 0u : 0x04040404u) | (d.y < 0.0f ? 0u : 0x02020202u) | (d.z < 0.0f ? 0u : 0x01010101u);
+}
+/* cwbvh.fs:369-372 */
+static inline uint32_t sign_extend_s8x4(uint32_t x) { return ((x >> 7) & 0x01010101u) * 0xffu; }
+
+/* cwbvh.fs:376-446 with: far plane = min(min()), tmin clamped to 0, tmax clamped to max_t,
+ * child hit iff tmin <= tmax.  t = fmaf(q, 2^e*invdir, (p-o)*invdir). */
+static uint32_t node8_intersect(const uint8_t* n, v3 o, v3 d, v3 inv, uint32_t oct4, float max_t) {
+    v3 p = V(ld_f32(n), ld_f32(n + 4), ld_f32(n + 8));
+    uint32_t e_imask = ld_u32(n + 12);
+    v3 adj_inv = V(u2f((e_imask & 0xffu) << 23) * inv.x, u2f(((e_imask >> 8) & 0xffu) << 23) * inv.y,
+                   u2f(((e_imask >> 16) & 0xffu) << 23) * inv.z);
+    v3 adj_o = mul(sub(p, o), inv);
+    uint32_t hit_mask = 0;
+    for (int i = 0; i < 2; ++i) {
+        uint32_t meta4 = ld_u32(n + 24 + 4 * i);
+        uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        uint32_t inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
+        uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1F1F1F1Fu;
+        uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+        uint32_t qlox = ld_u32(n + 32 + 4 * i), qhix = ld_u32(n + 40 + 4 * i);
+        uint32_t qloy = ld_u32(n + 48 + 4 * i), qhiy = ld_u32(n + 56 + 4 * i);
+        uint32_t qloz = ld_u32(n + 64 + 4 * i), qhiz = ld_u32(n + 72 + 4 * i);
+        uint32_t xmin = d.x < 0.0f ? qhix : qlox, xmax = d.x < 0.0f ? qlox : qhix;
+        uint32_t ymin = d.y < 0.0f ? qhiy : qloy, ymax = d.y < 0.0f ? qloy : qhiy;
+        uint32_t zmin = d.z < 0.0f ? qhiz : qloz, zmax = d.z < 0.0f ? qloz : qhiz;
+        for (int j = 0; j < 4; ++j) {
+            float tminx = fmaf((float)((xmin >> (8 * j)) & 0xffu), adj_inv.x, adj_o.x);
+            float tminy = fmaf((float)((ymin >> (8 * j)) & 0xffu), adj_inv.y, adj_o.y);
+            float tminz = fmaf((float)((zmin >> (8 * j)) & 0xffu), adj_inv.z, adj_o.z);
+            float tmaxx = fmaf((float)((xmax >> (8 * j)) & 0xffu), adj_inv.x, adj_o.x);
+            float tmaxy = fmaf((float)((ymax >> (8 * j)) & 0xffu), adj_inv.y, adj_o.y);
+            float tmaxz = fmaf((float)((zmax >> (8 * j)) & 0xffu), adj_inv.z, adj_o.z);
+            float tmin = fmaxf(fmaxf(tminx, tminy), fmaxf(tminz, 0.0f));
+            float tmax = fminf(fminf(tmaxx, tmaxy), fminf(tmaxz, max_t));
+            if (tmin <= tmax) {
+                uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
+                uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
+                hit_mask |= child_bits << bit_index;
+            }
+        }
+    }
+    return hit_mask;
+}
+
+/* cwbvh.fs:448-536 (closest) and :538-616 (any): one walker, `any` returns at the first hit. */
+static int bvh8_walk(const orc_scene* s, v3 o, v3 d, float tmax_in, int any, rec_t* rec, int tie, cnt_t* c) {
+    uint32_t stack_x[BVH8_STACK], stack_y[BVH8_STACK];
+    int sp = 0;
+    float max_t = tmax_in;
+    if (rec) { rec->t = tmax_in; rec->slot = -1; rec->id = -1; }
+    const uint32_t oct4 = oct_inv4(d);
+    const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t cur_x = 0, cur_y = 0x80000000u;
+    for (;;) {
+        uint32_t tri_x, tri_y;
+        if (cur_y & 0xff000000u) {
+            uint32_t hits_imask = cur_y;
+            int off = msb(hits_imask);
+            uint32_t base = cur_x;
+            cur_y &= ~(1u << off);
+            if (cur_y & 0xff000000u) {
+                if (sp < BVH8_STACK) { stack_x[sp] = cur_x; stack_y[sp] = cur_y; sp++; }
+            }
+            uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+            uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+            uint32_t node_index = base + rel;
+            const uint8_t* n = s->bvh8 + 80 * (size_t)node_index;
+            c->nodes++;
+            uint32_t hitmask = node8_intersect(n, o, d, inv, oct4, max_t);
+            uint32_t imask = n[15];
+            cur_x = ld_u32(n + 16);
+            tri_x = ld_u32(n + 20);
+            cur_y = (hitmask & 0xff000000u) | imask;
+            tri_y = hitmask & 0x00ffffffu;
+        } else {
+            tri_x = cur_x; tri_y = cur_y;
+            cur_x = 0; cur_y = 0;
+        }
+        while (tri_y) {
+            int b = msb(tri_y);
+            tri_y &= ~(1u << b);
+            int slot = s->bvh8_tri_slots[tri_x + (uint32_t)b];
+            if (any) {
+                if (any_test(s, o, d, slot, max_t, c)) return 1;
+            } else {
+                closest_update(s, o, d, slot, rec, tie, c);
+                max_t = rec->t;
+            }
+        }
+        if (!(cur_y & 0xff000000u)) {
+            if (sp == 0) break;
+            --sp;                                   /* cwbvh.fs:524 post-decrements; corrected */
+            cur_x = stack_x[sp]; cur_y = stack_y[sp];
+        }
+    }
+    return rec ? rec->slot >= 0 : 0;
+}
+
+/* --------------------------------------------------------- dispatch helpers -- */
+
+static void closest(const orc_scene* s, int accel, int tie, v3 o, v3 d, float tmax, rec_t* rec, cnt_t* c) {
+    if (accel == ORC_ACCEL_BVH8) bvh8_walk(s, o, d, tmax, 0, rec, tie, c);
+    else if (accel == ORC_ACCEL_BVH2) bvh2_closest(s, o, d, tmax, rec, tie, c);
+    else brute_closest(s, o, d, tmax, rec, tie, c);
+}
+static int occluded(const orc_scene* s, int accel, v3 o, v3 d, float max_t, cnt_t* c) {
+    if (accel == ORC_ACCEL_BVH8) return bvh8_walk(s, o, d, max_t, 1, NULL, 0, c);
+    if (accel == ORC_ACCEL_BVH2) return bvh2_any(s, o, d, max_t, c);
+    return brute_any(s, o, d, max_t, c);
+}
+
+typedef struct {
+    const orc_scene* s; int accel, mode, tie;
+    const orc_ray* rays; orc_hit* hits; orc_ray_stats* stats;
+    size_t i0, i1;
+} trace_job;
+
+static void* trace_worker(void* arg) {
+    trace_job* j = (trace_job*)arg;
+    for (size_t i = j->i0; i < j->i1; ++i) {
+        const orc_ray* r = j->rays + i;
+        v3 o = ld3(r->o), d = ld3(r->d);
+        cnt_t c = {0, 0};
+        orc_hit h = {0.f, 0.f, 0.f, -1};
+        if (j->mode == ORC_ANY) {
+            if (occluded(j->s, j->accel, o, d, r->tmax, &c)) h.tri = 0;
+        } else {
+            rec_t rec;
+            closest(j->s, j->accel, j->tie, o, d, r->tmax, &rec, &c);
+            if (rec.slot >= 0) { h.t = rec.t; h.u = rec.u; h.v = rec.v; h.tri = rec.id; }
+        }
+        j->hits[i] = h;
+        if (j->stats) {
+            j->stats[i].nodes = (uint16_t)(c.nodes > 65535 ? 65535 : c.nodes);
+            j->stats[i].tris = (uint16_t)(c.tris > 65535 ? 65535 : c.tris);
+        }
+    }
+    return NULL;
+}
+
+void orc_trace(const orc_scene* s, int accel, int mode, int tie, const orc_ray* rays, size_t n,
+               orc_hit* hits, orc_ray_stats* stats, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    trace_job jobs[256];
+    pthread_t th[256];
+    size_t chunk = (n + (size_t)n_threads - 1) / (size_t)n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        size_t a = chunk * (size_t)t, b = a + chunk;
+        if (a > n) a = n;
+        if (b > n) b = n;
+        trace_job j = {s, accel, mode, tie, rays, hits, stats, a, b};
+        jobs[t] = j;
+    }
+    if (n_threads == 1) { trace_worker(&jobs[0]); return; }
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, trace_worker, &jobs[t]);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+}
+
+/* ---------------------------------------------------------- ray generation -- */
+
+/* path_trace.fs:1026-1047.  tex = (pixel centre) / resolution (Quad.h:16-24 + path_trace.vs). */
+static void primary_ray(const orc_scene* s, int px, int py, float rx, float ry, int jitter, float seed[2],
+                        v3* o, v3* dir) {
+    const float W = (float)s->width, H = (float)s->height;
+    seed[0] = (float)px + 0.5f;
+    seed[1] = (float)py + 0.5f;
+    float jx = 0.f, jy = 0.f;
+    if (jitter) {
+        float r1 = 2.0f * orc_rand(seed, rx, ry);
+        float r2 = 2.0f * orc_rand(seed, rx, ry);
+        jx = r1 < 1.0f ? sqrtf(r1) - 1.0f : 1.0f - sqrtf(2.0f - r1);
+        jy = r2 < 1.0f ? sqrtf(r2) - 1.0f : 1.0f - sqrtf(2.0f - r2);
+        jx = jx / (W * 0.5f);
+        jy = jy / (H * 0.5f);
+    }
+    float tx = ((float)px + 0.5f) / W, ty = ((float)py + 0.5f) / H;
+    float dx = (2.0f * tx - 1.0f) + jx;
+    float dy = (2.0f * ty - 1.0f) + jy;
+    float tan_fov = tanf(s->camera.fov * 0.5f);
+    dx = dx * (W / H * tan_fov);
+    dy = dy * tan_fov;
+    v3 right = ld3(s->camera.right), up = ld3(s->camera.up), fwd = ld3(s->camera.forward);
+    *dir = norm3(add(add(scl(right, dx), scl(up, dy)), fwd));
+    *o = ld3(s->camera.position);
+}
+
+void orc_primary_rays(const orc_scene* s, float rx, float ry, int jitter, orc_ray* out) {
+    for (int py = 0; py < s->height; ++py)
+        for (int px = 0; px < s->width; ++px) {
+            float seed[2];
+            v3 o, d;
+            primary_ray(s, px, py, rx, ry, jitter, seed, &o, &d);
+            orc_ray* r = out + (size_t)py * (size_t)s->width + (size_t)px;
+            r->o[0] = o.x; r->o[1] = o.y; r->o[2] = o.z; r->tmax = ORC_INF;
+            r->d[0] = d.x; r->d[1] = d.y; r->d[2] = d.z; r->pad = 0;
+        }
+}
+
+/* ---------------------------------------------------------------- integrator -- */
+
+/* path_trace.fs:414-489, texture branch omitted (no texture data crosses the boundary yet). */
+static void hit_attributes(const orc_scene* s, const rec_t* rec, v3* n, const float** mat) {
+    const int32_t* vn = s->triangles + 12 * (size_t)rec->slot + 4;
+    if (vn[3] == 0) {
+        *n = V((float)vn[0], (float)vn[1], (float)vn[2]);
+    } else {
+        v3 a = ld3(s->normals + 3 * (size_t)vn[0]);
+        v3 b = ld3(s->normals + 3 * (size_t)vn[1]);
+        v3 c = ld3(s->normals + 3 * (size_t)vn[2]);
+        float w = 1.0f - rec->u - rec->v;      /* path_trace.fs:317-320 */
+        *n = add(add(scl(a, w), scl(b, rec->u)), scl(c, rec->v));
+    }
+    *mat = s->materials + 16 * (size_t)rec->mtl;
+}
+
+/* path_trace.fs:214-218 */
+static inline float power_heuristic(float a, float b) { float t = a * a; return t / (b * b + t); }
+
+/* path_trace.fs:857-1024; loop bound is max_depth (the shader hard-codes 3, :867). */
+static v3 path_trace(const orc_scene* s, int accel, int tie, v3 o, v3 d, float seed[2], float rx, float ry,
+                     uint64_t counters[4]) {
+    v3 L = V(0.f, 0.f, 0.f), T = V(1.f, 1.f, 1.f);
+    float prev_pdf = 1.0f;
+    int is_specular = 1;
+    for (int i = 0; i < s->max_depth; ++i) {
+        rec_t rec;
+        cnt_t c = {0, 0};
+        closest(s, accel, tie, o, d, ORC_INF, &rec, &c);
+        counters[0]++; counters[2] += c.nodes; counters[3] += c.tris;
+        if (rec.slot < 0) return L;
+        v3 n; const float* mat;
+        hit_attributes(s, &rec, &n, &mat);
+        float cos_incident = dot3(d, n);
+        v3 original_n = n;
+        if (cos_incident > 0) n = neg(n);
+        const float* emission = mat + 4;
+        if (emission[3] != -1.0f) {
+            if (is_specular) return add(L, mul(T, ld3(emission)));
+            v3 ld = scl(d, rec.t);
+            float length = len3(ld);
+            ld = norm3(ld);
+            float cos_light = -1.0f * dot3(ld, n);
+            float length2 = length * length;
+            int li = (int)emission[3];
+            const float* ap = s->lights + 18 * (size_t)li + 15;
+            float pdf_light = length2 / (ap[0] * cos_light) * ap[1];
+            float w = power_heuristic(prev_pdf, pdf_light);
+            return add(L, scl(mul(T, ld3(emission)), w));
+        }
+        v3 hit_point = add(add(o, scl(d, rec.t)), scl(n, 0.0002f));
+        const float* specular = mat + 8;
+        v3 albedo = ld3(mat);
+        if (specular[3] == 0.0f && s->n_lights <= 0) {
+            /* the shader would read light 0 of an empty buffer; keep the RNG stream, skip NEE */
+            orc_rand(seed, rx, ry); orc_rand(seed, rx, ry); orc_rand(seed, rx, ry);
+        } else if (specular[3] == 0.0f) {
+            int li = (int)(orc_rand(seed, rx, ry) * (float)s->n_lights);
+            if (li > s->n_lights - 1) li = s->n_lights - 1;   /* guards the one-ulp case rand*n == n */
+            const float* Lt = s->lights + 18 * (size_t)li;
+            float sq = sqrtf(orc_rand(seed, rx, ry));          /* path_trace.fs:843-855 */
+            float b0 = 1.0f - sq;
+            float b1 = orc_rand(seed, rx, ry) * sq;
+            v3 lp = add(add(ld3(Lt), scl(ld3(Lt + 3), b0)), scl(ld3(Lt + 6), b1));
+            v3 ldir = sub(lp, hit_point);
+            float length = len3(ldir);
+            float ilength = 1.0f / length;
+            ldir = scl(ldir, ilength);
+            float cos_mtl = dot3(ldir, original_n);
+            float cos_light = dot3(ldir, ld3(Lt + 9));
+            if (cos_mtl > 0.0f && cos_light < 0.0f) {
+                cnt_t cs = {0, 0};
+                int occ = occluded(s, accel, hit_point, ldir, length - ORC_EPS, &cs);
+                counters[1]++; counters[2] += cs.nodes; counters[3] += cs.tris;
+                if (!occ) {
+                    v3 le = ld3(Lt + 12);
+                    float pdf_light = (length * length) / (Lt[15] * -cos_light) * Lt[16];
+                    float bsdf_pdf = dot3(ldir, n) * 1.0f / ORC_PI;   /* `cos * ipi`, ipi = `1.0f / pi` unparenthesised (:18, :294) */
+                    float w = power_heuristic(pdf_light, bsdf_pdf);
+                    v3 contrib = scl(mul(mul(T, le), albedo), w);
+                    contrib = V(contrib.x / pdf_light, contrib.y / pdf_light, contrib.z / pdf_light);
+                    L = add(L, contrib);
+                }
+            }
+        }
+        /* path_trace.fs:44-60 onb, :257-270 cosine sample, :274-289 diffuse_sample */
+        v3 bu, bv;
+        if (n.z < -0.9999999f) { bu = V(0.f, -1.f, 0.f); bv = V(-1.f, 0.f, 0.f); }
+        else {
+            float a = 1.0f / (1.0f + n.z);
+            float b = -n.x * n.y * a;
+            bu = V(1.0f + b, b, -n.x);
+            bv = V(b, 1.0f + b, -n.y);
+        }
+        float u1 = orc_rand(seed, rx, ry);
+        float u2 = orc_rand(seed, rx, ry);
+        float r = sqrtf(u1);
+        float phi = ORC_PI2 * u2;
+        v3 dl = V(r * orc_cos(phi), r * orc_sin(phi), sqrtf(1.0f - u1));
+        v3 sdir = add(add(scl(bu, dl.x), scl(bv, dl.y)), scl(n, dl.z));
+        float bsdf_pdf = dot3(sdir, n) * 1.0f / ORC_PI;
+        T = mul(T, albedo);
+        prev_pdf = bsdf_pdf;
+        is_specular = 0;
+        o = hit_point;
+        d = sdir;
+    }
+    return L;
+}
+
+void orc_render_rows(const orc_scene* s, int accel, int tie, float rx, float ry, float* sum,
+                     uint64_t counters[4], int y0, int y1) {
+    for (int py = y0; py < y1; ++py)
+        for (int px = 0; px < s->width; ++px) {
+            float seed[2];
+            v3 o, d;
+            primary_ray(s, px, py, rx, ry, 1, seed, &o, &d);
+            v3 c = path_trace(s, accel, tie, o, d, seed, rx, ry, counters);
+            float* p = sum + 3 * ((size_t)py * (size_t)s->width + (size_t)px);
+            p[0] = c.x + p[0]; p[1] = c.y + p[1]; p[2] = c.z + p[2];   /* path_trace.fs:1059 */
+        }
+}
+
+typedef struct {
+    const orc_scene* s; int accel, tie; float rx, ry; float* sum; uint64_t counters[4];
+    volatile int* next_row; int rows_per_grab;
+} frame_job;
+
+static void* frame_worker(void* arg) {
+    frame_job* j = (frame_job*)arg;
+    for (;;) {
+        int y0 = __sync_fetch_and_add(j->next_row, j->rows_per_grab);
+        if (y0 >= j->s->height) break;
+        int y1 = y0 + j->rows_per_grab;
+        if (y1 > j->s->height) y1 = j->s->height;
+        orc_render_rows(j->s, j->accel, j->tie, j->rx, j->ry, j->sum, j->counters, y0, y1);
+    }
+    return NULL;
+}
+
+void orc_render_frame(const orc_scene* s, int accel, int tie, float rx, float ry, float* sum,
+                      uint64_t counters[4], int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    volatile int next_row = 0;
+    frame_job jobs[256];
+    pthread_t th[256];
+    for (int t = 0; t < n_threads; ++t) {
+        frame_job j = {s, accel, tie, rx, ry, sum, {0, 0, 0, 0}, &next_row, 4};
+        jobs[t] = j;
+    }
+    if (n_threads == 1) frame_worker(&jobs[0]);
+    else {
+        for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, frame_worker, &jobs[t]);
+        for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    }
+    if (counters)
+        for (int t = 0; t < n_threads; ++t)
+            for (int k = 0; k < 4; ++k) counters[k] += jobs[t].counters[k];
+}
+
+/* Shader/output.fs:9-20: c = S*inv; c *= 1/(1 + lum/2); pow(c, 1/2.2); 8-bit UNORM write. */
+void orc_resolve(const float* sum, size_t n_pixels, float inv_count, uint8_t* rgba) {
+    for (size_t i = 0; i < n_pixels; ++i) {
+        float c[3] = {sum[3 * i] * inv_count, sum[3 * i + 1] * inv_count, sum[3 * i + 2] * inv_count};
+        float lum = 0.3f * c[0] + 0.6f * c[1] + 0.1f * c[2];
+        float k = 1.0f / (1.0f + lum / 2.0f);
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = powf(c[ch] * 1.0f * k, 1.0f / 2.2f);
+            v = v < 0.f ? 0.f : v > 1.f ? 1.f : v;
+            if (v != v) v = 0.f;
+            rgba[4 * i + ch] = (uint8_t)(v * 255.0f + 0.5f);
+        }
+        rgba[4 * i + 3] = 255;
+    }
+}
+
+int orc_hardware_threads(void) {
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n < 1 ? 1 : (int)n;
+}

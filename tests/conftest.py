@@ -1,0 +1,112 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _build_once():
+    import __graft_entry__ as g
+    g.build()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    _build_once()
+
+
+@pytest.fixture(scope="session")
+def cr(built):
+    import caitlynrenderer_amd
+    return caitlynrenderer_amd
+
+
+@pytest.fixture(scope="session")
+def ob(built):
+    from oracle import binding
+    return binding
+
+
+@pytest.fixture(scope="session")
+def survey():
+    with open(os.path.join(GOLDEN, "survey_known_answers.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def vectors():
+    return dict(np.load(os.path.join(GOLDEN, "oracle_vectors.npz")))
+
+
+class _Cam:
+    """crt_camera rebuilt from the fixture (no /root/reference on the GPU box)."""
+
+    def __init__(self, cr, d):
+        from caitlynrenderer_amd._lib import crt_camera
+        self.c = crt_camera()
+        for k in ("position", "right", "up", "forward"):
+            for i in range(3):
+                getattr(self.c, k)[i] = d[k][i]
+        self.c.fov = d["fov"]
+        self.c.focal_dist, self.c.aperture = 0.1, 0.0
+    position = property(lambda s: np.array(s.c.position[:], np.float32))
+    fov = property(lambda s: float(s.c.fov))
+
+
+@pytest.fixture(scope="session")
+def cornell(cr):
+    """(mesh, camera) of the Cornell box from the committed fixture."""
+    with open(os.path.join(GOLDEN, "cornell_box.json")) as f:
+        j = json.load(f)
+    mesh = cr.Mesh(np.array(j["vertices"], np.float32), np.array(j["normals"], np.float32), np.zeros((0, 2), np.float32),
+                   np.array(j["triangles"], np.int32), np.array(j["materials"], np.float32),
+                   np.array(j["lights"], np.float32), np.array(j["vertex_min"], np.float32))
+    return mesh, _Cam(cr, j["camera"])
+
+
+@pytest.fixture(scope="session")
+def cornell_data(cr, cornell):
+    mesh, cam = cornell
+    return cr.SceneData.build(mesh, cam)
+
+
+@pytest.fixture(scope="session")
+def tess8(cr, cornell):
+    from caitlynrenderer_amd.meshgen import tessellated_cornell
+    mesh, cam = cornell
+    m = tessellated_cornell(mesh, 8)
+    return m, cr.SceneData.build(m, cam)
+
+
+@pytest.fixture(scope="session")
+def tess40(cr, cornell):
+    from caitlynrenderer_amd.meshgen import tessellated_cornell
+    mesh, cam = cornell
+    m = tessellated_cornell(mesh, 40)
+    return m, cr.SceneData.build(m, cam)
+
+
+def seeded_rays(mesh, n, seed, dt):
+    rng = np.random.default_rng(seed)
+    lo, hi = mesh.vertices.min(0), mesh.vertices.max(0)
+    rays = np.zeros(n, dt)
+    rays["o"] = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    rays["d"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["tmax"] = np.float32(1e9)
+    return rays
+
+
+def have_reference():
+    return os.path.isdir(os.path.join(REFERENCE, "Models"))
