@@ -47,7 +47,8 @@ class crt_scene_desc(C.Structure):
 class crt_frame_stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("any_rays", C.c_uint64), ("ms_total", C.c_float),
                 ("ms_trace_closest", C.c_float), ("ms_trace_any", C.c_float), ("ms_shade", C.c_float),
-                ("ms_raygen", C.c_float), ("n_trace_launches", C.c_uint32)]
+                ("ms_raygen", C.c_float), ("n_trace_launches", C.c_uint32),
+                ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("tris_any", C.c_uint64)]
 
 
 class crt_bvh_info(C.Structure):

@@ -91,6 +91,10 @@ struct crt_scene {
     crt_camera cam{};
     bool have_camera = false;
     uint32_t jitter = 1;
+    bool count_visits = false;
+    uint32_t* d_visit_stats = nullptr;          // per-ray counters of the current launch (count_visits)
+    unsigned long long* d_visit_totals = nullptr;   // closest nodes/tris, any nodes/tris
+    unsigned long long* h_visit_totals = nullptr;   // pinned
 
     // scratch for crt_trace (host rays)
     float4* d_t_rays = nullptr; float4* d_t_hits = nullptr; uint32_t* d_t_stats = nullptr; size_t t_cap = 0;
@@ -101,6 +105,7 @@ struct crt_scene {
     crt_frame_stats stats{};
     bool stats_pending = false;
     bool stats_from_frame = false;
+    bool stats_counted = false;
     uint32_t trace_occupancy = 5;
 
     ~crt_scene() {
@@ -108,9 +113,10 @@ struct crt_scene {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_hits, d_shadow, d_shadow_hits, pb.L, pb.T, pb.seed, pb.C, d_counts,
-                        d_t_rays, d_t_hits, d_t_stats};
+                        d_t_rays, d_t_hits, d_t_stats, d_visit_stats, d_visit_totals};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_counts) hipHostFree(h_counts);
+        if (h_visit_totals) hipHostFree(h_visit_totals);
         for (EventSpan& s : spans) { if (s.a) hipEventDestroy(s.a); if (s.b) hipEventDestroy(s.b); }
         if (stream) hipStreamDestroy(stream);
     }
@@ -234,6 +240,13 @@ int collect_stats(crt_scene* s) {
     }
     st.closest_rays = s->stats.closest_rays;
     st.any_rays = s->stats.any_rays;
+    if (s->stats_from_frame && s->stats_counted && s->h_visit_totals) {
+        // padding pixels of ragged tiles are tmax = -1 rays: one root fetch each, not real rays
+        const uint64_t pads = s->n_local_pixels - s->n_local_in_frame;
+        st.nodes_closest = s->h_visit_totals[0] >= pads ? s->h_visit_totals[0] - pads : 0;
+        st.tris_closest = s->h_visit_totals[1];
+        st.nodes_any = s->h_visit_totals[2]; st.tris_any = s->h_visit_totals[3];
+    }
     s->stats = st;
     s->stats_pending = false;
     return CRT_OK;
@@ -402,6 +415,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     if (!s || !name) return fail(CRT_ERR_INVALID, "crt_set_option: null argument");
     if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
+    else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;
 }
@@ -417,6 +431,15 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
     const uint32_t P = s->n_local_pixels;
     const crt::FrameArgs f = frame_args(s, rx, ry);
     s->n_spans = 0;
+    if (s->count_visits) {
+        if (!s->d_visit_totals) {
+            if ((rc = dev_alloc(&s->d_visit_totals, 4))) return rc;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 4 * sizeof(unsigned long long)));
+        }
+        if (s->d_visit_stats) hipFree(s->d_visit_stats);
+        if ((rc = dev_alloc(&s->d_visit_stats, P))) return rc;
+        HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 4 * sizeof(unsigned long long), s->stream));
+    }
     HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * 17 * sizeof(uint32_t), s->stream));
     HIPCHK(hipMemcpyAsync(s->d_counts, &s->n_local_pixels, sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
 
@@ -434,9 +457,11 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         crt::TraceArgs ta{};
         ta.nodes = s->d_nodes; ta.tris = s->d_tris; ta.rays = rin; ta.hits = s->d_hits; ta.stats = nullptr;
         ta.count_ptr = c_in; ta.n = P; ta.out_orig_id = 0;
+        ta.stats = s->count_visits ? s->d_visit_stats : nullptr;
         sp = s->begin_span(1);
-        crt::launch_trace(ta, CRT_TRACE_CLOSEST, false, s->trace_grid(P), s->stream);
+        crt::launch_trace(ta, CRT_TRACE_CLOSEST, s->count_visits, s->trace_grid(P), s->stream);
         s->end_span(sp);
+        if (s->count_visits) crt::launch_reduce_stats(s->d_visit_stats, c_in, P, s->d_visit_totals, s->flat_grid(P), s->stream);
 
         crt::ShadeArgs sa{};
         sa.rays_in = rin; sa.hits = s->d_hits; sa.count_in = c_in;
@@ -452,8 +477,9 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         crt::TraceArgs tb = ta;
         tb.rays = s->d_shadow; tb.hits = s->d_shadow_hits; tb.count_ptr = c_shadow;
         sp = s->begin_span(2);
-        crt::launch_trace(tb, CRT_TRACE_ANY, false, s->trace_grid(P), s->stream);
+        crt::launch_trace(tb, CRT_TRACE_ANY, s->count_visits, s->trace_grid(P), s->stream);
         s->end_span(sp);
+        if (s->count_visits) crt::launch_reduce_stats(s->d_visit_stats, c_shadow, P, s->d_visit_totals + 2, s->flat_grid(P), s->stream);
 
         sp = s->begin_span(3);
         crt::launch_shadow_resolve(s->d_shadow, s->d_shadow_hits, c_shadow, s->pb, s->flat_grid(P), s->stream);
@@ -463,6 +489,9 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
     crt::launch_accumulate(s->d_sum, s->pb, P, s->flat_grid(P), s->stream);
     s->end_span(sp);
     HIPCHK(hipMemcpyAsync(s->h_counts, s->d_counts, 2 * 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    if (s->count_visits)
+        HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    s->stats_counted = s->count_visits;
     HIPCHK(hipGetLastError());
     s->stats_pending = true;
     s->stats_from_frame = true;   // ray counts come from h_counts at the next sync

@@ -455,6 +455,26 @@ __global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linea
     }
 }
 
+// Sum of the per-ray visit counters of one traversal launch: out[0] += nodes, out[1] += tris.
+__global__ void __launch_bounds__(256) k_reduce_stats(const uint32_t* __restrict__ stats, const uint32_t* __restrict__ count_ptr,
+                                                      uint32_t n_fixed, unsigned long long* __restrict__ out) {
+    const uint32_t n = count_ptr ? *count_ptr : n_fixed;
+    unsigned long long nodes = 0, tris = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = stats[i];
+        nodes += v & 0xffffu;
+        tris += v >> 16;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        nodes += __shfl_down(nodes, off);
+        tris += __shfl_down(tris, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (nodes) atomicAdd(&out[0], nodes);
+        if (tris) atomicAdd(&out[1], tris);
+    }
+}
+
 // ------------------------------------------------------------------ launchers --------
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream) {
@@ -466,6 +486,10 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipSt
         if (stats) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, stream, a);
         else       hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, stream, a);
     }
+}
+void launch_reduce_stats(const uint32_t* stats, const uint32_t* count_ptr, uint32_t n, unsigned long long* out, uint32_t grid,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(k_reduce_stats, dim3(grid), dim3(256), 0, stream, stats, count_ptr, n, out);
 }
 void launch_raygen(const FrameArgs& f, const PathBuffers& pb, float4* rays, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(256), 0, stream, f, pb, rays);

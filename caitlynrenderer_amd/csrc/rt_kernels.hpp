@@ -55,6 +55,8 @@ struct ShadeArgs {
 };
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
+void launch_reduce_stats(const uint32_t* stats, const uint32_t* count_ptr, uint32_t n, unsigned long long* out, uint32_t grid,
+                         hipStream_t stream);
 void launch_raygen(const FrameArgs& f, const PathBuffers& pb, float4* rays, uint32_t grid, hipStream_t stream);
 void launch_shade(const ShadeArgs& a, const PathBuffers& pb, uint32_t grid, hipStream_t stream);
 void launch_shadow_resolve(const float4* rays_shadow, const float4* hits, const uint32_t* count, const PathBuffers& pb,

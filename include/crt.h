@@ -125,7 +125,8 @@ int crt_render_frame(crt_scene* s, float rx, float ry);
 int crt_render_frame_async(crt_scene* s, float rx, float ry);
 int crt_sync(crt_scene* s);
 /* knobs: "jitter" (0/1, tent-filter jitter of path_trace.fs:1030-1037; default 1),
- * "trace_occupancy" (persistent workgroups per CU for the traversal kernels). */
+ * "trace_occupancy" (persistent workgroups per CU for the traversal kernels),
+ * "count_visits" (0/1: traversal launches also count node fetches / triangle tests). */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);
@@ -159,6 +160,9 @@ typedef struct crt_frame_stats {
     float ms_trace_closest, ms_trace_any;/* summed over bounces                  */
     float ms_shade, ms_raygen;
     uint32_t n_trace_launches;
+    /* visit totals of the frame's traversal launches; filled only when the option
+     * "count_visits" is on (the counting kernels are slower: never time such a frame) */
+    uint64_t nodes_closest, tris_closest, nodes_any, tris_any;
 } crt_frame_stats;
 int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out);
 /* structural facts about the device-resident CWBVH */

@@ -1,0 +1,190 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Hit ids, t, u, v and the
+per-ray visit counters are bit-exact; radiance is within abs 1e-5 + rel 1e-4 per channel (the oracle
+and the kernels share every floating-point rule, so in practice the sums are bit-identical too)."""
+import numpy as np
+import pytest
+
+from conftest import seeded_rays
+
+pytestmark = pytest.mark.gpu
+
+RX1, RY1 = 0.6591631174087524, 0.9108020067214966      # frame-1 randomVector
+
+
+def _assert_hits_equal(got, want):
+    assert np.array_equal(got["tri"], want["tri"])
+    for k in ("t", "u", "v"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+
+
+@pytest.fixture(scope="module")
+def scenes(cr, ob, cornell, cornell_data, tess8, tess40):
+    out = {}
+    for name, data in (("cornell", cornell_data), ("tess8", tess8[1]), ("tess40", tess40[1])):
+        out[name] = (cr.Scene(data, 256, 144, 3), ob.Oracle(data, 256, 144, 3, cornell[1]), data)
+    yield out
+    for s, _, _ in out.values():
+        s.close()
+
+
+def test_native_library_is_the_one_running(cr):
+    import torch
+    from caitlynrenderer_amd import _lib
+    assert torch.cuda.is_available() and _lib.lib().crt_device_count() >= 1
+    assert "caitlynrenderer_amd/libcrt.so" in open("/proc/self/maps").read()
+
+
+@pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
+def test_closest_hit_bit_exact(cr, ob, cornell, tess8, tess40, scenes, name):
+    scene, orc, data = scenes[name]
+    mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
+    rays = np.concatenate([seeded_rays(mesh, 50000, 3, cr.RAY_DT), orc.primary_rays(RX1, RY1, jitter=True).astype(cr.RAY_DT)])
+    got, gst = scene.trace(rays, cr.CRT_TRACE_CLOSEST, stats=True)
+    want, wst = orc.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, stats=True, threads=8)
+    _assert_hits_equal(got, want)
+    assert np.array_equal(gst["nodes"], wst["nodes"]) and np.array_equal(gst["tris"], wst["tris"])
+    assert (got["tri"] >= 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
+def test_any_hit_bit_exact(cr, ob, cornell, tess8, tess40, scenes, name):
+    scene, orc, data = scenes[name]
+    mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
+    rays = seeded_rays(mesh, 60000, 4, cr.RAY_DT)
+    rays["tmax"] = np.random.default_rng(9).random(len(rays)).astype(np.float32) * 6
+    got, gst = scene.trace(rays, cr.CRT_TRACE_ANY, stats=True)
+    want, wst = orc.trace(rays, ob.BVH8, ob.ANY, stats=True, threads=8)
+    assert np.array_equal(got["tri"] >= 0, want["tri"] >= 0)
+    assert np.array_equal(gst["nodes"], wst["nodes"]) and np.array_equal(gst["tris"], wst["tris"])
+    # property: occluded <=> closest hit nearer than tmax
+    c = scene.trace(np.array(rays, copy=True), cr.CRT_TRACE_CLOSEST)
+    far = rays.copy(); far["tmax"] = np.float32(1e9)
+    c = scene.trace(far, cr.CRT_TRACE_CLOSEST)
+    assert np.array_equal(got["tri"] >= 0, (c["tri"] >= 0) & (c["t"] < rays["tmax"]))
+
+
+def test_edge_cases(cr, ob, scenes, cornell):
+    scene, orc, _ = scenes["cornell"]
+    assert len(scene.trace(np.zeros(0, cr.RAY_DT))) == 0                      # empty input
+    rays = np.zeros(70, cr.RAY_DT)                                            # ragged: not a multiple of 64
+    dirs = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    for i in range(70):
+        rays[i]["o"] = (2.78, 2.75, 2.8) if i % 2 == 0 else (0.0, 2.75, 2.8)  # inside / exactly on a wall plane
+        rays[i]["d"] = dirs[i % 6]                                            # zero components: 0*inf = NaN slabs
+        rays[i]["tmax"] = [1e9, 0.0, -1.0, 1e-30, 3.0][i % 5]                 # includes tmax <= 0
+    got = scene.trace(rays, cr.CRT_TRACE_CLOSEST)
+    _assert_hits_equal(got, orc.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID))
+    got = scene.trace(rays, cr.CRT_TRACE_ANY)
+    assert np.array_equal(got["tri"] >= 0, orc.trace(rays, ob.BVH8, ob.ANY)["tri"] >= 0)
+
+
+def test_exact_ties_resolve_to_lowest_original_id(cr, ob):
+    """Two coincident triangles: every hit is an exact tie; the lower original id must win."""
+    v = np.array([[0, 0, 0], [4, 0, 0], [0, 4, 0], [0, 0, 0], [4, 0, 0], [0, 4, 0], [0, 0, 1], [4, 0, 1], [0, 4, 1]], np.float32)
+    t = np.zeros((3, 12), np.int32)
+    t[:, :3] = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]        # ids 1 and 2 coincide
+    mats = np.zeros((1, 16), np.float32); mats[0, 4:8] = -1; mats[0, 12:16] = -1
+    mesh = cr.Mesh(v, np.zeros((0, 3)), np.zeros((0, 2)), t, mats, np.zeros((0, 18)))
+    cam = cr.Camera((1, 1, -5), (1, 1, 0), 40)
+    data = cr.SceneData.build(mesh, cam)
+    scene = cr.Scene(data, 32, 32, 1)
+    rays = np.zeros(64, cr.RAY_DT)
+    rays["o"] = [(0.5 + 0.03 * i, 0.5, -3) for i in range(64)]
+    rays["d"] = (0, 0, 1)
+    rays["tmax"] = 1e9
+    got = scene.trace(rays)
+    assert (got["tri"] == 1).all() and (got["t"] == 3.0).all()
+    _assert_hits_equal(got, ob.Oracle(data, 32, 32, 1, cam).trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID))
+    scene.close()
+
+
+@pytest.mark.parametrize("name,depth", [("cornell", 1), ("cornell", 3), ("tess8", 3), ("tess40", 4)])
+def test_radiance_matches_oracle(cr, ob, cornell, scenes, name, depth):
+    _, _, data = scenes[name]
+    W, H = 200, 120                                   # not a multiple of the 64-pixel tile: ragged tiles
+    scene = cr.Scene(data, W, H, depth)
+    orc = ob.Oracle(data, W, H, depth, cornell[1])
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    n_closest = n_any = 0
+    for frame in range(4):                            # frames 1..4 with the host RNG's randomVectors
+        rx, ry = rnd.randf2(), rnd.randf2()
+        scene.render_frame(rx, ry)
+        _, cnt = orc.render_frame(rx, ry, ref, threads=8)
+        st = scene.frame_stats()
+        assert st["closest_rays"] == cnt[0] and st["any_rays"] == cnt[1]
+        out = scene.read_sum()
+        err = np.abs(out - ref)
+        assert (err <= 1e-5 + 1e-4 * np.abs(ref)).all(), (frame, float(err.max()))
+    assert ref.max() > 0.5
+    # resolve: Shader/output.fs within one 8-bit step (powf differs by ulps between libm and the device)
+    img = scene.resolve(0.25)
+    want = ob.resolve(ref, 0.25)
+    assert np.abs(img.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    # reset clears the sum (Scene.h:1160-1172)
+    scene.reset()
+    assert not scene.read_sum().any()
+    scene.close()
+
+
+def test_full_resolution_cornell_frame(cr, ob, cornell, cornell_data):
+    """Config 2: 1920x1080, 1 spp, primary + shadow; hit-id image and radiance against the oracle."""
+    W, H = 1920, 1080
+    scene = cr.Scene(cornell_data, W, H, 1)
+    orc = ob.Oracle(cornell_data, W, H, 1, cornell[1])
+    rays = orc.primary_rays(RX1, RY1, jitter=True)
+    got = scene.trace(rays.astype(cr.RAY_DT))
+    want = orc.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=8)
+    _assert_hits_equal(got, want)
+    scene.render_frame(RX1, RY1)
+    ref, cnt = orc.render_frame(RX1, RY1, threads=8)
+    out = scene.read_sum()
+    err = np.abs(out - ref)
+    assert (err <= 1e-5 + 1e-4 * np.abs(ref)).all(), float(err.max())
+    st = scene.frame_stats()
+    assert st["closest_rays"] == W * H == cnt[0] and st["any_rays"] == cnt[1]
+    # size-independent properties: determinism and additivity of the running sum
+    scene.render_frame(RX1, RY1)
+    out2 = scene.read_sum()
+    assert np.array_equal(out2.view(np.uint32), (out + out).view(np.uint32))
+    scene.close()
+
+
+def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data):
+    """world=3 shards rendered on one GPU: the union of the ranks' pixels is bit-identical to world=1."""
+    from caitlynrenderer_amd import tiles
+    W, H, T = 200, 120, 16
+    full = cr.Scene(cornell_data, W, H, 3)
+    full.set_shard(0, 1, T)
+    full.render_frame(RX1, RY1)
+    want = full.read_sum()
+    acc = np.zeros_like(want)
+    frame = np.zeros_like(want)
+    for r in range(3):
+        s = cr.Scene(cornell_data, W, H, 3)
+        s.set_shard(r, 3, T)
+        s.render_frame(RX1, RY1)
+        part = s.read_sum()
+        assert not (acc != 0)[part != 0].any()        # shards are disjoint
+        acc += part
+        nt, tile, nf = s.packed_info()
+        assert nt == len(tiles.local_tiles(W, H, T, r, 3)) and tile == T
+        tiles.untile_into(frame, s.read_packed(), tiles.local_tiles(W, H, T, r, 3), T)
+        s.close()
+    assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(frame.view(np.uint32), want.view(np.uint32))
+    full.close()
+
+
+def test_device_resident_trace_and_torch_interop(cr, ob, cornell, scenes):
+    """crt_trace_device on torch-owned HBM buffers (the bench path): same bits as the host-buffer entry."""
+    import torch
+    scene, orc, _ = scenes["tess40"]
+    rays = orc.primary_rays(RX1, RY1, jitter=True).astype(cr.RAY_DT)
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1, 32)).cuda()
+    d_hits = torch.empty((len(rays), 16), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    scene.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), cr.CRT_TRACE_CLOSEST)
+    got = d_hits.cpu().numpy().view(cr.HIT_DT).ravel()
+    _assert_hits_equal(got, scene.trace(rays))
+    assert scene.frame_stats()["ms_trace_closest"] > 0
