@@ -112,6 +112,28 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same SONAME as
+    /opt/rocm's); if both copies get loaded, the second one initialised sees no devices.  When torch
+    is installed, load ITS runtime first (RTLD_GLOBAL) so libcrt.so's NEEDED libamdhip64.so.7 binds to
+    it, whichever of torch / this package is imported first.  Without torch, /opt/rocm's is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libamdhip64.so",):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libcrt.so once; raise loudly when it has not been built."""
     global _lib
@@ -120,6 +142,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run __graft_entry__.build() or `make -C caitlynrenderer_amd/csrc`); there is no fallback path")
+        _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)   # AttributeError if the library lacks a declared symbol
