@@ -240,8 +240,8 @@ __global__ void __launch_bounds__(256) k_raygen(FrameArgs f, PathBuffers pb, flo
         if (f.jitter) {
             const float r1 = 2.0f * shader_rand(sx, sy, f.rv);
             const float r2 = 2.0f * shader_rand(sx, sy, f.rv);
-            jx = r1 < 1.0f ? __fsqrt_rn(r1) - 1.0f : 1.0f - __fsqrt_rn(2.0f - r1);
-            jy = r2 < 1.0f ? __fsqrt_rn(r2) - 1.0f : 1.0f - __fsqrt_rn(2.0f - r2);
+            jx = r1 < 1.0f ? sqrt_ieee(r1) - 1.0f : 1.0f - sqrt_ieee(2.0f - r1);
+            jy = r2 < 1.0f ? sqrt_ieee(r2) - 1.0f : 1.0f - sqrt_ieee(2.0f - r2);
             jx = __fdiv_rn(jx, W * 0.5f);
             jy = __fdiv_rn(jy, H * 0.5f);
         }
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a, PathBuffers pb) {
                             int li = (int)(shader_rand(seed.x, seed.y, a.rv) * (float)a.n_lights);
                             if (li > a.n_lights - 1) li = a.n_lights - 1;
                             const float* Lt = a.lights + 18 * (size_t)li;
-                            const float sq = __fsqrt_rn(shader_rand(seed.x, seed.y, a.rv));   // :843-855
+                            const float sq = sqrt_ieee(shader_rand(seed.x, seed.y, a.rv));   // :843-855
                             const float b0 = 1.0f - sq;
                             const float b1 = shader_rand(seed.x, seed.y, a.rv) * sq;
                             const vec3 lp = (V3(Lt[0], Lt[1], Lt[2]) + V3(Lt[3], Lt[4], Lt[5]) * b0) + V3(Lt[6], Lt[7], Lt[8]) * b1;
@@ -372,9 +372,9 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a, PathBuffers pb) {
                         }
                         const float u1 = shader_rand(seed.x, seed.y, a.rv);    // :257-270
                         const float u2 = shader_rand(seed.x, seed.y, a.rv);
-                        const float r = __fsqrt_rn(u1);
+                        const float r = sqrt_ieee(u1);
                         const float phi = CRT_PI2 * u2;
-                        const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), __fsqrt_rn(1.0f - u1));
+                        const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), sqrt_ieee(1.0f - u1));
                         const vec3 sdir = (ou * dl.x + ov * dl.y) + n * dl.z;
                         const float bsdf_pdf = __fdiv_rn(dot(sdir, n) * 1.0f, CRT_PI);
                         T = T * albedo;

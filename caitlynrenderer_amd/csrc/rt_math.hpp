@@ -19,10 +19,15 @@ __device__ __forceinline__ float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y *
 __device__ __forceinline__ vec3 cross(vec3 a, vec3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ float length(vec3 a) { return __fsqrt_rn(dot(a, a)); }
+// IEEE correctly rounded square root.  NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS the HIP
+// headers map that to __ocml_native_sqrt_f32 (bare v_sqrt_f32, 1 ulp).  sqrtf lowers to llvm.sqrt.f32,
+// which hipcc expands to v_sqrt_f32 + fma refinement under its default
+// -fhip-fp32-correctly-rounded-divide-sqrt.
+__device__ __forceinline__ float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float length(vec3 a) { return sqrt_ieee(dot(a, a)); }
 // v * (1/sqrt(dot)): two correctly rounded operations then three multiplies (glm::normalize).
 __device__ __forceinline__ vec3 normalize(vec3 a) {
-    float inv = __fdiv_rn(1.0f, __fsqrt_rn(dot(a, a)));
+    float inv = __fdiv_rn(1.0f, sqrt_ieee(dot(a, a)));
     return a * inv;
 }
 __device__ __forceinline__ float rcp_ieee(float x) { return __fdiv_rn(1.0f, x); }

@@ -157,4 +157,24 @@ def rand_sequence(px, py, rx, ry, n):
 
 
 def hardware_threads():
-    return int(lib().orc_hardware_threads())
+    """Host threads this process may actually use: the affinity mask and the cgroup CPU quota, not
+    the machine's core count (a one-GPU box exposes 256 logical CPUs but grants a share of them)."""
+    n = int(lib().orc_hardware_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+        except Exception:
+            pass
+    return max(1, min(n, 64))

@@ -115,7 +115,8 @@ def test_radiance_matches_oracle(cr, ob, cornell, scenes, name, depth):
         assert st["closest_rays"] == cnt[0] and st["any_rays"] == cnt[1]
         out = scene.read_sum()
         err = np.abs(out - ref)
-        assert (err <= 1e-5 + 1e-4 * np.abs(ref)).all(), (frame, float(err.max()))
+        assert (err <= 1e-5 + 1e-4 * np.abs(ref)).all(), (frame, float(err.max()))      # the stated tolerance
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(err.max()))   # and in fact bit-exact
     assert ref.max() > 0.5
     # resolve: Shader/output.fs within one 8-bit step (powf differs by ulps between libm and the device)
     img = scene.resolve(0.25)
@@ -141,12 +142,30 @@ def test_full_resolution_cornell_frame(cr, ob, cornell, cornell_data):
     out = scene.read_sum()
     err = np.abs(out - ref)
     assert (err <= 1e-5 + 1e-4 * np.abs(ref)).all(), float(err.max())
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), float(err.max())
     st = scene.frame_stats()
     assert st["closest_rays"] == W * H == cnt[0] and st["any_rays"] == cnt[1]
     # size-independent properties: determinism and additivity of the running sum
     scene.render_frame(RX1, RY1)
     out2 = scene.read_sum()
     assert np.array_equal(out2.view(np.uint32), (out + out).view(np.uint32))
+    scene.close()
+
+
+def test_full_resolution_mesh_frame_with_visit_counters(cr, ob, cornell, tess40):
+    """1920x1080 on the 48k-triangle mesh, 3 segments: radiance bit-exact, ray counts and the summed
+    node/triangle visit counters (the roofline's algorithmic-bytes inputs) equal to the oracle's."""
+    W, H = 1920, 1080
+    scene = cr.Scene(tess40[1], W, H, 3)
+    orc = ob.Oracle(tess40[1], W, H, 3, cornell[1])
+    scene.set_option("count_visits", 1)
+    scene.render_frame(RX1, RY1)
+    ref, cnt = orc.render_frame(RX1, RY1, threads=16)
+    st = scene.frame_stats()
+    assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1])
+    assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
+    out = scene.read_sum()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), float(np.abs(out - ref).max())
     scene.close()
 
 
