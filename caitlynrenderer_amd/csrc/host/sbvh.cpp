@@ -5,9 +5,15 @@
 // against the known-answer values of SURVEY.md §8c.
 #include "sbvh.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
+#include <future>
+#include <thread>
 
 namespace crt {
 namespace {
@@ -238,6 +244,30 @@ struct Builder {
         n.leaf = true;
     }
 
+    // One split decision on the tail of `refs` (the body of the loop at sbvh.h:250-279).  Afterwards the
+    // tail is [left refs ..., right refs ...], duplicates of a spatial split included.
+    void split_once(const Spec& spec, Spec& left, Spec& right) {
+        const float node_area = spec.box.half_area();
+        const float node_sah = 2.0f * node_area;
+        ObjectSplit object = find_object_split(spec, node_sah);
+        SpatialSplit spatial;
+        if (spatial_enabled) {
+            Aabb overlap = object.lb;
+            overlap.clip(object.rb);
+            if (overlap.half_area() >= min_overlap) spatial = find_spatial_split(spec, node_sah);
+        }
+        const float min_sah = fmin_(object.sah, spatial.sah);
+        if (spatial_enabled && min_sah == spatial.sah) {
+            do_spatial_split(left, right, spec, spatial);
+        } else {                                   // sbvh.h:379-389
+            sort_tail(spec.n, object.dim);
+            left.n = object.n_left;
+            left.box = object.lb;
+            right.n = spec.n - object.n_left;
+            right.box = object.rb;
+        }
+    }
+
     // sbvh.h:218-283.  The right child is pushed last and therefore built first: it owns
     // the tail of `refs`, which is what make_leaf pops.
     void run(const Spec& root) {
@@ -254,27 +284,8 @@ struct Builder {
                 make_leaf(top.node, top.spec);
                 continue;
             }
-            const float node_area = top.spec.box.half_area();
-            const float node_sah = 2.0f * node_area;
-
-            ObjectSplit object = find_object_split(top.spec, node_sah);
-            SpatialSplit spatial;
-            if (spatial_enabled) {
-                Aabb overlap = object.lb;
-                overlap.clip(object.rb);
-                if (overlap.half_area() >= min_overlap) spatial = find_spatial_split(top.spec, node_sah);
-            }
-            const float min_sah = fmin_(object.sah, spatial.sah);
             Spec left, right;
-            if (spatial_enabled && min_sah == spatial.sah) {
-                do_spatial_split(left, right, top.spec, spatial);
-            } else {                                   // sbvh.h:379-389
-                sort_tail(top.spec.n, object.dim);
-                left.n = object.n_left;
-                left.box = object.lb;
-                right.n = top.spec.n - object.n_left;
-                right.box = object.rb;
-            }
+            split_once(top.spec, left, right);
             const int l = (int)nodes.size();
             nodes.emplace_back();
             nodes.emplace_back();
@@ -284,7 +295,96 @@ struct Builder {
             stack.push_back({l + 1, right});
         }
     }
+
+    void prepare(size_t n) {
+        for (int d = 0; d < 3; ++d) bins[d].assign(kBins, Bin());
+        right_bounds.resize(std::max<size_t>(n, kBins) - 1);     // sbvh.h:124
+    }
 };
+
+// A finished subtree: nodes with local child indices (root = 0) and its leaf ids in creation order
+// (leaf `start` values are offsets into that local list).
+struct Subtree {
+    std::vector<BuildNode> nodes;
+    std::vector<int32_t> leaf_ids;
+};
+
+struct Shared {
+    const crt_triangle* tris;
+    const float3* verts;
+    bool spatial_enabled;
+    float min_overlap;
+    size_t parallel_threshold;   // subtrees with more references than this may fork
+};
+
+// The result of building a node depends only on its Spec and on the order of its own references (the
+// reference algorithm never looks below the tail it is splitting), so the two children of a split can
+// be built concurrently from private copies of their ranges and stitched back in the order the
+// sequential algorithm would have produced them: right subtree's leaves first, then the left's.
+Subtree build_rec(const Shared& sh, const Spec& spec, std::vector<Ref>&& refs) {
+    Builder b;
+    b.tris = sh.tris; b.verts = sh.verts; b.spatial_enabled = sh.spatial_enabled; b.min_overlap = sh.min_overlap;
+    b.refs = std::move(refs);
+    b.prepare(b.refs.size());
+    Subtree out;
+    if ((size_t)spec.n <= sh.parallel_threshold || spec.n <= kLeafRefs) {
+        b.run(spec);
+        out.nodes = std::move(b.nodes);
+        out.leaf_ids = std::move(b.leaf_ids);
+        return out;
+    }
+    Spec left, right;
+    b.split_once(spec, left, right);
+    std::vector<Ref> lrefs(b.refs.begin(), b.refs.begin() + left.n);
+    std::vector<Ref> rrefs(b.refs.begin() + left.n, b.refs.end());
+    std::vector<Ref>().swap(b.refs);
+    std::future<Subtree> rf = std::async(std::launch::async, [&sh, right, &rrefs]() { return build_rec(sh, right, std::move(rrefs)); });
+    Subtree L = build_rec(sh, left, std::move(lrefs));
+    Subtree R = rf.get();
+
+    BuildNode root;
+    root.box = spec.box;
+    const int r_base = 1, l_base = 1 + (int)R.nodes.size();
+    root.child[0] = l_base;
+    root.child[1] = r_base;
+    out.nodes.reserve(1 + R.nodes.size() + L.nodes.size());
+    out.nodes.push_back(root);
+    for (BuildNode n : R.nodes) {
+        if (!n.leaf) { n.child[0] += r_base; n.child[1] += r_base; }
+        out.nodes.push_back(n);
+    }
+    const uint32_t l_leaf_base = (uint32_t)R.leaf_ids.size();
+    for (BuildNode n : L.nodes) {
+        if (!n.leaf) { n.child[0] += l_base; n.child[1] += l_base; }
+        else n.start += l_leaf_base;
+        out.nodes.push_back(n);
+    }
+    out.leaf_ids = std::move(R.leaf_ids);
+    out.leaf_ids.insert(out.leaf_ids.end(), L.leaf_ids.begin(), L.leaf_ids.end());
+    return out;
+}
+
+// CPUs this process may use: affinity mask and cgroup quota, overridable with CRT_BUILD_THREADS.
+unsigned usable_threads() {
+    if (const char* e = std::getenv("CRT_BUILD_THREADS")) {
+        int v = std::atoi(e);
+        if (v >= 1) return (unsigned)v;
+    }
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && quota[0] != 'm' && period > 0) {
+            long q = std::atol(quota) / period;
+            if (q >= 1) n = std::min<unsigned>(n, (unsigned)q);
+        }
+        std::fclose(f);
+    }
+    return std::max(1u, std::min(n, 64u));
+}
 
 }  // namespace
 
@@ -295,23 +395,25 @@ void SBVH::build(const crt_triangle* trs, size_t n_trs, const float3* vertices, 
     depth = 0;
     if (n_trs == 0) return;
 
-    Builder b;
-    b.tris = trs;
-    b.verts = vertices;
-    b.spatial_enabled = !(flags & NO_SPATIAL_SPLITS);
-    for (int d = 0; d < 3; ++d) b.bins[d].resize(kBins);
-
     Spec root;
     root.n = (int)n_trs;
-    b.refs.resize(n_trs);
+    std::vector<Ref> refs(n_trs);
     for (size_t i = 0; i < n_trs; ++i) {             // sbvh.h:109-118
-        b.refs[i].id = (int)i;
-        for (int j = 0; j < 3; ++j) b.refs[i].box.grow(vertices[trs[i].v[j]]);
-        root.box.grow(b.refs[i].box);
+        refs[i].id = (int)i;
+        for (int j = 0; j < 3; ++j) refs[i].box.grow(vertices[trs[i].v[j]]);
+        root.box.grow(refs[i].box);
     }
-    b.min_overlap = root.box.half_area() * kSplitAlpha;            // sbvh.h:120
-    b.right_bounds.resize(std::max<size_t>(n_trs, kBins) - 1);    // sbvh.h:124
-    b.run(root);
+    Shared sh;
+    sh.tris = trs;
+    sh.verts = vertices;
+    sh.spatial_enabled = !(flags & NO_SPATIAL_SPLITS);
+    sh.min_overlap = root.box.half_area() * kSplitAlpha;           // sbvh.h:120
+    const unsigned threads = usable_threads();
+    // fork while a subtree holds more than ~1/(4*threads) of the input; below that, or with one
+    // thread, the plain sequential algorithm runs
+    sh.parallel_threshold = threads <= 1 ? n_trs : std::max<size_t>(4096, n_trs / (4 * (size_t)threads));
+    Subtree tree = build_rec(sh, root, std::move(refs));
+    struct { std::vector<BuildNode> nodes; std::vector<int32_t> leaf_ids; } b{std::move(tree.nodes), std::move(tree.leaf_ids)};
 
     // sbvh.h:130-139: the triangle array is re-ordered into leaf order (with duplicates).
     triangle_indices = b.leaf_ids;

@@ -278,3 +278,23 @@ def test_meshgen_counts(cr, cornell):
     # deterministic
     m2 = tessellated_cornell(mesh, 8)
     assert np.array_equal(m.vertices.view(np.uint32), m2.vertices.view(np.uint32))
+
+
+def test_sbvh_is_identical_for_any_thread_count(cr, tess40):
+    """Subtrees are built concurrently from private copies and stitched in the sequential order, so
+    the tree must not depend on CRT_BUILD_THREADS (csrc/host/sbvh.cpp build_rec)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import __graft_entry__ as g; import caitlynrenderer_amd as cr;"
+            "from caitlynrenderer_amd.meshgen import tessellated_cornell; m = tessellated_cornell(g._cornell()[0], 40);"
+            "sb = cr.SBVH(m.triangles, m.vertices); print(hashlib.sha1(sb.flat_nodes.tobytes() + sb.triangle_indices.tobytes()).hexdigest())") % ROOT
+    digests = set()
+    for th in ("1", "3", "8"):
+        env = dict(os.environ, CRT_BUILD_THREADS=th)
+        digests.add(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip())
+    import hashlib
+    mesh, data = tess40
+    digests.add(hashlib.sha1(data.bvh.tobytes() + data.tri_orig_ids.tobytes()).hexdigest())
+    assert len(digests) == 1
