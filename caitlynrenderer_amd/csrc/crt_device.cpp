@@ -608,6 +608,25 @@ int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
     return CRT_OK;
 }
 
+// Debug/test hook: copy out one of the frame's ray queues as left by the last crt_render_frame.
+// which: 0/1 = path-ray queue written for an even/odd segment, 2 = shadow-ray queue of the last segment.
+int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst, size_t cap, size_t* n_out) {
+    if (!s || !n_out) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (!s->frame_buffers_ready || segment > 16) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: no frame rendered");
+    uint32_t counts[2 * 17];
+    HIPCHK(hipMemcpy(counts, s->d_counts, sizeof counts, hipMemcpyDeviceToHost));
+    const float4* src = which == 2 ? s->d_shadow : s->d_rays[segment & 1];
+    size_t n = which == 2 ? counts[2 * segment + 1] : counts[2 * segment];
+    *n_out = n;
+    if (dst) {
+        if (n > cap) n = cap;
+        HIPCHK(hipMemcpy(dst, src, n * sizeof(crt_ray), hipMemcpyDeviceToHost));
+    }
+    return CRT_OK;
+}
+
 int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, int mode, void* d_stats, int sync) {
     if (!s || !d_rays || !d_hits) return fail(CRT_ERR_INVALID, "crt_trace_device: null argument");
     if (mode != CRT_TRACE_CLOSEST && mode != CRT_TRACE_ANY) return fail(CRT_ERR_INVALID, "crt_trace_device: bad mode");

@@ -71,6 +71,11 @@ __device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 
     return hit_mask;
 }
 
+__device__ __forceinline__ float clamp_dir(float d) {
+    const float eps = 0x1p-80f;
+    return __builtin_fabsf(d) > eps ? d : __builtin_copysignf(eps, d);
+}
+
 struct HitState {
     float t, u, v;
     int tri;   // index into the CWBVH-ordered triangle array, -1 = none
@@ -104,11 +109,17 @@ template <bool ANY, bool STATS>
 __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o,
                                          vec3 d, float tmax_in, uint2* stk, HitState& best, uint32_t& n_nodes,
                                          uint32_t& n_tris) {
-    const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
-    const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);   // cwbvh.fs:348-353
-    const vec3 inv = V3(rcp_ieee(d.x), rcp_ieee(d.y), rcp_ieee(d.z));
-    float max_t = tmax_in;
     best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
+    // a non-finite origin makes every slab NaN (all children pass): such a ray can hit nothing
+    if (!(__builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z))) return false;
+    // Zero direction components (common: the shader RNG returns exactly 0 once in ~400 calls, which makes
+    // the cosine sample equal an axis-aligned normal) would turn (p-o)*inf into NaN and drop the axis from
+    // the slab test.  Traversal uses +-2^-80 instead (octant and reciprocal only); the triangle test keeps d.
+    const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+    const bool negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
+    const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);   // cwbvh.fs:348-353
+    const vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+    float max_t = tmax_in;
     int sp = 0;
     uint2 cur = make_uint2(0u, 0x80000000u);
     for (;;) {

@@ -129,6 +129,14 @@ class Scene:
         check(lib().crt_trace_device(self._h, C.c_void_p(d_rays), int(n), C.c_void_p(d_hits), int(mode),
                                      C.c_void_p(d_stats) if d_stats else None, 1 if sync else 0))
 
+    def debug_read_queue(self, which, segment):
+        """Rays entering `segment` (which=0) or its shadow rays (which=2) as left by the last frame."""
+        n = C.c_size_t()
+        check(lib().crt_debug_read_queue(self._h, int(which), int(segment), None, 0, C.byref(n)))
+        out = np.empty(n.value, RAY_DT)
+        check(lib().crt_debug_read_queue(self._h, int(which), int(segment), _ptr(out), n.value, C.byref(n)))
+        return out
+
     def set_shard(self, rank, world, tile=64):
         check(lib().crt_set_shard(self._h, int(rank), int(world), int(tile)))
 

@@ -143,6 +143,10 @@ int crt_trace(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits, int mo
  * on the scene's stream unless sync != 0. */
 int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, int mode, void* d_stats, int sync);
 
+/* test hook: read back a ray queue of the last rendered frame (which: 0 = path rays entering
+ * `segment`, 2 = that segment's shadow rays).  dst may be NULL to query the count. */
+int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst, size_t cap, size_t* n_out);
+
 /* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is
  * cut into tile x tile squares dealt round-robin in Morton order to `world` ranks;
  * this scene renders only rank's tiles.  Call before the first crt_render_frame. */

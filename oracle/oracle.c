@@ -329,7 +329,7 @@ static inline uint32_t sign_extend_s8x4(uint32_t x) { return ((x >> 7) & 0x01010
 
 /* cwbvh.fs:376-446 with: far plane = min(min()), tmin clamped to 0, tmax clamped to max_t,
  * child hit iff tmin <= tmax.  t = fmaf(q, 2^e*invdir, (p-o)*invdir). */
-static uint32_t node8_intersect(const uint8_t* n, v3 o, v3 d, v3 inv, uint32_t oct4, float max_t) {
+static uint32_t node8_intersect(const uint8_t* n, v3 o, int negx, int negy, int negz, v3 inv, uint32_t oct4, float max_t) {
     v3 p = V(ld_f32(n), ld_f32(n + 4), ld_f32(n + 8));
     uint32_t e_imask = ld_u32(n + 12);
     v3 adj_inv = V(u2f((e_imask & 0xffu) << 23) * inv.x, u2f(((e_imask >> 8) & 0xffu) << 23) * inv.y,
@@ -345,9 +345,9 @@ static uint32_t node8_intersect(const uint8_t* n, v3 o, v3 d, v3 inv, uint32_t o
         uint32_t qlox = ld_u32(n + 32 + 4 * i), qhix = ld_u32(n + 40 + 4 * i);
         uint32_t qloy = ld_u32(n + 48 + 4 * i), qhiy = ld_u32(n + 56 + 4 * i);
         uint32_t qloz = ld_u32(n + 64 + 4 * i), qhiz = ld_u32(n + 72 + 4 * i);
-        uint32_t xmin = d.x < 0.0f ? qhix : qlox, xmax = d.x < 0.0f ? qlox : qhix;
-        uint32_t ymin = d.y < 0.0f ? qhiy : qloy, ymax = d.y < 0.0f ? qloy : qhiy;
-        uint32_t zmin = d.z < 0.0f ? qhiz : qloz, zmax = d.z < 0.0f ? qloz : qhiz;
+        uint32_t xmin = negx ? qhix : qlox, xmax = negx ? qlox : qhix;
+        uint32_t ymin = negy ? qhiy : qloy, ymax = negy ? qloy : qhiy;
+        uint32_t zmin = negz ? qhiz : qloz, zmax = negz ? qloz : qhiz;
         for (int j = 0; j < 4; ++j) {
             float tminx = fmaf((float)((xmin >> (8 * j)) & 0xffu), adj_inv.x, adj_o.x);
             float tminy = fmaf((float)((ymin >> (8 * j)) & 0xffu), adj_inv.y, adj_o.y);
@@ -367,14 +367,30 @@ static uint32_t node8_intersect(const uint8_t* n, v3 o, v3 d, v3 inv, uint32_t o
     return hit_mask;
 }
 
+/* The shader forms 1/d directly (cwbvh.fs:460); with a zero direction component that makes
+ * (p-o)*inf and q*inf+(-inf) NaN, the axis drops out of the slab test and the walk degenerates into
+ * visiting everything the other axes overlap.  Such rays are common here: fract(sin()*43758.5453)
+ * returns exactly 0 about once in 400 calls, which makes the cosine sample equal the (axis-aligned)
+ * surface normal.  The usual CWBVH remedy is used: components smaller than 2^-80 in magnitude are
+ * replaced by +-2^-80 for the traversal only (octant, reciprocal); Moller-Trumbore keeps the true d.
+ * The slabs stay conservative, so hits are unchanged. */
+static inline float clamp_dir(float d) {
+    const float eps = 0x1p-80f;
+    return fabsf(d) > eps ? d : copysignf(eps, d);
+}
+
 /* cwbvh.fs:448-536 (closest) and :538-616 (any): one walker, `any` returns at the first hit. */
 static int bvh8_walk(const orc_scene* s, v3 o, v3 d, float tmax_in, int any, rec_t* rec, int tie, cnt_t* c) {
     uint32_t stack_x[BVH8_STACK], stack_y[BVH8_STACK];
     int sp = 0;
     float max_t = tmax_in;
     if (rec) { rec->t = tmax_in; rec->slot = -1; rec->id = -1; }
-    const uint32_t oct4 = oct_inv4(d);
-    const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    /* a non-finite origin makes every slab NaN (all children pass): such a ray can hit nothing */
+    if (!(isfinite(o.x) && isfinite(o.y) && isfinite(o.z))) return 0;
+    const v3 dc = V(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+    const int negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
+    const uint32_t oct4 = oct_inv4(dc);
+    const v3 inv = V(1.0f / dc.x, 1.0f / dc.y, 1.0f / dc.z);
     uint32_t cur_x = 0, cur_y = 0x80000000u;
     for (;;) {
         uint32_t tri_x, tri_y;
@@ -391,7 +407,7 @@ static int bvh8_walk(const orc_scene* s, v3 o, v3 d, float tmax_in, int any, rec
             uint32_t node_index = base + rel;
             const uint8_t* n = s->bvh8 + 80 * (size_t)node_index;
             c->nodes++;
-            uint32_t hitmask = node8_intersect(n, o, d, inv, oct4, max_t);
+            uint32_t hitmask = node8_intersect(n, o, negx, negy, negz, inv, oct4, max_t);
             uint32_t imask = n[15];
             cur_x = ld_u32(n + 16);
             tri_x = ld_u32(n + 20);

@@ -78,6 +78,25 @@ def test_edge_cases(cr, ob, scenes, cornell):
     assert np.array_equal(got["tri"] >= 0, orc.trace(rays, ob.BVH8, ob.ANY)["tri"] >= 0)
 
 
+def test_zero_components_and_non_finite_rays(cr, ob, scenes):
+    scene, orc, _ = scenes["tess40"]
+    rng = np.random.default_rng(2)
+    rays = np.zeros(4096, cr.RAY_DT)
+    rays["o"] = (0.3 + 4.9 * rng.random((4096, 3))).astype(np.float32)
+    dirs = np.array([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (0, 0.6, 0.8), (0.6, 0, -0.8),
+                     (-0.0, 1, 0), (0, 0, 0)], np.float32)
+    rays["d"] = dirs[np.arange(4096) % len(dirs)]
+    rays["tmax"] = np.float32(1e9)
+    rays["o"][5] = (np.nan, 1, 1); rays["o"][6] = (1, -np.inf, 1); rays["d"][7] = (np.nan, 1, 0)
+    got, gst = scene.trace(rays, cr.CRT_TRACE_CLOSEST, stats=True)
+    want, wst = orc.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, stats=True, threads=8)
+    _assert_hits_equal(got, want)
+    assert np.array_equal(gst["nodes"], wst["nodes"]) and np.array_equal(gst["tris"], wst["tris"])
+    assert gst["nodes"].max() < 400                      # nothing degenerates into a full-tree walk
+    got = scene.trace(rays, cr.CRT_TRACE_ANY)
+    assert np.array_equal(got["tri"] >= 0, orc.trace(rays, ob.BVH8, ob.ANY, threads=8)["tri"] >= 0)
+
+
 def test_exact_ties_resolve_to_lowest_original_id(cr, ob):
     """Two coincident triangles: every hit is an exact tie; the lower original id must win."""
     v = np.array([[0, 0, 0], [4, 0, 0], [0, 4, 0], [0, 0, 0], [4, 0, 0], [0, 4, 0], [0, 0, 1], [4, 0, 1], [0, 4, 1]], np.float32)

@@ -119,6 +119,37 @@ def test_axis_parallel_and_degenerate_rays(ob, cornell, cornell_data):
     assert (hb["tri"][[0, 1, 2, 3, 5]] >= 0).all() and hb["tri"][4] == -1   # the box is open towards +z
 
 
+def test_zero_direction_components_do_not_degenerate(ob, cornell, tess8):
+    """fract(sin()*43758.5453) returns exactly 0 about once in 400 calls, so cosine samples equal to an
+    axis-aligned normal (two zero components) are routine.  The CWBVH walk clamps such components to
+    +-2^-80 for the slab test: hits equal brute force and the visit count stays that of a normal ray."""
+    mesh, data = tess8
+    o = ob.Oracle(data, 64, 64, 3, cornell[1])
+    rng = np.random.default_rng(1)
+    rays = np.zeros(600, ob.RAY_DT)
+    rays["o"] = (0.3 + 4.9 * rng.random((600, 3))).astype(np.float32)
+    dirs = np.array([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (0, 0.6, 0.8), (0.6, 0, -0.8), (-0.0, 1, 0)], np.float32)
+    rays["d"] = dirs[np.arange(600) % len(dirs)]
+    rays["tmax"] = np.float32(1e9)
+    hb = o.trace(rays, ob.BRUTE, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=4)
+    h8, st = o.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, stats=True)
+    assert np.array_equal(h8["tri"], hb["tri"]) and np.array_equal(h8["t"].view(np.uint32), hb["t"].view(np.uint32))
+    generic = rays.copy()
+    generic["d"] = (generic["d"] + np.float32(0.01)) / np.linalg.norm(generic["d"] + np.float32(0.01), axis=1, keepdims=True)
+    _, sg = o.trace(generic, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, stats=True)
+    assert st["nodes"].mean() < 1.5 * sg["nodes"].mean() + 2 and st["nodes"].max() < 200
+    # the shader RNG really does return exact zeros at that rate
+    seqs = np.array([ob.rand_sequence(px, 7, 0.6591631, 0.910802, 4) for px in range(0, 1920, 2)], np.float32)
+    assert 0.0005 < (seqs == 0).mean() < 0.01 and (seqs < 1).all()
+    # non-finite origins and directions terminate immediately instead of walking the whole tree
+    bad = np.zeros(3, ob.RAY_DT)
+    bad["o"] = [(np.nan, 1, 1), (1, np.inf, 1), (1, 1, 1)]
+    bad["d"] = [(0, 0, 1), (0, 0, 1), (np.nan, np.nan, np.nan)]
+    bad["tmax"] = 1e9
+    hbad, sbad = o.trace(bad, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, stats=True)
+    assert (hbad["tri"] == -1).all() and sbad["nodes"][:2].max() == 0 and sbad["nodes"][2] < 50
+
+
 def test_integrator_statistics_and_energy(ob, cr, cornell, cornell_data):
     """Frame sums: oracle paths through BVH2 and CWBVH give the same radiance; rays are counted."""
     o = ob.Oracle(cornell_data, 128, 72, 3, cornell[1])
