@@ -79,11 +79,10 @@ struct crt_scene {
     float* d_sum = nullptr;
     float* d_linear = nullptr;
     uint8_t* d_rgba = nullptr;
-    float4* d_rays[2] = {nullptr, nullptr};
-    float4* d_hits = nullptr;
-    float4* d_shadow = nullptr;
-    float4* d_shadow_hits = nullptr;
+    float4* d_rays[2] = {nullptr, nullptr};   // path-ray queues, only for max_depth > 1
+    float4* d_shadow = nullptr;               // 4 x float4 per shadow ray: ray, ray, C, L so far
     crt::PathBuffers pb{};
+    uint32_t stack_entries = CRT_STACK_ENTRIES;
     uint32_t* d_counts = nullptr;        // [2 * b] = rays into segment b, [2 * b + 1] = shadow rays of segment b
     uint32_t* h_counts = nullptr;        // pinned
     bool frame_buffers_ready = false;
@@ -92,7 +91,6 @@ struct crt_scene {
     bool have_camera = false;
     uint32_t jitter = 1;
     bool count_visits = false;
-    uint32_t* d_visit_stats = nullptr;          // per-ray counters of the current launch (count_visits)
     unsigned long long* d_visit_totals = nullptr;   // closest nodes/tris, any nodes/tris
     unsigned long long* h_visit_totals = nullptr;   // pinned
 
@@ -106,14 +104,14 @@ struct crt_scene {
     bool stats_pending = false;
     bool stats_from_frame = false;
     bool stats_counted = false;
-    uint32_t trace_occupancy = 5;
+    uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
 
     ~crt_scene() {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
-                        d_rays[0], d_rays[1], d_hits, d_shadow, d_shadow_hits, pb.L, pb.T, pb.seed, pb.C, d_counts,
-                        d_t_rays, d_t_hits, d_t_stats, d_visit_stats, d_visit_totals};
+                        d_rays[0], d_rays[1], d_shadow, pb.L, pb.T, pb.seed, d_counts,
+                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_counts) hipHostFree(h_counts);
         if (h_visit_totals) hipHostFree(h_visit_totals);
@@ -121,10 +119,16 @@ struct crt_scene {
         if (stream) hipStreamDestroy(stream);
     }
 
-    uint32_t trace_grid(uint64_t n) const {
+    // persistent grid: workgroups per CU bounded by LDS (stack) and registers; always a multiple of 8
+    // (the XCD-aware schedule in rt_kernels.hip groups workgroups by blockIdx & 7)
+    // reg_cap = workgroups per CU the kernel's VGPR count admits (k_segment ~90 VGPRs -> 5, k_trace/k_shadow <= 64 -> 8)
+    uint32_t trace_grid(uint64_t n, uint32_t reg_cap) const {
+        const uint64_t lds = (uint64_t)(CRT_TRACE_BLOCK / 64) * stack_entries * 64 * 8;
+        uint64_t per_cu = std::min<uint64_t>(std::min(trace_occupancy, reg_cap), std::max<uint64_t>(1, (160 * 1024) / lds));
         uint64_t blocks = (n + CRT_TRACE_BLOCK - 1) / CRT_TRACE_BLOCK;
-        uint64_t cap = (uint64_t)n_cu * trace_occupancy;
-        return (uint32_t)std::max<uint64_t>(1, std::min(blocks, cap));
+        uint64_t g = std::min(blocks, (uint64_t)n_cu * per_cu);
+        g = (std::max<uint64_t>(g, 8) + 7) / 8 * 8;
+        return (uint32_t)g;
     }
     uint32_t flat_grid(uint64_t n) const {
         uint64_t blocks = (n + 255) / 256;
@@ -175,8 +179,7 @@ int build_shard(crt_scene* s) {
 
 void free_frame_buffers(crt_scene* s) {
     void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
-                     (void**)&s->d_rays[1], (void**)&s->d_hits, (void**)&s->d_shadow, (void**)&s->d_shadow_hits,
-                     (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed, (void**)&s->pb.C};
+                     (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     s->frame_buffers_ready = false;
 }
@@ -190,15 +193,14 @@ int alloc_frame_buffers(crt_scene* s) {
     HIPCHK(hipMemcpy(s->d_tile_xy, s->tiles.data(), s->tiles.size() * sizeof(uint2), hipMemcpyHostToDevice));
     if ((rc = dev_alloc(&s->d_sum, 3 * P))) return rc;
     HIPCHK(hipMemset(s->d_sum, 0, 3 * std::max<size_t>(P, 1) * sizeof(float)));
-    if ((rc = dev_alloc(&s->d_rays[0], 2 * P))) return rc;
-    if ((rc = dev_alloc(&s->d_rays[1], 2 * P))) return rc;
-    if ((rc = dev_alloc(&s->d_hits, P))) return rc;
-    if ((rc = dev_alloc(&s->d_shadow, 2 * P))) return rc;
-    if ((rc = dev_alloc(&s->d_shadow_hits, P))) return rc;
-    if ((rc = dev_alloc(&s->pb.L, P))) return rc;
-    if ((rc = dev_alloc(&s->pb.T, P))) return rc;
-    if ((rc = dev_alloc(&s->pb.seed, P))) return rc;
-    if ((rc = dev_alloc(&s->pb.C, P))) return rc;
+    if ((rc = dev_alloc(&s->d_shadow, 4 * P))) return rc;
+    if (s->max_depth > 1) {                      // path state and ray queues exist only for multi-segment paths
+        if ((rc = dev_alloc(&s->d_rays[0], 2 * P))) return rc;
+        if ((rc = dev_alloc(&s->d_rays[1], 2 * P))) return rc;
+        if ((rc = dev_alloc(&s->pb.L, P))) return rc;
+        if ((rc = dev_alloc(&s->pb.T, P))) return rc;
+        if ((rc = dev_alloc(&s->pb.seed, P))) return rc;
+    }
     s->frame_buffers_ready = true;
     return CRT_OK;
 }
@@ -241,9 +243,7 @@ int collect_stats(crt_scene* s) {
     st.closest_rays = s->stats.closest_rays;
     st.any_rays = s->stats.any_rays;
     if (s->stats_from_frame && s->stats_counted && s->h_visit_totals) {
-        // padding pixels of ragged tiles are tmax = -1 rays: one root fetch each, not real rays
-        const uint64_t pads = s->n_local_pixels - s->n_local_in_frame;
-        st.nodes_closest = s->h_visit_totals[0] >= pads ? s->h_visit_totals[0] - pads : 0;
+        st.nodes_closest = s->h_visit_totals[0];
         st.tris_closest = s->h_visit_totals[1];
         st.nodes_any = s->h_visit_totals[2]; st.tris_any = s->h_visit_totals[3];
     }
@@ -329,6 +329,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
+    s->stack_entries = std::min<uint32_t>(CRT_STACK_ENTRIES, std::max<uint32_t>(2, depth8));
     s->info.n_nodes8 = n_nodes8; s->info.n_tris8 = n_tris8; s->info.n_bvh2_nodes = d->n_bvh; s->info.max_depth8 = depth8;
 
     // pre-gathered intersection records in CWBVH triangle order: (v0|orig id) (e1|slot) (e2|material).
@@ -436,58 +437,34 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
             if ((rc = dev_alloc(&s->d_visit_totals, 4))) return rc;
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 4 * sizeof(unsigned long long)));
         }
-        if (s->d_visit_stats) hipFree(s->d_visit_stats);
-        if ((rc = dev_alloc(&s->d_visit_stats, P))) return rc;
         HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 4 * sizeof(unsigned long long), s->stream));
     }
     HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * 17 * sizeof(uint32_t), s->stream));
-    HIPCHK(hipMemcpyAsync(s->d_counts, &s->n_local_pixels, sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-
-    EventSpan* sp = s->begin_span(0);
-    crt::launch_raygen(f, s->pb, s->d_rays[0], s->flat_grid(P), s->stream);
-    s->end_span(sp);
 
     for (uint32_t b = 0; b < s->max_depth; ++b) {
-        float4* rin = s->d_rays[b & 1];
-        float4* rnext = s->d_rays[(b + 1) & 1];
-        uint32_t* c_in = s->d_counts + 2 * b;
-        uint32_t* c_shadow = s->d_counts + 2 * b + 1;
-        uint32_t* c_next = s->d_counts + 2 * (b + 1);
-
-        crt::TraceArgs ta{};
-        ta.nodes = s->d_nodes; ta.tris = s->d_tris; ta.rays = rin; ta.hits = s->d_hits; ta.stats = nullptr;
-        ta.count_ptr = c_in; ta.n = P; ta.out_orig_id = 0;
-        ta.stats = s->count_visits ? s->d_visit_stats : nullptr;
-        sp = s->begin_span(1);
-        crt::launch_trace(ta, CRT_TRACE_CLOSEST, s->count_visits, s->trace_grid(P), s->stream);
-        s->end_span(sp);
-        if (s->count_visits) crt::launch_reduce_stats(s->d_visit_stats, c_in, P, s->d_visit_totals, s->flat_grid(P), s->stream);
-
-        crt::ShadeArgs sa{};
-        sa.rays_in = rin; sa.hits = s->d_hits; sa.count_in = c_in;
-        sa.rays_next = rnext; sa.count_next = c_next;
-        sa.rays_shadow = s->d_shadow; sa.count_shadow = c_shadow;
-        sa.tris = s->d_tris; sa.triangles = s->d_triangles; sa.normals = s->d_normals;
+        crt::SegmentArgs sa{};
+        sa.nodes = s->d_nodes; sa.tris = s->d_tris; sa.triangles = s->d_triangles; sa.normals = s->d_normals;
         sa.materials = s->d_materials; sa.lights = s->d_lights; sa.n_lights = (int32_t)s->n_lights;
-        sa.rv = f.rv; sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
-        sp = s->begin_span(3);
-        crt::launch_shade(sa, s->pb, s->flat_grid(P), s->stream);
+        sa.stack_entries = s->stack_entries;
+        sa.f = f;
+        sa.rays_in = s->d_rays[b & 1]; sa.count_in = s->d_counts + 2 * b;
+        sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = s->d_counts + 2 * (b + 1);
+        sa.shadow = s->d_shadow; sa.count_shadow = s->d_counts + 2 * b + 1;
+        sa.pb = s->pb; sa.sum = s->d_sum;
+        sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
+        sa.visit_totals = s->d_visit_totals;
+        EventSpan* sp = s->begin_span(1);
+        crt::launch_segment(sa, b == 0, s->count_visits, s->trace_grid(P, 5), s->stream);
         s->end_span(sp);
 
-        crt::TraceArgs tb = ta;
-        tb.rays = s->d_shadow; tb.hits = s->d_shadow_hits; tb.count_ptr = c_shadow;
+        crt::ShadowArgs sh{};
+        sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = s->d_counts + 2 * b + 1;
+        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries;
+        sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sp = s->begin_span(2);
-        crt::launch_trace(tb, CRT_TRACE_ANY, s->count_visits, s->trace_grid(P), s->stream);
-        s->end_span(sp);
-        if (s->count_visits) crt::launch_reduce_stats(s->d_visit_stats, c_shadow, P, s->d_visit_totals + 2, s->flat_grid(P), s->stream);
-
-        sp = s->begin_span(3);
-        crt::launch_shadow_resolve(s->d_shadow, s->d_shadow_hits, c_shadow, s->pb, s->flat_grid(P), s->stream);
+        crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->stream);
         s->end_span(sp);
     }
-    sp = s->begin_span(3);
-    crt::launch_accumulate(s->d_sum, s->pb, P, s->flat_grid(P), s->stream);
-    s->end_span(sp);
     HIPCHK(hipMemcpyAsync(s->h_counts, s->d_counts, 2 * 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     if (s->count_visits)
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
@@ -519,9 +496,11 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
         HIPCHK(hipStreamSynchronize(s->stream));
         if (s->stats_from_frame) {
             uint64_t closest = 0, any = 0;
-            for (uint32_t b = 0; b < s->max_depth; ++b) { closest += s->h_counts[2 * b]; any += s->h_counts[2 * b + 1]; }
-            // segment 0 walks the padded tile grid; padding pixels are immediate misses, not rays
-            if (closest >= s->n_local_pixels) closest -= (s->n_local_pixels - s->n_local_in_frame);
+            closest = s->n_local_in_frame;             // segment 0: one primary ray per in-frame pixel
+            for (uint32_t b = 0; b < s->max_depth; ++b) {
+                if (b) closest += s->h_counts[2 * b];
+                any += s->h_counts[2 * b + 1];
+            }
             s->stats.closest_rays = closest; s->stats.any_rays = any;
         }
         int rc = collect_stats(s);
@@ -622,7 +601,11 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
     *n_out = n;
     if (dst) {
         if (n > cap) n = cap;
-        HIPCHK(hipMemcpy(dst, src, n * sizeof(crt_ray), hipMemcpyDeviceToHost));
+        if (!src) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: that queue does not exist at max_depth 1");
+        if (which == 2)    // shadow entries are 64 B (ray, ray, C, L): copy the leading crt_ray of each
+            HIPCHK(hipMemcpy2D(dst, sizeof(crt_ray), src, 4 * sizeof(float4), sizeof(crt_ray), n, hipMemcpyDeviceToHost));
+        else
+            HIPCHK(hipMemcpy(dst, src, n * sizeof(crt_ray), hipMemcpyDeviceToHost));
     }
     return CRT_OK;
 }
@@ -637,9 +620,10 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     ta.nodes = s->d_nodes; ta.tris = s->d_tris;
     ta.rays = static_cast<const float4*>(d_rays); ta.hits = static_cast<float4*>(d_hits);
     ta.stats = static_cast<uint32_t*>(d_stats); ta.count_ptr = nullptr; ta.n = (uint32_t)n; ta.out_orig_id = 1;
+    ta.stack_entries = s->stack_entries;
     s->n_spans = 0;
     EventSpan* sp = s->begin_span(mode == CRT_TRACE_ANY ? 2 : 1);
-    crt::launch_trace(ta, mode, d_stats != nullptr, s->trace_grid(n), s->stream);
+    crt::launch_trace(ta, mode, d_stats != nullptr, s->trace_grid(n, 8), s->stream);
     s->end_span(sp);
     HIPCHK(hipGetLastError());
     s->stats_pending = true;

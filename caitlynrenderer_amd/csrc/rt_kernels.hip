@@ -104,11 +104,12 @@ __device__ __forceinline__ bool mt_test(const float4 a, const float4 b, const fl
 }
 
 // One ray through the CWBVH (cwbvh.fs:448-536 closest, :538-616 any).  `stk` is this lane's column
-// of the wave's LDS stack: stk[level * 64].
+// of the wave's LDS stack: stk[level * 64]; stack_entries (<= CRT_STACK_ENTRIES) is sized from the
+// CWBVH's depth at scene creation so shallow trees leave more LDS for occupancy.
 template <bool ANY, bool STATS>
 __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o,
-                                         vec3 d, float tmax_in, uint2* stk, HitState& best, uint32_t& n_nodes,
-                                         uint32_t& n_tris) {
+                                         vec3 d, float tmax_in, uint2* stk, int stack_entries, HitState& best,
+                                         uint32_t& n_nodes, uint32_t& n_tris) {
     best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
     // a non-finite origin makes every slab NaN (all children pass): such a ray can hit nothing
     if (!(__builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z))) return false;
@@ -130,7 +131,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const uint32_t base = cur.x;
             cur.y &= ~(1u << off);
             if (cur.y & 0xff000000u) {
-                if (sp < CRT_STACK_ENTRIES) { stk[sp * 64] = cur; ++sp; }
+                if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; }
             }
             const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
@@ -176,24 +177,63 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
     return best.tri >= 0;
 }
 
-// Persistent-threads trace kernel: every wave walks the ray queue in 64-ray batches,
-// batch b -> wave (b mod total_waves).  count_ptr (device) overrides n when non-null so that
-// queue lengths produced on the device never round-trip through the host.
+// ------------------------------------------------------------------ scheduling -------
+
+// Static, XCD-aware batch schedule shared by all persistent kernels.  Work is cut into 64-ray batches
+// (one wave, one 8x8 pixel block for primary rays); 64 consecutive batches form a unit (one 64x64
+// tile).  Workgroups are dealt round-robin to the 8 XCDs by the dispatcher (blockIdx & 7 labels the
+// group that shares an L2; a performance heuristic only), so unit u is given to group u & 7: each L2
+// then sees the geometry behind 1/8 of the tiles instead of all of it.  Inside a group, a workgroup
+// takes 4 neighbouring batches at a time (one per wave) so its L1 sees one 16x16-pixel patch.
+struct Schedule {
+    uint32_t nb, xcd, chunk, chunk_step, n_chunks, wave;
+    __device__ __forceinline__ Schedule(uint32_t n_items) {
+        nb = (n_items + 63u) >> 6;
+        xcd = blockIdx.x & 7u;
+        chunk = blockIdx.x >> 3;
+        chunk_step = gridDim.x >> 3;          // the host launches a multiple of 8 workgroups
+        const uint32_t n_units = (nb + 63u) >> 6;
+        const uint32_t units_x = n_units > xcd ? (n_units - xcd + 7u) >> 3 : 0u;
+        n_chunks = units_x * 16u;
+        wave = threadIdx.x >> 6;
+    }
+    // batch index of this wave for the current chunk, or 0xffffffff when past the end (wave-uniform)
+    __device__ __forceinline__ uint32_t batch() const {
+        const uint32_t unit = (chunk >> 4) * 8u + xcd;
+        const uint32_t b = unit * 64u + (chunk & 15u) * 4u + wave;
+        return b < nb ? b : 0xffffffffu;
+    }
+};
+
+__device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, uint32_t nn, uint32_t nt) {
+    unsigned long long a = nn, b = nt;
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (a) atomicAdd(&totals[0], a);
+        if (b) atomicAdd(&totals[1], b);
+    }
+}
+
+// Persistent-threads trace kernel over an explicit ray buffer (crt_trace / crt_trace_device).
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
-    __shared__ uint2 s_stack[CRT_TRACE_BLOCK / 64][CRT_STACK_ENTRIES][64];
+    extern __shared__ uint2 s_stack[];   // [wave][level][lane]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = &s_stack[wave][0][lane];
+    uint2* stk = s_stack + (size_t)wave * a.stack_entries * 64u + lane;
     const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
-    const uint32_t waves_total = gridDim.x * (CRT_TRACE_BLOCK / 64);
-    const uint32_t wave_id = blockIdx.x * (CRT_TRACE_BLOCK / 64) + wave;
-    for (uint32_t base = wave_id * 64u; base < n; base += waves_total * 64u) {
-        const uint32_t i = base + lane;
+    for (Schedule sc(n); sc.chunk < sc.n_chunks; sc.chunk += sc.chunk_step) {
+        const uint32_t b = sc.batch();
+        if (b == 0xffffffffu) continue;
+        const uint32_t i = b * 64u + lane;
         if (i >= n) continue;
         const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
         HitState best;
         uint32_t nn = 0, nt = 0;
-        traverse<ANY, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk, best, nn, nt);
+        traverse<ANY, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk, (int)a.stack_entries,
+                             best, nn, nt);
         float4 h;
         h.x = ANY ? 0.f : (best.tri >= 0 ? best.t : 0.f);
         h.y = ANY ? 0.f : best.u;
@@ -203,9 +243,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
         else if (a.out_orig_id) out = best.tri >= 0 ? best.id : -1;
         h.w = __int_as_float(out);
         a.hits[i] = h;
-        if (STATS) {
-            a.stats[i] = ((nt > 65535u ? 65535u : nt) << 16) | (nn > 65535u ? 65535u : nn);
-        }
+        if (STATS) a.stats[i] = ((nt > 65535u ? 65535u : nt) << 16) | (nn > 65535u ? 65535u : nn);
     }
 }
 
@@ -236,199 +274,228 @@ __device__ __forceinline__ bool pixel_of(const FrameArgs& f, uint32_t i, uint32_
     return px < f.width && py < f.height;
 }
 
-// ------------------------------------------------------------------ ray generation ---
-
-// path_trace.fs:1026-1047.  Writes the dense primary-ray queue (index == local pixel index) and
-// the initial path state.  Out-of-frame padding pixels get tmax = -1 (an immediate miss).
-__global__ void __launch_bounds__(256) k_raygen(FrameArgs f, PathBuffers pb, float4* __restrict__ rays) {
-    const uint32_t n = f.n_local_pixels;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint32_t px, py;
-        const bool in_frame = pixel_of(f, i, px, py);
-        float sx = (float)px + 0.5f, sy = (float)py + 0.5f;
-        const float W = (float)f.width, H = (float)f.height;
-        float jx = 0.f, jy = 0.f;
-        if (f.jitter) {
-            const float r1 = 2.0f * shader_rand(sx, sy, f.rv);
-            const float r2 = 2.0f * shader_rand(sx, sy, f.rv);
-            jx = r1 < 1.0f ? sqrt_ieee(r1) - 1.0f : 1.0f - sqrt_ieee(2.0f - r1);
-            jy = r2 < 1.0f ? sqrt_ieee(r2) - 1.0f : 1.0f - sqrt_ieee(2.0f - r2);
-            jx = __fdiv_rn(jx, W * 0.5f);
-            jy = __fdiv_rn(jy, H * 0.5f);
-        }
-        const float tx = __fdiv_rn((float)px + 0.5f, W), ty = __fdiv_rn((float)py + 0.5f, H);
-        float dx = (2.0f * tx - 1.0f) + jx;
-        float dy = (2.0f * ty - 1.0f) + jy;
-        dx = dx * f.aspect_tan;   // (W / H * tan(fov/2)), formed on the host like the oracle does
-        dy = dy * f.tan_fov;
-        const vec3 right = V3(f.cam_right[0], f.cam_right[1], f.cam_right[2]);
-        const vec3 up = V3(f.cam_up[0], f.cam_up[1], f.cam_up[2]);
-        const vec3 fwd = V3(f.cam_forward[0], f.cam_forward[1], f.cam_forward[2]);
-        const vec3 dir = normalize((right * dx + up * dy) + fwd);
-        rays[2 * (size_t)i] = make_float4(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2], in_frame ? CRT_INF : -1.0f);
-        rays[2 * (size_t)i + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i));
-        pb.L[i] = make_float4(0.f, 0.f, 0.f, 1.0f);                       // L, prev_pdf
-        pb.T[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(1u));        // T, is_specular
-        pb.seed[i] = make_float2(sx, sy);
-    }
+__device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix, vec3 L) {   // path_trace.fs:1055-1059
+    float* s = sum + 3 * (size_t)pix;
+    s[0] = L.x + s[0];
+    s[1] = L.y + s[1];
+    s[2] = L.z + s[2];
 }
 
-// ------------------------------------------------------------------ shading ----------
+// ------------------------------------------------------------------ path segment -----
 
-// One path segment after its closest-hit traversal: path_trace.fs:872-1018 for the hit case.
-// Emits at most one shadow ray (NEE, :940-998) and, unless this was the last segment, the next
-// path ray (:1004-1018), both appended with wave ballots.
-__global__ void __launch_bounds__(256) k_shade(ShadeArgs a, PathBuffers pb) {
-    const uint32_t n = *a.count_in;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // keep whole waves in the loop so the ballots in wave_append see every lane
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_round; e += stride) {
-        bool emit_shadow = false, emit_next = false;
-        float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, nx0 = sh0, nx1 = sh0;
-        if (e < n) {
+// One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
+// shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
+// wave-ballot compaction.  Nothing but the two output queues (and, for paths that go on, 40 B of path
+// state) touches HBM; a path that ends here adds its radiance to the sum buffer directly.
+template <bool FIRST, bool STATS>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_segment(SegmentArgs a) {
+    extern __shared__ uint2 s_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2* stk = s_stack + (size_t)wave * a.stack_entries * 64u + lane;
+    const FrameArgs& f = a.f;
+    const uint32_t n = FIRST ? f.n_local_pixels : *a.count_in;
+    uint32_t nn = 0, nt = 0;
+    for (Schedule sc(n); sc.chunk < sc.n_chunks; sc.chunk += sc.chunk_step) {
+        const uint32_t b = sc.batch();
+        if (b == 0xffffffffu) continue;                     // wave-uniform
+        const uint32_t e = b * 64u + lane;
+        bool active = e < n;
+        uint32_t pix = 0;
+        vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
+        vec3 L = V3(0.f, 0.f, 0.f), T = V3(1.f, 1.f, 1.f);
+        float prev_pdf = 1.0f, sx = 0.f, sy = 0.f;
+        bool is_specular = true;
+        if (FIRST) {                                        // path_trace.fs:1026-1047
+            uint32_t px = 0, py = 0;
+            pix = e;
+            active = active && pixel_of(f, e, px, py);
+            sx = (float)px + 0.5f; sy = (float)py + 0.5f;
+            const float W = (float)f.width, H = (float)f.height;
+            float jx = 0.f, jy = 0.f;
+            if (f.jitter) {
+                const float r1 = 2.0f * shader_rand(sx, sy, f.rv);
+                const float r2 = 2.0f * shader_rand(sx, sy, f.rv);
+                jx = r1 < 1.0f ? sqrt_ieee(r1) - 1.0f : 1.0f - sqrt_ieee(2.0f - r1);
+                jy = r2 < 1.0f ? sqrt_ieee(r2) - 1.0f : 1.0f - sqrt_ieee(2.0f - r2);
+                jx = __fdiv_rn(jx, W * 0.5f);
+                jy = __fdiv_rn(jy, H * 0.5f);
+            }
+            const float tx = __fdiv_rn((float)px + 0.5f, W), ty = __fdiv_rn((float)py + 0.5f, H);
+            float dx = (2.0f * tx - 1.0f) + jx;
+            float dy = (2.0f * ty - 1.0f) + jy;
+            dx = dx * f.aspect_tan;                         // (W / H * tan(fov/2)), formed on the host like the oracle does
+            dy = dy * f.tan_fov;
+            const vec3 right = V3(f.cam_right[0], f.cam_right[1], f.cam_right[2]);
+            const vec3 up = V3(f.cam_up[0], f.cam_up[1], f.cam_up[2]);
+            const vec3 fwd = V3(f.cam_forward[0], f.cam_forward[1], f.cam_forward[2]);
+            d = normalize((right * dx + up * dy) + fwd);
+            o = V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+        } else if (active) {
             const float4 r0 = a.rays_in[2 * (size_t)e], r1 = a.rays_in[2 * (size_t)e + 1];
-            const float4 h = a.hits[e];
-            const uint32_t pix = __float_as_uint(r1.w);
-            const int tri = __float_as_int(h.w);
-            if (tri >= 0) {
-                const vec3 o = V3(r0.x, r0.y, r0.z), d = V3(r1.x, r1.y, r1.z);
-                const float t = h.x, bu = h.y, bv = h.z;
-                const float4 tb = a.tris[3 * (size_t)tri + 1], tc = a.tris[3 * (size_t)tri + 2];
-                const int slot = __float_as_int(tb.w), mtl = __float_as_int(tc.w);
-                // path_trace.fs:440-454
-                const int4 vn = a.triangles[3 * (size_t)slot + 1];
-                vec3 n;
-                if (vn.w == 0) n = V3((float)vn.x, (float)vn.y, (float)vn.z);
-                else {
-                    const float* N = a.normals;
-                    const vec3 na = V3(N[3 * (size_t)vn.x], N[3 * (size_t)vn.x + 1], N[3 * (size_t)vn.x + 2]);
-                    const vec3 nb = V3(N[3 * (size_t)vn.y], N[3 * (size_t)vn.y + 1], N[3 * (size_t)vn.y + 2]);
-                    const vec3 nc = V3(N[3 * (size_t)vn.z], N[3 * (size_t)vn.z + 1], N[3 * (size_t)vn.z + 2]);
-                    const float w = 1.0f - bu - bv;
-                    n = (na * w + nb * bu) + nc * bv;
-                }
-                const float4 m_albedo = a.materials[4 * (size_t)mtl], m_emission = a.materials[4 * (size_t)mtl + 1],
-                             m_specular = a.materials[4 * (size_t)mtl + 2];
-                float4 Lp = pb.L[pix];
-                float4 Tp = pb.T[pix];
-                float2 seed = pb.seed[pix];
-                vec3 L = V3(Lp.x, Lp.y, Lp.z), T = V3(Tp.x, Tp.y, Tp.z);
-                const float prev_pdf = Lp.w;
-                const bool is_specular = __float_as_uint(Tp.w) != 0u;
+            o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z);
+            pix = __float_as_uint(r1.w);
+            const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
+            const float2 sd = a.pb.seed[pix];
+            L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w;
+            T = V3(Tp.x, Tp.y, Tp.z); is_specular = __float_as_uint(Tp.w) != 0u;
+            sx = sd.x; sy = sd.y;
+        }
 
-                const float cos_incident = dot(d, n);
-                const vec3 original_n = n;
-                if (cos_incident > 0) n = -n;
-                if (m_emission.w != -1.0f) {                                   // path_trace.fs:894-928
-                    const vec3 em = V3(m_emission.x, m_emission.y, m_emission.z);
-                    if (is_specular) L = L + T * em;
+        HitState hit;
+        hit.tri = -1;
+        if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, hit, nn, nt);
+
+        bool emit_shadow = false, emit_next = false, finished = active;
+        float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, sh3 = sh0, nx0 = sh0, nx1 = sh0;
+        if (active && hit.tri >= 0) {
+            const float t = hit.t, bu = hit.u, bv = hit.v;
+            const float4 tb = a.tris[3 * (size_t)hit.tri + 1], tc = a.tris[3 * (size_t)hit.tri + 2];
+            const int slot = __float_as_int(tb.w), mtl = __float_as_int(tc.w);
+            const int4 vn = a.triangles[3 * (size_t)slot + 1];                    // path_trace.fs:440-454
+            vec3 n;
+            if (vn.w == 0) n = V3((float)vn.x, (float)vn.y, (float)vn.z);
+            else {
+                const float* N = a.normals;
+                const vec3 na = V3(N[3 * (size_t)vn.x], N[3 * (size_t)vn.x + 1], N[3 * (size_t)vn.x + 2]);
+                const vec3 nb = V3(N[3 * (size_t)vn.y], N[3 * (size_t)vn.y + 1], N[3 * (size_t)vn.y + 2]);
+                const vec3 nc = V3(N[3 * (size_t)vn.z], N[3 * (size_t)vn.z + 1], N[3 * (size_t)vn.z + 2]);
+                const float w = 1.0f - bu - bv;
+                n = (na * w + nb * bu) + nc * bv;
+            }
+            const float4 m_albedo = a.materials[4 * (size_t)mtl], m_emission = a.materials[4 * (size_t)mtl + 1],
+                         m_specular = a.materials[4 * (size_t)mtl + 2];
+            const float cos_incident = dot(d, n);
+            const vec3 original_n = n;
+            if (cos_incident > 0) n = -n;
+            if (m_emission.w != -1.0f) {                                          // path_trace.fs:894-928
+                const vec3 em = V3(m_emission.x, m_emission.y, m_emission.z);
+                if (is_specular) L = L + T * em;
+                else {
+                    vec3 ld = d * t;
+                    const float len = length(ld);
+                    ld = normalize(ld);
+                    const float cos_light = -1.0f * dot(ld, n);
+                    const float len2 = len * len;
+                    const int li = (int)m_emission.w;
+                    const float* ap = a.lights + 18 * (size_t)li + 15;
+                    const float pdf_light = __fdiv_rn(len2, ap[0] * cos_light) * ap[1];
+                    const float tt = prev_pdf * prev_pdf;                         // power_heuristic :214-218
+                    const float w = __fdiv_rn(tt, pdf_light * pdf_light + tt);
+                    L = L + (T * em) * w;
+                }
+            } else {
+                const vec3 hit_point = (o + d * t) + n * 0.0002f;                 // path_trace.fs:930
+                const vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
+                if (m_specular.w == 0.0f) {
+                    if (a.n_lights <= 0) {
+                        shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv);
+                    } else {
+                        int li = (int)(shader_rand(sx, sy, f.rv) * (float)a.n_lights);
+                        if (li > a.n_lights - 1) li = a.n_lights - 1;
+                        const float* Lt = a.lights + 18 * (size_t)li;
+                        const float sq = sqrt_ieee(shader_rand(sx, sy, f.rv));    // :843-855
+                        const float b0 = 1.0f - sq;
+                        const float b1 = shader_rand(sx, sy, f.rv) * sq;
+                        const vec3 lp = (V3(Lt[0], Lt[1], Lt[2]) + V3(Lt[3], Lt[4], Lt[5]) * b0) + V3(Lt[6], Lt[7], Lt[8]) * b1;
+                        vec3 ldir = lp - hit_point;
+                        const float len = length(ldir);
+                        const float ilen = rcp_ieee(len);
+                        ldir = ldir * ilen;
+                        const float cos_mtl = dot(ldir, original_n);
+                        const float cos_light = dot(ldir, V3(Lt[9], Lt[10], Lt[11]));
+                        if (cos_mtl > 0.0f && cos_light < 0.0f) {                 // :968 (the occlusion test runs in k_shadow)
+                            const vec3 le = V3(Lt[12], Lt[13], Lt[14]);
+                            const float pdf_light = __fdiv_rn(len * len, Lt[15] * -cos_light) * Lt[16];
+                            const float bsdf_pdf = __fdiv_rn(dot(ldir, n) * 1.0f, CRT_PI);
+                            const float tt = pdf_light * pdf_light;
+                            const float w = __fdiv_rn(tt, bsdf_pdf * bsdf_pdf + tt);
+                            vec3 c = ((T * le) * albedo) * w;
+                            c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
+                            emit_shadow = true;
+                            sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
+                            sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix | (a.last_segment ? 0x80000000u : 0u)));
+                            sh2 = make_float4(c.x, c.y, c.z, 0.f);
+                            sh3 = make_float4(L.x, L.y, L.z, 0.f);
+                        }
+                    }
+                }
+                if (!a.last_segment) {
+                    vec3 ou, ov;                                                  // path_trace.fs:44-60
+                    if (n.z < -0.9999999f) { ou = V3(0.f, -1.f, 0.f); ov = V3(-1.f, 0.f, 0.f); }
                     else {
-                        vec3 ld = d * t;
-                        const float len = length(ld);
-                        ld = normalize(ld);
-                        const float cos_light = -1.0f * dot(ld, n);
-                        const float len2 = len * len;
-                        const int li = (int)m_emission.w;
-                        const float* ap = a.lights + 18 * (size_t)li + 15;
-                        const float pdf_light = __fdiv_rn(len2, ap[0] * cos_light) * ap[1];
-                        const float tt = prev_pdf * prev_pdf;                  // power_heuristic :214-218
-                        const float w = __fdiv_rn(tt, pdf_light * pdf_light + tt);
-                        L = L + (T * em) * w;
+                        const float aa = rcp_ieee(1.0f + n.z);
+                        const float bb = -n.x * n.y * aa;
+                        ou = V3(1.0f + bb, bb, -n.x);
+                        ov = V3(bb, 1.0f + bb, -n.y);
                     }
-                    pb.L[pix] = make_float4(L.x, L.y, L.z, prev_pdf);
-                } else {
-                    const vec3 hit_point = (o + d * t) + n * 0.0002f;          // path_trace.fs:930
-                    const vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
-                    if (m_specular.w == 0.0f) {
-                        if (a.n_lights <= 0) {
-                            shader_rand(seed.x, seed.y, a.rv); shader_rand(seed.x, seed.y, a.rv); shader_rand(seed.x, seed.y, a.rv);
-                        } else {
-                            int li = (int)(shader_rand(seed.x, seed.y, a.rv) * (float)a.n_lights);
-                            if (li > a.n_lights - 1) li = a.n_lights - 1;
-                            const float* Lt = a.lights + 18 * (size_t)li;
-                            const float sq = sqrt_ieee(shader_rand(seed.x, seed.y, a.rv));   // :843-855
-                            const float b0 = 1.0f - sq;
-                            const float b1 = shader_rand(seed.x, seed.y, a.rv) * sq;
-                            const vec3 lp = (V3(Lt[0], Lt[1], Lt[2]) + V3(Lt[3], Lt[4], Lt[5]) * b0) + V3(Lt[6], Lt[7], Lt[8]) * b1;
-                            vec3 ldir = lp - hit_point;
-                            const float len = length(ldir);
-                            const float ilen = rcp_ieee(len);
-                            ldir = ldir * ilen;
-                            const float cos_mtl = dot(ldir, original_n);
-                            const float cos_light = dot(ldir, V3(Lt[9], Lt[10], Lt[11]));
-                            if (cos_mtl > 0.0f && cos_light < 0.0f) {           // :968 (shadow test happens in k_trace<ANY>)
-                                const vec3 le = V3(Lt[12], Lt[13], Lt[14]);
-                                const float pdf_light = __fdiv_rn(len * len, Lt[15] * -cos_light) * Lt[16];
-                                const float bsdf_pdf = __fdiv_rn(dot(ldir, n) * 1.0f, CRT_PI);
-                                const float tt = pdf_light * pdf_light;
-                                const float w = __fdiv_rn(tt, bsdf_pdf * bsdf_pdf + tt);
-                                vec3 c = ((T * le) * albedo) * w;
-                                c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
-                                pb.C[pix] = make_float4(c.x, c.y, c.z, 0.f);
-                                emit_shadow = true;
-                                sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
-                                sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix));
-                            }
-                        }
-                    }
-                    if (!a.last_segment) {
-                        vec3 ou, ov;                                            // path_trace.fs:44-60
-                        if (n.z < -0.9999999f) { ou = V3(0.f, -1.f, 0.f); ov = V3(-1.f, 0.f, 0.f); }
-                        else {
-                            const float aa = rcp_ieee(1.0f + n.z);
-                            const float bb = -n.x * n.y * aa;
-                            ou = V3(1.0f + bb, bb, -n.x);
-                            ov = V3(bb, 1.0f + bb, -n.y);
-                        }
-                        const float u1 = shader_rand(seed.x, seed.y, a.rv);    // :257-270
-                        const float u2 = shader_rand(seed.x, seed.y, a.rv);
-                        const float r = sqrt_ieee(u1);
-                        const float phi = CRT_PI2 * u2;
-                        const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), sqrt_ieee(1.0f - u1));
-                        const vec3 sdir = (ou * dl.x + ov * dl.y) + n * dl.z;
-                        const float bsdf_pdf = __fdiv_rn(dot(sdir, n) * 1.0f, CRT_PI);
-                        T = T * albedo;
-                        pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
-                        pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(0u));
-                        pb.seed[pix] = seed;
-                        emit_next = true;
-                        nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
-                        nx1 = make_float4(sdir.x, sdir.y, sdir.z, __uint_as_float(pix));
-                    }
+                    const float u1 = shader_rand(sx, sy, f.rv);                   // :257-270
+                    const float u2 = shader_rand(sx, sy, f.rv);
+                    const float r = sqrt_ieee(u1);
+                    const float phi = CRT_PI2 * u2;
+                    const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), sqrt_ieee(1.0f - u1));
+                    const vec3 sdir = (ou * dl.x + ov * dl.y) + n * dl.z;
+                    const float bsdf_pdf = __fdiv_rn(dot(sdir, n) * 1.0f, CRT_PI);
+                    T = T * albedo;
+                    a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
+                    a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(0u));
+                    a.pb.seed[pix] = make_float2(sx, sy);
+                    emit_next = true;
+                    finished = false;
+                    nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
+                    nx1 = make_float4(sdir.x, sdir.y, sdir.z, __uint_as_float(pix));
+                } else if (emit_shadow) {
+                    finished = false;                                             // k_shadow finishes this path
                 }
             }
         }
+        // a path that ends here with nothing pending adds its radiance to the running sum now
+        if (finished && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, pix, L);
         const uint32_t si = wave_append(emit_shadow, a.count_shadow);
-        if (emit_shadow) { a.rays_shadow[2 * (size_t)si] = sh0; a.rays_shadow[2 * (size_t)si + 1] = sh1; }
+        if (emit_shadow) {
+            float4* q = a.shadow + 4 * (size_t)si;
+            q[0] = sh0; q[1] = sh1; q[2] = sh2; q[3] = sh3;
+        }
         const uint32_t ni = wave_append(emit_next, a.count_next);
         if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
     }
+    if (STATS) flush_visit_totals(a.visit_totals, nn, nt);
 }
 
-// L += C for every unoccluded shadow ray (path_trace.fs:968-998).
-__global__ void __launch_bounds__(256) k_shadow_resolve(const float4* __restrict__ rays_shadow, const float4* __restrict__ hits,
-                                                        const uint32_t* __restrict__ count, PathBuffers pb) {
-    const uint32_t n = *count;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        if (__float_as_int(hits[e].w) >= 0) continue;
-        const uint32_t pix = __float_as_uint(rays_shadow[2 * (size_t)e + 1].w);
-        const float4 c = pb.C[pix];
-        float4 L = pb.L[pix];
-        L.x += c.x; L.y += c.y; L.z += c.z;
-        pb.L[pix] = L;
+// NEE occlusion test (path_trace.fs:968) fused with its resolve: an unoccluded ray adds its pending
+// contribution C to the path's radiance; if the path ended with this segment the total goes straight
+// into the sum buffer, otherwise into the path state the next segment reads.
+template <bool STATS>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
+    extern __shared__ uint2 s_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2* stk = s_stack + (size_t)wave * a.stack_entries * 64u + lane;
+    const uint32_t n = *a.count;
+    uint32_t nn = 0, nt = 0;
+    for (Schedule sc(n); sc.chunk < sc.n_chunks; sc.chunk += sc.chunk_step) {
+        const uint32_t b = sc.batch();
+        if (b == 0xffffffffu) continue;
+        const uint32_t e = b * 64u + lane;
+        if (e >= n) continue;
+        const float4* q = a.shadow + 4 * (size_t)e;
+        const float4 r0 = q[0], r1 = q[1];
+        HitState hit;
+        const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
+                                                    (int)a.stack_entries, hit, nn, nt);
+        const uint32_t tag = __float_as_uint(r1.w);
+        const uint32_t pix = tag & 0x7fffffffu;
+        if (tag & 0x80000000u) {                             // the path ended with this segment
+            const float4 c = q[2], l = q[3];
+            vec3 L = V3(l.x, l.y, l.z);
+            if (!occluded) L = L + V3(c.x, c.y, c.z);
+            if (L.x != 0.f || L.y != 0.f || L.z != 0.f) add_to_sum(a.sum, pix, L);
+        } else if (!occluded) {
+            const float4 c = q[2];
+            float4 L = a.L[pix];
+            L.x += c.x; L.y += c.y; L.z += c.z;
+            a.L[pix] = L;
+        }
     }
-}
-
-// sum += L (path_trace.fs:1055-1059); sum is the packed tile-major RGB32F buffer.
-__global__ void __launch_bounds__(256) k_accumulate(float* __restrict__ sum, PathBuffers pb, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 L = pb.L[i];
-        float* s = sum + 3 * (size_t)i;
-        s[0] = L.x + s[0];
-        s[1] = L.y + s[1];
-        s[2] = L.z + s[2];
-    }
+    if (STATS) flush_visit_totals(a.visit_totals, nn, nt);
 }
 
 // packed tile-major -> linear frame (bottom row first); pixels of other ranks stay untouched.
@@ -466,54 +533,37 @@ __global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linea
     }
 }
 
-// Sum of the per-ray visit counters of one traversal launch: out[0] += nodes, out[1] += tris.
-__global__ void __launch_bounds__(256) k_reduce_stats(const uint32_t* __restrict__ stats, const uint32_t* __restrict__ count_ptr,
-                                                      uint32_t n_fixed, unsigned long long* __restrict__ out) {
-    const uint32_t n = count_ptr ? *count_ptr : n_fixed;
-    unsigned long long nodes = 0, tris = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t v = stats[i];
-        nodes += v & 0xffffu;
-        tris += v >> 16;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        nodes += __shfl_down(nodes, off);
-        tris += __shfl_down(tris, off);
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        if (nodes) atomicAdd(&out[0], nodes);
-        if (tris) atomicAdd(&out[1], tris);
-    }
-}
-
 // ------------------------------------------------------------------ launchers --------
+
+static inline size_t stack_bytes(uint32_t entries) { return (size_t)(CRT_TRACE_BLOCK / 64) * entries * 64 * sizeof(uint2); }
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const size_t lds = stack_bytes(a.stack_entries);
     if (mode == 1) {
-        if (stats) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, stream, a);
-        else       hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, stream, a);
+        if (stats) hipLaunchKernelGGL((k_trace<true, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_trace<true, false>), g, b, lds, stream, a);
     } else {
-        if (stats) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, stream, a);
-        else       hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, stream, a);
+        if (stats) hipLaunchKernelGGL((k_trace<false, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_trace<false, false>), g, b, lds, stream, a);
     }
 }
-void launch_reduce_stats(const uint32_t* stats, const uint32_t* count_ptr, uint32_t n, unsigned long long* out, uint32_t grid,
-                         hipStream_t stream) {
-    hipLaunchKernelGGL(k_reduce_stats, dim3(grid), dim3(256), 0, stream, stats, count_ptr, n, out);
+void launch_segment(const SegmentArgs& a, bool first, bool stats, uint32_t grid, hipStream_t stream) {
+    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const size_t lds = stack_bytes(a.stack_entries);
+    if (first) {
+        if (stats) hipLaunchKernelGGL((k_segment<true, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_segment<true, false>), g, b, lds, stream, a);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_segment<false, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_segment<false, false>), g, b, lds, stream, a);
+    }
 }
-void launch_raygen(const FrameArgs& f, const PathBuffers& pb, float4* rays, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(256), 0, stream, f, pb, rays);
-}
-void launch_shade(const ShadeArgs& a, const PathBuffers& pb, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, stream, a, pb);
-}
-void launch_shadow_resolve(const float4* rays_shadow, const float4* hits, const uint32_t* count, const PathBuffers& pb,
-                           uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(256), 0, stream, rays_shadow, hits, count, pb);
-}
-void launch_accumulate(float* sum, const PathBuffers& pb, uint32_t n, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, stream, sum, pb, n);
+void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
+    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const size_t lds = stack_bytes(a.stack_entries);
+    if (stats) hipLaunchKernelGGL((k_shadow<true>), g, b, lds, stream, a);
+    else       hipLaunchKernelGGL((k_shadow<false>), g, b, lds, stream, a);
 }
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_untile, dim3(grid), dim3(256), 0, stream, f, packed, linear);

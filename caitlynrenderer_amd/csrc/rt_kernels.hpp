@@ -5,8 +5,8 @@
 
 namespace crt {
 
-// Traversal stack entries per ray, kept in LDS (reference LOCAL_STACK_SIZE, cwbvh.fs:374).
-// crt_scene_create refuses a CWBVH deeper than this.
+// Upper bound of traversal-stack entries per ray, kept in LDS (reference LOCAL_STACK_SIZE, cwbvh.fs:374).
+// crt_scene_create refuses a CWBVH deeper than this; the launch uses min(this, depth of the tree).
 #define CRT_STACK_ENTRIES 16
 #define CRT_TRACE_BLOCK 256
 
@@ -19,13 +19,13 @@ struct TraceArgs {
     const uint32_t* count_ptr; // device-side ray count, or null
     uint32_t n;
     uint32_t out_orig_id;      // 1: hit.tri = original triangle id, 0: CWBVH triangle index
+    uint32_t stack_entries;
 };
 
-struct PathBuffers {           // indexed by local pixel
+struct PathBuffers {           // indexed by local pixel; touched only by paths longer than one segment
     float4* L;                 // radiance so far, prev_pdf
     float4* T;                 // throughput, is_specular
     float2* seed;              // shader RNG state (path_trace.fs:27)
-    float4* C;                 // pending NEE contribution
 };
 
 struct FrameArgs {
@@ -38,30 +38,40 @@ struct FrameArgs {
     float cam_pos[3], cam_right[3], cam_up[3], cam_forward[3];
 };
 
-struct ShadeArgs {
-    const float4* rays_in;
-    const float4* hits;
-    const uint32_t* count_in;
-    float4* rays_next;   uint32_t* count_next;
-    float4* rays_shadow; uint32_t* count_shadow;
+struct SegmentArgs {
+    const uint4* nodes;
     const float4* tris;
     const int4* triangles;     // 3 x int4 per BVH2-ordered triangle (v, vn, vt)
     const float* normals;
     const float4* materials;
     const float* lights;
     int32_t n_lights;
-    float rv;
+    uint32_t stack_entries;
+    FrameArgs f;
+    const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
+    const uint32_t* count_in;
+    float4* rays_next;   uint32_t* count_next;
+    float4* shadow;      uint32_t* count_shadow;   // 4 x float4 per entry: (o,tmax) (d,pixel|final<<31) (C) (L so far)
+    PathBuffers pb;
+    float* sum;                // packed tile-major RGB32F
     uint32_t last_segment;
+    unsigned long long* visit_totals;   // STATS: [0] += nodes, [1] += tris
+};
+
+struct ShadowArgs {
+    const uint4* nodes;
+    const float4* tris;
+    const float4* shadow;
+    const uint32_t* count;
+    float4* L;
+    float* sum;
+    uint32_t stack_entries;
+    unsigned long long* visit_totals;
 };
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
-void launch_reduce_stats(const uint32_t* stats, const uint32_t* count_ptr, uint32_t n, unsigned long long* out, uint32_t grid,
-                         hipStream_t stream);
-void launch_raygen(const FrameArgs& f, const PathBuffers& pb, float4* rays, uint32_t grid, hipStream_t stream);
-void launch_shade(const ShadeArgs& a, const PathBuffers& pb, uint32_t grid, hipStream_t stream);
-void launch_shadow_resolve(const float4* rays_shadow, const float4* hits, const uint32_t* count, const PathBuffers& pb,
-                           uint32_t grid, hipStream_t stream);
-void launch_accumulate(float* sum, const PathBuffers& pb, uint32_t n, uint32_t grid, hipStream_t stream);
+void launch_segment(const SegmentArgs& a, bool first, bool stats, uint32_t grid, hipStream_t stream);
+void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 
