@@ -29,6 +29,10 @@ using crt::fail;
 namespace {
 
 constexpr int kMaxEvents = 8 + 8 * 16;
+constexpr uint32_t kCounterStride = 32;                        // == CRT_COUNTER_STRIDE in rt_kernels.hip (128 B)
+// kind 0 = rays into the segment, 1 = its shadow rays
+constexpr uint32_t kCounters = 2 * 17 * 8 * kCounterStride;    // (segment, kind, group) x stride
+inline uint32_t counter_index(uint32_t seg, uint32_t kind, uint32_t group) { return ((seg * 2 + kind) * 8 + group) * kCounterStride; }
 
 struct EventSpan { hipEvent_t a = nullptr, b = nullptr; int kind = 0; };   // kind: 0 raygen 1 closest 2 any 3 shade/other
 
@@ -83,7 +87,8 @@ struct crt_scene {
     float4* d_shadow = nullptr;               // 4 x float4 per shadow ray: ray, ray, C, L so far
     crt::PathBuffers pb{};
     uint32_t stack_entries = CRT_STACK_ENTRIES;
-    uint32_t* d_counts = nullptr;        // [2 * b] = rays into segment b, [2 * b + 1] = shadow rays of segment b
+    uint32_t sub_capacity = 0;                // entries per sub-queue (8 per queue)
+    uint32_t* d_counts = nullptr;        // counter(seg, kind, group): kind 0 = rays into segment, 1 = its shadow rays
     uint32_t* h_counts = nullptr;        // pinned
     bool frame_buffers_ready = false;
 
@@ -104,6 +109,7 @@ struct crt_scene {
     bool stats_pending = false;
     bool stats_from_frame = false;
     bool stats_counted = false;
+    uint32_t segment_waves = 5;              // register budget of k_segment as waves per SIMD (5, 6 or 8)
     uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
 
     ~crt_scene() {
@@ -193,10 +199,13 @@ int alloc_frame_buffers(crt_scene* s) {
     HIPCHK(hipMemcpy(s->d_tile_xy, s->tiles.data(), s->tiles.size() * sizeof(uint2), hipMemcpyHostToDevice));
     if ((rc = dev_alloc(&s->d_sum, 3 * P))) return rc;
     HIPCHK(hipMemset(s->d_sum, 0, 3 * std::max<size_t>(P, 1) * sizeof(float)));
-    if ((rc = dev_alloc(&s->d_shadow, 4 * P))) return rc;
+    // a workgroup group handles every 8th unit of 4096 pixels/rays, so it can emit at most this many rays per segment
+    s->sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096);
+    const size_t Q = 8 * (size_t)s->sub_capacity;
+    if ((rc = dev_alloc(&s->d_shadow, 4 * Q))) return rc;
     if (s->max_depth > 1) {                      // path state and ray queues exist only for multi-segment paths
-        if ((rc = dev_alloc(&s->d_rays[0], 2 * P))) return rc;
-        if ((rc = dev_alloc(&s->d_rays[1], 2 * P))) return rc;
+        if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
+        if ((rc = dev_alloc(&s->d_rays[1], 2 * Q))) return rc;
         if ((rc = dev_alloc(&s->pb.L, P))) return rc;
         if ((rc = dev_alloc(&s->pb.T, P))) return rc;
         if ((rc = dev_alloc(&s->pb.seed, P))) return rc;
@@ -327,6 +336,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("CRT_SEGMENT_WAVES")) { int v = std::atoi(e); s->segment_waves = v >= 8 ? 8u : v >= 6 ? 6u : 5u; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
     s->stack_entries = std::min<uint32_t>(CRT_STACK_ENTRIES, std::max<uint32_t>(2, depth8));
@@ -364,8 +374,8 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     UP(s->d_materials, reinterpret_cast<const float4*>(d->materials), d->n_materials * 4, float4);
     UP(s->d_lights, reinterpret_cast<const float*>(d->lights), d->n_lights * 18, float);
 #undef UP
-    if ((rc = dev_alloc(&s->d_counts, 2 * 17))) return bail(rc);
-    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), 2 * 17 * sizeof(uint32_t)) != hipSuccess)
+    if ((rc = dev_alloc(&s->d_counts, kCounters))) return bail(rc);
+    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
         return bail(fail(CRT_ERR_NOMEM, "hipHostMalloc failed"));
     s->spans.resize(kMaxEvents);
     for (EventSpan& sp : s->spans)
@@ -417,6 +427,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
+    else if (!std::strcmp(name, "segment_waves")) s->segment_waves = value >= 8 ? 8u : value >= 6 ? 6u : 5u;
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;
 }
@@ -439,7 +450,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         }
         HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 4 * sizeof(unsigned long long), s->stream));
     }
-    HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * 17 * sizeof(uint32_t), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_counts, 0, kCounters * sizeof(uint32_t), s->stream));
 
     for (uint32_t b = 0; b < s->max_depth; ++b) {
         crt::SegmentArgs sa{};
@@ -447,25 +458,25 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.materials = s->d_materials; sa.lights = s->d_lights; sa.n_lights = (int32_t)s->n_lights;
         sa.stack_entries = s->stack_entries;
         sa.f = f;
-        sa.rays_in = s->d_rays[b & 1]; sa.count_in = s->d_counts + 2 * b;
-        sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = s->d_counts + 2 * (b + 1);
-        sa.shadow = s->d_shadow; sa.count_shadow = s->d_counts + 2 * b + 1;
+        sa.sub_capacity = s->sub_capacity;
+        sa.rays_in = s->d_rays[b & 1]; sa.count_in = s->d_counts + counter_index(b, 0, 0);
+        sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = s->d_counts + counter_index(b + 1, 0, 0);
+        sa.shadow = s->d_shadow; sa.count_shadow = s->d_counts + counter_index(b, 1, 0);
         sa.pb = s->pb; sa.sum = s->d_sum;
         sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
         sa.visit_totals = s->d_visit_totals;
         EventSpan* sp = s->begin_span(1);
-        crt::launch_segment(sa, b == 0, s->count_visits, s->trace_grid(P, 5), s->stream);
+        crt::launch_segment(sa, b == 0, s->count_visits, (int)s->segment_waves, s->trace_grid(P, s->count_visits ? 6 : s->segment_waves), s->stream);
         s->end_span(sp);
 
         crt::ShadowArgs sh{};
-        sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = s->d_counts + 2 * b + 1;
-        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries;
+        sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = s->d_counts + counter_index(b, 1, 0);
+        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sp = s->begin_span(2);
         crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->stream);
         s->end_span(sp);
     }
-    HIPCHK(hipMemcpyAsync(s->h_counts, s->d_counts, 2 * 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     if (s->count_visits)
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     s->stats_counted = s->count_visits;
@@ -495,12 +506,15 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
     if (s->stats_pending) {
         HIPCHK(hipStreamSynchronize(s->stream));
         if (s->stats_from_frame) {
+            // the queue counters stay valid until the next frame's memset: fetch them only when asked
+            HIPCHK(hipMemcpy(s->h_counts, s->d_counts, kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
             uint64_t closest = 0, any = 0;
             closest = s->n_local_in_frame;             // segment 0: one primary ray per in-frame pixel
-            for (uint32_t b = 0; b < s->max_depth; ++b) {
-                if (b) closest += s->h_counts[2 * b];
-                any += s->h_counts[2 * b + 1];
-            }
+            for (uint32_t b = 0; b < s->max_depth; ++b)
+                for (uint32_t g = 0; g < 8; ++g) {
+                    if (b) closest += s->h_counts[counter_index(b, 0, g)];
+                    any += s->h_counts[counter_index(b, 1, g)];
+                }
             s->stats.closest_rays = closest; s->stats.any_rays = any;
         }
         int rc = collect_stats(s);
@@ -594,18 +608,25 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (!s->frame_buffers_ready || segment > 16) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: no frame rendered");
-    uint32_t counts[2 * 17];
-    HIPCHK(hipMemcpy(counts, s->d_counts, sizeof counts, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> counts(kCounters);
+    HIPCHK(hipMemcpy(counts.data(), s->d_counts, kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const float4* src = which == 2 ? s->d_shadow : s->d_rays[segment & 1];
-    size_t n = which == 2 ? counts[2 * segment + 1] : counts[2 * segment];
-    *n_out = n;
+    const size_t entry = which == 2 ? 4 * sizeof(float4) : sizeof(crt_ray);
+    size_t total = 0;
+    for (uint32_t g = 0; g < 8; ++g) total += counts[counter_index(segment, which == 2 ? 1 : 0, g)];
+    *n_out = total;
     if (dst) {
-        if (n > cap) n = cap;
         if (!src) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: that queue does not exist at max_depth 1");
-        if (which == 2)    // shadow entries are 64 B (ray, ray, C, L): copy the leading crt_ray of each
-            HIPCHK(hipMemcpy2D(dst, sizeof(crt_ray), src, 4 * sizeof(float4), sizeof(crt_ray), n, hipMemcpyDeviceToHost));
-        else
-            HIPCHK(hipMemcpy(dst, src, n * sizeof(crt_ray), hipMemcpyDeviceToHost));
+        size_t done = 0;
+        for (uint32_t g = 0; g < 8 && done < cap; ++g) {
+            size_t n = counts[counter_index(segment, which == 2 ? 1 : 0, g)];
+            n = std::min(n, cap - done);
+            if (!n) continue;
+            const char* from = reinterpret_cast<const char*>(src) + (size_t)g * s->sub_capacity * entry;
+            // shadow entries are 64 B (ray, ray, C, L): copy the leading crt_ray of each
+            HIPCHK(hipMemcpy2D(dst + done, sizeof(crt_ray), from, entry, sizeof(crt_ray), n, hipMemcpyDeviceToHost));
+            done += n;
+        }
     }
     return CRT_OK;
 }

@@ -179,31 +179,47 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
 
 // ------------------------------------------------------------------ scheduling -------
 
-// Static, XCD-aware batch schedule shared by all persistent kernels.  Work is cut into 64-ray batches
-// (one wave, one 8x8 pixel block for primary rays); 64 consecutive batches form a unit (one 64x64
-// tile).  Workgroups are dealt round-robin to the 8 XCDs by the dispatcher (blockIdx & 7 labels the
-// group that shares an L2; a performance heuristic only), so unit u is given to group u & 7: each L2
-// then sees the geometry behind 1/8 of the tiles instead of all of it.  Inside a group, a workgroup
-// takes 4 neighbouring batches at a time (one per wave) so its L1 sees one 16x16-pixel patch.
-struct Schedule {
-    uint32_t nb, xcd, chunk, chunk_step, n_chunks, wave;
-    __device__ __forceinline__ Schedule(uint32_t n_items) {
-        nb = (n_items + 63u) >> 6;
-        xcd = blockIdx.x & 7u;
-        chunk = blockIdx.x >> 3;
-        chunk_step = gridDim.x >> 3;          // the host launches a multiple of 8 workgroups
-        const uint32_t n_units = (nb + 63u) >> 6;
-        const uint32_t units_x = n_units > xcd ? (n_units - xcd + 7u) >> 3 : 0u;
-        n_chunks = units_x * 16u;
-        wave = threadIdx.x >> 6;
-    }
-    // batch index of this wave for the current chunk, or 0xffffffff when past the end (wave-uniform)
-    __device__ __forceinline__ uint32_t batch() const {
-        const uint32_t unit = (chunk >> 4) * 8u + xcd;
-        const uint32_t b = unit * 64u + (chunk & 15u) * 4u + wave;
-        return b < nb ? b : 0xffffffffu;
-    }
-};
+// Static, XCD-aware work distribution shared by all persistent kernels.
+//
+// Work is cut into 64-ray batches (one wave; one 8x8 pixel block for primary rays) and chunks of 4
+// batches (one workgroup pass, a 16x16 pixel patch).  Every chunk belongs to one of 8 *groups*:
+//   - dense index spaces (pixels, explicit ray buffers): 64 consecutive batches form a unit (one 64x64
+//     tile) and unit u belongs to group u & 7;
+//   - device-written queues (path rays, shadow rays) are 8 sub-queues, one per group: a group appends to
+//     and later consumes its own sub-queue, so a ray stays with the group (and normally the L2) that
+//     already holds its neighbourhood, and the append atomics are spread over 8 counters on separate
+//     cache lines (a single counter saturates near 90 returning atomics per microsecond: at one atomic
+//     per 64-ray wave that capped a whole 1080p frame at ~0.18 ms; measured 0.183 -> 0.074 ms).
+// Workgroups are dealt round-robin to the 8 XCDs by the dispatcher, so blockIdx & 7 labels workgroups
+// that share an L2 (a speed heuristic only; correctness never depends on placement).  Workgroup j of a
+// group takes that group's chunks j, j + groups_size, ...  A dynamic variant (one returning atomic per
+// chunk on a per-group counter, stealing from other groups when drained) was measured and dropped: equal
+// on the 1 M-triangle scenes (0.404 vs 0.396 ms) and 1.8x slower on Cornell (0.132 vs 0.074 ms), where the
+// per-chunk atomic + two barriers sit on the critical path of very short rays.
+#define CRT_COUNTER_STRIDE 32u   // uint32 slots between two per-group counters (128 B)
+#define CRT_NO_WORK 0xffffffffu
+
+__device__ __forceinline__ uint32_t dense_chunks_of_group(uint32_t n_items, uint32_t g) {
+    const uint32_t n_units = (((n_items + 63u) >> 6) + 63u) >> 6;
+    return n_units > g ? ((n_units - g + 7u) >> 3) * 16u : 0u;
+}
+__device__ __forceinline__ uint32_t queue_chunks(uint32_t n) { return (((n + 63u) >> 6) + 3u) >> 2; }
+
+// (group << 28 | chunk) for iteration `it` of this workgroup, or CRT_NO_WORK; uniform over the workgroup.
+template <bool DENSE>
+__device__ __forceinline__ uint32_t static_chunk(const uint32_t* counts, uint32_t n_dense, uint32_t it) {
+    const uint32_t g = blockIdx.x & 7u;
+    const uint32_t nch = DENSE ? dense_chunks_of_group(n_dense, g) : queue_chunks(counts[g * CRT_COUNTER_STRIDE]);
+    const uint32_t c = (blockIdx.x >> 3) + it * (gridDim.x >> 3);     // the host launches a multiple of 8 workgroups
+    return c < nch ? (g << 28) | c : CRT_NO_WORK;
+}
+
+// index of this lane's item for a dense chunk (>= n_items when past the end)
+__device__ __forceinline__ uint32_t dense_item(uint32_t v, uint32_t wave, uint32_t lane) {
+    const uint32_t g = v >> 28, c = v & 0x0fffffffu;
+    const uint32_t unit = (c >> 4) * 8u + g;
+    return (unit * 64u + (c & 15u) * 4u + wave) * 64u + lane;
+}
 
 __device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, uint32_t nn, uint32_t nt) {
     unsigned long long a = nn, b = nt;
@@ -220,14 +236,14 @@ __device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, u
 // Persistent-threads trace kernel over an explicit ray buffer (crt_trace / crt_trace_device).
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
-    extern __shared__ uint2 s_stack[];   // [wave][level][lane]
+    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = s_stack + (size_t)wave * a.stack_entries * 64u + lane;
+    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
     const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
-    for (Schedule sc(n); sc.chunk < sc.n_chunks; sc.chunk += sc.chunk_step) {
-        const uint32_t b = sc.batch();
-        if (b == 0xffffffffu) continue;
-        const uint32_t i = b * 64u + lane;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t v = static_chunk<true>(nullptr, n, it);
+        if (v == CRT_NO_WORK) break;
+        const uint32_t i = dense_item(v, wave, lane);
         if (i >= n) continue;
         const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
         HitState best;
@@ -287,18 +303,29 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
 // wave-ballot compaction.  Nothing but the two output queues (and, for paths that go on, 40 B of path
 // state) touches HBM; a path that ends here adds its radiance to the sum buffer directly.
-template <bool FIRST, bool STATS>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_segment(SegmentArgs a) {
-    extern __shared__ uint2 s_stack[];
+template <bool FIRST, bool STATS, int WAVES>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, WAVES) k_segment(SegmentArgs a) {
+    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = s_stack + (size_t)wave * a.stack_entries * 64u + lane;
+    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
     const FrameArgs& f = a.f;
-    const uint32_t n = FIRST ? f.n_local_pixels : *a.count_in;
     uint32_t nn = 0, nt = 0;
-    for (Schedule sc(n); sc.chunk < sc.n_chunks; sc.chunk += sc.chunk_step) {
-        const uint32_t b = sc.batch();
-        if (b == 0xffffffffu) continue;                     // wave-uniform
-        const uint32_t e = b * 64u + lane;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t v = static_chunk<FIRST>(a.count_in, f.n_local_pixels, it);
+        if (v == CRT_NO_WORK) break;
+        const uint32_t g = v >> 28;                         // owner group of this chunk: its sub-queues get the output
+        uint32_t* const count_shadow = a.count_shadow + g * CRT_COUNTER_STRIDE;
+        uint32_t* const count_next = a.count_next + g * CRT_COUNTER_STRIDE;
+        float4* const shadow_q = a.shadow + 4 * (size_t)g * a.sub_capacity;
+        float4* const next_q = a.rays_next + 2 * (size_t)g * a.sub_capacity;
+        uint32_t e, n;
+        if (FIRST) {
+            e = dense_item(v, wave, lane);
+            n = f.n_local_pixels;
+        } else {
+            e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
+            n = a.count_in[g * CRT_COUNTER_STRIDE];
+        }
         bool active = e < n;
         uint32_t pix = 0;
         vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
@@ -331,7 +358,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_segment(SegmentArgs a) {
             d = normalize((right * dx + up * dy) + fwd);
             o = V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         } else if (active) {
-            const float4 r0 = a.rays_in[2 * (size_t)e], r1 = a.rays_in[2 * (size_t)e + 1];
+            const float4* rq = a.rays_in + 2 * ((size_t)g * a.sub_capacity + e);
+            const float4 r0 = rq[0], r1 = rq[1];
             o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z);
             pix = __float_as_uint(r1.w);
             const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
@@ -450,13 +478,13 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_segment(SegmentArgs a) {
         }
         // a path that ends here with nothing pending adds its radiance to the running sum now
         if (finished && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, pix, L);
-        const uint32_t si = wave_append(emit_shadow, a.count_shadow);
+        const uint32_t si = wave_append(emit_shadow, count_shadow);
         if (emit_shadow) {
-            float4* q = a.shadow + 4 * (size_t)si;
+            float4* q = shadow_q + 4 * (size_t)si;
             q[0] = sh0; q[1] = sh1; q[2] = sh2; q[3] = sh3;
         }
-        const uint32_t ni = wave_append(emit_next, a.count_next);
-        if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
+        const uint32_t ni = wave_append(emit_next, count_next);
+        if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
     }
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt);
 }
@@ -466,17 +494,17 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_segment(SegmentArgs a) {
 // into the sum buffer, otherwise into the path state the next segment reads.
 template <bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
-    extern __shared__ uint2 s_stack[];
+    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = s_stack + (size_t)wave * a.stack_entries * 64u + lane;
-    const uint32_t n = *a.count;
+    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
     uint32_t nn = 0, nt = 0;
-    for (Schedule sc(n); sc.chunk < sc.n_chunks; sc.chunk += sc.chunk_step) {
-        const uint32_t b = sc.batch();
-        if (b == 0xffffffffu) continue;
-        const uint32_t e = b * 64u + lane;
-        if (e >= n) continue;
-        const float4* q = a.shadow + 4 * (size_t)e;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t v = static_chunk<false>(a.count, 0u, it);
+        if (v == CRT_NO_WORK) break;
+        const uint32_t g = v >> 28;
+        const uint32_t e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
+        if (e >= a.count[g * CRT_COUNTER_STRIDE]) continue;
+        const float4* q = a.shadow + 4 * ((size_t)g * a.sub_capacity + e);
         const float4 r0 = q[0], r1 = q[1];
         HitState hit;
         const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
@@ -548,15 +576,23 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipSt
         else       hipLaunchKernelGGL((k_trace<false, false>), g, b, lds, stream, a);
     }
 }
-void launch_segment(const SegmentArgs& a, bool first, bool stats, uint32_t grid, hipStream_t stream) {
+// waves = registers-per-lane budget expressed as resident waves per SIMD (5: ~96 VGPRs, 6: 80, 8: 64 with
+// a few spills outside the traversal loop); the counting variants exist only at 6.
+void launch_segment(const SegmentArgs& a, bool first, bool stats, int waves, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);
     const size_t lds = stack_bytes(a.stack_entries);
-    if (first) {
-        if (stats) hipLaunchKernelGGL((k_segment<true, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_segment<true, false>), g, b, lds, stream, a);
+    if (stats) {
+        if (first) hipLaunchKernelGGL((k_segment<true, true, 6>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_segment<false, true, 6>), g, b, lds, stream, a);
+    } else if (waves >= 8) {
+        if (first) hipLaunchKernelGGL((k_segment<true, false, 8>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_segment<false, false, 8>), g, b, lds, stream, a);
+    } else if (waves >= 6) {
+        if (first) hipLaunchKernelGGL((k_segment<true, false, 6>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_segment<false, false, 6>), g, b, lds, stream, a);
     } else {
-        if (stats) hipLaunchKernelGGL((k_segment<false, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_segment<false, false>), g, b, lds, stream, a);
+        if (first) hipLaunchKernelGGL((k_segment<true, false, 5>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_segment<false, false, 5>), g, b, lds, stream, a);
     }
 }
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream) {

@@ -48,8 +48,9 @@ struct SegmentArgs {
     int32_t n_lights;
     uint32_t stack_entries;
     FrameArgs f;
+    uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
-    const uint32_t* count_in;
+    const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart
     float4* rays_next;   uint32_t* count_next;
     float4* shadow;      uint32_t* count_shadow;   // 4 x float4 per entry: (o,tmax) (d,pixel|final<<31) (C) (L so far)
     PathBuffers pb;
@@ -66,11 +67,12 @@ struct ShadowArgs {
     float4* L;
     float* sum;
     uint32_t stack_entries;
+    uint32_t sub_capacity;
     unsigned long long* visit_totals;
 };
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
-void launch_segment(const SegmentArgs& a, bool first, bool stats, uint32_t grid, hipStream_t stream);
+void launch_segment(const SegmentArgs& a, bool first, bool stats, int waves, uint32_t grid, hipStream_t stream);
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
