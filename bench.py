@@ -8,8 +8,8 @@ One step = one pass of the hot path over one batch: one sample per pixel of this
 resident in HBM.  Default workload = BASELINE.json configs[1]: Cornell box, CWBVH, 1 spp,
 primary + shadow, 1920x1080 on one GPU.  N > 1 (launched by torch.distributed.run, one rank per
 GPU, RCCL) shards framebuffer tiles over the ranks with no data-path collective (weak scaling: the
-frame grows with N so every rank keeps ~1920x1080 pixels) and gathers the per-tile radiance once,
-inside the timed region, at read-back.
+frame grows with N so every rank keeps ~1920x1080 pixels) and gathers the per-tile radiance to rank 0
+once, inside the timed region, at read-back.
 
 Prints ONE JSON line on rank 0 with the driver's keys plus "roofline" (dominant kernel = the
 closest-hit traversal: algorithmic bytes of SURVEY §8d / hipEvent launch time on the kernel's own
@@ -81,7 +81,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the traversal path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also at N = 1: same code path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -110,21 +111,25 @@ def main():
     scene.reset()
 
     _, tile, n_floats = scene.packed_info()
-    gather_buf = torch.empty(tiles.max_local_tiles(W, H, tile, world) * tile * tile * 3, dtype=torch.float32, device="cuda")
-    recv = torch.empty(world * gather_buf.numel(), dtype=torch.float32, device="cuda") if world > 1 else None
+    gather_buf = torch.zeros(tiles.max_local_tiles(W, H, tile, world) * tile * tile * 3, dtype=torch.float32, device="cuda")
+    recv = torch.empty(world * gather_buf.numel(), dtype=torch.float32, device="cuda") if (use_dist and rank == 0) else None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         scene.sync()
 
+    def read_back():
+        """RCCL gather over xGMI of the per-tile radiance to rank 0 (at read-back only)."""
+        scene.copy_packed_device(gather_buf.data_ptr(), n_floats)
+        tiles.gather_packed_to_root(gather_buf, recv, world)
+
     for i in range(args.warmup):
         scene.render_frame(*rvs[1 + i], sync=False)
     scene.sync()
-    if world > 1:   # warm the collective too
-        scene.copy_packed_device(gather_buf.data_ptr(), n_floats)
-        dist.all_gather_into_tensor(recv, gather_buf)
+    if use_dist:    # warm the collective too
+        read_back()
     barrier()
     t0 = time.perf_counter()
     trace_ms = []
@@ -132,12 +137,11 @@ def main():
     for i in range(args.steps):
         scene.render_frame(*rvs[1 + args.warmup + i], sync=False)
     scene.sync()
-    if world > 1:   # read-back: RCCL all-gather of the packed per-tile radiance over xGMI
-        scene.copy_packed_device(gather_buf.data_ptr(), n_floats)
-        dist.all_gather_into_tensor(recv, gather_buf)
+    if use_dist:
+        read_back()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -153,7 +157,7 @@ def main():
         any_ms.append(s["ms_trace_any"] / max(1, args.depth))
         total_ms.append(s["ms_total"])
     rays_step = st["closest_rays"] + st["any_rays"]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([float(rays_step)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         rays_all = float(t.item())
@@ -181,8 +185,8 @@ def main():
             "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": 1, "path_segments": args.depth,
                        "rays_per_step": int(rays_all), "closest_rays_rank0": int(st["closest_rays"]),
                        "any_rays_rank0": int(st["any_rays"]), "tile": tile, "parallelism": f"tiles/{world}",
-                       "gather": "one RCCL all-gather of packed tiles per timed region" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                       "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
+            "roofline": {"bound": "hbm", "kernel": "k_segment (raygen|queue fetch + CWBVH closest hit + shading + queue emission)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_closest),
                          "bytes_per_ray": round(alg_closest / max(1, cs["closest_rays"] / launches), 2),
@@ -197,7 +201,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(data, cam, W, H, args.depth, rvs[0], cs)
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

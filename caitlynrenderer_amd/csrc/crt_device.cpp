@@ -109,6 +109,7 @@ struct crt_scene {
     bool stats_pending = false;
     bool stats_from_frame = false;
     bool stats_counted = false;
+    uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
     uint32_t segment_waves = 5;              // register budget of k_segment as waves per SIMD (5, 6 or 8)
     uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
 
@@ -336,6 +337,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("CRT_SEGMENT_WAVES")) { int v = std::atoi(e); s->segment_waves = v >= 8 ? 8u : v >= 6 ? 6u : 5u; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
@@ -427,6 +429,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
+    else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else if (!std::strcmp(name, "segment_waves")) s->segment_waves = value >= 8 ? 8u : value >= 6 ? 6u : 5u;
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;
@@ -471,7 +474,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
 
         crt::ShadowArgs sh{};
         sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = s->d_counts + counter_index(b, 1, 0);
-        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity;
+        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sp = s->begin_span(2);
         crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->stream);
@@ -642,6 +645,7 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     ta.rays = static_cast<const float4*>(d_rays); ta.hits = static_cast<float4*>(d_hits);
     ta.stats = static_cast<uint32_t*>(d_stats); ta.count_ptr = nullptr; ta.n = (uint32_t)n; ta.out_orig_id = 1;
     ta.stack_entries = s->stack_entries;
+    ta.refill_min = s->refill_min;
     s->n_spans = 0;
     EventSpan* sp = s->begin_span(mode == CRT_TRACE_ANY ? 2 : 1);
     crt::launch_trace(ta, mode, d_stats != nullptr, s->trace_grid(n, 8), s->stream);

@@ -177,6 +177,123 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
     return best.tri >= 0;
 }
 
+// Wave-level traversal of a POOL of rays with lane refill (persistent threads in the sense of Aila & Laine):
+// a lane whose ray has finished immediately takes the next ray of the wave's pool instead of idling until
+// the slowest ray of its 64-ray batch is done.  Incoherent rays (bounces, shadow rays) ran at 21 % VALU lane
+// utilisation in lock-step batches; per-ray work and its order are unchanged, so hits and visit counters stay
+// bit-identical to the oracle.
+//   load(idx, o, d, tmax)  fetches ray idx of the pool;  done(idx, best, occluded)  consumes its result.
+// The pool is [pool_begin, pool_end); refill happens when at least `refill_min` lanes are idle (or none is busy).
+template <bool ANY, bool STATS, typename Load, typename Done>
+__device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* stk,
+                                              int stack_entries, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
+                                              Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t next = pool_begin;                     // wave-uniform
+    bool busy = false;
+    uint32_t idx = 0;
+    vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
+    bool negx = false, negy = false, negz = false;
+    uint32_t oct4 = 0;
+    float max_t = 0.f;
+    HitState best;
+    best.t = 0.f; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
+    int sp = 0;
+    uint2 cur = make_uint2(0u, 0u);
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (next < pool_end && (n_idle >= refill_min || n_idle == 64u)) {
+            const uint32_t mine = next + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+            if (!busy && mine < pool_end) {
+                idx = mine;
+                float tmax_in;
+                load(idx, o, d, tmax_in);
+                best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
+                max_t = tmax_in;
+                sp = 0;
+                busy = true;
+                // same prologue as traverse(): non-finite origin -> immediate miss; clamp zero direction components
+                const bool finite = __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z);
+                const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+                negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
+                oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+                inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+                cur = finite ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
+            }
+            next = next + n_idle < pool_end ? next + n_idle : pool_end;
+        }
+        if (__ballot(busy) == 0ull) break;          // pool drained and every lane finished
+
+        // ---- node step.  (A wave-level dedup of the node loads — one leader lane per distinct node, followers fed
+        // by ds_bpermute — was measured and dropped: 0.469 vs 0.394 ms on coherent primary rays, 0.509 vs 0.434 ms
+        // on bounce rays; the kernel is bound by VALU issue, not by the texture-address unit.)
+        bool finished = false;
+        uint2 tg = make_uint2(0u, 0u);
+        const bool want_node = busy && (cur.y & 0xff000000u);
+        uint32_t nidx = 0u;
+        if (want_node) {
+            const uint32_t hits_imask = cur.y;
+            const int off = 31 - __builtin_clz(hits_imask);
+            const uint32_t base = cur.x;
+            cur.y &= ~(1u << off);
+            if (cur.y & 0xff000000u) {
+                if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; }
+            }
+            const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+            nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+        } else if (busy) {
+            tg = cur;
+            cur = make_uint2(0u, 0u);
+        }
+        uint4 n0, n1, n2, n3, n4;
+        n0 = n1 = n2 = n3 = n4 = make_uint4(0u, 0u, 0u, 0u);
+        if (want_node) {
+            const uint4* np = nodes + (size_t)nidx * 5;
+            n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+        }
+        if (want_node) {
+            if (STATS) ++n_nodes;
+            const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
+            cur.x = n1.x;
+            tg.x = n1.y;
+            cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+            tg.y = hitmask & 0x00ffffffu;
+        }
+        // ---- triangle steps for the lanes that have leaf hits
+        if (busy) {
+            while (tg.y) {
+                const int b = 31 - __builtin_clz(tg.y);
+                tg.y &= ~(1u << b);
+                const uint32_t ti = tg.x + (uint32_t)b;
+                const float4* tp = tris + (size_t)ti * 3;
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                if (STATS) ++n_tris;
+                float u, v, t;
+                if (mt_test(ta, tb, tc, o, d, u, v, t)) {
+                    if (ANY) {
+                        if (t < max_t) { best.tri = (int)ti; finished = true; tg.y = 0u; }
+                    } else {
+                        const int id = __float_as_int(ta.w);
+                        if (t < best.t || (t == best.t && best.tri >= 0 && id < best.id)) {
+                            best.t = t; best.u = u; best.v = v; best.tri = (int)ti; best.id = id;
+                            max_t = t;
+                        }
+                    }
+                }
+            }
+            if (!finished && !(cur.y & 0xff000000u)) {
+                if (sp == 0) finished = true;
+                else { --sp; cur = stk[sp * 64]; }
+            }
+            if (finished) {
+                done(idx, best, best.tri >= 0);
+                busy = false;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ scheduling -------
 
 // Static, XCD-aware work distribution shared by all persistent kernels.
@@ -214,6 +331,26 @@ __device__ __forceinline__ uint32_t static_chunk(const uint32_t* counts, uint32_
     return c < nch ? (g << 28) | c : CRT_NO_WORK;
 }
 
+// Pool-based kernels: a workgroup chunk is 1024 items, 256 consecutive items per wave (its refill pool).
+__device__ __forceinline__ uint32_t dense_pool_chunks_of_group(uint32_t n_items, uint32_t g) {
+    const uint32_t n_units = (n_items + 4095u) >> 12;
+    return n_units > g ? ((n_units - g + 7u) >> 3) * 4u : 0u;
+}
+__device__ __forceinline__ uint32_t queue_pool_chunks(uint32_t n) { return (n + 1023u) >> 10; }
+template <bool DENSE>
+__device__ __forceinline__ uint32_t static_pool_chunk(const uint32_t* counts, uint32_t n_dense, uint32_t it) {
+    const uint32_t g = blockIdx.x & 7u;
+    const uint32_t nch = DENSE ? dense_pool_chunks_of_group(n_dense, g) : queue_pool_chunks(counts[g * CRT_COUNTER_STRIDE]);
+    const uint32_t c = (blockIdx.x >> 3) + it * (gridDim.x >> 3);
+    return c < nch ? (g << 28) | c : CRT_NO_WORK;
+}
+// first item of this wave's pool for a dense pool chunk
+__device__ __forceinline__ uint32_t dense_pool_first(uint32_t v, uint32_t wave) {
+    const uint32_t g = v >> 28, c = v & 0x0fffffffu;
+    const uint32_t unit = (c >> 2) * 8u + g;
+    return unit * 4096u + (c & 3u) * 1024u + wave * 256u;
+}
+
 // index of this lane's item for a dense chunk (>= n_items when past the end)
 __device__ __forceinline__ uint32_t dense_item(uint32_t v, uint32_t wave, uint32_t lane) {
     const uint32_t g = v >> 28, c = v & 0x0fffffffu;
@@ -240,27 +377,40 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
     const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
+    uint32_t nn_total = 0, nt_total = 0;
     for (uint32_t it = 0;; ++it) {
-        const uint32_t v = static_chunk<true>(nullptr, n, it);
+        const uint32_t v = static_pool_chunk<true>(nullptr, n, it);
         if (v == CRT_NO_WORK) break;
-        const uint32_t i = dense_item(v, wave, lane);
-        if (i >= n) continue;
-        const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
-        HitState best;
+        const uint32_t first = dense_pool_first(v, wave);
+        if (first >= n) continue;
+        const uint32_t last = first + 256u < n ? first + 256u : n;
         uint32_t nn = 0, nt = 0;
-        traverse<ANY, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk, (int)a.stack_entries,
-                             best, nn, nt);
-        float4 h;
-        h.x = ANY ? 0.f : (best.tri >= 0 ? best.t : 0.f);
-        h.y = ANY ? 0.f : best.u;
-        h.z = ANY ? 0.f : best.v;
-        int out = best.tri;
-        if (ANY) out = best.tri >= 0 ? 0 : -1;
-        else if (a.out_orig_id) out = best.tri >= 0 ? best.id : -1;
-        h.w = __int_as_float(out);
-        a.hits[i] = h;
-        if (STATS) a.stats[i] = ((nt > 65535u ? 65535u : nt) << 16) | (nn > 65535u ? 65535u : nn);
+        // per-ray counters need the count of ONE ray: sample the running totals at load and at completion
+        uint32_t nn0 = 0, nt0 = 0;
+        auto load = [&](uint32_t i, vec3& o, vec3& d, float& tmax) {
+                const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
+                o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
+                nn0 = nn; nt0 = nt;
+            };
+        auto done = [&](uint32_t i, const HitState& best, bool hit) {
+                float4 h;
+                h.x = ANY ? 0.f : (hit ? best.t : 0.f);
+                h.y = ANY ? 0.f : best.u;
+                h.z = ANY ? 0.f : best.v;
+                int out = best.tri;
+                if (ANY) out = hit ? 0 : -1;
+                else if (a.out_orig_id) out = hit ? best.id : -1;
+                h.w = __int_as_float(out);
+                a.hits[i] = h;
+                if (STATS) {
+                    const uint32_t dn = nn - nn0, dt = nt - nt0;
+                    a.stats[i] = ((dt > 65535u ? 65535u : dt) << 16) | (dn > 65535u ? 65535u : dn);
+                }
+            };
+        traverse_pool<ANY, STATS>(a.nodes, a.tris, stk, (int)a.stack_entries, first, last, a.refill_min, load, done, nn, nt);
+        nn_total += nn; nt_total += nt;
     }
+    (void)nn_total; (void)nt_total; (void)lane;
 }
 
 // ------------------------------------------------------------------ queue helpers ----
@@ -491,7 +641,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, WAVES) k_segment(SegmentArgs 
 
 // NEE occlusion test (path_trace.fs:968) fused with its resolve: an unoccluded ray adds its pending
 // contribution C to the path's radiance; if the path ended with this segment the total goes straight
-// into the sum buffer, otherwise into the path state the next segment reads.
+// into the sum buffer, otherwise into the path state the next segment reads.  Lock-step 64-ray batches:
+// any-hit rays are short and neighbouring pixels aim at the same light, so lane refill costs more than
+// it recovers here (measured 0.235 vs 0.180 ms at 1 M triangles).
 template <bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]

@@ -20,6 +20,7 @@ struct TraceArgs {
     uint32_t n;
     uint32_t out_orig_id;      // 1: hit.tri = original triangle id, 0: CWBVH triangle index
     uint32_t stack_entries;
+    uint32_t refill_min;       // idle lanes that trigger a pool refill (traverse_pool)
 };
 
 struct PathBuffers {           // indexed by local pixel; touched only by paths longer than one segment
@@ -68,6 +69,7 @@ struct ShadowArgs {
     float* sum;
     uint32_t stack_entries;
     uint32_t sub_capacity;
+    uint32_t refill_min;
     unsigned long long* visit_totals;
 };
 

@@ -75,3 +75,26 @@ def gather_frame(local_packed, width, height, tile, rank, world, group=None):
         tl = local_tiles(width, height, tile, r, world)
         untile_into(frame, host[r][: len(tl) * tile * tile * 3], tl, tile)
     return frame
+
+
+def gather_packed_to_root(local_packed, recv, world, group=None, dst=0):
+    """Read-back collective of bench.py: every rank sends its (padded) packed tile buffer to rank `dst`
+    (RCCL grouped send/recv: each peer's slice crosses its own xGMI link once).  `recv` is a
+    (world * local_packed.numel()) tensor on the root, ignored elsewhere."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    if rank == dst:
+        parts = list(recv.view(world, -1).unbind(0))
+        dist.gather(local_packed, parts, dst=dst, group=group)
+    else:
+        dist.gather(local_packed, None, dst=dst, group=group)
+
+
+def untile_gathered(recv_host, width, height, tile, world):
+    """Root side: (world, cap) packed buffers -> (H, W, 3) frame."""
+    frame = np.zeros((height, width, 3), np.float32)
+    cap = recv_host.shape[1]
+    for r in range(world):
+        tl = local_tiles(width, height, tile, r, world)
+        untile_into(frame, recv_host[r][: len(tl) * tile * tile * 3], tl, tile)
+    return frame

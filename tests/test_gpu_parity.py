@@ -226,3 +226,48 @@ def test_device_resident_trace_and_torch_interop(cr, ob, cornell, scenes):
     got = d_hits.cpu().numpy().view(cr.HIT_DT).ravel()
     _assert_hits_equal(got, scene.trace(rays))
     assert scene.frame_stats()["ms_trace_closest"] > 0
+
+
+def _shard_worker(rank, world, port, W, H, T, out_dir):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import caitlynrenderer_amd as cr
+    from caitlynrenderer_amd import tiles
+    import __graft_entry__ as g
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)                       # both ranks share the one GPU of the test box
+    mesh, cam = g._cornell()
+    scene = cr.Scene(cr.SceneData.build(mesh, cam), W, H, 3)
+    scene.set_shard(rank, world, T)
+    rnd = cr.Rnd()
+    for _ in range(2):
+        scene.render_frame(rnd.randf2(), rnd.randf2())
+    packed = torch.from_numpy(scene.read_packed())
+    frame = tiles.gather_frame(packed, W, H, T, rank, world)
+    np.save(os.path.join(out_dir, f"frame{rank}.npy"), frame)
+    scene.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_render_shards_and_gather(cr, ob, cornell, cornell_data, tmp_path):
+    """One process per rank (the bench.py --gpus N structure, gloo instead of RCCL because the test box has
+    one GPU): each rank renders its Morton-dealt tiles with the HIP path, the packed tiles are all-gathered
+    and un-tiled; the result is bit-identical to the oracle's full frame."""
+    import socket
+    import torch.multiprocessing as mp
+    W, H, T = 200, 120, 16
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_shard_worker, args=(2, port, W, H, T, str(tmp_path)), nprocs=2, join=True)
+    orc = ob.Oracle(cornell_data, W, H, 3, cornell[1])
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    for _ in range(2):
+        orc.render_frame(rnd.randf2(), rnd.randf2(), ref, threads=8)
+    for r in range(2):
+        got = np.load(tmp_path / f"frame{r}.npy")
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
