@@ -271,3 +271,36 @@ def test_two_ranks_render_shards_and_gather(cr, ob, cornell, cornell_data, tmp_p
     for r in range(2):
         got = np.load(tmp_path / f"frame{r}.npy")
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_cpp_host_scene_matches_python_path(cr, ob, cornell, tmp_path):
+    """examples/render_obj.cpp (crt::Scene: Read_Object -> build_bvh -> gpu_data -> Render x N, the
+    reference's call sequence) gives the same running sum as the Python mirror and the oracle, and a PPM."""
+    import os
+    import subprocess
+    from conftest import ROOT, write_obj
+    from caitlynrenderer_amd.image import read_ppm
+    mesh, _ = cornell
+    obj = str(tmp_path / "cornell.obj")
+    write_obj(mesh, obj)
+    W, H, frames, depth = 160, 96, 3, 3
+    out = subprocess.run([os.path.join(ROOT, "examples", "render_obj"), obj, str(tmp_path / "o.ppm"), str(W), str(H), str(frames),
+                          str(depth), str(tmp_path / "sum.f32")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = np.fromfile(tmp_path / "sum.f32", np.float32).reshape(H, W, 3)
+    cam = cr.Camera((-2.755610, 2.745992, 7.58545), (-2.755610, 2.745992, 6.58545), 40.0)   # Scene.h:468
+    data = cr.SceneData.from_obj(obj, cam)
+    orc = ob.Oracle(data, W, H, depth, cam)
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    for _ in range(frames):
+        orc.render_frame(rnd.randf2(), rnd.randf2(), ref, threads=8)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    scene = cr.Scene(data, W, H, depth)
+    for _ in range(frames):
+        scene.Render()
+    assert np.array_equal(scene.read_sum().view(np.uint32), ref.view(np.uint32)) and scene.frame_count == frames
+    img = read_ppm(str(tmp_path / "o.ppm"))
+    assert np.abs(img.astype(np.int32) - scene.resolve()[:, :, :3].astype(np.int32)).max() == 0
+    assert img.max() > 100
+    scene.close()

@@ -298,3 +298,30 @@ def test_sbvh_is_identical_for_any_thread_count(cr, tess40):
     mesh, data = tess40
     digests.add(hashlib.sha1(data.bvh.tobytes() + data.tri_orig_ids.tobytes()).hexdigest())
     assert len(digests) == 1
+
+
+def test_obj_round_trip_and_ppm(cr, cornell, tmp_path):
+    """write_obj -> Read_Object reproduces the scene (up to the fp32 re-translation of vertices), and the
+    PPM writer flips the bottom-up frame."""
+    from conftest import write_obj
+    from caitlynrenderer_amd.image import read_ppm, write_ppm
+    mesh, _ = cornell
+    write_obj(mesh, str(tmp_path / "c.obj"))
+    m = cr.Mesh.read_object(str(tmp_path / "c.obj"))
+    assert np.array_equal(m.triangles[:, :8], mesh.triangles[:, :8])
+    np.testing.assert_allclose(m.vertices, mesh.vertices, atol=2e-6)
+    assert np.array_equal(m.lights.shape, mesh.lights.shape) and m.materials.shape == mesh.materials.shape
+    np.testing.assert_allclose(m.materials[:, :8], mesh.materials[:, :8])
+    img = (np.arange(5 * 7 * 4) % 251).astype(np.uint8).reshape(5, 7, 4)
+    write_ppm(str(tmp_path / "a.ppm"), img)
+    assert np.array_equal(read_ppm(str(tmp_path / "a.ppm")), img[:, :, :3])
+
+
+def test_cpp_example_builds_and_reports_usage(cr):
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "render_obj")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr

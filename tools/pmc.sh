@@ -17,5 +17,5 @@ WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 GRBM_GUI_ACTIVE GRBM_TA_BUSY
 GROUPS
-python3 $GRAFT_REPO_ROOT/scratch/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
