@@ -67,6 +67,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: anything a library prints there (RCCL's version banner at
+    # communicator creation, for one) is sent to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -199,7 +204,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, cam, W, H, args.depth, rvs[0], cs)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     scene.close()
     if use_dist:
         dist.barrier()
