@@ -5,11 +5,11 @@ include/crt.h); this package is the thin host-side mirror of the reference's Sce
 SBVH / CWBVH interface plus tile sharding helpers.  Importing it without a built libcrt.so fails.
 """
 from . import _lib
-from ._lib import CRT_TRACE_ANY, CRT_TRACE_CLOSEST, CrtError
+from ._lib import CRT_TRACE_ANY, CRT_TRACE_BVH2, CRT_TRACE_CLOSEST, CRT_TRACE_TIE_LOWEST_ID, CrtError
 from .host import CWBVH, SBVH, Camera, Mesh, Rnd, pcg_hash
 from .scene import HIT_DT, RAY_DT, STATS_DT, Scene, SceneData
 
 _lib.lib()   # fail loudly at import time if the HIP extension is missing
 
 __all__ = ["Scene", "SceneData", "Camera", "Mesh", "SBVH", "CWBVH", "Rnd", "pcg_hash", "CrtError",
-           "RAY_DT", "HIT_DT", "STATS_DT", "CRT_TRACE_CLOSEST", "CRT_TRACE_ANY"]
+           "RAY_DT", "HIT_DT", "STATS_DT", "CRT_TRACE_CLOSEST", "CRT_TRACE_ANY", "CRT_TRACE_BVH2", "CRT_TRACE_TIE_LOWEST_ID"]

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libcrt.so")
 
 CRT_ABI_VERSION = 1
 CRT_OK, CRT_ERR_INVALID, CRT_ERR_NO_DEVICE, CRT_ERR_HIP, CRT_ERR_IO, CRT_ERR_LIMIT, CRT_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
-CRT_TRACE_CLOSEST, CRT_TRACE_ANY = 0, 1
+CRT_TRACE_CLOSEST, CRT_TRACE_ANY, CRT_TRACE_BVH2, CRT_TRACE_TIE_LOWEST_ID = 0, 1, 2, 4
 
 
 class CrtError(RuntimeError):

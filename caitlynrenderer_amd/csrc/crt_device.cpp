@@ -73,6 +73,9 @@ struct crt_scene {
     float4* d_materials = nullptr;
     float* d_lights = nullptr;
     crt_bvh_info info{};
+    float4* d_bvh2 = nullptr;            // FlatNode array as uploaded by the reference (only when desc.bvh was given)
+    float4* d_tris2 = nullptr;           // intersection records in BVH2 leaf-slot order
+    uint32_t bvh2_stack = 0;             // BVH2 depth + 2
 
     // shard + frame buffers
     uint32_t rank = 0, world = 1, tile = 64;
@@ -116,7 +119,7 @@ struct crt_scene {
     ~crt_scene() {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
-        void* ptrs[] = {d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
+        void* ptrs[] = {d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals};
         for (void* p : ptrs) if (p) hipFree(p);
@@ -376,6 +379,39 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     UP(s->d_materials, reinterpret_cast<const float4*>(d->materials), d->n_materials * 4, float4);
     UP(s->d_lights, reinterpret_cast<const float*>(d->lights), d->n_lights * 18, float);
 #undef UP
+    if (d->bvh) {
+        // the BVH2 itself, for the reference-order walk (crt_trace with CRT_TRACE_BVH2): nodes as uploaded, one
+        // intersection record per leaf slot, and the stack bound from the tree's depth
+        std::vector<uint32_t> level(d->n_bvh, 0);
+        uint32_t depth2 = 0;
+        for (size_t i = 0; i < d->n_bvh; ++i) {
+            if (d->bvh[i].bmax[3] != 0.0f) { depth2 = std::max(depth2, level[i]); continue; }
+            const size_t l = (size_t)d->bvh[i].bmin[3];
+            if (l <= i || l + 1 >= d->n_bvh) return bail(fail(CRT_ERR_INVALID, "crt_scene_create: BVH2 child link out of order"));
+            level[l] = level[l + 1] = level[i] + 1;
+        }
+        if (depth2 + 2 > 96) return bail(fail(CRT_ERR_LIMIT, "crt_scene_create: BVH2 deeper than 94 levels"));
+        s->bvh2_stack = depth2 + 2;
+        std::vector<float4> rec2(3 * d->n_triangles);
+        for (size_t slot = 0; slot < d->n_triangles; ++slot) {
+            const crt_triangle& t = d->triangles[slot];
+            const float* v0 = d->vertices + 3 * (size_t)t.v[0];
+            const float* v1 = d->vertices + 3 * (size_t)t.v[1];
+            const float* v2 = d->vertices + 3 * (size_t)t.v[2];
+            const int32_t id = d->tri_orig_ids ? d->tri_orig_ids[slot] : (int32_t)slot, sl = (int32_t)slot;
+            float4 a, b, c;
+            a.x = v0[0]; a.y = v0[1]; a.z = v0[2]; std::memcpy(&a.w, &id, 4);
+            b.x = v1[0] - v0[0]; b.y = v1[1] - v0[1]; b.z = v1[2] - v0[2]; std::memcpy(&b.w, &sl, 4);
+            c.x = v2[0] - v0[0]; c.y = v2[1] - v0[1]; c.z = v2[2] - v0[2]; std::memcpy(&c.w, &t.v[3], 4);
+            rec2[3 * slot] = a; rec2[3 * slot + 1] = b; rec2[3 * slot + 2] = c;
+        }
+        if ((rc = dev_alloc(&s->d_bvh2, d->n_bvh * 2))) return bail(rc);
+        if (hipMemcpy(s->d_bvh2, d->bvh, d->n_bvh * sizeof(crt_flatnode), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));
+        if ((rc = dev_alloc(&s->d_tris2, rec2.size()))) return bail(rc);
+        if (hipMemcpy(s->d_tris2, rec2.data(), rec2.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));
+    }
     if ((rc = dev_alloc(&s->d_counts, kCounters))) return bail(rc);
     if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
         return bail(fail(CRT_ERR_NOMEM, "hipHostMalloc failed"));
@@ -636,7 +672,8 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
 
 int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, int mode, void* d_stats, int sync) {
     if (!s || !d_rays || !d_hits) return fail(CRT_ERR_INVALID, "crt_trace_device: null argument");
-    if (mode != CRT_TRACE_CLOSEST && mode != CRT_TRACE_ANY) return fail(CRT_ERR_INVALID, "crt_trace_device: bad mode");
+    if (mode < 0 || mode > (CRT_TRACE_ANY | CRT_TRACE_BVH2 | CRT_TRACE_TIE_LOWEST_ID)) return fail(CRT_ERR_INVALID, "crt_trace_device: bad mode");
+    const bool any_hit = (mode & CRT_TRACE_ANY) != 0;
     if (n >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_trace_device: too many rays for one launch");
     HIPCHK(hipSetDevice(s->device));
     if (n == 0) return CRT_OK;
@@ -647,14 +684,25 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     ta.stack_entries = s->stack_entries;
     ta.refill_min = s->refill_min;
     s->n_spans = 0;
-    EventSpan* sp = s->begin_span(mode == CRT_TRACE_ANY ? 2 : 1);
-    crt::launch_trace(ta, mode, d_stats != nullptr, s->trace_grid(n, 8), s->stream);
+    EventSpan* sp = s->begin_span(any_hit ? 2 : 1);
+    if (mode & CRT_TRACE_BVH2) {
+        if (!s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_trace: the scene was created without a BVH2 (desc.bvh)");
+        crt::Bvh2Args ba{};
+        ba.nodes = s->d_bvh2; ba.tris = s->d_tris2; ba.rays = ta.rays; ba.hits = ta.hits; ba.stats = ta.stats;
+        ba.n = (uint32_t)n; ba.tie = (mode & CRT_TRACE_TIE_LOWEST_ID) ? 1u : 0u; ba.stack_entries = s->bvh2_stack;
+        const uint64_t lds = (uint64_t)(CRT_TRACE_BLOCK / 64) * ba.stack_entries * 64 * 4;
+        uint64_t g = std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cu * std::max<uint64_t>(1, std::min<uint64_t>(8, 160 * 1024 / lds)));
+        g = (std::max<uint64_t>(g, 8) + 7) / 8 * 8;
+        crt::launch_trace_bvh2(ba, any_hit, d_stats != nullptr, (uint32_t)g, s->stream);
+    } else {
+        crt::launch_trace(ta, any_hit ? 1 : 0, d_stats != nullptr, s->trace_grid(n, 8), s->stream);
+    }
     s->end_span(sp);
     HIPCHK(hipGetLastError());
     s->stats_pending = true;
     s->stats_from_frame = false;
-    s->stats.closest_rays = mode == CRT_TRACE_CLOSEST ? n : 0;
-    s->stats.any_rays = mode == CRT_TRACE_ANY ? n : 0;
+    s->stats.closest_rays = any_hit ? 0 : n;
+    s->stats.any_rays = any_hit ? n : 0;
     if (sync) HIPCHK(hipStreamSynchronize(s->stream));
     return CRT_OK;
 }

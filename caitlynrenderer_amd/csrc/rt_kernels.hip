@@ -413,6 +413,106 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     (void)nn_total; (void)nt_total; (void)lane;
 }
 
+// ------------------------------------------------------------------ BVH2 (the reference's live path) ----
+
+// path_trace.fs:84-109
+__device__ __forceinline__ float hit_bbox2(vec3 o, vec3 bmin, vec3 bmax, vec3 invdir, float& tl) {
+    bmin = (bmin - o) * invdir;
+    bmax = (bmax - o) * invdir;
+    const vec3 tmax = V3(__builtin_fmaxf(bmax.x, bmin.x), __builtin_fmaxf(bmax.y, bmin.y), __builtin_fmaxf(bmax.z, bmin.z));
+    const vec3 tmin = V3(__builtin_fminf(bmax.x, bmin.x), __builtin_fminf(bmax.y, bmin.y), __builtin_fminf(bmax.z, bmin.z));
+    const float th = __builtin_fminf(tmax.x, __builtin_fminf(tmax.y, tmax.z));
+    tl = __builtin_fmaxf(tmin.x, __builtin_fmaxf(tmin.y, tmin.z));
+    return th;
+}
+
+// The walk the reference actually ships: binary BVH, two-child slab test, near child first, far child on a
+// per-ray stack (path_trace.fs:511-652 closest hit, :669-819 any hit), on the FlatNode array as uploaded
+// (Scene.h:1057-1062).  Raw 1/d like the shader.  tie = 0 keeps the shader's first-visited rule (strict '<'),
+// tie = 1 is the lowest-original-id rule of the CWBVH path.  Lock-step 64-ray batches, int stack in LDS.
+template <bool ANY, bool STATS>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace_bvh2(Bvh2Args a) {
+    extern __shared__ int s_stk2[];      // [wave][level][lane]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    int* stk = s_stk2 + (size_t)wave * a.stack_entries * 64u + lane;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t v = static_chunk<true>(nullptr, a.n, it);
+        if (v == CRT_NO_WORK) break;
+        const uint32_t i = dense_item(v, wave, lane);
+        if (i >= a.n) continue;
+        const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
+        const vec3 o = V3(r0.x, r0.y, r0.z), d = V3(r1.x, r1.y, r1.z);
+        const vec3 invdir = V3(rcp_ieee(d.x), rcp_ieee(d.y), rcp_ieee(d.z));
+        float best_t = r0.w, best_u = 0.f, best_v = 0.f;
+        int best_slot = -1, best_id = -1;
+        bool occluded = false;
+        uint32_t nn = 0, nt = 0;
+        int ptr = 0;
+        stk[0] = -1; ptr = 1;
+        int ind = 0;
+        while (ind > -1) {
+            const float4 bmin = a.nodes[2 * (size_t)ind], bmax = a.nodes[2 * (size_t)ind + 1];
+            if (STATS) ++nn;
+            const int left = (int)bmin.w;
+            if (bmax.w == 0.0f) {
+                const float4 amin = a.nodes[2 * (size_t)left], amax = a.nodes[2 * (size_t)left + 1];
+                const float4 cmin = a.nodes[2 * (size_t)left + 2], cmax = a.nodes[2 * (size_t)left + 3];
+                float tl1, tl2;
+                const float th1 = hit_bbox2(o, V3(amin.x, amin.y, amin.z), V3(amax.x, amax.y, amax.z), invdir, tl1);
+                const float th2 = hit_bbox2(o, V3(cmin.x, cmin.y, cmin.z), V3(cmax.x, cmax.y, cmax.z), invdir, tl2);
+                bool l, r;
+                if (ANY) {                                   // path_trace.fs:741-742
+                    l = th1 >= 0 && th1 >= tl1 && tl1 <= best_t;
+                    r = th2 >= 0 && th2 >= tl2 && tl2 <= best_t;
+                } else {                                     // path_trace.fs:562-563 ('<=' under the lowest-id rule)
+                    l = th1 > 0 && th1 >= tl1 && (a.tie ? tl1 <= best_t : tl1 < best_t);
+                    r = th2 > 0 && th2 >= tl2 && (a.tie ? tl2 <= best_t : tl2 < best_t);
+                }
+                if (l) {
+                    ind = left;
+                    if (r) {
+                        const int off = tl1 > tl2 ? 1 : 0;
+                        if (ptr < (int)a.stack_entries) { stk[ptr * 64] = ind + 1 - off; ++ptr; }
+                        ind += off;
+                    }
+                    continue;
+                } else if (r) {
+                    ind = left + 1;
+                    continue;
+                }
+            } else {
+                const int range = (int)bmax.w;
+                for (int s = left; s < left + range; ++s) {
+                    const float4* tp = a.tris + 3 * (size_t)s;
+                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    if (STATS) ++nt;
+                    float u, vv, t;
+                    if (mt_test(ta, tb, tc, o, d, u, vv, t)) {
+                        if (ANY) {
+                            if (t < best_t) { occluded = true; break; }
+                        } else {
+                            const int id = __float_as_int(ta.w);
+                            if (t < best_t || (a.tie && t == best_t && best_slot >= 0 && id < best_id)) {
+                                best_t = t; best_u = u; best_v = vv; best_slot = s; best_id = id;
+                            }
+                        }
+                    }
+                }
+                if (ANY && occluded) break;
+            }
+            --ptr;
+            ind = stk[ptr * 64];
+        }
+        float4 h;
+        h.x = ANY ? 0.f : (best_slot >= 0 ? best_t : 0.f);
+        h.y = ANY ? 0.f : best_u;
+        h.z = ANY ? 0.f : best_v;
+        h.w = __int_as_float(ANY ? (occluded ? 0 : -1) : best_id);
+        a.hits[i] = h;
+        if (STATS) a.stats[i] = ((nt > 65535u ? 65535u : nt) << 16) | (nn > 65535u ? 65535u : nn);
+    }
+}
+
 // ------------------------------------------------------------------ queue helpers ----
 
 // Wave-aggregated append: one atomic per wave, lanes get consecutive slots in lane order.
@@ -730,6 +830,17 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipSt
 }
 // waves = registers-per-lane budget expressed as resident waves per SIMD (5: ~96 VGPRs, 6: 80, 8: 64 with
 // a few spills outside the traversal loop); the counting variants exist only at 6.
+void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream) {
+    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const size_t lds = (size_t)(CRT_TRACE_BLOCK / 64) * a.stack_entries * 64 * sizeof(int);
+    if (any) {
+        if (stats) hipLaunchKernelGGL((k_trace_bvh2<true, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_trace_bvh2<true, false>), g, b, lds, stream, a);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_trace_bvh2<false, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((k_trace_bvh2<false, false>), g, b, lds, stream, a);
+    }
+}
 void launch_segment(const SegmentArgs& a, bool first, bool stats, int waves, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);
     const size_t lds = stack_bytes(a.stack_entries);

@@ -23,6 +23,17 @@ struct TraceArgs {
     uint32_t refill_min;       // idle lanes that trigger a pool refill (traverse_pool)
 };
 
+struct Bvh2Args {               // the reference's live BVH2 walk (path_trace.fs:511-819) for crt_trace
+    const float4* nodes;       // FlatNode: (bmin.xyz, link) (bmax.xyz, count), Scene.h:1057-1062
+    const float4* tris;        // 3 x 16 B per BVH2 leaf slot: (v0|orig id) (e1|slot) (e2|material)
+    const float4* rays;
+    float4* hits;
+    uint32_t* stats;
+    uint32_t n;
+    uint32_t tie;              // 0: first visited wins (path_trace.fs:363), 1: lowest original id
+    uint32_t stack_entries;    // >= BVH2 depth + 1
+};
+
 struct PathBuffers {           // indexed by local pixel; touched only by paths longer than one segment
     float4* L;                 // radiance so far, prev_pdf
     float4* T;                 // throughput, is_specular
@@ -74,6 +85,7 @@ struct ShadowArgs {
 };
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
+void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream);
 void launch_segment(const SegmentArgs& a, bool first, bool stats, int waves, uint32_t grid, hipStream_t stream);
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);

@@ -83,7 +83,12 @@ typedef struct crt_ray { float o[3]; float tmax; float d[3]; uint32_t pad; } crt
 typedef struct crt_hit { float t, u, v; int32_t tri; } crt_hit;   /* tri = original triangle id, -1 = miss */
 typedef struct crt_ray_stats { uint16_t nodes, tris; } crt_ray_stats;  /* per-ray visit counters (optional) */
 
-enum { CRT_TRACE_CLOSEST = 0, CRT_TRACE_ANY = 1 };
+/* crt_trace mode = CLOSEST or ANY, optionally OR-ed with:
+ *   CRT_TRACE_BVH2          walk the BVH2 exactly as the shipped shader does (path_trace.fs:511-819:
+ *                           FlatNode array, near child first, raw 1/d) instead of the CWBVH;
+ *   CRT_TRACE_TIE_LOWEST_ID with BVH2: equal-t hits resolve to the lowest original id (the CWBVH path's rule)
+ *                           instead of the shader's first-visited rule (path_trace.fs:363). */
+enum { CRT_TRACE_CLOSEST = 0, CRT_TRACE_ANY = 1, CRT_TRACE_BVH2 = 2, CRT_TRACE_TIE_LOWEST_ID = 4 };
 
 /* Everything Scene::gpu_data uploads (Scene.h:1015-1078) plus the intended bvh8
  * buffer.  All pointers are HOST memory and are COPIED (the reference frees its CPU

@@ -339,3 +339,26 @@ def test_million_triangle_mesh_full_frame(cr, ob, cornell):
     c = scene.trace(far, cr.CRT_TRACE_CLOSEST)
     assert np.array_equal(occ, (c["tri"] >= 0) & (c["t"] < shadow["tmax"]))
     scene.close()
+
+
+@pytest.mark.parametrize("name", ["cornell", "tess40"])
+def test_bvh2_reference_order_walk_on_device(cr, ob, cornell, tess40, scenes, name):
+    """CRT_TRACE_BVH2: the shipped shader's own walk (path_trace.fs:511-819) on the FlatNode array, bit-exact
+    against the oracle's restatement of it: hit ids, t/u/v and the per-ray node/triangle counters, under the
+    shader's first-visited rule and under the lowest-id rule; and it agrees with the CWBVH walk."""
+    scene, orc, data = scenes[name]
+    mesh = cornell[0] if name == "cornell" else tess40[0]
+    rays = np.concatenate([seeded_rays(mesh, 40000, 13, cr.RAY_DT), orc.primary_rays(RX1, RY1, jitter=True).astype(cr.RAY_DT)])
+    got, gst = scene.trace(rays, cr.CRT_TRACE_CLOSEST | cr.CRT_TRACE_BVH2, stats=True)
+    want, wst = orc.trace(rays, ob.BVH2, ob.CLOSEST, ob.TIE_FIRST_VISITED, stats=True, threads=8)
+    _assert_hits_equal(got, want)
+    assert np.array_equal(gst["nodes"], wst["nodes"]) and np.array_equal(gst["tris"], wst["tris"])
+    got2 = scene.trace(rays, cr.CRT_TRACE_CLOSEST | cr.CRT_TRACE_BVH2 | cr.CRT_TRACE_TIE_LOWEST_ID)
+    _assert_hits_equal(got2, orc.trace(rays, ob.BVH2, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=8))
+    _assert_hits_equal(got2, scene.trace(rays, cr.CRT_TRACE_CLOSEST))          # BVH2 == CWBVH on (id, t, u, v)
+    ra = rays.copy()
+    ra["tmax"] = np.random.default_rng(5).random(len(ra)).astype(np.float32) * 6
+    ga, gsa = scene.trace(ra, cr.CRT_TRACE_ANY | cr.CRT_TRACE_BVH2, stats=True)
+    wa, wsa = orc.trace(ra, ob.BVH2, ob.ANY, stats=True, threads=8)
+    assert np.array_equal(ga["tri"] >= 0, wa["tri"] >= 0)
+    assert np.array_equal(gsa["nodes"], wsa["nodes"]) and np.array_equal(gsa["tris"], wsa["tris"])
