@@ -362,3 +362,28 @@ def test_bvh2_reference_order_walk_on_device(cr, ob, cornell, tess40, scenes, na
     wa, wsa = orc.trace(ra, ob.BVH2, ob.ANY, stats=True, threads=8)
     assert np.array_equal(ga["tri"] >= 0, wa["tri"] >= 0)
     assert np.array_equal(gsa["nodes"], wsa["nodes"]) and np.array_equal(gsa["tris"], wsa["tris"])
+
+
+def test_4k_frame_config5_geometry_on_one_gpu(cr, ob, cornell, cornell_data):
+    """BASELINE config 5's 3840x2160 framebuffer (2,040 tiles) rendered by ONE rank and by rank 3 of 8:
+    bit-exact against the oracle; the shard holds exactly its Morton-dealt tiles."""
+    from caitlynrenderer_amd import tiles
+    W, H = 3840, 2160
+    orc = ob.Oracle(cornell_data, W, H, 1, cornell[1])
+    ref, cnt = orc.render_frame(RX1, RY1, threads=16)
+    full = cr.Scene(cornell_data, W, H, 1)
+    full.render_frame(RX1, RY1)
+    assert np.array_equal(full.read_sum().view(np.uint32), ref.view(np.uint32))
+    st = full.frame_stats()
+    assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and cnt[0] == W * H
+    full.close()
+    shard = cr.Scene(cornell_data, W, H, 1)
+    shard.set_shard(3, 8, 64)
+    shard.render_frame(RX1, RY1)
+    part = shard.read_sum()
+    mine = np.zeros((H, W), bool)
+    for tx, ty in tiles.local_tiles(W, H, 64, 3, 8):
+        mine[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = True
+    assert np.array_equal(part[mine].view(np.uint32), ref[mine].view(np.uint32)) and not part[~mine].any()
+    assert shard.packed_info()[0] == len(tiles.local_tiles(W, H, 64, 3, 8)) == 255
+    shard.close()

@@ -173,3 +173,21 @@ def test_resolve_matches_output_shader_formula(ob):
     want = np.clip((c / (1 + lum / 2)[..., None]) ** (1 / 2.2), 0, 1) * 255 + 0.5
     assert np.abs(got[..., :3].astype(np.int32) - want.astype(np.int32)).max() <= 1
     assert (got[..., 3] == 255).all()
+
+
+def test_config1_sah_bvh_primary_rays_cpu(ob, cr, cornell):
+    """BASELINE config 1: Cornell box, SAH BVH (exact-sweep object splits only, sbvh.h:338-378 with spatial
+    splits disabled), primary rays only, CPU scalar traversal.  Same hits as the SBVH tree and as brute force."""
+    mesh, cam = cornell
+    sah = cr.SceneData.build(mesh, cam, sbvh_flags=cr.SBVH.NO_SPATIAL_SPLITS)
+    full = cr.SceneData.build(mesh, cam)
+    assert sah.bvh.shape[0] == 2 * mesh.triangles.shape[0] - 1 and sorted(sah.tri_orig_ids.tolist()) == list(range(32))
+    o_sah, o_full = ob.Oracle(sah, 1920, 1080, 1, cam), ob.Oracle(full, 1920, 1080, 1, cam)
+    rays = o_sah.primary_rays(0.6591631, 0.910802, jitter=True)          # frame-1 randomVector (SURVEY 8d config 1)
+    h_sah = o_sah.trace(rays, ob.BVH2, ob.CLOSEST, ob.TIE_FIRST_VISITED, threads=4)
+    h_full = o_full.trace(rays, ob.BVH2, ob.CLOSEST, ob.TIE_FIRST_VISITED, threads=4)
+    assert np.array_equal(h_sah["tri"], h_full["tri"]) and np.array_equal(h_sah["t"].view(np.uint32), h_full["t"].view(np.uint32))
+    sample = slice(None, None, 53)
+    hb = o_sah.trace(rays[sample], ob.BRUTE, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=4)
+    assert np.array_equal(hb["tri"], h_sah["tri"][sample])
+    assert 0.5 < (h_sah["tri"] >= 0).mean() < 0.6                      # 56 % of a 16:9 frame sees the box
