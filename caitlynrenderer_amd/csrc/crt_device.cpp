@@ -72,6 +72,9 @@ struct crt_scene {
     float* d_normals = nullptr;
     float4* d_materials = nullptr;
     float* d_lights = nullptr;
+    float2* d_texcoords = nullptr;
+    float* d_textures = nullptr;         // albedo array as RGB32F (c / 255.0f)
+    int32_t tex_width = 0, tex_height = 0, n_textures = 0;
     crt_bvh_info info{};
     float4* d_bvh2 = nullptr;            // FlatNode array as uploaded by the reference (only when desc.bvh was given)
     float4* d_tris2 = nullptr;           // intersection records in BVH2 leaf-slot order
@@ -119,7 +122,7 @@ struct crt_scene {
     ~crt_scene() {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
-        void* ptrs[] = {d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
+        void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals};
         for (void* p : ptrs) if (p) hipFree(p);
@@ -301,6 +304,24 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
                 if (t.vn[j] < 0 || (size_t)t.vn[j] >= d->n_normals || !d->normals)
                     return fail(CRT_ERR_INVALID, "crt_scene_create: normal index out of range");
     }
+    const bool have_tex = d->albedo_textures && d->n_textures > 0;
+    if (have_tex && (d->tex_width == 0 || d->tex_height == 0 || d->tex_width > 16384 || d->tex_height > 16384))
+        return fail(CRT_ERR_INVALID, "crt_scene_create: bad texture size");
+    for (size_t m = 0; m < d->n_materials; ++m) {
+        const float tx = d->materials[m].tex_ind[0];
+        if (have_tex && tx != -1.0f) {
+            if (!(tx >= 0.0f && tx < (float)d->n_textures)) return fail(CRT_ERR_INVALID, "crt_scene_create: material texture index out of range");
+            if (!d->texcoords) return fail(CRT_ERR_INVALID, "crt_scene_create: textured material but no texcoords");
+        }
+    }
+    if (have_tex)
+        for (size_t i = 0; i < d->n_triangles; ++i) {
+            const crt_triangle& t = d->triangles[i];
+            const float tx = d->materials[t.v[3] < 0 || (size_t)t.v[3] >= d->n_materials ? 0 : t.v[3]].tex_ind[0];
+            if (tx == -1.0f) continue;
+            for (int j = 0; j < 3; ++j)
+                if (t.vt[j] < 0 || (size_t)t.vt[j] >= d->n_texcoords) return fail(CRT_ERR_INVALID, "crt_scene_create: texcoord index out of range");
+        }
     for (size_t m = 0; m < d->n_materials; ++m) {
         const float ew = d->materials[m].emission[3];
         if (ew != -1.0f && !(ew >= 0.0f && (size_t)ew < d->n_lights))
@@ -378,6 +399,14 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     UP(s->d_normals, d->normals, d->n_normals * 3, float);
     UP(s->d_materials, reinterpret_cast<const float4*>(d->materials), d->n_materials * 4, float4);
     UP(s->d_lights, reinterpret_cast<const float*>(d->lights), d->n_lights * 18, float);
+    if (have_tex) {
+        UP(s->d_texcoords, reinterpret_cast<const float2*>(d->texcoords), d->n_texcoords, float2);
+        const size_t n_tex = (size_t)d->tex_width * d->tex_height * d->n_textures * 3;
+        std::vector<float> texf(n_tex);
+        for (size_t i = 0; i < n_tex; ++i) texf[i] = (float)d->albedo_textures[i] / 255.0f;   // UNORM8 -> float, as the oracle does per fetch
+        UP(s->d_textures, texf.data(), n_tex, float);
+        s->tex_width = (int32_t)d->tex_width; s->tex_height = (int32_t)d->tex_height; s->n_textures = (int32_t)d->n_textures;
+    }
 #undef UP
     if (d->bvh) {
         // the BVH2 itself, for the reference-order walk (crt_trace with CRT_TRACE_BVH2): nodes as uploaded, one
@@ -496,6 +525,8 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.nodes = s->d_nodes; sa.tris = s->d_tris; sa.triangles = s->d_triangles; sa.normals = s->d_normals;
         sa.materials = s->d_materials; sa.lights = s->d_lights; sa.n_lights = (int32_t)s->n_lights;
         sa.stack_entries = s->stack_entries;
+        sa.texcoords = s->d_texcoords; sa.textures = s->d_textures;
+        sa.tex_width = s->tex_width; sa.tex_height = s->tex_height; sa.n_textures = s->n_textures;
         sa.f = f;
         sa.sub_capacity = s->sub_capacity;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = s->d_counts + counter_index(b, 0, 0);

@@ -540,6 +540,32 @@ __device__ __forceinline__ bool pixel_of(const FrameArgs& f, uint32_t i, uint32_
     return px < f.width && py < f.height;
 }
 
+// texture(albedo_textures, vec3(uv, layer)) — GL_LINEAR, GL_REPEAT, RGB8 (Scene.h:1065-1078); filter arithmetic as
+// defined in oracle/oracle.c sample_albedo (texels were converted to c/255.0f at upload).
+__device__ __forceinline__ int wrap_i(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+__device__ __forceinline__ vec3 sample_albedo(const SegmentArgs& a, float u, float v, int layer) {
+    const int W = a.tex_width, H = a.tex_height;
+    layer = layer < 0 ? 0 : layer > a.n_textures - 1 ? a.n_textures - 1 : layer;
+    const float* img = a.textures + (size_t)layer * (size_t)W * (size_t)H * 3;
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+    float fx = x - x0, fy = y - y0;
+    if (!(__builtin_fabsf(x0) < 1e9f)) { x0 = 0.f; fx = 0.f; }
+    if (!(__builtin_fabsf(y0) < 1e9f)) { y0 = 0.f; fy = 0.f; }
+    const int i0 = wrap_i((int)x0, W), i1 = wrap_i((int)x0 + 1, W);
+    const int j0 = wrap_i((int)y0, H), j1 = wrap_i((int)y0 + 1, H);
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float t00 = img[3 * ((size_t)j0 * W + i0) + k], t10 = img[3 * ((size_t)j0 * W + i1) + k];
+        const float t01 = img[3 * ((size_t)j1 * W + i0) + k], t11 = img[3 * ((size_t)j1 * W + i1) + k];
+        const float top = t00 * (1.0f - fx) + t10 * fx;
+        const float bot = t01 * (1.0f - fx) + t11 * fx;
+        c[k] = top * (1.0f - fy) + bot * fy;
+    }
+    return V3(c[0], c[1], c[2]);
+}
+
 __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix, vec3 L) {   // path_trace.fs:1055-1059
     float* s = sum + 3 * (size_t)pix;
     s[0] = L.x + s[0];
@@ -663,7 +689,20 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, WAVES) k_segment(SegmentArgs 
                 }
             } else {
                 const vec3 hit_point = (o + d * t) + n * 0.0002f;                 // path_trace.fs:930
-                const vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
+                vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
+                if (a.textures != nullptr) {                                      // path_trace.fs:471-483
+                    const float tex = a.materials[4 * (size_t)mtl + 3].x;
+                    if (tex != -1.0f) {
+                        const int4 vt = a.triangles[3 * (size_t)slot + 2];
+                        const float2 ta = a.texcoords[vt.x], tb2 = a.texcoords[vt.y], tc2 = a.texcoords[vt.z];
+                        const float w = 1.0f - bu - bv;
+                        const float tu = (ta.x * w + tb2.x * bu) + tc2.x * bv;
+                        const float tv = (ta.y * w + tb2.y * bu) + tc2.y * bv;
+                        const vec3 c = sample_albedo(a, tu, tv, (int)tex);
+                        albedo = V3((float)pow((double)c.x, (double)2.2f), (float)pow((double)c.y, (double)2.2f),
+                                    (float)pow((double)c.z, (double)2.2f));
+                    }
+                }
                 if (m_specular.w == 0.0f) {
                     if (a.n_lights <= 0) {
                         shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv);

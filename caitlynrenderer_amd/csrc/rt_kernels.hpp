@@ -59,6 +59,9 @@ struct SegmentArgs {
     const float* lights;
     int32_t n_lights;
     uint32_t stack_entries;
+    const float2* texcoords;   // uv pairs (Scene.h:1029-1034)
+    const float* textures;     // albedo array as RGB32F = c/255 (Scene.h:1065-1078), layer-major; null when absent
+    int32_t tex_width, tex_height, n_textures;
     FrameArgs f;
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel

@@ -74,6 +74,7 @@ class Mesh:
         self.materials = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 16)
         self.lights = np.ascontiguousarray(lights, dtype=np.float32).reshape(-1, 18)
         self.vertex_min = np.zeros(3, np.float32) if vertex_min is None else np.asarray(vertex_min, dtype=np.float32)
+        self.albedo_textures = None   # optional (layers, H, W, 3) uint8 array; materials[:, 12] = layer index or -1
 
     @staticmethod
     def read_object(path, camera=None):

@@ -29,6 +29,7 @@ class SceneData:
         self.bvh8 = cwbvh.nodes if cwbvh is not None else None
         self.bvh8_tri_slots = cwbvh.tri_slots if cwbvh is not None else None
         self.camera = camera
+        self.albedo_textures = getattr(mesh, "albedo_textures", None)   # (layers, H, W, 3) uint8 or None (Scene.h:1065-1078)
         self.n_source_triangles = int(mesh.triangles.shape[0])
 
     @staticmethod
@@ -73,6 +74,12 @@ class Scene:
         if data.bvh8 is not None:
             b8 = arr(data.bvh8, np.uint8); d.bvh8, d.n_bvh8 = _ptr(b8), b8.shape[0]
             sl = arr(data.bvh8_tri_slots, np.int32); d.bvh8_tri_slots, d.n_bvh8_tris = _ptr(sl), sl.shape[0]
+        tex = getattr(data, "albedo_textures", None)
+        if tex is not None:
+            tex = arr(tex, np.uint8)
+            assert tex.ndim == 4 and tex.shape[3] == 3, "albedo_textures must be (layers, H, W, 3) uint8"
+            d.albedo_textures = _ptr(tex)
+            d.n_textures, d.tex_height, d.tex_width = tex.shape[0], tex.shape[1], tex.shape[2]
         d.width, d.height, d.max_depth = self.width, self.height, self.max_depth
         check(lib().crt_scene_create(C.byref(d), C.byref(self._h)))
         if data.camera is not None:

@@ -33,7 +33,8 @@ class orc_scene(C.Structure):
                 ("lights", C.c_void_p), ("bvh2", C.c_void_p), ("bvh8", C.c_void_p), ("bvh8_tri_slots", C.c_void_p),
                 ("n_triangles", C.c_int32), ("n_lights", C.c_int32), ("n_bvh2", C.c_int32), ("n_bvh8", C.c_int32),
                 ("n_bvh8_tris", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32),
-                ("camera", orc_camera)]
+                ("camera", orc_camera),
+                ("albedo_textures", C.c_void_p), ("tex_width", C.c_int32), ("tex_height", C.c_int32), ("n_textures", C.c_int32)]
 
 
 def build(force=False):
@@ -105,6 +106,12 @@ class Oracle:
         s.n_bvh8 = 0 if bvh8 is None else bvh8.reshape(-1, 80).shape[0]
         s.n_bvh8_tris = 0 if slots is None else slots.shape[0]
         s.width, s.height, s.max_depth = int(width), int(height), int(max_depth)
+        tex = getattr(data, "albedo_textures", None)
+        if tex is not None:
+            tex = arr(tex, np.uint8)
+            assert tex.ndim == 4 and tex.shape[3] == 3, "albedo_textures must be (layers, H, W, 3) uint8"
+            s.albedo_textures = _p(tex)
+            s.n_textures, s.tex_height, s.tex_width = int(tex.shape[0]), int(tex.shape[1]), int(tex.shape[2])
         self.s = s
         self.set_camera(camera if camera is not None else data.camera)
 

@@ -540,8 +540,38 @@ void orc_primary_rays(const orc_scene* s, float rx, float ry, int jitter, orc_ra
 
 /* ---------------------------------------------------------------- integrator -- */
 
-/* path_trace.fs:414-489, texture branch omitted (no texture data crosses the boundary yet). */
-static void hit_attributes(const orc_scene* s, const rec_t* rec, v3* n, const float** mat) {
+/* texture(albedo_textures, vec3(uv, layer)) as Scene.h:1065-1078 sets the array up: RGB8 UNORM, GL_LINEAR
+ * min/mag filter, default GL_REPEAT wrap, no mipmaps.  GL leaves the filter arithmetic to the implementation;
+ * this project's definition (shared with the kernel): texel = c / 255.0f; unnormalised coordinate x = u*W - 0.5;
+ * i0 = floor(x), f = x - i0, indices wrapped with a mathematical modulo; top = t00*(1-fx) + t10*fx,
+ * bot = t01*(1-fx) + t11*fx, result = top*(1-fy) + bot*fy. */
+static inline int wrap_i(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+static v3 sample_albedo(const orc_scene* s, float u, float v, int layer) {
+    const int W = s->tex_width, H = s->tex_height;
+    if (layer < 0) layer = 0;
+    if (layer > s->n_textures - 1) layer = s->n_textures - 1;
+    const uint8_t* img = s->albedo_textures + (size_t)layer * (size_t)W * (size_t)H * 3;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    /* huge or non-finite coordinates: keep the index arithmetic defined */
+    if (!(fabsf(x0) < 1e9f)) { x0 = 0.f; fx = 0.f; }
+    if (!(fabsf(y0) < 1e9f)) { y0 = 0.f; fy = 0.f; }
+    int i0 = wrap_i((int)x0, W), i1 = wrap_i((int)x0 + 1, W);
+    int j0 = wrap_i((int)y0, H), j1 = wrap_i((int)y0 + 1, H);
+    float c[3];
+    for (int k = 0; k < 3; ++k) {
+        float t00 = (float)img[3 * ((size_t)j0 * W + i0) + k] / 255.0f, t10 = (float)img[3 * ((size_t)j0 * W + i1) + k] / 255.0f;
+        float t01 = (float)img[3 * ((size_t)j1 * W + i0) + k] / 255.0f, t11 = (float)img[3 * ((size_t)j1 * W + i1) + k] / 255.0f;
+        float top = t00 * (1.0f - fx) + t10 * fx;
+        float bot = t01 * (1.0f - fx) + t11 * fx;
+        c[k] = top * (1.0f - fy) + bot * fy;
+    }
+    return V(c[0], c[1], c[2]);
+}
+
+/* path_trace.fs:414-489 including the textured-albedo branch (:471-483). */
+static void hit_attributes(const orc_scene* s, const rec_t* rec, v3* n, const float** mat, v3* albedo) {
     const int32_t* vn = s->triangles + 12 * (size_t)rec->slot + 4;
     if (vn[3] == 0) {
         *n = V((float)vn[0], (float)vn[1], (float)vn[2]);
@@ -553,6 +583,21 @@ static void hit_attributes(const orc_scene* s, const rec_t* rec, v3* n, const fl
         *n = add(add(scl(a, w), scl(b, rec->u)), scl(c, rec->v));
     }
     *mat = s->materials + 16 * (size_t)rec->mtl;
+    const float tex = (*mat)[12];
+    if (tex != -1.0f && s->albedo_textures && s->n_textures > 0 && s->texcoords) {
+        const int32_t* vt = s->triangles + 12 * (size_t)rec->slot + 8;
+        const float* ta = s->texcoords + 2 * (size_t)vt[0];
+        const float* tb = s->texcoords + 2 * (size_t)vt[1];
+        const float* tc = s->texcoords + 2 * (size_t)vt[2];
+        float w = 1.0f - rec->u - rec->v;                                   /* path_trace.fs:312-315 */
+        float tu = (ta[0] * w + tb[0] * rec->u) + tc[0] * rec->v;
+        float tv = (ta[1] * w + tb[1] * rec->u) + tc[1] * rec->v;
+        v3 c = sample_albedo(s, tu, tv, (int)tex);
+        /* pow(c, vec3(2.2f)): evaluated in double and rounded once (GLSL pow precision is implementation-defined) */
+        *albedo = V((float)pow((double)c.x, (double)2.2f), (float)pow((double)c.y, (double)2.2f), (float)pow((double)c.z, (double)2.2f));
+    } else {
+        *albedo = ld3(*mat);
+    }
 }
 
 /* path_trace.fs:214-218 */
@@ -570,8 +615,8 @@ static v3 path_trace(const orc_scene* s, int accel, int tie, v3 o, v3 d, float s
         closest(s, accel, tie, o, d, ORC_INF, &rec, &c);
         counters[0]++; counters[2] += c.nodes; counters[3] += c.tris;
         if (rec.slot < 0) return L;
-        v3 n; const float* mat;
-        hit_attributes(s, &rec, &n, &mat);
+        v3 n, albedo; const float* mat;
+        hit_attributes(s, &rec, &n, &mat, &albedo);
         float cos_incident = dot3(d, n);
         v3 original_n = n;
         if (cos_incident > 0) n = neg(n);
@@ -591,7 +636,6 @@ static v3 path_trace(const orc_scene* s, int accel, int tie, v3 o, v3 d, float s
         }
         v3 hit_point = add(add(o, scl(d, rec.t)), scl(n, 0.0002f));
         const float* specular = mat + 8;
-        v3 albedo = ld3(mat);
         if (specular[3] == 0.0f && s->n_lights <= 0) {
             /* the shader would read light 0 of an empty buffer; keep the RNG stream, skip NEE */
             orc_rand(seed, rx, ry); orc_rand(seed, rx, ry); orc_rand(seed, rx, ry);

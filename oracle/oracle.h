@@ -38,6 +38,9 @@ typedef struct orc_scene {
     int32_t n_triangles, n_lights, n_bvh2, n_bvh8, n_bvh8_tris;
     int32_t width, height, max_depth;
     orc_camera camera;
+    /* RGB8 albedo texture array (Scene.h:1065-1078): n_textures layers of tex_height x tex_width x 3; may be NULL */
+    const uint8_t* albedo_textures;
+    int32_t tex_width, tex_height, n_textures;
 } orc_scene;
 
 enum { ORC_CLOSEST = 0, ORC_ANY = 1 };

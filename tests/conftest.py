@@ -135,3 +135,23 @@ def write_obj(mesh, path, mtl_name="scene.mtl"):
         e = mat[4:7] if mat[7] != -1 else (0.0, 0.0, 0.0)
         m.append("Ke %.9g %.9g %.9g" % tuple(float(x) for x in e))
     open(os.path.join(os.path.dirname(path), mtl_name), "w").write("\n".join(m) + "\n")
+
+
+@pytest.fixture(scope="session")
+def textured(cr, cornell):
+    """Cornell box with uv coordinates on every quad and two materials switched to texture layers 0 / 1
+    (16x8 and wrap-exercising uv > 1): the textured-albedo branch of path_trace.fs:471-483."""
+    mesh, cam = cornell
+    tris = mesh.triangles.copy()
+    uv = np.array([[0.0, 0.0], [1.7, 0.0], [1.7, 2.3], [0.0, 2.3], [-0.4, 0.25], [0.9, 0.25], [0.9, 1.5], [-0.4, 1.5]], np.float32)
+    for q in range(tris.shape[0] // 2):
+        o = 4 * (q % 2)
+        tris[2 * q, 8:12] = (o + 0, o + 1, o + 2, 0)
+        tris[2 * q + 1, 8:12] = (o + 0, o + 2, o + 3, 0)
+    mats = mesh.materials.copy()
+    mats[3, 12] = 0.0     # Khaki (boxes, floor...) -> layer 0
+    mats[2, 12] = 1.0     # HalveRed wall -> layer 1
+    m = cr.Mesh(mesh.vertices, mesh.normals, uv, tris, mats, mesh.lights, mesh.vertex_min)
+    rng = np.random.default_rng(42)
+    m.albedo_textures = rng.integers(0, 256, size=(2, 8, 16, 3), dtype=np.uint8)
+    return m, cr.SceneData.build(m, cam), cam

@@ -387,3 +387,29 @@ def test_4k_frame_config5_geometry_on_one_gpu(cr, ob, cornell, cornell_data):
     assert np.array_equal(part[mine].view(np.uint32), ref[mine].view(np.uint32)) and not part[~mine].any()
     assert shard.packed_info()[0] == len(tiles.local_tiles(W, H, 64, 3, 8)) == 255
     shard.close()
+
+
+def test_textured_albedo_matches_oracle(cr, ob, textured):
+    """a7's texture branch on the device: same bilinear/repeat definition and pow(., 2.2) as the oracle.
+    Stated tolerance abs 1e-5 + rel 1e-4 (the device and libm double pow may differ in the last place before
+    the rounding to float); in practice bit-identical."""
+    mesh, data, cam = textured
+    W, H = 320, 180
+    scene = cr.Scene(data, W, H, 3)
+    orc = ob.Oracle(data, W, H, 3, cam)
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    for _ in range(3):
+        rx, ry = rnd.randf2(), rnd.randf2()
+        scene.render_frame(rx, ry)
+        orc.render_frame(rx, ry, ref, threads=8)
+    out = scene.read_sum()
+    err = np.abs(out - ref)
+    assert (err <= 1e-5 + 1e-4 * np.abs(ref)).all(), float(err.max())
+    assert (out.view(np.uint32) != ref.view(np.uint32)).mean() < 1e-3
+    untex = cr.Scene(cr.SceneData.build(cr.Mesh(mesh.vertices, mesh.normals, mesh.texcoords, mesh.triangles,
+                                                np.where(np.arange(16) == 12, -1, mesh.materials).astype(np.float32), mesh.lights), cam), W, H, 3)
+    untex.render_frame(0.6591631, 0.910802)
+    scene.reset(); scene.render_frame(0.6591631, 0.910802)
+    assert np.abs(untex.read_sum() - scene.read_sum()).max() > 0.01     # the texture is really used
+    untex.close(); scene.close()

@@ -191,3 +191,29 @@ def test_config1_sah_bvh_primary_rays_cpu(ob, cr, cornell):
     hb = o_sah.trace(rays[sample], ob.BRUTE, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=4)
     assert np.array_equal(hb["tri"], h_sah["tri"][sample])
     assert 0.5 < (h_sah["tri"] >= 0).mean() < 0.6                      # 56 % of a 16:9 frame sees the box
+
+
+def test_textured_albedo_definition(ob, cr, textured):
+    """The texture branch (path_trace.fs:471-483): bilinear GL_LINEAR / GL_REPEAT fetch of the RGB8 array and
+    pow(., 2.2), checked against an independent numpy evaluation on a frame where only texture data changes."""
+    mesh, data, cam = textured
+    assert data.albedo_textures is not None and data.texcoords.shape == (8, 2)
+    o = ob.Oracle(data, 96, 54, 1, cam)
+    s1, _ = o.render_frame(0.6591631, 0.910802)
+    # constant textures equal to a material colour c must reproduce the untextured render with albedo c^2.2
+    flat = type("D", (), {})()
+    flat.__dict__.update(data.__dict__)
+    flat.albedo_textures = np.full((2, 8, 16, 3), 128, np.uint8)
+    s_flat, _ = ob.Oracle(flat, 96, 54, 1, cam).render_frame(0.6591631, 0.910802)
+    plain = type("D", (), {})()
+    plain.__dict__.update(data.__dict__)
+    plain.albedo_textures = None
+    plain.materials = data.materials.copy()
+    c = np.float32(np.float64(np.float32(128) / np.float32(255)) ** np.float64(np.float32(2.2)))
+    for m in (2, 3):
+        plain.materials[m, 0:3] = c
+        plain.materials[m, 12] = -1
+    s_plain, _ = ob.Oracle(plain, 96, 54, 1, cam).render_frame(0.6591631, 0.910802)
+    np.testing.assert_allclose(s_flat, s_plain, rtol=2e-6, atol=1e-7)
+    assert np.abs(s1 - s_flat).max() > 0.01          # the random texture really modulates the image
+    assert np.isfinite(s1).all()
