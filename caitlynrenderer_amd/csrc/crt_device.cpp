@@ -116,7 +116,6 @@ struct crt_scene {
     bool stats_from_frame = false;
     bool stats_counted = false;
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
-    uint32_t segment_waves = 5;              // register budget of k_segment as waves per SIMD (5, 6 or 8)
     uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
 
     ~crt_scene() {
@@ -362,7 +361,6 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
-    if (const char* e = std::getenv("CRT_SEGMENT_WAVES")) { int v = std::atoi(e); s->segment_waves = v >= 8 ? 8u : v >= 6 ? 6u : 5u; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
     s->stack_entries = std::min<uint32_t>(CRT_STACK_ENTRIES, std::max<uint32_t>(2, depth8));
@@ -495,7 +493,6 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
-    else if (!std::strcmp(name, "segment_waves")) s->segment_waves = value >= 8 ? 8u : value >= 6 ? 6u : 5u;
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;
 }
@@ -536,7 +533,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
         sa.visit_totals = s->d_visit_totals;
         EventSpan* sp = s->begin_span(1);
-        crt::launch_segment(sa, b == 0, s->count_visits, (int)s->segment_waves, s->trace_grid(P, s->count_visits ? 6 : s->segment_waves), s->stream);
+        crt::launch_segment(sa, b == 0, s->count_visits, s->trace_grid(P, 5), s->stream);
         s->end_span(sp);
 
         crt::ShadowArgs sh{};

@@ -579,8 +579,10 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
 // wave-ballot compaction.  Nothing but the two output queues (and, for paths that go on, 40 B of path
 // state) touches HBM; a path that ends here adds its radiance to the sum buffer directly.
-template <bool FIRST, bool STATS, int WAVES>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, WAVES) k_segment(SegmentArgs a) {
+// TEX compiles the textured-albedo branch in (its double-precision pow costs registers the untextured path
+// should not pay for).  96-VGPR budget = 5 waves per SIMD; 80 and 64 were measured slower.
+template <bool FIRST, bool STATS, bool TEX>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
@@ -690,7 +692,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, WAVES) k_segment(SegmentArgs 
             } else {
                 const vec3 hit_point = (o + d * t) + n * 0.0002f;                 // path_trace.fs:930
                 vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
-                if (a.textures != nullptr) {                                      // path_trace.fs:471-483
+                if (TEX) {                                                        // path_trace.fs:471-483
                     const float tex = a.materials[4 * (size_t)mtl + 3].x;
                     if (tex != -1.0f) {
                         const int4 vt = a.triangles[3 * (size_t)slot + 2];
@@ -867,8 +869,6 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipSt
         else       hipLaunchKernelGGL((k_trace<false, false>), g, b, lds, stream, a);
     }
 }
-// waves = registers-per-lane budget expressed as resident waves per SIMD (5: ~96 VGPRs, 6: 80, 8: 64 with
-// a few spills outside the traversal loop); the counting variants exist only at 6.
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);
     const size_t lds = (size_t)(CRT_TRACE_BLOCK / 64) * a.stack_entries * 64 * sizeof(int);
@@ -880,22 +880,19 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hi
         else       hipLaunchKernelGGL((k_trace_bvh2<false, false>), g, b, lds, stream, a);
     }
 }
-void launch_segment(const SegmentArgs& a, bool first, bool stats, int waves, uint32_t grid, hipStream_t stream) {
+void launch_segment(const SegmentArgs& a, bool first, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);
     const size_t lds = stack_bytes(a.stack_entries);
-    if (stats) {
-        if (first) hipLaunchKernelGGL((k_segment<true, true, 6>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_segment<false, true, 6>), g, b, lds, stream, a);
-    } else if (waves >= 8) {
-        if (first) hipLaunchKernelGGL((k_segment<true, false, 8>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_segment<false, false, 8>), g, b, lds, stream, a);
-    } else if (waves >= 6) {
-        if (first) hipLaunchKernelGGL((k_segment<true, false, 6>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_segment<false, false, 6>), g, b, lds, stream, a);
+    const bool tex = a.textures != nullptr;
+#define CRT_LAUNCH_SEG(F, S, T) hipLaunchKernelGGL((k_segment<F, S, T>), g, b, lds, stream, a)
+    if (first) {
+        if (stats) { if (tex) CRT_LAUNCH_SEG(true, true, true); else CRT_LAUNCH_SEG(true, true, false); }
+        else       { if (tex) CRT_LAUNCH_SEG(true, false, true); else CRT_LAUNCH_SEG(true, false, false); }
     } else {
-        if (first) hipLaunchKernelGGL((k_segment<true, false, 5>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_segment<false, false, 5>), g, b, lds, stream, a);
+        if (stats) { if (tex) CRT_LAUNCH_SEG(false, true, true); else CRT_LAUNCH_SEG(false, true, false); }
+        else       { if (tex) CRT_LAUNCH_SEG(false, false, true); else CRT_LAUNCH_SEG(false, false, false); }
     }
+#undef CRT_LAUNCH_SEG
 }
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);
