@@ -413,3 +413,30 @@ def test_textured_albedo_matches_oracle(cr, ob, textured):
     scene.reset(); scene.render_frame(0.6591631, 0.910802)
     assert np.abs(untex.read_sum() - scene.read_sum()).max() > 0.01     # the texture is really used
     untex.close(); scene.close()
+
+
+def test_scene_input_variants(cr, ob, cornell, cornell_data, scenes):
+    """crt_scene_desc accepts the BVH2 alone (converted to CWBVH inside, what a reference caller has today),
+    a caller-built bvh8 alone, or both; all three trace identically.  BVH2-mode tracing needs the BVH2."""
+    import copy
+    from caitlynrenderer_amd import _lib
+    _, orc, _ = scenes["cornell"]
+    rays = seeded_rays(cornell[0], 20000, 21, cr.RAY_DT)
+    want = orc.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=8)
+    only2 = copy.copy(cornell_data); only2.bvh8 = None; only2.bvh8_tri_slots = None
+    only8 = copy.copy(cornell_data); only8.bvh = None
+    for data in (only2, only8, cornell_data):
+        s = cr.Scene(data, 64, 64, 1)
+        _assert_hits_equal(s.trace(rays), want)
+        if data.bvh is None:
+            with pytest.raises(cr.CrtError) as e:
+                s.trace(rays, cr.CRT_TRACE_BVH2)
+            assert e.value.code == _lib.CRT_ERR_INVALID
+        s.close()
+    # a corrupted caller-supplied CWBVH is refused instead of being walked
+    bad = copy.copy(cornell_data)
+    bad.bvh8 = cornell_data.bvh8.copy()
+    bad.bvh8[0, 16:20] = np.frombuffer(np.uint32(10 ** 6).tobytes(), np.uint8)   # child_base_index out of range
+    with pytest.raises(cr.CrtError) as e:
+        cr.Scene(bad, 64, 64, 1)
+    assert e.value.code == _lib.CRT_ERR_INVALID and "CWBVH rejected" in str(e.value)
