@@ -33,7 +33,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(name):
+def build_workload(name, builder="sbvh"):
     import numpy as np
     import __graft_entry__ as g
     import caitlynrenderer_amd as cr
@@ -45,7 +45,9 @@ def build_workload(name):
         mesh = tessellated_cornell(mesh, n)
         label = f"procedural tessellated Cornell n={n}: {mesh.triangles.shape[0]} tris, CWBVH"
     t0 = time.time()
-    data = cr.SceneData.build(mesh, cam)
+    data = cr.SceneData.build(mesh, cam, builder=builder)
+    if builder == "lbvh":
+        label += " over a GPU-built LBVH"
     return data, cam, label, time.time() - t0
 
 
@@ -64,6 +66,8 @@ def main():
     ap.add_argument("--workload", default="cornell")
     ap.add_argument("--depth", type=int, default=1, help="path segments per sample (1 = primary + shadow)")
     ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--builder", default="sbvh", choices=["sbvh", "lbvh"],
+                    help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,7 +100,7 @@ def main():
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd import tiles
 
-    data, cam, label, build_s = build_workload(args.workload)
+    data, cam, label, build_s = build_workload(args.workload, args.builder)
     W, H = frame_size(world)
     scene = cr.Scene(data, W, H, args.depth)
     scene.set_shard(rank, world, args.tile)

@@ -88,6 +88,8 @@ SYMBOLS = {
     "crt_sbvh_triangle_indices": (_P, [_P]),
     "crt_sbvh_triangles": (_P, [_P]),
     "crt_sbvh_free": (None, [_P]),
+    "crt_lbvh_build": (_I, [_P, _SZ, _P, _SZ, _U32, C.POINTER(_P)]),
+    "crt_lbvh_last_build_ms": (None, [C.POINTER(_F), C.POINTER(_F)]),
     "crt_cwbvh_convert": (_I, [_P, _SZ, _SZ, C.POINTER(_P)]),
     "crt_cwbvh_num_nodes": (_SZ, [_P]),
     "crt_cwbvh_num_tris": (_SZ, [_P]),

@@ -5,6 +5,7 @@
 
 #include "../../include/crt.h"
 #include "crt_error.hpp"
+#include "crt_handles.hpp"
 #include "host/camera.hpp"
 #include "host/cwbvh.hpp"
 #include "host/obj_loader.hpp"
@@ -18,9 +19,6 @@ int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 
 using crt::fail;
 
-struct crt_sbvh { crt::SBVH bvh; };
-struct crt_cwbvh { crt::CWBVH bvh; };
-struct crt_mesh { crt::Mesh mesh; };
 
 extern "C" {
 

@@ -110,12 +110,19 @@ class SBVH:
     """SBVH(trs, vertices) (sbvh.h:99): flat_nodes, triangle_indices and the re-ordered triangles."""
     NO_SPATIAL_SPLITS = 1
 
-    def __init__(self, triangles, vertices, flags=0):
+    def __init__(self, triangles, vertices, flags=0, builder="sbvh"):
+        """builder="sbvh": the reference's split-BVH on the host; builder="lbvh": GPU linear BVH (crt_lbvh_build)."""
         L = lib()
         tris = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 12)
         verts = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         h = C.c_void_p()
-        check(L.crt_sbvh_build(_ptr(tris), tris.shape[0], _ptr(verts), verts.shape[0], int(flags), C.byref(h)))
+        build = L.crt_lbvh_build if builder == "lbvh" else L.crt_sbvh_build
+        check(build(_ptr(tris), tris.shape[0], _ptr(verts), verts.shape[0], int(flags), C.byref(h)))
+        self.build_ms = None
+        if builder == "lbvh":
+            dev, tot = C.c_float(), C.c_float()
+            L.crt_lbvh_last_build_ms(C.byref(dev), C.byref(tot))
+            self.build_ms = (dev.value, tot.value)
         try:
             nn, ns = L.crt_sbvh_num_nodes(h), L.crt_sbvh_num_slots(h)
             self.flat_nodes = _copy(L.crt_sbvh_nodes(h), C.c_float, (nn, 8), np.float32)

@@ -33,9 +33,10 @@ class SceneData:
         self.n_source_triangles = int(mesh.triangles.shape[0])
 
     @staticmethod
-    def build(mesh, camera, sbvh_flags=0, with_cwbvh=True):
-        """Scene::build_bvh (Scene.h:929-959) followed by the intended CWBVH::convert."""
-        sbvh = SBVH(mesh.triangles, mesh.vertices, sbvh_flags)
+    def build(mesh, camera, sbvh_flags=0, with_cwbvh=True, builder="sbvh"):
+        """Scene::build_bvh (Scene.h:929-959) followed by the intended CWBVH::convert.
+        builder="lbvh" swaps the host SBVH for the GPU linear BVH (crt_lbvh_build)."""
+        sbvh = SBVH(mesh.triangles, mesh.vertices, sbvh_flags, builder=builder)
         cw = CWBVH().convert(sbvh) if with_cwbvh else None
         return SceneData(mesh, sbvh, cw, camera)
 

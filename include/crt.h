@@ -201,6 +201,14 @@ const int32_t*      crt_sbvh_triangle_indices(const crt_sbvh*); /* slot -> origi
 const crt_triangle* crt_sbvh_triangles(const crt_sbvh*);        /* reordered trs, sbvh.h:130-139 */
 void crt_sbvh_free(crt_sbvh*);
 
+/* GPU BVH construction (needs a GPU).  A linear BVH (Morton codes, device radix sort, Karras'
+ * radix tree, bottom-up refit) in the same FlatNode/leaf-order layout, returned through the same handle as
+ * crt_sbvh_build so either builder can feed crt_scene_desc.bvh / crt_cwbvh_convert.  Not the reference's
+ * SBVH: no SAH and no spatial splits — a different, lower-quality tree built ~100x faster. */
+int  crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertices, size_t n_vertices,
+                    uint32_t flags, crt_sbvh** out);
+void crt_lbvh_last_build_ms(float* device_ms, float* total_ms);
+
 /* CWBVH converter, Caitlyn/cwbvh.h:58-73 CWBVH::convert(SBVH&) with the defects of
  * SURVEY 8a corrected (appendix C) [host]. */
 typedef struct crt_cwbvh crt_cwbvh;

@@ -440,3 +440,60 @@ def test_scene_input_variants(cr, ob, cornell, cornell_data, scenes):
     with pytest.raises(cr.CrtError) as e:
         cr.Scene(bad, 64, 64, 1)
     assert e.value.code == _lib.CRT_ERR_INVALID and "CWBVH rejected" in str(e.value)
+
+
+def _check_lbvh(flat, tris, verts):
+    n = flat.shape[0]
+    leaf = flat[:, 7] != 0
+    assert (flat[leaf, 7] == 1).all() and n == 2 * tris.shape[0] - 1
+    inner = np.nonzero(~leaf)[0]
+    left = flat[inner, 3].astype(np.int64)
+    assert np.array_equal(left, 2 * np.arange(len(inner)) + 1)              # BFS, children adjacent
+    assert sorted(flat[leaf, 3].astype(np.int64).tolist()) == list(range(tris.shape[0]))
+    tri_lo, tri_hi = verts[tris[:, :3]].min(1), verts[tris[:, :3]].max(1)
+    slots = flat[leaf, 3].astype(np.int64)
+    assert np.array_equal(flat[leaf, 0:3], tri_lo[slots]) and np.array_equal(flat[leaf, 4:7], tri_hi[slots])   # exact leaf boxes
+    # every interior box is exactly the union of its children (refit), checked bottom-up in one sweep
+    lo, hi = flat[:, 0:3].copy(), flat[:, 4:7].copy()
+    assert np.array_equal(lo[inner], np.minimum(lo[left], lo[left + 1])) and np.array_equal(hi[inner], np.maximum(hi[left], hi[left + 1]))
+
+
+@pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
+def test_gpu_lbvh_builder(cr, ob, cornell, tess8, tess40, scenes, name):
+    """crt_lbvh_build: Morton sort + Karras tree + device refit.  The tree is valid, the scene
+    built on it (LBVH -> host CWBVH conversion) returns exactly the hits of the reference-builder scene."""
+    mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
+    sb = cr.SBVH(mesh.triangles, mesh.vertices, builder="lbvh")
+    assert sb.build_ms is not None and sb.build_ms[0] > 0
+    _check_lbvh(sb.flat_nodes, sb.triangles, mesh.vertices)
+    assert sorted(sb.triangle_indices.tolist()) == list(range(mesh.triangles.shape[0]))       # no duplicates: a permutation
+    assert np.array_equal(sb.triangles, mesh.triangles[sb.triangle_indices])
+    data = cr.SceneData.build(mesh, cornell[1], builder="lbvh")
+    scene_l = cr.Scene(data, 64, 64, 1)
+    scene_s, orc, _ = scenes[name]
+    rays = np.concatenate([seeded_rays(mesh, 40000, 31, cr.RAY_DT), orc.primary_rays(RX1, RY1, jitter=True).astype(cr.RAY_DT)])
+    got = scene_l.trace(rays)
+    _assert_hits_equal(got, scene_s.trace(rays))                            # same closest hits through either tree
+    _assert_hits_equal(got, ob.Oracle(data, 64, 64, 1, cornell[1]).trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=8))
+    _assert_hits_equal(scene_l.trace(rays, cr.CRT_TRACE_BVH2 | cr.CRT_TRACE_TIE_LOWEST_ID), got)
+    # deterministic: same tree on a second build
+    sb2 = cr.SBVH(mesh.triangles, mesh.vertices, builder="lbvh")
+    assert np.array_equal(sb2.flat_nodes.view(np.uint32), sb.flat_nodes.view(np.uint32)) and np.array_equal(sb2.triangle_indices, sb.triangle_indices)
+    scene_l.close()
+
+
+def test_gpu_lbvh_edge_cases(cr):
+    for n in (1, 2, 3):
+        v = (np.arange(9 * n, dtype=np.float32).reshape(-1, 3) * np.float32(0.37)) % 5
+        t = np.zeros((n, 12), np.int32)
+        t[:, :3] = np.arange(3 * n).reshape(-1, 3)
+        sb = cr.SBVH(t, v, builder="lbvh")
+        _check_lbvh(sb.flat_nodes, sb.triangles, v)
+    # identical centroids (equal Morton codes): index tie-break keeps the keys unique
+    v = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (50, 1))
+    t = np.zeros((50, 12), np.int32)
+    t[:, :3] = np.arange(150).reshape(-1, 3)
+    sb = cr.SBVH(t, v, builder="lbvh")
+    _check_lbvh(sb.flat_nodes, sb.triangles, v)
+    cw = cr.CWBVH().convert(sb)
+    assert cw.depth <= 16
