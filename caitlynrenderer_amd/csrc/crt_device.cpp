@@ -91,6 +91,8 @@ struct crt_scene {
     uint8_t* d_rgba = nullptr;
     float4* d_rays[2] = {nullptr, nullptr};   // path-ray queues, only for max_depth > 1
     float4* d_shadow = nullptr;               // 4 x float4 per shadow ray: ray, ray, C, L so far
+    float4* d_qhits = nullptr;                // closest hits of the path-ray queue (max_depth > 1, refill tracing)
+    uint32_t bounce_refill = 1;               // segments >= 1: trace with lane refill + separate shading (0: fused lock-step)
     crt::PathBuffers pb{};
     uint32_t stack_entries = CRT_STACK_ENTRIES;
     uint32_t sub_capacity = 0;                // entries per sub-queue (8 per queue)
@@ -122,7 +124,7 @@ struct crt_scene {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
-                        d_rays[0], d_rays[1], d_shadow, pb.L, pb.T, pb.seed, d_counts,
+                        d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_counts) hipHostFree(h_counts);
@@ -191,7 +193,7 @@ int build_shard(crt_scene* s) {
 
 void free_frame_buffers(crt_scene* s) {
     void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
-                     (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed};
+                     (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     s->frame_buffers_ready = false;
 }
@@ -212,6 +214,7 @@ int alloc_frame_buffers(crt_scene* s) {
     if (s->max_depth > 1) {                      // path state and ray queues exist only for multi-segment paths
         if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
         if ((rc = dev_alloc(&s->d_rays[1], 2 * Q))) return rc;
+        if ((rc = dev_alloc(&s->d_qhits, Q))) return rc;
         if ((rc = dev_alloc(&s->pb.L, P))) return rc;
         if ((rc = dev_alloc(&s->pb.T, P))) return rc;
         if ((rc = dev_alloc(&s->pb.seed, P))) return rc;
@@ -360,6 +363,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
@@ -492,6 +496,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
+    else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;
@@ -533,7 +538,16 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
         sa.visit_totals = s->d_visit_totals;
         EventSpan* sp = s->begin_span(1);
-        crt::launch_segment(sa, b == 0, s->count_visits, s->trace_grid(P, 5), s->stream);
+        const bool pretraced = b > 0 && s->bounce_refill;
+        if (pretraced) {
+            crt::QueueTraceArgs qa{};
+            qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
+            qa.stack_entries = s->stack_entries; qa.sub_capacity = s->sub_capacity; qa.refill_min = s->refill_min;
+            qa.visit_totals = s->d_visit_totals;
+            crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8), s->stream);
+            sa.hits_in = s->d_qhits;
+        }
+        crt::launch_segment(sa, b == 0, pretraced, s->count_visits, s->trace_grid(P, 5), s->stream);
         s->end_span(sp);
 
         crt::ShadowArgs sh{};

@@ -581,7 +581,9 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // state) touches HBM; a path that ends here adds its radiance to the sum buffer directly.
 // TEX compiles the textured-albedo branch in (its double-precision pow costs registers the untextured path
 // should not pay for).  96-VGPR budget = 5 waves per SIMD; 80 and 64 were measured slower.
-template <bool FIRST, bool STATS, bool TEX>
+// PRETRACED: the closest hit of each queue entry was found by k_closest_queue (incoherent bounce rays are
+// traced with lane refill, which cannot be fused with lock-step shading); the kernel then only shades.
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -649,7 +651,14 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
 
         HitState hit;
         hit.tri = -1;
-        if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, hit, nn, nt);
+        if (PRETRACED) {
+            if (active) {
+                const float4 h = a.hits_in[(size_t)g * a.sub_capacity + e];
+                hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = __float_as_int(h.w);
+            }
+        } else if (active) {
+            traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, hit, nn, nt);
+        }
 
         bool emit_shadow = false, emit_next = false, finished = active;
         float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, sh3 = sh0, nx0 = sh0, nx1 = sh0;
@@ -777,6 +786,40 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         const uint32_t ni = wave_append(emit_next, count_next);
         if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
     }
+    if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt);
+    (void)stk;
+}
+
+// Closest hit for a device-written path-ray queue (segments >= 1): per-wave 256-ray pools with lane refill
+// (traverse_pool); hits go to a buffer parallel to the queue and k_segment<PRETRACED> shades them.
+template <bool STATS>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArgs a) {
+    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
+    uint32_t nn = 0, nt = 0;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t v = static_pool_chunk<false>(a.count, 0u, it);
+        if (v == CRT_NO_WORK) break;
+        const uint32_t g = v >> 28;
+        const uint32_t n = a.count[g * CRT_COUNTER_STRIDE];
+        const uint32_t first = (v & 0x0fffffffu) * 1024u + wave * 256u;
+        if (first >= n) continue;
+        const uint32_t last = first + 256u < n ? first + 256u : n;
+        const float4* const rays = a.rays + 2 * (size_t)g * a.sub_capacity;
+        float4* const hits = a.hits + (size_t)g * a.sub_capacity;
+        traverse_pool<false, STATS>(
+            a.nodes, a.tris, stk, (int)a.stack_entries, first, last, a.refill_min,
+            [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
+                const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
+                o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
+            },
+            [&](uint32_t e, const HitState& best, bool hit) {
+                hits[e] = make_float4(best.t, best.u, best.v, __int_as_float(hit ? best.tri : -1));
+            },
+            nn, nt);
+    }
+    (void)lane;
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt);
 }
 
@@ -880,19 +923,29 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hi
         else       hipLaunchKernelGGL((k_trace_bvh2<false, false>), g, b, lds, stream, a);
     }
 }
-void launch_segment(const SegmentArgs& a, bool first, bool stats, uint32_t grid, hipStream_t stream) {
+// first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
+// !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);
     const size_t lds = stack_bytes(a.stack_entries);
     const bool tex = a.textures != nullptr;
-#define CRT_LAUNCH_SEG(F, S, T) hipLaunchKernelGGL((k_segment<F, S, T>), g, b, lds, stream, a)
+#define CRT_LAUNCH_SEG(F, S, T, P) hipLaunchKernelGGL((k_segment<F, S, T, P>), g, b, lds, stream, a)
     if (first) {
-        if (stats) { if (tex) CRT_LAUNCH_SEG(true, true, true); else CRT_LAUNCH_SEG(true, true, false); }
-        else       { if (tex) CRT_LAUNCH_SEG(true, false, true); else CRT_LAUNCH_SEG(true, false, false); }
+        if (stats) { if (tex) CRT_LAUNCH_SEG(true, true, true, false); else CRT_LAUNCH_SEG(true, true, false, false); }
+        else       { if (tex) CRT_LAUNCH_SEG(true, false, true, false); else CRT_LAUNCH_SEG(true, false, false, false); }
+    } else if (pretraced) {
+        if (tex) CRT_LAUNCH_SEG(false, false, true, true); else CRT_LAUNCH_SEG(false, false, false, true);
     } else {
-        if (stats) { if (tex) CRT_LAUNCH_SEG(false, true, true); else CRT_LAUNCH_SEG(false, true, false); }
-        else       { if (tex) CRT_LAUNCH_SEG(false, false, true); else CRT_LAUNCH_SEG(false, false, false); }
+        if (stats) { if (tex) CRT_LAUNCH_SEG(false, true, true, false); else CRT_LAUNCH_SEG(false, true, false, false); }
+        else       { if (tex) CRT_LAUNCH_SEG(false, false, true, false); else CRT_LAUNCH_SEG(false, false, false, false); }
     }
 #undef CRT_LAUNCH_SEG
+}
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
+    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const size_t lds = stack_bytes(a.stack_entries);
+    if (stats) hipLaunchKernelGGL((k_closest_queue<true>), g, b, lds, stream, a);
+    else       hipLaunchKernelGGL((k_closest_queue<false>), g, b, lds, stream, a);
 }
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g(grid), b(CRT_TRACE_BLOCK);

@@ -66,12 +66,25 @@ struct SegmentArgs {
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart
+    const float4* hits_in;     // k_segment<PRETRACED>: (t, u, v, CWBVH triangle) per queue entry
     float4* rays_next;   uint32_t* count_next;
     float4* shadow;      uint32_t* count_shadow;   // 4 x float4 per entry: (o,tmax) (d,pixel|final<<31) (C) (L so far)
     PathBuffers pb;
     float* sum;                // packed tile-major RGB32F
     uint32_t last_segment;
     unsigned long long* visit_totals;   // STATS: [0] += nodes, [1] += tris
+};
+
+struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-written path-ray queue
+    const uint4* nodes;
+    const float4* tris;
+    const float4* rays;        // 8 sub-queues of crt_ray
+    const uint32_t* count;
+    float4* hits;              // parallel to the queue
+    uint32_t stack_entries;
+    uint32_t sub_capacity;
+    uint32_t refill_min;
+    unsigned long long* visit_totals;
 };
 
 struct ShadowArgs {
@@ -89,7 +102,8 @@ struct ShadowArgs {
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream);
-void launch_segment(const SegmentArgs& a, bool first, bool stats, uint32_t grid, hipStream_t stream);
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool stats, uint32_t grid, hipStream_t stream);
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
