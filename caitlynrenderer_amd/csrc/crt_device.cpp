@@ -117,6 +117,7 @@ struct crt_scene {
     bool stats_pending = false;
     bool stats_from_frame = false;
     bool stats_counted = false;
+    uint32_t tri_min = 8;                   // traverse_pool: pending-triangle lanes that trigger a triangle step
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
     uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
 
@@ -364,6 +365,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
@@ -497,6 +499,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
+    else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(1, value));
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;
@@ -531,6 +534,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.tex_width = s->tex_width; sa.tex_height = s->tex_height; sa.n_textures = s->n_textures;
         sa.f = f;
         sa.sub_capacity = s->sub_capacity;
+        sa.tri_min = s->info.n_nodes8 < 64 ? 0u : s->tri_min;   // tiny trees: plain per-lane loop
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = s->d_counts + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = s->d_counts + counter_index(b + 1, 0, 0);
         sa.shadow = s->d_shadow; sa.count_shadow = s->d_counts + counter_index(b, 1, 0);
@@ -542,7 +546,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         if (pretraced) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
-            qa.stack_entries = s->stack_entries; qa.sub_capacity = s->sub_capacity; qa.refill_min = s->refill_min;
+            qa.stack_entries = s->stack_entries; qa.sub_capacity = s->sub_capacity; qa.refill_min = s->refill_min; qa.tri_min = s->tri_min;
             qa.visit_totals = s->d_visit_totals;
             crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8), s->stream);
             sa.hits_in = s->d_qhits;
@@ -552,7 +556,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
 
         crt::ShadowArgs sh{};
         sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = s->d_counts + counter_index(b, 1, 0);
-        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min;
+        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = s->tri_min;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sp = s->begin_span(2);
         crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->stream);
@@ -725,6 +729,7 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     ta.stats = static_cast<uint32_t*>(d_stats); ta.count_ptr = nullptr; ta.n = (uint32_t)n; ta.out_orig_id = 1;
     ta.stack_entries = s->stack_entries;
     ta.refill_min = s->refill_min;
+    ta.tri_min = s->tri_min;
     s->n_spans = 0;
     EventSpan* sp = s->begin_span(any_hit ? 2 : 1);
     if (mode & CRT_TRACE_BVH2) {

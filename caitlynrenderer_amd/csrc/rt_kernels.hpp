@@ -21,6 +21,7 @@ struct TraceArgs {
     uint32_t out_orig_id;      // 1: hit.tri = original triangle id, 0: CWBVH triangle index
     uint32_t stack_entries;
     uint32_t refill_min;       // idle lanes that trigger a pool refill (traverse_pool)
+    uint32_t tri_min;          // lanes with a pending triangle group that trigger a triangle step (traverse_pool)
 };
 
 struct Bvh2Args {               // the reference's live BVH2 walk (path_trace.fs:511-819) for crt_trace
@@ -64,6 +65,7 @@ struct SegmentArgs {
     int32_t tex_width, tex_height, n_textures;
     FrameArgs f;
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
+    uint32_t tri_min;          // triangle-step vote threshold (traverse_pool)
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart
     const float4* hits_in;     // k_segment<PRETRACED>: (t, u, v, CWBVH triangle) per queue entry
@@ -84,6 +86,7 @@ struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-writ
     uint32_t stack_entries;
     uint32_t sub_capacity;
     uint32_t refill_min;
+    uint32_t tri_min;
     unsigned long long* visit_totals;
 };
 
@@ -97,6 +100,7 @@ struct ShadowArgs {
     uint32_t stack_entries;
     uint32_t sub_capacity;
     uint32_t refill_min;
+    uint32_t tri_min;
     unsigned long long* visit_totals;
 };
 
