@@ -117,7 +117,7 @@ struct crt_scene {
     bool stats_pending = false;
     bool stats_from_frame = false;
     bool stats_counted = false;
-    uint32_t tri_min = 8;                   // traverse_pool: pending-triangle lanes that trigger a triangle step
+    uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
     uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
 
@@ -556,7 +556,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
 
         crt::ShadowArgs sh{};
         sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = s->d_counts + counter_index(b, 1, 0);
-        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = s->tri_min;
+        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = 0;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sp = s->begin_span(2);
         crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->stream);

@@ -228,8 +228,8 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
 
         // ---- one step per iteration: either a node step (lanes in state N: inner hits pending, no triangle
         // group pending) or a triangle step (lanes in state T: a triangle group pending).  The wave votes: triangle
-        // tests are postponed until at least `tri_min` lanes have one pending (or nobody can do a node step), so
-        // the 90-instruction Moller-Trumbore block runs with more lanes enabled.  A lane's own sequence of node
+        // tests are postponed while node-ready lanes outnumber waiting lanes tri_min : 1 (tri_min is a ratio), so the
+        // 90-instruction Moller-Trumbore block and the 200-instruction node block each run with more lanes enabled.  A lane's own sequence of node
         // fetches and triangle tests is unchanged (it cannot fetch a node while its triangle group is pending),
         // so hits and visit counters stay bit-identical to the oracle.
         // (A wave-level dedup of the node loads — one leader lane per distinct node, followers fed by ds_bpermute —
@@ -238,7 +238,11 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
         const bool has_tri = busy && tg.y != 0u;
         const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
         const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
-        const bool node_phase = __ballot(can_node) != 0ull && n_tri < tri_min;
+        const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+        // node step only while the lanes that can fetch a node outnumber the lanes waiting for a triangle test by
+        // vote_ratio : 1 (measured at 1 M triangles, ratio 1 / 2: 0.293 / 0.283 ms against 0.311 ms for a fixed
+        // threshold of 8 waiting lanes and 0.397 ms for the un-voted loop)
+        const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;
         bool finished = false;
         if (node_phase) {
             if (can_node) {
@@ -851,8 +855,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
         const float4* q = a.shadow + 4 * ((size_t)g * a.sub_capacity + e);
         const float4 r0 = q[0], r1 = q[1];
         HitState hit;
-        // plain per-lane loop: the voting loop of traverse_pool costs more than it recovers on these short rays
-        // (measured 0.231 vs 0.180 ms at 1 M triangles, 0.036 vs 0.028 ms on Cornell)
+        // plain per-lane loop: neither lane refill (0.235 ms) nor the voting loop (0.193 ms at ratio 2) beats it
+        // (0.180 ms) on these short, fairly coherent rays
         const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
                                                     (int)a.stack_entries, hit, nn, nt);
         const uint32_t tag = __float_as_uint(r1.w);

@@ -21,7 +21,7 @@ struct TraceArgs {
     uint32_t out_orig_id;      // 1: hit.tri = original triangle id, 0: CWBVH triangle index
     uint32_t stack_entries;
     uint32_t refill_min;       // idle lanes that trigger a pool refill (traverse_pool)
-    uint32_t tri_min;          // lanes with a pending triangle group that trigger a triangle step (traverse_pool)
+    uint32_t tri_min;          // vote ratio of traverse_pool: node step while node-ready lanes >= tri_min x triangle-waiting lanes
 };
 
 struct Bvh2Args {               // the reference's live BVH2 walk (path_trace.fs:511-819) for crt_trace
@@ -65,7 +65,7 @@ struct SegmentArgs {
     int32_t tex_width, tex_height, n_textures;
     FrameArgs f;
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
-    uint32_t tri_min;          // triangle-step vote threshold (traverse_pool)
+    uint32_t tri_min;          // vote ratio of traverse_pool; 0 = plain per-lane loop (tiny trees)
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart
     const float4* hits_in;     // k_segment<PRETRACED>: (t, u, v, CWBVH triangle) per queue entry
