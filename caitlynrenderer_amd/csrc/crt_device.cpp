@@ -96,7 +96,10 @@ struct crt_scene {
     crt::PathBuffers pb{};
     uint32_t stack_entries = CRT_STACK_ENTRIES;
     uint32_t sub_capacity = 0;                // entries per sub-queue (8 per queue)
-    uint32_t* d_counts = nullptr;        // counter(seg, kind, group): kind 0 = rays into segment, 1 = its shadow rays
+    uint32_t* d_counts = nullptr;        // 2 banks (frame parity) of counter(seg, kind, group): kind 0 = rays into segment, 1 = its shadow rays
+    uint32_t bank = 0;                   // bank of the most recent frame
+    bool counts_clean = false;           // both banks known to be zero where the next frame needs them
+    uint32_t* counts() const { return d_counts + (size_t)bank * kCounters; }
     uint32_t* h_counts = nullptr;        // pinned
     bool frame_buffers_ready = false;
 
@@ -120,6 +123,8 @@ struct crt_scene {
     uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
     uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
+    uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
+    bool timing_accumulate = false;          // spans pile up over frames (crt_frame_stats then holds sums) instead of per frame
 
     ~crt_scene() {
         hipSetDevice(device);
@@ -150,6 +155,7 @@ struct crt_scene {
         return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)n_cu * 8));
     }
     EventSpan* begin_span(int kind) {
+        if (timing == 0u || (timing == 1u && kind != 1)) return nullptr;
         if (n_spans >= (int)spans.size()) return nullptr;
         EventSpan* s = &spans[n_spans++];
         s->kind = kind;
@@ -365,6 +371,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
@@ -445,7 +452,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         if (hipMemcpy(s->d_tris2, rec2.data(), rec2.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));
     }
-    if ((rc = dev_alloc(&s->d_counts, kCounters))) return bail(rc);
+    if ((rc = dev_alloc(&s->d_counts, 2 * kCounters))) return bail(rc);
     if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
         return bail(fail(CRT_ERR_NOMEM, "hipHostMalloc failed"));
     s->spans.resize(kMaxEvents);
@@ -499,6 +506,20 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
+    else if (!std::strcmp(name, "timing")) s->timing = (uint32_t)std::max(0, value);
+    else if (!std::strcmp(name, "timing_accumulate")) {
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->timing_accumulate = value != 0;
+        s->n_spans = 0;
+        const size_t want = value > 0 ? (size_t)std::min(value, 1 << 14) : 0;   // value = launches to make room for
+        while (s->spans.size() < want) {
+            EventSpan sp;
+            HIPCHK(hipEventCreate(&sp.a));
+            if (hipEventCreate(&sp.b) != hipSuccess) { hipEventDestroy(sp.a); return fail(CRT_ERR_HIP, "hipEventCreate"); }
+            s->spans.push_back(sp);
+        }
+    }
     else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(1, value));
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
@@ -515,7 +536,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
     if (s->n_local_pixels == 0) return CRT_OK;
     const uint32_t P = s->n_local_pixels;
     const crt::FrameArgs f = frame_args(s, rx, ry);
-    s->n_spans = 0;
+    if (!s->timing_accumulate) s->n_spans = 0;
     if (s->count_visits) {
         if (!s->d_visit_totals) {
             if ((rc = dev_alloc(&s->d_visit_totals, 4))) return rc;
@@ -523,7 +544,12 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         }
         HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 4 * sizeof(unsigned long long), s->stream));
     }
-    HIPCHK(hipMemsetAsync(s->d_counts, 0, kCounters * sizeof(uint32_t), s->stream));
+    // counter banks alternate per frame; k_segment<FIRST> clears the other bank for the frame after this one, so a
+    // memset is only needed for the very first frame (or after a failed launch left the banks in an unknown state)
+    s->bank ^= 1u;
+    if (!s->counts_clean) HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * kCounters * sizeof(uint32_t), s->stream));
+    s->counts_clean = false;
+    uint32_t* const cnt = s->counts();
 
     for (uint32_t b = 0; b < s->max_depth; ++b) {
         crt::SegmentArgs sa{};
@@ -535,12 +561,13 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.f = f;
         sa.sub_capacity = s->sub_capacity;
         sa.tri_min = s->info.n_nodes8 < 64 ? 0u : s->tri_min;   // tiny trees: plain per-lane loop
-        sa.rays_in = s->d_rays[b & 1]; sa.count_in = s->d_counts + counter_index(b, 0, 0);
-        sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = s->d_counts + counter_index(b + 1, 0, 0);
-        sa.shadow = s->d_shadow; sa.count_shadow = s->d_counts + counter_index(b, 1, 0);
+        sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
+        sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
+        sa.shadow = s->d_shadow; sa.count_shadow = cnt + counter_index(b, 1, 0);
         sa.pb = s->pb; sa.sum = s->d_sum;
         sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
         sa.visit_totals = s->d_visit_totals;
+        if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
         EventSpan* sp = s->begin_span(1);
         const bool pretraced = b > 0 && s->bounce_refill;
         if (pretraced) {
@@ -555,7 +582,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         s->end_span(sp);
 
         crt::ShadowArgs sh{};
-        sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = s->d_counts + counter_index(b, 1, 0);
+        sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = cnt + counter_index(b, 1, 0);
         sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = 0;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sp = s->begin_span(2);
@@ -566,6 +593,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     s->stats_counted = s->count_visits;
     HIPCHK(hipGetLastError());
+    s->counts_clean = true;
     s->stats_pending = true;
     s->stats_from_frame = true;   // ray counts come from h_counts at the next sync
     return CRT_OK;
@@ -592,7 +620,7 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
         HIPCHK(hipStreamSynchronize(s->stream));
         if (s->stats_from_frame) {
             // the queue counters stay valid until the next frame's memset: fetch them only when asked
-            HIPCHK(hipMemcpy(s->h_counts, s->d_counts, kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(s->h_counts, s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
             uint64_t closest = 0, any = 0;
             closest = s->n_local_in_frame;             // segment 0: one primary ray per in-frame pixel
             for (uint32_t b = 0; b < s->max_depth; ++b)
@@ -694,7 +722,7 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
     HIPCHK(hipStreamSynchronize(s->stream));
     if (!s->frame_buffers_ready || segment > 16) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: no frame rendered");
     std::vector<uint32_t> counts(kCounters);
-    HIPCHK(hipMemcpy(counts.data(), s->d_counts, kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts.data(), s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const float4* src = which == 2 ? s->d_shadow : s->d_rays[segment & 1];
     const size_t entry = which == 2 ? 4 * sizeof(float4) : sizeof(crt_ray);
     size_t total = 0;

@@ -592,6 +592,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
     const FrameArgs& f = a.f;
     uint32_t nn = 0, nt = 0;
+    // Queue counters are double-banked by frame parity: the first kernel of a frame clears the bank the next
+    // frame will append to (last touched by the previous frame, which stream order has retired).
+    if (FIRST && a.zero_counts && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x) a.zero_counts[i] = 0u;
     for (uint32_t it = 0;; ++it) {
         const uint32_t v = static_chunk<FIRST>(a.count_in, f.n_local_pixels, it);
         if (v == CRT_NO_WORK) break;

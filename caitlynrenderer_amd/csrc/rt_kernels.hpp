@@ -75,6 +75,8 @@ struct SegmentArgs {
     float* sum;                // packed tile-major RGB32F
     uint32_t last_segment;
     unsigned long long* visit_totals;   // STATS: [0] += nodes, [1] += tris
+    uint32_t* zero_counts;     // FIRST: the other frame's counter bank, cleared here for the next frame (no memset launch)
+    uint32_t n_zero;
 };
 
 struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-written path-ray queue

@@ -131,7 +131,11 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry);
 int crt_sync(crt_scene* s);
 /* knobs: "jitter" (0/1, tent-filter jitter of path_trace.fs:1030-1037; default 1),
  * "trace_occupancy" (persistent workgroups per CU for the traversal kernels),
- * "count_visits" (0/1: traversal launches also count node fetches / triangle tests). */
+ * "count_visits" (0/1: traversal launches also count node fetches / triangle tests),
+ * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = around every launch (default), 1 = closest-hit
+ * launches only, 0 = none), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
+ * restarting every frame — crt_frame_stats.ms_* are then sums over n_trace_launches launches; 0: per frame),
+ * tuning: "tri_min" (vote ratio of the traversal loop, 0 = per-lane loop), "refill_min", "bounce_refill". */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);

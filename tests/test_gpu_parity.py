@@ -188,6 +188,38 @@ def test_full_resolution_mesh_frame_with_visit_counters(cr, ob, cornell, tess40)
     scene.close()
 
 
+def test_async_frames_and_timing_options_do_not_change_results(cr, scenes):
+    """Frames queued back to back (counter banks alternate, the kernels clear the next frame's bank) with the
+    event spans reduced / accumulated give the same sum and ray counts as synchronous frames with full timing."""
+    _, _, data = scenes["tess8"]
+    W, H, depth, frames = 320, 200, 3, 7
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(frames)]
+    a = cr.Scene(data, W, H, depth)
+    for rx, ry in rvs:
+        a.render_frame(rx, ry)
+    want, want_st = a.read_sum(), a.frame_stats()
+    assert want_st["n_trace_launches"] == 2 * depth and want_st["ms_trace_closest"] > 0 and want_st["ms_trace_any"] > 0
+    a.close()
+    for timing in (0, 1, 2):
+        b = cr.Scene(data, W, H, depth)
+        b.set_option("timing", timing)
+        b.set_option("timing_accumulate", frames * depth * 2)
+        for rx, ry in rvs:
+            b.render_frame(rx, ry, sync=False)
+        b.sync()
+        st = b.frame_stats()
+        assert np.array_equal(b.read_sum().view(np.uint32), want.view(np.uint32)), timing
+        assert (st["closest_rays"], st["any_rays"]) == (want_st["closest_rays"], want_st["any_rays"])
+        assert st["n_trace_launches"] == (0, frames * depth, 2 * frames * depth)[timing]
+        assert (st["ms_trace_closest"] > 0) == (timing > 0) and (st["ms_trace_any"] > 0) == (timing > 1)
+        b.set_option("timing_accumulate", 0)
+        b.set_option("timing", 2)
+        b.render_frame(*rvs[0])
+        assert b.frame_stats()["n_trace_launches"] == 2 * depth
+        b.close()
+
+
 def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data):
     """world=3 shards rendered on one GPU: the union of the ranks' pixels is bit-identical to world=1."""
     from caitlynrenderer_amd import tiles
