@@ -380,6 +380,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) crt::set_waves_per_workgroup((uint32_t)std::atoi(e));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
@@ -516,6 +517,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
+    else if (!std::strcmp(name, "waves_per_workgroup")) crt::set_waves_per_workgroup((uint32_t)value);
     else if (!std::strcmp(name, "timing")) s->timing = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "timing_accumulate")) {
         HIPCHK(hipSetDevice(s->device));

@@ -325,11 +325,29 @@ __device__ __forceinline__ uint32_t dense_chunks_of_group(uint32_t n_items, uint
 __device__ __forceinline__ uint32_t queue_chunks(uint32_t n) { return (((n + 63u) >> 6) + 3u) >> 2; }
 
 // (group << 28 | chunk) for iteration `it` of this workgroup, or CRT_NO_WORK; uniform over the workgroup.
+// A workgroup is either 4 waves (256 threads) or a single wave (64 threads): with one wave per workgroup, 4
+// consecutive workgroups of the same XCD stand for one chunk, so the dispatcher refills CUs wave by wave.
+struct WaveId { uint32_t lane, wave, lds_wave, vblock, vgrid; };
+__device__ __forceinline__ WaveId wave_id() {
+    WaveId w;
+    w.lane = threadIdx.x & 63u;
+    w.lds_wave = threadIdx.x >> 6;
+    if (blockDim.x == 64u) {
+        const uint32_t q = blockIdx.x >> 3;
+        w.wave = q & 3u;
+        w.vblock = ((q >> 2) << 3) | (blockIdx.x & 7u);
+        w.vgrid = gridDim.x >> 2;
+    } else {
+        w.wave = w.lds_wave; w.vblock = blockIdx.x; w.vgrid = gridDim.x;
+    }
+    return w;
+}
+
 template <bool DENSE>
-__device__ __forceinline__ uint32_t static_chunk(const uint32_t* counts, uint32_t n_dense, uint32_t it) {
-    const uint32_t g = blockIdx.x & 7u;
+__device__ __forceinline__ uint32_t static_chunk(const WaveId& w, const uint32_t* counts, uint32_t n_dense, uint32_t it) {
+    const uint32_t g = w.vblock & 7u;
     const uint32_t nch = DENSE ? dense_chunks_of_group(n_dense, g) : queue_chunks(counts[g * CRT_COUNTER_STRIDE]);
-    const uint32_t c = (blockIdx.x >> 3) + it * (gridDim.x >> 3);     // the host launches a multiple of 8 workgroups
+    const uint32_t c = (w.vblock >> 3) + it * (w.vgrid >> 3);     // the host launches a multiple of 8 workgroups
     return c < nch ? (g << 28) | c : CRT_NO_WORK;
 }
 
@@ -340,10 +358,10 @@ __device__ __forceinline__ uint32_t dense_pool_chunks_of_group(uint32_t n_items,
 }
 __device__ __forceinline__ uint32_t queue_pool_chunks(uint32_t n) { return (n + 1023u) >> 10; }
 template <bool DENSE>
-__device__ __forceinline__ uint32_t static_pool_chunk(const uint32_t* counts, uint32_t n_dense, uint32_t it) {
-    const uint32_t g = blockIdx.x & 7u;
+__device__ __forceinline__ uint32_t static_pool_chunk(const WaveId& w, const uint32_t* counts, uint32_t n_dense, uint32_t it) {
+    const uint32_t g = w.vblock & 7u;
     const uint32_t nch = DENSE ? dense_pool_chunks_of_group(n_dense, g) : queue_pool_chunks(counts[g * CRT_COUNTER_STRIDE]);
-    const uint32_t c = (blockIdx.x >> 3) + it * (gridDim.x >> 3);
+    const uint32_t c = (w.vblock >> 3) + it * (w.vgrid >> 3);
     return c < nch ? (g << 28) | c : CRT_NO_WORK;
 }
 // first item of this wave's pool for a dense pool chunk
@@ -376,12 +394,13 @@ __device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, u
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
+    const WaveId wid = wave_id();
+    const uint32_t lane = wid.lane, wave = wid.wave;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
     uint32_t nn_total = 0, nt_total = 0;
     for (uint32_t it = 0;; ++it) {
-        const uint32_t v = static_pool_chunk<true>(nullptr, n, it);
+        const uint32_t v = static_pool_chunk<true>(wid, nullptr, n, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t first = dense_pool_first(v, wave);
         if (first >= n) continue;
@@ -435,10 +454,11 @@ __device__ __forceinline__ float hit_bbox2(vec3 o, vec3 bmin, vec3 bmax, vec3 in
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace_bvh2(Bvh2Args a) {
     extern __shared__ int s_stk2[];      // [wave][level][lane]
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    int* stk = s_stk2 + (size_t)wave * a.stack_entries * 64u + lane;
+    const WaveId wid = wave_id();
+    const uint32_t lane = wid.lane, wave = wid.wave;
+    int* stk = s_stk2 + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     for (uint32_t it = 0;; ++it) {
-        const uint32_t v = static_chunk<true>(nullptr, a.n, it);
+        const uint32_t v = static_chunk<true>(wid, nullptr, a.n, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t i = dense_item(v, wave, lane);
         if (i >= a.n) continue;
@@ -588,16 +608,17 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 template <bool FIRST, bool STATS, bool TEX, bool PRETRACED>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
+    const WaveId wid = wave_id();
+    const uint32_t lane = wid.lane, wave = wid.wave;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     const FrameArgs& f = a.f;
     uint32_t nn = 0, nt = 0;
     // Queue counters are double-banked by frame parity: the first kernel of a frame clears the bank the next
     // frame will append to (last touched by the previous frame, which stream order has retired).
-    if (FIRST && a.zero_counts && blockIdx.x == 0)
+    if (FIRST && a.zero_counts && blockIdx.x == 0)   // 64 or 256 threads, either works
         for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x) a.zero_counts[i] = 0u;
     for (uint32_t it = 0;; ++it) {
-        const uint32_t v = static_chunk<FIRST>(a.count_in, f.n_local_pixels, it);
+        const uint32_t v = static_chunk<FIRST>(wid, a.count_in, f.n_local_pixels, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t g = v >> 28;                         // owner group of this chunk: its sub-queues get the output
         uint32_t* const count_shadow = a.count_shadow + g * CRT_COUNTER_STRIDE;
@@ -811,11 +832,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
 template <bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
+    const WaveId wid = wave_id();
+    const uint32_t lane = wid.lane, wave = wid.wave;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     uint32_t nn = 0, nt = 0;
     for (uint32_t it = 0;; ++it) {
-        const uint32_t v = static_pool_chunk<false>(a.count, 0u, it);
+        const uint32_t v = static_pool_chunk<false>(wid, a.count, 0u, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t g = v >> 28;
         const uint32_t n = a.count[g * CRT_COUNTER_STRIDE];
@@ -847,11 +869,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
 template <bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* stk = s_lds + (size_t)wave * a.stack_entries * 64u + lane;
+    const WaveId wid = wave_id();
+    const uint32_t lane = wid.lane, wave = wid.wave;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     uint32_t nn = 0, nt = 0;
     for (uint32_t it = 0;; ++it) {
-        const uint32_t v = static_chunk<false>(a.count, 0u, it);
+        const uint32_t v = static_chunk<false>(wid, a.count, 0u, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t g = v >> 28;
         const uint32_t e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
@@ -917,10 +940,15 @@ __global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linea
 
 // ------------------------------------------------------------------ launchers --------
 
-static inline size_t stack_bytes(uint32_t entries) { return (size_t)(CRT_TRACE_BLOCK / 64) * entries * 64 * sizeof(uint2); }
+static uint32_t g_waves_per_group = 1;   // measured: 1 M mesh k_segment 0.246 -> 0.226 ms, Cornell 0.079 -> 0.074 ms
+void set_waves_per_workgroup(uint32_t n) { g_waves_per_group = n == 1u ? 1u : 4u; }
+static inline size_t stack_bytes(uint32_t entries) { return (size_t)g_waves_per_group * entries * 64 * sizeof(uint2); }
+// `grid` counts 4-wave chunks; with single-wave workgroups each of them becomes 4 workgroups
+static inline dim3 grid_dim(uint32_t grid) { return dim3(g_waves_per_group == 1u ? grid * 4u : grid); }
+static inline dim3 block_dim() { return dim3(g_waves_per_group * 64u); }
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
     if (mode == 1) {
         if (stats) hipLaunchKernelGGL((k_trace<true, true>), g, b, lds, stream, a);
@@ -931,8 +959,8 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipSt
     }
 }
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g(grid), b(CRT_TRACE_BLOCK);
-    const size_t lds = (size_t)(CRT_TRACE_BLOCK / 64) * a.stack_entries * 64 * sizeof(int);
+    const dim3 g = grid_dim(grid), b = block_dim();
+    const size_t lds = (size_t)g_waves_per_group * a.stack_entries * 64 * sizeof(int);
     if (any) {
         if (stats) hipLaunchKernelGGL((k_trace_bvh2<true, true>), g, b, lds, stream, a);
         else       hipLaunchKernelGGL((k_trace_bvh2<true, false>), g, b, lds, stream, a);
@@ -944,7 +972,7 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hi
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
 void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
     const bool tex = a.textures != nullptr;
 #define CRT_LAUNCH_SEG(F, S, T, P) hipLaunchKernelGGL((k_segment<F, S, T, P>), g, b, lds, stream, a)
@@ -960,13 +988,13 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool stats
 #undef CRT_LAUNCH_SEG
 }
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
     if (stats) hipLaunchKernelGGL((k_closest_queue<true>), g, b, lds, stream, a);
     else       hipLaunchKernelGGL((k_closest_queue<false>), g, b, lds, stream, a);
 }
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g(grid), b(CRT_TRACE_BLOCK);
+    const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
     if (stats) hipLaunchKernelGGL((k_shadow<true>), g, b, lds, stream, a);
     else       hipLaunchKernelGGL((k_shadow<false>), g, b, lds, stream, a);
