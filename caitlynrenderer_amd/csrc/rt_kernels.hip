@@ -26,7 +26,9 @@ __device__ __forceinline__ uint32_t sign_extend_s8x4(uint32_t x) { return ((x >>
 __device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }          // v_cvt_f32_ubyteN
 
 // 8-wide quantised child-box test (cwbvh.fs:376-446, corrected: far = min(min()), tmin clamped to 0,
-// tmax clamped to max_t, hit iff tmin <= tmax).  Returns the hit mask: inner children in the top
+// tmax clamped to max_t, hit iff tmin <= tmax).  ~19 VALU instructions per child (6 cvt_f32_ubyte, 6 fma, max3,
+// min3, 2 clamps, compare, shift, select); pairing the near/far fmas of an axis into v_pk_fma_f32 (24 instead of
+// 48) was measured: no change (0.228 vs 0.226 ms) for 9 more VGPRs, so the scalar form stays.  Returns the hit mask: inner children in the top
 // byte at bit (24+slot)^oct, leaf triangles as unary-count bits in the low 24.
 __device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3,
                                                     const uint4 n4, vec3 o, vec3 inv, bool negx, bool negy, bool negz,
@@ -882,8 +884,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
         const float4* q = a.shadow + 4 * ((size_t)g * a.sub_capacity + e);
         const float4 r0 = q[0], r1 = q[1];
         HitState hit;
-        // plain per-lane loop: neither lane refill (0.235 ms) nor the voting loop (0.193 ms at ratio 2) beats it
-        // (0.180 ms) on these short, fairly coherent rays
+        // plain per-lane loop: neither lane refill (0.235 ms) nor the voting loop (0.193 ms at ratio 2) beat it
+        // (0.180 ms) on these short, fairly coherent rays; re-measured with single-wave workgroups: voting at
+        // ratio 1/2/3 0.164/0.163/0.164 vs 0.154 ms (and it costs 93 instead of 64 VGPRs)
         const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
                                                     (int)a.stack_entries, hit, nn, nt);
         const uint32_t tag = __float_as_uint(r1.w);
