@@ -182,6 +182,10 @@ def main():
     if rank == 0:
         launches = max(1, args.depth)
         alg_closest = (NODE_BYTES * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches
+        # tiny trees: k_segment also walks the NEE shadow rays (no k_shadow launch), so their visits are this launch's bytes too
+        fused_shadow = st["any_rays"] > 0 and float(np.median(any_ms)) == 0.0
+        if fused_shadow:
+            alg_closest += (NODE_BYTES * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches
         t_closest = launch_ms_timed * 1e-3
         achieved = alg_closest / t_closest / 1e9 if t_closest > 0 else 0.0
         traffic = None
@@ -200,12 +204,14 @@ def main():
                        "rays_per_step": int(rays_all), "closest_rays_rank0": int(st["closest_rays"]),
                        "any_rays_rank0": int(st["any_rays"]), "tile": tile, "parallelism": f"tiles/{world}",
                        "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_segment (raygen|queue fetch + CWBVH closest hit + shading + queue emission)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_segment (raygen + CWBVH closest hit + shading + in-place NEE any-hit walk)" if fused_shadow else "k_segment (raygen|queue fetch + CWBVH closest hit + shading + queue emission)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_closest),
-                         "bytes_per_ray": round(alg_closest / max(1, cs["closest_rays"] / launches), 2),
+                         "bytes_per_ray": round(alg_closest / max(1, (cs["closest_rays"] + (cs["any_rays"] if fused_shadow else 0)) / launches), 2),
                          "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3),
                          "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
+                         "any_hit_nodes_per_ray": round(cs["nodes_any"] / max(1, cs["any_rays"]), 3),
+                         "any_hit_tris_per_ray": round(cs["tris_any"] / max(1, cs["any_rays"]), 3),
                          "launch_ms": round(t_closest * 1e3, 4), "launches_timed": int(n_timed_launches),
                          "any_hit_launch_ms": round(float(np.median(any_ms)), 4),
                          "frame_device_ms": round(float(np.median(total_ms)), 4),

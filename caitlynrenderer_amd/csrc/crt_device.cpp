@@ -572,7 +572,9 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.tex_width = s->tex_width; sa.tex_height = s->tex_height; sa.n_textures = s->n_textures;
         sa.f = f;
         sa.sub_capacity = s->sub_capacity;
-        sa.tri_min = s->info.n_nodes8 < 64 ? 0u : s->tri_min;   // tiny trees: plain per-lane loop
+        // tiny trees (or tri_min = 0): plain per-lane loop and the shadow ray traced inside k_segment, no k_shadow launch
+        const bool tiny = s->info.n_nodes8 < 64 || s->tri_min == 0u;
+        sa.tri_min = s->tri_min;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
         sa.shadow = s->d_shadow; sa.count_shadow = cnt + counter_index(b, 1, 0);
@@ -581,7 +583,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.visit_totals = s->d_visit_totals;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
         EventSpan* sp = s->begin_span(1);
-        const bool pretraced = b > 0 && s->bounce_refill;
+        const bool pretraced = b > 0 && s->bounce_refill && !tiny;
         if (pretraced) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
@@ -590,9 +592,10 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
             crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8, 1024), s->stream);
             sa.hits_in = s->d_qhits;
         }
-        crt::launch_segment(sa, b == 0, pretraced, s->count_visits, s->trace_grid(P, 5), s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, tiny, s->count_visits, s->trace_grid(P, 5), s->stream);
         s->end_span(sp);
 
+        if (tiny) continue;                          // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};
         sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = cnt + counter_index(b, 1, 0);
         sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = 0;

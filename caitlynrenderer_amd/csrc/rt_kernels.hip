@@ -607,14 +607,18 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // should not pay for).  96-VGPR budget = 5 waves per SIMD; 80 and 64 were measured slower.
 // PRETRACED: the closest hit of each queue entry was found by k_closest_queue (incoherent bounce rays are
 // traced with lane refill, which cannot be fused with lock-step shading); the kernel then only shades.
-template <bool FIRST, bool STATS, bool TEX, bool PRETRACED>
+// TINY (trees of a few nodes, e.g. the 32-triangle Cornell box): plain per-lane loop instead of the voting loop
+// (0.0755 vs 0.0816 ms) and the NEE shadow ray is traced right here instead of going through the shadow queue and
+// k_shadow — with ~1 node per ray the queue traffic (64 B written + read back per ray) and the second launch cost
+// more than the idle lanes of an in-place any-hit walk.
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool TINY>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     const FrameArgs& f = a.f;
-    uint32_t nn = 0, nt = 0;
+    uint32_t nn = 0, nt = 0, nn_any = 0, nt_any = 0;
     // Queue counters are double-banked by frame parity: the first kernel of a frame clears the bank the next
     // frame will append to (last touched by the previous frame, which stream order has retired).
     if (FIRST && a.zero_counts && blockIdx.x == 0)   // 64 or 256 threads, either works
@@ -685,8 +689,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                 const float4 h = a.hits_in[(size_t)g * a.sub_capacity + e];
                 hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = __float_as_int(h.w);
             }
-        } else if (a.tri_min == 0u) {
-            // tiny trees (Cornell: 3 nodes): the plain per-lane loop is faster than voting (0.0755 vs 0.0816 ms)
+        } else if (TINY) {
             if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, hit, nn, nt);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
@@ -778,7 +781,16 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                             const float w = __fdiv_rn(tt, bsdf_pdf * bsdf_pdf + tt);
                             vec3 c = ((T * le) * albedo) * w;
                             c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
-                            emit_shadow = true;
+                            if (TINY) {
+                                // the occlusion test of path_trace.fs:968 in place (what k_shadow does with a queue entry)
+                                const unsigned long long m = __ballot(true);
+                                if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
+                                HitState sh;
+                                if (!traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, sh, nn_any, nt_any))
+                                    L = L + c;
+                            } else {
+                                emit_shadow = true;
+                            }
                             sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
                             sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix | (a.last_segment ? 0x80000000u : 0u)));
                             sh2 = make_float4(c.x, c.y, c.z, 0.f);
@@ -817,15 +829,18 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         }
         // a path that ends here with nothing pending adds its radiance to the running sum now
         if (finished && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, pix, L);
-        const uint32_t si = wave_append(emit_shadow, count_shadow);
-        if (emit_shadow) {
-            float4* q = shadow_q + 4 * (size_t)si;
-            q[0] = sh0; q[1] = sh1; q[2] = sh2; q[3] = sh3;
+        if (!TINY) {
+            const uint32_t si = wave_append(emit_shadow, count_shadow);
+            if (emit_shadow) {
+                float4* q = shadow_q + 4 * (size_t)si;
+                q[0] = sh0; q[1] = sh1; q[2] = sh2; q[3] = sh3;
+            }
         }
         const uint32_t ni = wave_append(emit_next, count_next);
         if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
     }
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt);
+    if (STATS && TINY) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any);
     (void)stk;
 }
 
@@ -974,20 +989,18 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hi
 }
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool stats, uint32_t grid, hipStream_t stream) {
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
     const bool tex = a.textures != nullptr;
-#define CRT_LAUNCH_SEG(F, S, T, P) hipLaunchKernelGGL((k_segment<F, S, T, P>), g, b, lds, stream, a)
-    if (first) {
-        if (stats) { if (tex) CRT_LAUNCH_SEG(true, true, true, false); else CRT_LAUNCH_SEG(true, true, false, false); }
-        else       { if (tex) CRT_LAUNCH_SEG(true, false, true, false); else CRT_LAUNCH_SEG(true, false, false, false); }
-    } else if (pretraced) {
-        if (tex) CRT_LAUNCH_SEG(false, false, true, true); else CRT_LAUNCH_SEG(false, false, false, true);
-    } else {
-        if (stats) { if (tex) CRT_LAUNCH_SEG(false, true, true, false); else CRT_LAUNCH_SEG(false, true, false, false); }
-        else       { if (tex) CRT_LAUNCH_SEG(false, false, true, false); else CRT_LAUNCH_SEG(false, false, false, false); }
-    }
+#define CRT_LAUNCH_SEG(F, S, T, P, Y) hipLaunchKernelGGL((k_segment<F, S, T, P, Y>), g, b, lds, stream, a)
+#define CRT_LAUNCH_SEG_T(F, S, P, Y) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y); else CRT_LAUNCH_SEG(F, S, false, P, Y); } while (0)
+#define CRT_LAUNCH_SEG_S(F, P, Y) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y); else CRT_LAUNCH_SEG_T(F, false, P, Y); } while (0)
+    if (pretraced) CRT_LAUNCH_SEG_T(false, false, true, false);          // shade-only: never tiny (the host falls back to lock-step)
+    else if (first) { if (tiny) CRT_LAUNCH_SEG_S(true, false, true); else CRT_LAUNCH_SEG_S(true, false, false); }
+    else            { if (tiny) CRT_LAUNCH_SEG_S(false, false, true); else CRT_LAUNCH_SEG_S(false, false, false); }
+#undef CRT_LAUNCH_SEG_S
+#undef CRT_LAUNCH_SEG_T
 #undef CRT_LAUNCH_SEG
 }
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
