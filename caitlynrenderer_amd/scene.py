@@ -33,11 +33,12 @@ class SceneData:
         self.n_source_triangles = int(mesh.triangles.shape[0])
 
     @staticmethod
-    def build(mesh, camera, sbvh_flags=0, with_cwbvh=True, builder="sbvh"):
+    def build(mesh, camera, sbvh_flags=0, with_cwbvh=True, builder="sbvh", convert="host"):
         """Scene::build_bvh (Scene.h:929-959) followed by the intended CWBVH::convert.
-        builder="lbvh" swaps the host SBVH for the GPU linear BVH (crt_lbvh_build)."""
+        builder="lbvh" swaps the host SBVH for the GPU linear BVH (crt_lbvh_build); convert="device" runs
+        the CWBVH conversion on the GPU (crt_cwbvh_convert_device, same bytes as the host converter)."""
         sbvh = SBVH(mesh.triangles, mesh.vertices, sbvh_flags, builder=builder)
-        cw = CWBVH().convert(sbvh) if with_cwbvh else None
+        cw = CWBVH().convert(sbvh, device=(convert == "device")) if with_cwbvh else None
         return SceneData(mesh, sbvh, cw, camera)
 
     @staticmethod

@@ -217,6 +217,10 @@ void crt_lbvh_last_build_ms(float* device_ms, float* total_ms);
  * SURVEY 8a corrected (appendix C) [host]. */
 typedef struct crt_cwbvh crt_cwbvh;
 int crt_cwbvh_convert(const crt_flatnode* bvh2, size_t n_nodes, size_t n_slots, crt_cwbvh** out);
+/* The same conversion on the GPU (needs a GPU): byte-identical node, triangle-slot and child arrays
+ * (the per-node arithmetic is shared source, host/cwbvh_core.hpp), returned through the same handle. */
+int  crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_slots, crt_cwbvh** out);
+void crt_cwbvh_last_convert_ms(float* device_ms, float* total_ms);
 size_t crt_cwbvh_num_nodes(const crt_cwbvh*);
 size_t crt_cwbvh_num_tris(const crt_cwbvh*);
 const crt_node8* crt_cwbvh_nodes(const crt_cwbvh*);

@@ -347,6 +347,8 @@ def test_million_triangle_mesh_full_frame(cr, ob, cornell):
     big = tessellated_cornell(mesh, 183)
     assert big.triangles.shape[0] == 1004672 and big.vertices.shape[0] == 507844
     data = cr.SceneData.build(big, cam)
+    dev = cr.CWBVH().convert_arrays(data.bvh, data.triangles.shape[0], device=True)    # the device converter at full size
+    assert np.array_equal(dev.nodes, data.bvh8) and np.array_equal(dev.tri_slots, data.bvh8_tri_slots)
     W, H = 1920, 1080
     scene = cr.Scene(data, W, H, 2)
     info = scene.bvh_info()
@@ -529,3 +531,45 @@ def test_gpu_lbvh_edge_cases(cr):
     _check_lbvh(sb.flat_nodes, sb.triangles, v)
     cw = cr.CWBVH().convert(sb)
     assert cw.depth <= 16
+
+
+def _same_cwbvh(a, b):
+    assert a.depth == b.depth and a.nodes.shape == b.nodes.shape
+    assert np.array_equal(a.nodes, b.nodes), int((a.nodes != b.nodes).any(axis=1).sum())
+    assert np.array_equal(a.tri_slots, b.tri_slots) and np.array_equal(a.child_bvh2, b.child_bvh2)
+
+
+@pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
+@pytest.mark.parametrize("builder", ["sbvh", "lbvh"])
+def test_device_cwbvh_conversion_is_byte_identical_to_the_host_converter(cr, cornell, tess8, tess40, name, builder):
+    """crt_cwbvh_convert_device: cost tables bottom-up with an arrival counter, node8 tree level by
+    level, depth-first numbering from subtree sizes — same 80-byte nodes, triangle order and child map as the host."""
+    mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
+    sb = cr.SBVH(mesh.triangles, mesh.vertices, builder=builder)
+    host = cr.CWBVH().convert(sb)
+    dev = cr.CWBVH().convert(sb, device=True)
+    assert dev.convert_ms is not None and dev.convert_ms[0] > 0
+    _same_cwbvh(dev, host)
+    _same_cwbvh(cr.CWBVH().convert(sb, device=True), host)                  # and deterministic (atomics only order work)
+
+
+def test_device_cwbvh_conversion_edge_cases_and_errors(cr, cornell):
+    from caitlynrenderer_amd import _lib
+    # a single leaf, a root with two leaves, a 3-triangle leaf
+    one = np.array([[0, 0, 0, 0, 1, 1, 1, 1]], np.float32)
+    two = np.array([[0, 0, 0, 1, 2, 1, 1, 0], [0, 0, 0, 0, 1, 1, 1, 1], [1, 0, 0, 1, 2, 1, 1, 1]], np.float32)
+    fat = np.array([[0, 0, 0, 1, 2, 1, 1, 0], [0, 0, 0, 0, 1, 1, 1, 3], [1, 0, 0, 3, 2, 1, 1, 2]], np.float32)
+    for flat, n_slots in ((one, 1), (two, 2), (fat, 5)):
+        _same_cwbvh(cr.CWBVH().convert_arrays(flat, n_slots, device=True), cr.CWBVH().convert_arrays(flat, n_slots))
+    # refused inputs: same classes of error as the host converter
+    sb = cr.SBVH(cornell[0].triangles, cornell[0].vertices)
+    n_slots = sb.triangle_indices.shape[0]
+    big_leaf = sb.flat_nodes.copy(); big_leaf[np.nonzero(big_leaf[:, 7] != 0)[0][0], 7] = 4
+    bad_link = sb.flat_nodes.copy(); bad_link[1, 3] = 0
+    out_of_range = sb.flat_nodes.copy(); out_of_range[np.nonzero(out_of_range[:, 7] != 0)[0][0], 3] = n_slots + 5
+    twice = sb.flat_nodes.copy(); leaves = np.nonzero(twice[:, 7] != 0)[0]; twice[leaves[0], 3] = twice[leaves[1], 3]
+    for flat in (big_leaf, bad_link, out_of_range, twice):
+        for device in (False, True):
+            with pytest.raises(cr.CrtError) as e:
+                cr.CWBVH().convert_arrays(flat, n_slots, device=device)
+            assert e.value.code == _lib.CRT_ERR_INVALID, (device, str(e.value))
