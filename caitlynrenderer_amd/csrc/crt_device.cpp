@@ -90,7 +90,7 @@ struct crt_scene {
     float* d_linear = nullptr;
     uint8_t* d_rgba = nullptr;
     float4* d_rays[2] = {nullptr, nullptr};   // path-ray queues, only for max_depth > 1
-    float4* d_shadow = nullptr;               // 4 x float4 per shadow ray: ray, ray, C, L so far
+    float4* d_shadow = nullptr;               // 3 x float4 per shadow ray: ray, ray, pending contribution C
     float4* d_qhits = nullptr;                // closest hits of the path-ray queue (max_depth > 1, refill tracing)
     uint32_t bounce_refill = 1;               // segments >= 1: trace with lane refill + separate shading (0: fused lock-step)
     crt::PathBuffers pb{};
@@ -225,7 +225,7 @@ int alloc_frame_buffers(crt_scene* s) {
     // a workgroup group handles every 8th unit of 4096 pixels/rays, so it can emit at most this many rays per segment
     s->sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096);
     const size_t Q = 8 * (size_t)s->sub_capacity;
-    if ((rc = dev_alloc(&s->d_shadow, 4 * Q))) return rc;
+    if ((rc = dev_alloc(&s->d_shadow, 3 * Q))) return rc;
     if (s->max_depth > 1) {                      // path state and ray queues exist only for multi-segment paths
         if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
         if ((rc = dev_alloc(&s->d_rays[1], 2 * Q))) return rc;
@@ -739,7 +739,7 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
     std::vector<uint32_t> counts(kCounters);
     HIPCHK(hipMemcpy(counts.data(), s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const float4* src = which == 2 ? s->d_shadow : s->d_rays[segment & 1];
-    const size_t entry = which == 2 ? 4 * sizeof(float4) : sizeof(crt_ray);
+    const size_t entry = which == 2 ? 3 * sizeof(float4) : sizeof(crt_ray);
     size_t total = 0;
     for (uint32_t g = 0; g < 8; ++g) total += counts[counter_index(segment, which == 2 ? 1 : 0, g)];
     *n_out = total;

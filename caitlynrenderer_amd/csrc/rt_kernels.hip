@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         const uint32_t g = v >> 28;                         // owner group of this chunk: its sub-queues get the output
         uint32_t* const count_shadow = a.count_shadow + g * CRT_COUNTER_STRIDE;
         uint32_t* const count_next = a.count_next + g * CRT_COUNTER_STRIDE;
-        float4* const shadow_q = a.shadow + 4 * (size_t)g * a.sub_capacity;
+        float4* const shadow_q = a.shadow + 3 * (size_t)g * a.sub_capacity;
         float4* const next_q = a.rays_next + 2 * (size_t)g * a.sub_capacity;
         uint32_t e, n;
         if (FIRST) {
@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         }
 
         bool emit_shadow = false, emit_next = false, finished = active;
-        float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, sh3 = sh0, nx0 = sh0, nx1 = sh0;
+        float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, nx0 = sh0, nx1 = sh0;
         if (active && hit.tri >= 0) {
             const float t = hit.t, bu = hit.u, bv = hit.v;
             const float4 tb = a.tris[3 * (size_t)hit.tri + 1], tc = a.tris[3 * (size_t)hit.tri + 2];
@@ -794,7 +794,6 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                             sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
                             sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix | (a.last_segment ? 0x80000000u : 0u)));
                             sh2 = make_float4(c.x, c.y, c.z, 0.f);
-                            sh3 = make_float4(L.x, L.y, L.z, 0.f);
                         }
                     }
                 }
@@ -832,8 +831,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         if (!TINY) {
             const uint32_t si = wave_append(emit_shadow, count_shadow);
             if (emit_shadow) {
-                float4* q = shadow_q + 4 * (size_t)si;
-                q[0] = sh0; q[1] = sh1; q[2] = sh2; q[3] = sh3;
+                float4* q = shadow_q + 3 * (size_t)si;
+                q[0] = sh0; q[1] = sh1; q[2] = sh2;
+                // the radiance gathered so far waits in the path state (a 1-segment path has gathered none)
+                if (a.last_segment && a.pb.L) a.pb.L[pix] = make_float4(L.x, L.y, L.z, 0.f);
             }
         }
         const uint32_t ni = wave_append(emit_next, count_next);
@@ -896,7 +897,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
         const uint32_t g = v >> 28;
         const uint32_t e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
         if (e >= a.count[g * CRT_COUNTER_STRIDE]) continue;
-        const float4* q = a.shadow + 4 * ((size_t)g * a.sub_capacity + e);
+        const float4* q = a.shadow + 3 * ((size_t)g * a.sub_capacity + e);
         const float4 r0 = q[0], r1 = q[1];
         HitState hit;
         // plain per-lane loop: neither lane refill (0.235 ms) nor the voting loop (0.193 ms at ratio 2) beat it
@@ -907,8 +908,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
         const uint32_t tag = __float_as_uint(r1.w);
         const uint32_t pix = tag & 0x7fffffffu;
         if (tag & 0x80000000u) {                             // the path ended with this segment
-            const float4 c = q[2], l = q[3];
-            vec3 L = V3(l.x, l.y, l.z);
+            const float4 c = q[2];
+            vec3 L = V3(0.f, 0.f, 0.f);
+            if (a.L) { const float4 l = a.L[pix]; L = V3(l.x, l.y, l.z); }
             if (!occluded) L = L + V3(c.x, c.y, c.z);
             if (L.x != 0.f || L.y != 0.f || L.z != 0.f) add_to_sum(a.sum, pix, L);
         } else if (!occluded) {

@@ -70,7 +70,7 @@ struct SegmentArgs {
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart
     const float4* hits_in;     // k_segment<PRETRACED>: (t, u, v, CWBVH triangle) per queue entry
     float4* rays_next;   uint32_t* count_next;
-    float4* shadow;      uint32_t* count_shadow;   // 4 x float4 per entry: (o,tmax) (d,pixel|final<<31) (C) (L so far)
+    float4* shadow;      uint32_t* count_shadow;   // 3 x float4 per entry: (o,tmax) (d,pixel|final<<31) (C)
     PathBuffers pb;
     float* sum;                // packed tile-major RGB32F
     uint32_t last_segment;
