@@ -532,7 +532,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
             s->spans.push_back(sp);
         }
     }
-    else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(1, value));
+    else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: per-lane loop + shadow rays walked in place (what tiny trees get)
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;

@@ -135,7 +135,10 @@ int crt_sync(crt_scene* s);
  * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = around every launch (default), 1 = closest-hit
  * launches only, 0 = none), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
  * restarting every frame — crt_frame_stats.ms_* are then sums over n_trace_launches launches; 0: per frame),
- * tuning: "tri_min" (vote ratio of the traversal loop, 0 = per-lane loop), "refill_min", "bounce_refill". */
+ * tuning: "tri_min" (vote ratio of the traversal loop; 0 = per-lane loop with the NEE shadow ray walked inside
+ * the segment kernel, which trees under 64 nodes get anyway), "refill_min", "bounce_refill" (lane-refill pools for
+ * bounce rays), "oversubscribe" (0 = one 64-ray batch per workgroup, the hardware dispatcher balances; k >= 1 =
+ * persistent grid of k x the resident workgroups with a static schedule), "waves_per_workgroup" (1 or 4, process-wide). */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);

@@ -220,6 +220,36 @@ def test_async_frames_and_timing_options_do_not_change_results(cr, scenes):
         b.close()
 
 
+@pytest.mark.parametrize("name", ["cornell", "tess8"])
+def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
+    """Grid shape (one wave / four waves per workgroup, one batch per workgroup / persistent static schedule), the
+    vote ratio of the traversal loop and the bounce-ray pools only reorder work: sums and ray counts stay identical."""
+    _, _, data = scenes[name]
+    W, H, depth = 328, 200, 3
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(3)]
+
+    def run(options):
+        s = cr.Scene(data, W, H, depth)
+        for k, v in options.items():
+            s.set_option(k, v)
+        for rx, ry in rvs:
+            s.render_frame(rx, ry)
+        out, st = s.read_sum(), s.frame_stats()
+        s.set_option("waves_per_workgroup", 1)          # process-wide knob: back to the default
+        s.close()
+        return out, (st["closest_rays"], st["any_rays"])
+
+    want, want_counts = run({})
+    assert want.max() > 0.1
+    for options in ({"waves_per_workgroup": 4}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
+                    {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5},
+                    {"bounce_refill": 0}, {"refill_min": 1}, {"refill_min": 40}):
+        got, counts = run(options)
+        assert counts == want_counts, options
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), options
+
+
 def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data):
     """world=3 shards rendered on one GPU: the union of the ranks' pixels is bit-identical to world=1."""
     from caitlynrenderer_amd import tiles
