@@ -109,7 +109,10 @@ SYMBOLS = {
     "crt_mesh_materials": (_P, [_P]),
     "crt_mesh_lights": (_P, [_P]),
     "crt_mesh_vertex_min": (_P, [_P]),
+    "crt_mesh_albedo_textures": (_P, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crt_mesh_free": (None, [_P]),
+    "crt_image_decode": (_I, [_P, _SZ, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _SZ]),
+    "crt_texture_to_array_bytes": (_I, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "crt_last_error": (C.c_char_p, []),
     "crt_abi_version": (_U32, []),
 }

@@ -6,6 +6,7 @@
 #include "../../include/crt.h"
 #include "crt_error.hpp"
 #include "crt_handles.hpp"
+#include "host/image.hpp"
 #include "host/camera.hpp"
 #include "host/cwbvh.hpp"
 #include "host/obj_loader.hpp"
@@ -129,6 +130,39 @@ const crt_triangle* crt_mesh_triangles(const crt_mesh* h) { return h ? h->mesh.t
 const crt_material* crt_mesh_materials(const crt_mesh* h) { return h ? h->mesh.mats.data() : nullptr; }
 const crt_light* crt_mesh_lights(const crt_mesh* h) { return h ? h->mesh.lights.data() : nullptr; }
 const float* crt_mesh_vertex_min(const crt_mesh* h) { return h ? &h->mesh.vertex_min.x : nullptr; }
+const uint8_t* crt_mesh_albedo_textures(const crt_mesh* h, int32_t* width, int32_t* height, int32_t* n_layers) {
+    if (width) *width = h ? h->mesh.tex_width : 0;
+    if (height) *height = h ? h->mesh.tex_height : 0;
+    if (n_layers) *n_layers = h ? h->mesh.n_textures : 0;
+    return (h && h->mesh.n_textures > 0) ? h->mesh.albedo_textures.data() : nullptr;
+}
 void crt_mesh_free(crt_mesh* h) { delete h; }
+
+int crt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int32_t* width, int32_t* height, uint8_t* rgb, size_t rgb_capacity) {
+    if (!file_bytes || !width || !height) return fail(CRT_ERR_INVALID, "crt_image_decode: null argument");
+    int w = 0, h = 0;
+    std::vector<uint8_t> px;
+    std::string err;
+    try {
+        if (!crt::decode_image_rgb8(file_bytes, n_bytes, w, h, px, err)) return fail(CRT_ERR_INVALID, "crt_image_decode: " + err);
+    } catch (const std::exception& e) {
+        return fail(CRT_ERR_NOMEM, std::string("crt_image_decode: ") + e.what());
+    }
+    *width = w; *height = h;
+    if (rgb) {
+        if (rgb_capacity < px.size()) return fail(CRT_ERR_INVALID, "crt_image_decode: output buffer too small");
+        std::memcpy(rgb, px.data(), px.size());
+    }
+    return CRT_OK;
+}
+int crt_texture_to_array_bytes(const uint8_t* rgb, int32_t width, int32_t height, int32_t out_w, int32_t out_h, uint8_t* out) {
+    if (!rgb || !out || width <= 0 || height <= 0 || out_w <= 0 || out_h <= 0) return fail(CRT_ERR_INVALID, "crt_texture_to_array_bytes: bad argument");
+    try {
+        crt::texture_to_array_bytes(rgb, width, height, out_w, out_h, out);
+    } catch (const std::exception& e) {
+        return fail(CRT_ERR_NOMEM, std::string("crt_texture_to_array_bytes: ") + e.what());
+    }
+    return CRT_OK;
+}
 
 }  // extern "C"

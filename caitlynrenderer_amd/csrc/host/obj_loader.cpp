@@ -1,4 +1,5 @@
 #include "obj_loader.hpp"
+#include "image.hpp"
 
 #include <climits>
 #include <cstdio>
@@ -48,7 +49,7 @@ int parse_corners(const char* t, std::vector<Corner>& out, bool& double_slash) {
 
 }  // namespace
 
-bool Mesh::read_mtl(const std::string& file_name, std::vector<std::pair<std::string, int>>& mtl_map) {
+bool Mesh::read_mtl(const std::string& file_name, const std::string& directory, std::vector<std::pair<std::string, int>>& mtl_map) {
     std::ifstream f(file_name);
     if (!f) { error = "mtl file not found: " + file_name; return false; }   // Scene.h:510-511 prints and goes on
     std::vector<std::string> lines;
@@ -64,8 +65,31 @@ bool Mesh::read_mtl(const std::string& file_name, std::vector<std::pair<std::str
 
     int cur = -1, n_lights = 0;
     char name[256];
+    std::vector<std::string> texture_names;                            // Scene.h:555 texture_map, in order of first use
+    albedo_textures.clear();
+    n_textures = 0;
     for (const std::string& l : lines) {
         const char* t = skip_ws(l.c_str());
+        if (std::strncmp(t, "map_Kd", 6) == 0 && cur >= 0 && (size_t)cur < mats.size()) {   // Scene.h:597-677
+            if (std::sscanf(t + 6, "%255s", name) != 1) continue;
+            std::string real_name = name;                              // getfilename, Scene.h:179-184: the multi-character
+            const size_t bs = real_name.find_last_of('\\');             // literal '/\\' it searches for is a backslash
+            if (bs != std::string::npos) real_name = real_name.substr(bs + 1);
+            bool seen = false;
+            for (const std::string& n : texture_names) seen = seen || n == real_name;
+            if (seen) continue;                                        // Scene.h:604: a texture's second user keeps tex_ind = -1
+            int w = 0, h = 0;
+            std::vector<uint8_t> rgb;
+            std::string err;
+            if (!decode_image_rgb8(directory + real_name, w, h, rgb, err)) { error = err; return false; }
+            mats[cur].tex_ind[0] = (float)texture_names.size();
+            texture_names.push_back(real_name);
+            const size_t layer = (size_t)tex_width * tex_height * 3;
+            albedo_textures.resize(albedo_textures.size() + layer);
+            texture_to_array_bytes(rgb.data(), w, h, tex_width, tex_height, albedo_textures.data() + albedo_textures.size() - layer);
+            n_textures = (int)texture_names.size();
+            continue;
+        }
         if (std::strncmp(t, "newmtl", 6) == 0) {                       // Scene.h:567-575
             if (std::sscanf(t + 6, "%255s", name) == 1) mtl_map.emplace_back(name, ++cur);
         } else if (cur < 0 || (size_t)cur >= mats.size()) {
@@ -164,7 +188,7 @@ bool Mesh::read_object(const std::string& file_name) {
             }
         } else if (t[0] == 'm' && !read_mtl_done) {                    // Scene.h:890-899 (first `m…` line = mtllib)
             if (std::sscanf(t + 6, "%255s", name) == 1) {
-                if (!read_mtl(dir + name, mtl_map)) return false;
+                if (!read_mtl(dir + name, dir, mtl_map)) return false;
                 read_mtl_done = true;
             }
         }

@@ -31,6 +31,8 @@ struct Scene {
     std::vector<crt_material> mats;
     std::vector<crt_light> lights;
     std::vector<crt_flatnode> flat_nodes;
+    std::vector<uint8_t> albedo_textures_data;      // Scene.h:408: RGB8 layers of tex_height x tex_width
+    int tex_width = 0, tex_height = 0, n_textures = 0;
     Rnd rnd;                                        // Rnd.h:7 (thread_local there; one caller thread here too)
     uint32_t width = 700, height = 700, max_depth = 3;   // Scene.h:37, path_trace.fs:867
     std::string error;
@@ -59,6 +61,8 @@ struct Scene {
         if (!m.read_object(file_name)) { error = m.error; std::printf("%s\n", error.c_str()); return false; }   // prints and goes on, Scene.h:746-747
         vertices = std::move(m.vertices); normals = std::move(m.normals); texcoords = std::move(m.texcoords);
         triangles = std::move(m.triangles); mats = std::move(m.mats); lights = std::move(m.lights);
+        albedo_textures_data = std::move(m.albedo_textures);
+        tex_width = m.tex_width; tex_height = m.tex_height; n_textures = m.n_textures;
         camera.position += m.translation;           // Scene.h:924
         return true;
     }
@@ -81,6 +85,10 @@ struct Scene {
         d.materials = mats.data();                                d.n_materials = mats.size();
         d.lights = lights.data();                                 d.n_lights = lights.size();
         d.bvh = flat_nodes.data();                                d.n_bvh = flat_nodes.size();
+        if (n_textures > 0) {                                     // Scene.h:1065-1078
+            d.albedo_textures = albedo_textures_data.data();
+            d.tex_width = tex_width; d.tex_height = tex_height; d.n_textures = n_textures;
+        }
         d.width = width; d.height = height; d.max_depth = max_depth;
         if (crt_scene_create(&d, &gpu) != CRT_OK) { error = crt_last_error(); std::printf("%s\n", error.c_str()); gpu = nullptr; return; }
         update(0.0f);
@@ -133,6 +141,7 @@ struct Scene {
         std::vector<float3>().swap(vertices); std::vector<float3>().swap(normals); std::vector<float>().swap(texcoords);
         std::vector<crt_triangle>().swap(triangles); std::vector<crt_material>().swap(mats);
         std::vector<crt_light>().swap(lights); std::vector<crt_flatnode>().swap(flat_nodes);
+        std::vector<uint8_t>().swap(albedo_textures_data);
     }
     void delete_gpu_data() {                         // Scene.h:978-998
         if (gpu) { crt_scene_destroy(gpu); gpu = nullptr; }

@@ -98,12 +98,36 @@ class Mesh:
                 _copy(L.crt_mesh_lights(h), C.c_float, (nl, 18), np.float32),
                 _copy(L.crt_mesh_vertex_min(h), C.c_float, (3,), np.float32),
             )
+            tw, th, tl = C.c_int32(), C.c_int32(), C.c_int32()
+            tex = L.crt_mesh_albedo_textures(h, C.byref(tw), C.byref(th), C.byref(tl))
+            if tex and tl.value > 0:                      # map_Kd textures as the reference's RGB8 array (Scene.h:597-710)
+                m.albedo_textures = _copy(tex, C.c_uint8, (tl.value, th.value, tw.value, 3), np.uint8)
         finally:
             L.crt_mesh_free(h)
         if camera is not None:
             for k in range(3):
                 camera.c.position[k] = cam[k]
         return m
+
+
+def decode_image(file_bytes):
+    """crt_image_decode: (H, W, 3) uint8, top row first — what stbi_load(name, &w, &h, 0, 3) gives the reference."""
+    L = lib()
+    buf = np.frombuffer(bytes(file_bytes), np.uint8)
+    w, h = C.c_int32(), C.c_int32()
+    check(L.crt_image_decode(_ptr(buf), buf.size, C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    check(L.crt_image_decode(_ptr(buf), buf.size, C.byref(w), C.byref(h), _ptr(out), out.size))
+    return out
+
+
+def texture_to_array_bytes(rgb, out_w=256, out_h=256):
+    """crt_texture_to_array_bytes: the reference's resize + byte truncation (Scene.h:321-371, :648-662, :688-710)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    assert rgb.ndim == 3 and rgb.shape[2] == 3
+    out = np.empty((out_h, out_w, 3), np.uint8)
+    check(lib().crt_texture_to_array_bytes(_ptr(rgb), rgb.shape[1], rgb.shape[0], out_w, out_h, _ptr(out)))
+    return out
 
 
 class SBVH:

@@ -247,7 +247,19 @@ const crt_triangle* crt_mesh_triangles(const crt_mesh*);
 const crt_material* crt_mesh_materials(const crt_mesh*);
 const crt_light*    crt_mesh_lights(const crt_mesh*);
 const float*        crt_mesh_vertex_min(const crt_mesh*);   /* pre-translation minimum */
+/* map_Kd textures of the .mtl as the RGB8 array the reference uploads (Scene.h:597-710, :1065-1078): n_layers
+ * layers of height x width x 3 bytes, layer = crt_material.tex_ind[0]; NULL when the scene has none.  Feeds
+ * crt_scene_desc.albedo_textures / tex_width / tex_height / n_textures. */
+const uint8_t*      crt_mesh_albedo_textures(const crt_mesh*, int32_t* width, int32_t* height, int32_t* n_layers);
 void crt_mesh_free(crt_mesh*);
+
+/* Texture files [host].  crt_image_decode: what `stbi_load(name, &w, &h, 0, 3)` hands the reference (Scene.h:619)
+ * for the lossless formats (PNG non-interlaced, BMP, TGA, binary PNM): 8-bit RGB, top row first.  Call with
+ * rgb = NULL to get the size; JPEG and other lossy formats are refused (CRT_ERR_INVALID).
+ * crt_texture_to_array_bytes: the reference's bilinear resize to the texture-array size and its float -> byte
+ * truncation (Scene.h:321-371, :648-662, :688-710); out holds out_w * out_h * 3 bytes. */
+int crt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int32_t* width, int32_t* height, uint8_t* rgb, size_t rgb_capacity);
+int crt_texture_to_array_bytes(const uint8_t* rgb, int32_t width, int32_t height, int32_t out_w, int32_t out_h, uint8_t* out);
 
 const char* crt_last_error(void);
 uint32_t    crt_abi_version(void);

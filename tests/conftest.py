@@ -112,28 +112,37 @@ def have_reference():
     return os.path.isdir(os.path.join(REFERENCE, "Models"))
 
 
-def write_obj(mesh, path, mtl_name="scene.mtl"):
-    """Write a Mesh back as OBJ + MTL text (v//vn faces, %.9g so every float32 survives the round trip);
-    lets the C++ example and the loader tests run on the GPU box, where /root/reference does not exist."""
+def write_obj(mesh, path, mtl_name="scene.mtl", map_kd=None):
+    """Write a Mesh back as OBJ + MTL text (v//vn faces, or v/vt/vn when the mesh has texcoords; %.9g so every
+    float32 survives the round trip); lets the C++ example and the loader tests run on the GPU box, where
+    /root/reference does not exist.  map_kd: {material index: texture file name} -> `map_Kd` lines."""
     import os
     lines = [f"mtllib {mtl_name}"]
     for v in mesh.vertices + mesh.vertex_min:
         lines.append("v %.9g %.9g %.9g" % tuple(float(x) for x in v))
     for n in mesh.normals:
         lines.append("vn %.9g %.9g %.9g" % tuple(float(x) for x in n))
+    with_vt = mesh.texcoords.shape[0] > 0
+    for uv in mesh.texcoords:                         # the loader stores (u, 1 - v), Scene.h:801
+        lines.append("vt %.9g %.9g" % (float(uv[0]), float(np.float32(1) - uv[1])))
     cur = None
     for t in mesh.triangles:
         if t[3] != cur:
             cur = int(t[3])
             lines.append(f"usemtl m{cur}")
         assert t[7] == 1, "write_obj expects vertex normals"
-        lines.append("f " + " ".join(f"{int(t[k]) + 1}//{int(t[4 + k]) + 1}" for k in range(3)))
+        if with_vt:
+            lines.append("f " + " ".join(f"{int(t[k]) + 1}/{int(t[8 + k]) + 1}/{int(t[4 + k]) + 1}" for k in range(3)))
+        else:
+            lines.append("f " + " ".join(f"{int(t[k]) + 1}//{int(t[4 + k]) + 1}" for k in range(3)))
     open(path, "w").write("\n".join(lines) + "\n")
     m = []
     for i, mat in enumerate(mesh.materials):
         m += [f"newmtl m{i}", "Kd %.9g %.9g %.9g" % tuple(float(x) for x in mat[0:3])]
         e = mat[4:7] if mat[7] != -1 else (0.0, 0.0, 0.0)
         m.append("Ke %.9g %.9g %.9g" % tuple(float(x) for x in e))
+        if map_kd and i in map_kd:
+            m.append(f"map_Kd {map_kd[i]}")
     open(os.path.join(os.path.dirname(path), mtl_name), "w").write("\n".join(m) + "\n")
 
 

@@ -603,3 +603,43 @@ def test_device_cwbvh_conversion_edge_cases_and_errors(cr, cornell):
             with pytest.raises(cr.CrtError) as e:
                 cr.CWBVH().convert_arrays(flat, n_slots, device=device)
             assert e.value.code == _lib.CRT_ERR_INVALID, (device, str(e.value))
+
+
+def test_textured_scene_from_obj_mtl_and_image_files(cr, ob, textured, tmp_path):
+    """SURVEY 8f-4 end to end: OBJ + MTL with map_Kd textures (PNG and RLE TGA files) -> loader (decode, the reference's
+    256x256 resize) -> the Python path, the C++ crt::Scene path and the oracle agree on the running sum."""
+    import os
+    import subprocess
+    from conftest import ROOT, write_obj
+    from oracle import textures as T
+    mesh, _, _ = textured
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:300, 0:200]
+    checker = (((yy // 25 + xx // 25) % 2) * 180 + 40).astype(np.uint8)[..., None].repeat(3, 2) ^ rng.integers(0, 32, (300, 200, 3), dtype=np.uint8)
+    noise = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    open(tmp_path / "checker.png", "wb").write(T.write_png(checker))
+    open(tmp_path / "noise.tga", "wb").write(T.write_tga(noise, rle=True, top_down=True))
+    obj = str(tmp_path / "textured.obj")
+    write_obj(mesh, obj, map_kd={2: "noise.tga", 3: "checker.png"})
+    cam = cr.Camera((-2.755610, 2.745992, 7.58545), (-2.755610, 2.745992, 6.58545), 40.0)   # Scene.h:468
+    data = cr.SceneData.from_obj(obj, cam)
+    assert data.albedo_textures.shape == (2, 256, 256, 3) and np.array_equal(data.albedo_textures[0], noise)
+    assert np.array_equal(data.albedo_textures[1], T.texture_to_array_bytes(checker))
+    W, H, frames, depth = 200, 120, 3, 3
+    orc = ob.Oracle(data, W, H, depth, cam)
+    scene = cr.Scene(data, W, H, depth)
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    for _ in range(frames):
+        rx, ry = rnd.randf2(), rnd.randf2()
+        scene.render_frame(rx, ry)
+        orc.render_frame(rx, ry, ref, threads=8)
+    out = scene.read_sum()
+    err = np.abs(out - ref)
+    assert (err <= 1e-5 + 1e-4 * np.abs(ref)).all(), float(err.max())
+    run = subprocess.run([os.path.join(ROOT, "examples", "render_obj"), obj, str(tmp_path / "o.ppm"), str(W), str(H), str(frames),
+                          str(depth), str(tmp_path / "sum.f32")], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    got = np.fromfile(tmp_path / "sum.f32", np.float32).reshape(H, W, 3)
+    assert np.array_equal(got.view(np.uint32), out.view(np.uint32))          # C++ host path == Python host path, bit for bit
+    scene.close()

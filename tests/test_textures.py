@@ -1,0 +1,123 @@
+"""Texture path of the loader (Scene.h:597-710): decoders for the lossless formats stb_image reads,
+the reference's bilinear resize + byte truncation, and map_Kd handling.  The checker is oracle/textures.py (numpy
+restatement of Scene.h:321-371) and the known pixels the test files were written from.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import write_obj
+from oracle import textures as T
+
+
+@pytest.fixture(scope="module")
+def host():
+    import __graft_entry__ as g
+    g.build()
+    from caitlynrenderer_amd import host
+    return host
+
+
+def test_png_decoder_all_colour_types_depths_and_filters(host):
+    rng = np.random.default_rng(5)
+    h, w = 23, 31                                   # odd sizes: partial bytes at low bit depths
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    for ft in ("cycle", 0, 1, 2, 3, 4):
+        assert np.array_equal(host.decode_image(T.write_png(rgb, 2, 8, filters=ft)), rgb), ft
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+    assert np.array_equal(host.decode_image(T.write_png(rgba, 6, 8)), rgb)                      # alpha dropped, not multiplied
+    grey = rng.integers(0, 256, (h, w, 1), dtype=np.uint8)
+    assert np.array_equal(host.decode_image(T.write_png(grey, 0, 8)), grey.repeat(3, 2))
+    ga = np.concatenate([grey, 255 - grey], axis=2)
+    assert np.array_equal(host.decode_image(T.write_png(ga, 4, 8)), grey.repeat(3, 2))
+    for depth, scale in ((1, 255), (2, 85), (4, 17)):                                            # grey scaled to 0..255
+        g = rng.integers(0, 1 << depth, (h, w, 1), dtype=np.uint8)
+        assert np.array_equal(host.decode_image(T.write_png(g, 0, depth)), (g * scale).astype(np.uint8).repeat(3, 2)), depth
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    for depth in (1, 2, 4, 8):                                                                   # palette indices are not scaled
+        idx = rng.integers(0, min(16, 1 << depth), (h, w, 1), dtype=np.uint8)
+        assert np.array_equal(host.decode_image(T.write_png(idx, 3, depth, palette=pal)), pal[idx[..., 0]]), depth
+    deep = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16)
+    assert np.array_equal(host.decode_image(T.write_png(deep, 2, 16)), (deep >> 8).astype(np.uint8))   # high byte
+
+
+def test_bmp_tga_pnm_decoders(host):
+    rng = np.random.default_rng(6)
+    rgb = rng.integers(0, 256, (19, 27, 3), dtype=np.uint8)                 # 27*3 = 81: BMP rows need padding
+    rgb[3:9, 5:20] = rgb[3, 5]                                              # runs for the RLE encoder
+    grey = rng.integers(0, 256, (19, 27), dtype=np.uint8)
+    pal = rng.integers(0, 256, (200, 3), dtype=np.uint8)
+    idx = rng.integers(0, 200, (19, 27), dtype=np.uint8)
+    for td in (False, True):
+        assert np.array_equal(host.decode_image(T.write_bmp(rgb, 24, td)), rgb)
+        assert np.array_equal(host.decode_image(T.write_bmp(rgb, 32, td)), rgb)
+        assert np.array_equal(host.decode_image(T.write_bmp(idx, 8, td, palette=pal)), pal[idx])
+        for rle in (False, True):
+            assert np.array_equal(host.decode_image(T.write_tga(rgb, 2, rle, td)), rgb), (td, rle)
+            assert np.array_equal(host.decode_image(T.write_tga(rgb, 2, rle, td, alpha=True)), rgb)
+            assert np.array_equal(host.decode_image(T.write_tga(grey, 3, rle, td)), grey[..., None].repeat(3, 2))
+            assert np.array_equal(host.decode_image(T.write_tga(idx, 1, rle, td, palette=pal)), pal[idx])
+    assert np.array_equal(host.decode_image(T.write_pnm(rgb)), rgb)
+    assert np.array_equal(host.decode_image(T.write_pnm(grey)), grey[..., None].repeat(3, 2))
+    deep = rng.integers(0, 65536, (7, 5, 3), dtype=np.uint16)
+    assert np.array_equal(host.decode_image(T.write_pnm(deep, 65535)), (deep >> 8).astype(np.uint8))
+
+
+def test_refused_and_damaged_files(host):
+    import caitlynrenderer_amd as cr
+    from caitlynrenderer_amd import _lib
+    rgb = np.zeros((4, 4, 3), np.uint8)
+    png = T.write_png(rgb)
+    interlaced = bytearray(png); interlaced[28] = 1                          # IHDR interlace byte (CRC is not checked)
+    for data in (b"\xff\xd8\xff\xe0" + b"\0" * 64,                           # JPEG: refused by design
+                 bytes(interlaced), png[:40], T.write_bmp(rgb)[:60], T.write_tga(rgb)[:20], b"P6\n4 4\n255\n" + b"\0" * 10,
+                 b"not an image at all, just some text that is long enough"):
+        with pytest.raises(cr.CrtError) as e:
+            host.decode_image(data)
+        assert e.value.code == _lib.CRT_ERR_INVALID
+
+
+@pytest.mark.parametrize("size", [(256, 256), (300, 300), (512, 384), (100, 70), (256, 100), (64, 512), (1, 1), (257, 255), (3, 1000)])
+def test_resize_to_texture_array_matches_the_numpy_restatement(host, size):
+    """Scene.h:321-371 in fp32 with the reference's operation order, then float -> unsigned char truncation; includes
+    up-scaling, where ceil() indexes one column/row past the source (flat indexing, clamped at the very end)."""
+    h, w = size
+    rgb = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got, want = host.texture_to_array_bytes(rgb), T.texture_to_array_bytes(rgb)
+    assert got.shape == (256, 256, 3) and np.array_equal(got, want)
+    assert np.array_equal(host.texture_to_array_bytes(rgb, 64, 32), T.texture_to_array_bytes(rgb, 64, 32))
+
+
+def test_same_size_path_is_the_identity(host):
+    """255 * (b * (1/255.f)) truncated to a byte (Scene.h:653-661) gives b back for all 256 values."""
+    ramp = np.arange(256, dtype=np.uint8).reshape(1, 256, 1).repeat(256, 0).repeat(3, 2)
+    assert np.array_equal(host.texture_to_array_bytes(ramp), ramp) and np.array_equal(T.texture_to_array_bytes(ramp), ramp)
+
+
+def test_loader_map_kd(host, cornell, tmp_path):
+    """map_Kd in the .mtl (Scene.h:597-677): layers in order of first use, name = what follows the last backslash,
+    a texture's second user keeps tex_ind = -1 (Scene.h:604 has no else branch), files resized to 256x256."""
+    import caitlynrenderer_amd as cr
+    mesh, _ = cornell
+    rng = np.random.default_rng(8)
+    wood = rng.integers(0, 256, (300, 200, 3), dtype=np.uint8)
+    tiles = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    open(tmp_path / "wood.png", "wb").write(T.write_png(wood))
+    open(tmp_path / "tiles.tga", "wb").write(T.write_tga(tiles, rle=True))
+    uv = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]], np.float32)
+    tris = mesh.triangles.copy()
+    for q in range(tris.shape[0] // 2):
+        tris[2 * q, 8:12] = (0, 1, 2, 0)
+        tris[2 * q + 1, 8:12] = (0, 2, 3, 0)
+    m = cr.Mesh(mesh.vertices, mesh.normals, uv, tris, mesh.materials, mesh.lights, mesh.vertex_min)
+    write_obj(m, str(tmp_path / "scene.obj"), map_kd={1: "tiles.tga", 2: "textures\\\\wood.png", 3: "wood.png", 4: "tiles.tga"})
+    got = cr.Mesh.read_object(str(tmp_path / "scene.obj"))
+    assert got.albedo_textures is not None and got.albedo_textures.shape == (2, 256, 256, 3)
+    assert np.array_equal(got.albedo_textures[0], tiles)                                       # same size: passed through
+    assert np.array_equal(got.albedo_textures[1], T.texture_to_array_bytes(wood))
+    assert got.materials[:, 12].tolist() == [-1.0, 0.0, 1.0, -1.0, -1.0, -1.0]                 # 3 and 4 reuse a name: no layer
+    assert np.array_equal(got.texcoords, np.stack([uv[:, 0], np.float32(1) - (np.float32(1) - uv[:, 1])], axis=1))
+    # a missing or undecodable texture is an error, not a crash
+    write_obj(m, str(tmp_path / "bad.obj"), mtl_name="bad.mtl", map_kd={1: "nowhere.png"})
+    with pytest.raises(cr.CrtError):
+        cr.Mesh.read_object(str(tmp_path / "bad.obj"))
