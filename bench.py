@@ -33,7 +33,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(name, builder="sbvh"):
+def build_workload(name, builder="sbvh", convert="host"):
     import numpy as np
     import __graft_entry__ as g
     import caitlynrenderer_amd as cr
@@ -45,9 +45,11 @@ def build_workload(name, builder="sbvh"):
         mesh = tessellated_cornell(mesh, n)
         label = f"procedural tessellated Cornell n={n}: {mesh.triangles.shape[0]} tris, CWBVH"
     t0 = time.time()
-    data = cr.SceneData.build(mesh, cam, builder=builder)
+    data = cr.SceneData.build(mesh, cam, builder=builder, convert=convert)
     if builder == "lbvh":
         label += " over a GPU-built LBVH"
+    if convert == "device":
+        label += ", CWBVH converted on the GPU"
     return data, cam, label, time.time() - t0
 
 
@@ -68,6 +70,8 @@ def main():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--builder", default="sbvh", choices=["sbvh", "lbvh"],
                     help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build)")
+    ap.add_argument("--convert", default="host", choices=["host", "device"],
+                    help="BVH2 -> CWBVH conversion on the host (default) or on the GPU (crt_cwbvh_convert_device, same bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,7 +104,7 @@ def main():
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd import tiles
 
-    data, cam, label, build_s = build_workload(args.workload, args.builder)
+    data, cam, label, build_s = build_workload(args.workload, args.builder, args.convert)
     W, H = frame_size(world)
     scene = cr.Scene(data, W, H, args.depth)
     scene.set_shard(rank, world, args.tile)
