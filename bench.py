@@ -268,6 +268,7 @@ def cpu_baseline(data, cam, W, H, depth, rv, cs):
         check = bool(c[0] == cs["closest_rays"] and c[1] == cs["any_rays"] and
                      c[2] == cs["nodes_closest"] + cs["nodes_any"] and c[3] == cs["tris_closest"] + cs["tris_any"])
     return {"value": round(rays / float(np.median(times)) / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+            "single_thread_value": round(rate / 1e6, 3),          # one thread, 8 pixel rows through the image centre
             "sample": f"rows {y0}..{y1} of {H} ({rays} rays, same frame and CWBVH as the GPU step)",
             "visit_counters_match_gpu": check}
 
