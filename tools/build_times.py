@@ -1,0 +1,24 @@
+"""Build-side timings on the GPU box: LBVH build, CWBVH conversion (device vs host), scene creation at 1,004,672 triangles.
+usage: python tools/build_times.py   (profiles/r01_gpu_builders_* come from this under rocprofv3 --kernel-trace --stats)"""
+import os, time, numpy as np, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import __graft_entry__ as g
+g.build()
+import caitlynrenderer_amd as cr
+from caitlynrenderer_amd.meshgen import tessellated_cornell
+base, cam = g._cornell()
+mesh = tessellated_cornell(base, 183)
+for builder in ("lbvh", "sbvh"):
+    t0 = time.time(); sb = cr.SBVH(mesh.triangles, mesh.vertices, builder=builder); t1 = time.time()
+    print(builder, "build %.3fs" % (t1 - t0), sb.build_ms, "nodes", sb.flat_nodes.shape[0], flush=True)
+    for rep in range(2):
+        t0 = time.time(); d = cr.CWBVH().convert(sb, device=True); t1 = time.time()
+        print("  device convert %.1f ms wall, (device, total) ms =" % ((t1 - t0) * 1e3), d.convert_ms, "node8", d.nodes.shape[0], "depth", d.depth, flush=True)
+    t0 = time.time(); h = cr.CWBVH().convert(sb); t1 = time.time()
+    print("  host convert %.1f ms" % ((t1 - t0) * 1e3), "identical", np.array_equal(h.nodes, d.nodes) and np.array_equal(h.tri_slots, d.tri_slots), flush=True)
+data = cr.SceneData.build(mesh, cam, builder="lbvh", convert="device")
+for rep in range(2):
+    t0 = time.time(); s = cr.Scene(data, 1920, 1080, 1); t1 = time.time()
+    s.render_frame(0.5, 0.5); t2 = time.time()
+    print("scene create %.1f ms, first frame %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+    s.close()
