@@ -604,7 +604,8 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // wave-ballot compaction.  Nothing but the two output queues (and, for paths that go on, 40 B of path
 // state) touches HBM; a path that ends here adds its radiance to the sum buffer directly.
 // TEX compiles the textured-albedo branch in (its double-precision pow costs registers the untextured path
-// should not pay for).  96-VGPR budget = 5 waves per SIMD; 80 and 64 were measured slower.
+// should not pay for).  96-VGPR budget = 5 waves per SIMD; 80 and 64 were measured slower, and 80 again
+// under wave-granular dispatch: no change (0.225 vs 0.226 ms) with 56 bytes of scratch per lane.
 // PRETRACED: the closest hit of each queue entry was found by k_closest_queue (incoherent bounce rays are
 // traced with lane refill, which cannot be fused with lock-step shading); the kernel then only shades.
 // TINY (trees of a few nodes, e.g. the 32-triangle Cornell box): plain per-lane loop instead of the voting loop
