@@ -203,7 +203,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
     int sp = 0;
     uint2 cur = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
     for (;;) {
-        const unsigned long long idle = __ballot(!busy);
+        const unsigned long long idle = next < pool_end ? __ballot(!busy) : 0ull;     // a drained pool skips the refill logic
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
         if (next < pool_end && (n_idle >= refill_min || n_idle == 64u)) {
             const uint32_t mine = next + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
