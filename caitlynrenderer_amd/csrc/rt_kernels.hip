@@ -28,7 +28,7 @@ __device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x 
 // 8-wide quantised child-box test (cwbvh.fs:376-446, corrected: far = min(min()), tmin clamped to 0,
 // tmax clamped to max_t, hit iff tmin <= tmax).  ~19 VALU instructions per child (6 cvt_f32_ubyte, 6 fma, max3,
 // min3, 2 clamps, compare, shift, select); pairing the near/far fmas of an axis into v_pk_fma_f32 (24 instead of
-// 48) was measured: no change (0.228 vs 0.226 ms) for 9 more VGPRs, so the scalar form stays.  Returns the hit mask: inner children in the top
+// 48) was measured twice: 0.224 vs 0.217 ms (200-frame averages) and 9 more VGPRs, so the scalar form stays.  Returns the hit mask: inner children in the top
 // byte at bit (24+slot)^oct, leaf triangles as unary-count bits in the low 24.
 __device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3,
                                                     const uint4 n4, vec3 o, vec3 inv, bool negx, bool negy, bool negz,
