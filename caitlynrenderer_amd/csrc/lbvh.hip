@@ -3,9 +3,9 @@
 // A linear BVH in the FlatNode layout the path consumes (Caitlyn/FlatNode.h:34-40, BFS order, children
 // adjacent, one triangle per leaf like sbvh.h:285-324 leaves them): 30-bit Morton codes of the triangle
 // centroids, a device radix sort (rocPRIM), Karras' parallel binary radix tree, and a bottom-up refit in
-// which the second child to arrive at a node computes its box.  Topology and boxes are built on the
-// device; the BFS renumbering into FlatNode order is a single O(n) sweep on the host because the result
-// is handed back as host arrays anyway (crt_sbvh handle, interchangeable with crt_sbvh_build's).
+// which the second child to arrive at a node computes its box, then the renumbering into FlatNode BFS order
+// as one more radix sort of the nodes by (depth, first key of the node's range).  The result is handed back
+// as host arrays (crt_sbvh handle, interchangeable with crt_sbvh_build's).
 // This is NOT the reference's SBVH: no SAH, no spatial splits, hence a different (lower quality, ~100x
 // faster to build) tree; closest hits are identical by construction.
 #include <cstring>   // rocPRIM's texture_cache_iterator.hpp calls memset without including it
@@ -14,7 +14,6 @@
 #include <rocprim/rocprim.hpp>
 
 #include <chrono>
-#include <deque>
 #include <string>
 #include <vector>
 
@@ -87,7 +86,8 @@ __device__ __forceinline__ int delta(const unsigned long long* __restrict__ k, i
 }
 
 // Karras' binary radix tree: internal node i owns a key range; children >= n-1 encode leaves (n-1 + leaf).
-__global__ void k_radix_tree(const unsigned long long* __restrict__ keys, int n, int2* __restrict__ child, int* __restrict__ parent) {
+__global__ void k_radix_tree(const unsigned long long* __restrict__ keys, int n, int2* __restrict__ child, int* __restrict__ parent,
+                             int* __restrict__ range_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
@@ -109,6 +109,7 @@ __global__ void k_radix_tree(const unsigned long long* __restrict__ keys, int n,
     const int left = lo == gamma ? (n - 1) + gamma : gamma;
     const int right = hi == gamma + 1 ? (n - 1) + gamma + 1 : gamma + 1;
     child[i] = make_int2(left, right);
+    range_first[i] = lo;
     parent[left] = i;
     parent[right] = i;
     if (i == 0) parent[0] = -1;
@@ -144,6 +145,45 @@ __global__ void k_refit(const unsigned long long* __restrict__ keys, const float
     }
 }
 
+// BFS renumbering into FlatNode order (sbvh.h:570-609: children adjacent, parents before children) without a
+// queue: nodes of one level own disjoint key ranges, so sorting all nodes by (depth, first key of the range) IS the
+// breadth-first order a queue would produce (left child before right, parents in order).
+__global__ void k_bfs_keys(const int* __restrict__ parent, const int* __restrict__ range_first, int n, unsigned long long* __restrict__ keys,
+                           uint32_t* __restrict__ ids) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * n - 1) return;
+    uint32_t depth = 0;
+    for (int p = parent[id]; p >= 0; p = parent[p]) ++depth;
+    const uint32_t first = id >= n - 1 ? (uint32_t)(id - (n - 1)) : (uint32_t)range_first[id];
+    keys[id] = ((unsigned long long)depth << 32) | first;
+    ids[id] = (uint32_t)id;
+}
+__global__ void k_bfs_pos(const uint32_t* __restrict__ order, uint32_t total, uint32_t* __restrict__ pos) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < total) pos[order[p]] = p;
+}
+__global__ void k_flatten(const uint32_t* __restrict__ order, const uint32_t* __restrict__ pos, const int2* __restrict__ child,
+                          const float* __restrict__ node_box, int n, crt_flatnode* __restrict__ flat, uint32_t* __restrict__ bad) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (uint32_t)(2 * n - 1)) return;
+    const int id = (int)order[p];
+    const float* bx = node_box + 6 * (size_t)id;
+    crt_flatnode f;
+    f.bmin[0] = bx[0]; f.bmin[1] = bx[1]; f.bmin[2] = bx[2];
+    f.bmax[0] = bx[3]; f.bmax[1] = bx[4]; f.bmax[2] = bx[5];
+    if (id >= n - 1) {
+        f.bmin[3] = (float)(id - (n - 1));              // leaf slot = position in Morton order
+        f.bmax[3] = 1.0f;
+    } else {
+        const int2 c = child[id];
+        const uint32_t l = pos[c.x], r = pos[c.y];
+        if (r != l + 1u || l <= p) atomicOr(bad, 1u);   // children adjacent and after their parent
+        f.bmin[3] = (float)l;
+        f.bmax[3] = 0.0f;
+    }
+    flat[p] = f;
+}
+
 thread_local float g_last_device_ms = 0.f, g_last_total_ms = 0.f;
 
 }  // namespace
@@ -166,9 +206,12 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     int32_t* d_vidx = nullptr; float* d_verts = nullptr; float* d_leaf_box = nullptr; uint32_t* d_scene = nullptr;
     unsigned long long *d_keys = nullptr, *d_sorted = nullptr; void* d_tmp = nullptr;
     int2* d_child = nullptr; int* d_parent = nullptr; float* d_node_box = nullptr; uint32_t* d_arrivals = nullptr;
+    int* d_first = nullptr; unsigned long long *d_bkeys = nullptr, *d_bkeys2 = nullptr; uint32_t *d_ids = nullptr, *d_order = nullptr, *d_pos = nullptr, *d_bad = nullptr;
+    crt_flatnode* d_flat = nullptr; void* d_tmp2 = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = {d_vidx, d_verts, d_leaf_box, d_scene, d_keys, d_sorted, d_tmp, d_child, d_parent, d_node_box, d_arrivals};
+        void* ptrs[] = {d_vidx, d_verts, d_leaf_box, d_scene, d_keys, d_sorted, d_tmp, d_child, d_parent, d_node_box, d_arrivals,
+                        d_first, d_bkeys, d_bkeys2, d_ids, d_order, d_pos, d_bad, d_flat, d_tmp2};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -195,6 +238,18 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     size_t tmp_bytes = 0;
     LB_HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys, d_sorted, n_tris, 0, 64, (hipStream_t)0));
     LB_HIPCHK(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    LB_HIPCHK(hipMalloc(&d_first, std::max<size_t>(n_tris - 1, 1) * 4));
+    LB_HIPCHK(hipMalloc(&d_bkeys, n_nodes * 8));
+    LB_HIPCHK(hipMalloc(&d_bkeys2, n_nodes * 8));
+    LB_HIPCHK(hipMalloc(&d_ids, n_nodes * 4));
+    LB_HIPCHK(hipMalloc(&d_order, n_nodes * 4));
+    LB_HIPCHK(hipMalloc(&d_pos, n_nodes * 4));
+    LB_HIPCHK(hipMalloc(&d_bad, 4));
+    LB_HIPCHK(hipMalloc(&d_flat, n_nodes * sizeof(crt_flatnode)));
+    LB_HIPCHK(hipMemset(d_bad, 0, 4));
+    size_t tmp2_bytes = 0;
+    LB_HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp2_bytes, d_bkeys, d_bkeys2, d_ids, d_order, n_nodes, 0, 64, (hipStream_t)0));
+    LB_HIPCHK(hipMalloc(&d_tmp2, std::max<size_t>(tmp2_bytes, 16)));
     LB_HIPCHK(hipEventCreate(&ev0));
     LB_HIPCHK(hipEventCreate(&ev1));
 
@@ -203,58 +258,48 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     hipLaunchKernelGGL(k_tri_bounds, dim3(g), dim3(256), 0, 0, d_vidx, d_verts, (uint32_t)n, d_leaf_box, d_scene);
     hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, 0, d_leaf_box, d_scene, (uint32_t)n, d_keys);
     LB_HIPCHK(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, n_tris, 0, 64, (hipStream_t)0));
-    if (n > 1) hipLaunchKernelGGL(k_radix_tree, dim3((uint32_t)((n_tris - 1 + 255) / 256)), dim3(256), 0, 0, d_sorted, n, d_child, d_parent);
+    if (n > 1) hipLaunchKernelGGL(k_radix_tree, dim3((uint32_t)((n_tris - 1 + 255) / 256)), dim3(256), 0, 0, d_sorted, n, d_child, d_parent, d_first);
     else { const int minus1 = -1; LB_HIPCHK(hipMemcpyAsync(d_parent, &minus1, 4, hipMemcpyHostToDevice, 0)); }
     hipLaunchKernelGGL(k_refit, dim3(g), dim3(256), 0, 0, d_sorted, d_leaf_box, n, d_child, d_parent, d_node_box, d_arrivals);
+    const dim3 gn((uint32_t)((n_nodes + 255) / 256));
+    hipLaunchKernelGGL(k_bfs_keys, gn, dim3(256), 0, 0, d_parent, d_first, n, d_bkeys, d_ids);
+    LB_HIPCHK(rocprim::radix_sort_pairs(d_tmp2, tmp2_bytes, d_bkeys, d_bkeys2, d_ids, d_order, n_nodes, 0, 64, (hipStream_t)0));
+    hipLaunchKernelGGL(k_bfs_pos, gn, dim3(256), 0, 0, d_order, (uint32_t)n_nodes, d_pos);
+    hipLaunchKernelGGL(k_flatten, gn, dim3(256), 0, 0, d_order, d_pos, d_child, d_node_box, n, d_flat, d_bad);
     LB_HIPCHK(hipEventRecord(ev1, 0));
     LB_HIPCHK(hipDeviceSynchronize());
     LB_HIPCHK(hipGetLastError());
     LB_HIPCHK(hipEventElapsedTime(&g_last_device_ms, ev0, ev1));
 
-    std::vector<unsigned long long> sorted(n_tris);
-    std::vector<int2> child(std::max<size_t>(n_tris - 1, 1));
-    std::vector<float> node_box(6 * n_nodes);
-    LB_HIPCHK(hipMemcpy(sorted.data(), d_sorted, n_tris * 8, hipMemcpyDeviceToHost));
-    if (n > 1) LB_HIPCHK(hipMemcpy(child.data(), d_child, (n_tris - 1) * sizeof(int2), hipMemcpyDeviceToHost));
-    LB_HIPCHK(hipMemcpy(node_box.data(), d_node_box, node_box.size() * 4, hipMemcpyDeviceToHost));
-    cleanup();
-    ev0 = ev1 = nullptr; d_vidx = nullptr;   // (cleanup already ran; nothing below touches the device)
-
     crt_sbvh* h = new (std::nothrow) crt_sbvh;
-    if (!h) return fail(CRT_ERR_NOMEM, "crt_lbvh_build: out of memory");
+    if (!h) { cleanup(); return fail(CRT_ERR_NOMEM, "crt_lbvh_build: out of memory"); }
     crt::SBVH& b = h->bvh;
+    std::vector<unsigned long long> sorted;
+    uint32_t bad = 0;
+    unsigned long long last_key = 0;
+    try {
+        sorted.resize(n_tris);
+        b.flat_nodes.resize(n_nodes);
+        b.triangle_indices.resize(n_tris);
+        b.triangles.resize(n_tris);
+    } catch (const std::exception& e) {
+        delete h; cleanup();
+        return fail(CRT_ERR_NOMEM, std::string("crt_lbvh_build: ") + e.what());
+    }
+    if (hipMemcpy(sorted.data(), d_sorted, n_tris * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(b.flat_nodes.data(), d_flat, n_nodes * sizeof(crt_flatnode), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&last_key, d_bkeys2 + (n_nodes - 1), 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        delete h; cleanup();
+        return fail(CRT_ERR_HIP, "crt_lbvh_build: copy back failed");
+    }
+    cleanup();
+    if (bad) { delete h; return fail(CRT_ERR_HIP, "crt_lbvh_build: breadth-first renumbering is inconsistent"); }
+    b.depth = (int)(last_key >> 32);                     // the deepest level holds leaves only
     // leaf slot j <-> j-th triangle in Morton order
-    b.triangle_indices.resize(n_tris);
-    b.triangles.resize(n_tris);
     for (size_t jx = 0; jx < n_tris; ++jx) {
         b.triangle_indices[jx] = (int32_t)(sorted[jx] & 0xffffffffull);
         b.triangles[jx] = tris[b.triangle_indices[jx]];
-    }
-    // BFS renumbering into FlatNode order: an interior node's children are adjacent (sbvh.h:570-609)
-    b.flat_nodes.reserve(n_nodes);
-    std::deque<std::pair<int, int>> queue;   // (radix-tree node id, level); ids >= n-1 are leaves
-    queue.emplace_back(n > 1 ? 0 : (n - 1), 0);
-    int next_child = 0;
-    b.depth = 0;
-    while (!queue.empty()) {
-        const auto [id, level] = queue.front();
-        queue.pop_front();
-        crt_flatnode f;
-        const float* bx = node_box.data() + 6 * (size_t)id;
-        f.bmin[0] = bx[0]; f.bmin[1] = bx[1]; f.bmin[2] = bx[2];
-        f.bmax[0] = bx[3]; f.bmax[1] = bx[4]; f.bmax[2] = bx[5];
-        if (id >= n - 1) {
-            f.bmin[3] = (float)(id - (n - 1));
-            f.bmax[3] = 1.0f;
-            b.depth = std::max(b.depth, level);
-        } else {
-            f.bmin[3] = (float)(next_child + 1);
-            f.bmax[3] = 0.0f;
-            next_child += 2;
-            queue.emplace_back(child[id].x, level + 1);
-            queue.emplace_back(child[id].y, level + 1);
-        }
-        b.flat_nodes.push_back(f);
     }
     g_last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     *out = h;
