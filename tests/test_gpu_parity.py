@@ -643,3 +643,41 @@ def test_textured_scene_from_obj_mtl_and_image_files(cr, ob, textured, tmp_path)
     got = np.fromfile(tmp_path / "sum.f32", np.float32).reshape(H, W, 3)
     assert np.array_equal(got.view(np.uint32), out.view(np.uint32))          # C++ host path == Python host path, bit for bit
     scene.close()
+
+
+def test_hip_bvh2_walk_reproduces_the_survey_census(cr, ob, cornell_data, survey):
+    """The reference-side numbers of SURVEY 8c (probe of the reference's own BVH2 on its own scene: 1,163,374 of
+    2,073,600 pixel-centre rays hit, centre pixel hits triangle 8 at t = 10.515989, 6.12 nodes + 1.28 triangle tests
+    per ray) measured on the HIP path itself — BVH2 walk in the shader's order, and the CWBVH walk for the hits."""
+    ka = survey["bvh2_primary_census_1920x1080_no_jitter"]
+    scene = cr.Scene(cornell_data, 1920, 1080, 1)
+    rays = ob.Oracle(cornell_data, 1920, 1080, 1).primary_rays(jitter=False).astype(cr.RAY_DT)
+    assert rays.shape[0] == ka["rays"]
+    hits, st = scene.trace(rays, cr.CRT_TRACE_CLOSEST | cr.CRT_TRACE_BVH2, stats=True)
+    assert int((hits["tri"] >= 0).sum()) == ka["hits"]
+    c = hits[ka["centre_pixel"]["py"] * 1920 + ka["centre_pixel"]["px"]]
+    assert c["tri"] == ka["centre_pixel"]["triangle"] and abs(c["t"] - ka["centre_pixel"]["t"]) < 1e-6
+    assert abs(st["nodes"].mean() - ka["nodes_per_ray"]) < 0.005 and abs(st["tris"].mean() - ka["tris_per_ray"]) < 0.005
+    h8 = scene.trace(rays, cr.CRT_TRACE_CLOSEST)
+    assert int((h8["tri"] >= 0).sum()) == ka["hits"] and np.array_equal(h8["tri"], hits["tri"])
+    assert np.array_equal(h8["t"].view(np.uint32), hits["t"].view(np.uint32))
+    scene.close()
+
+
+def test_scene_from_bvh2_only_converts_on_the_device(cr, tess40, scenes):
+    """crt_scene_create with a BVH2 and no CWBVH converts internally — on the GPU for trees of 4096+ nodes; since the
+    device converter is byte-identical to the host one, the scene behaves exactly like the one given both."""
+    import copy
+    mesh, data = tess40
+    only2 = copy.copy(data)
+    only2.bvh8 = None
+    only2.bvh8_tri_slots = None
+    assert data.bvh.shape[0] >= 4096
+    a, b = cr.Scene(only2, 96, 64, 2), scenes["tess40"][0]
+    assert a.bvh_info() == b.bvh_info()
+    rays = seeded_rays(mesh, 50000, 77, cr.RAY_DT)
+    got, gst = a.trace(rays, stats=True)
+    want, wst = b.trace(rays, stats=True)
+    _assert_hits_equal(got, want)
+    assert np.array_equal(gst["nodes"], wst["nodes"]) and np.array_equal(gst["tris"], wst["tris"])   # same tree, same walk
+    a.close()
