@@ -192,6 +192,13 @@ def main():
             alg_closest += (NODE_BYTES * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches
         t_closest = launch_ms_timed * 1e-3
         achieved = alg_closest / t_closest / 1e9 if t_closest > 0 else 0.0
+        if fused_shadow:
+            kernel_label = "k_segment (raygen + CWBVH closest hit + shading + in-place NEE any-hit walk)"
+        elif args.depth > 1:
+            kernel_label = ("closest-hit launches, mean per path segment: k_segment (raygen + closest hit + shading + queue emission) "
+                            "for segment 0, k_closest_queue (lane-refill pools) + k_segment<PRETRACED> (shading) for bounce segments")
+        else:
+            kernel_label = "k_segment (raygen + CWBVH closest hit + shading + queue emission)"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from a separate rocprofv3 --pmc pass
         if os.path.exists(tpath):
@@ -208,7 +215,7 @@ def main():
                        "rays_per_step": int(rays_all), "closest_rays_rank0": int(st["closest_rays"]),
                        "any_rays_rank0": int(st["any_rays"]), "tile": tile, "parallelism": f"tiles/{world}",
                        "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_segment (raygen + CWBVH closest hit + shading + in-place NEE any-hit walk)" if fused_shadow else "k_segment (raygen|queue fetch + CWBVH closest hit + shading + queue emission)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_closest),
                          "bytes_per_ray": round(alg_closest / max(1, (cs["closest_rays"] + (cs["any_rays"] if fused_shadow else 0)) / launches), 2),
