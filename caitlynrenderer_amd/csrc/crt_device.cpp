@@ -162,15 +162,14 @@ struct crt_scene {
         uint64_t blocks = (n + 255) / 256;
         return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)n_cu * 8));
     }
-    EventSpan* begin_span(int kind) {
+    // a span's events are attached to the launches themselves (crt::set_launch_events), not recorded between them
+    EventSpan* new_span(int kind) {
         if (timing == 0u || (timing == 1u && kind != 1)) return nullptr;
         if (n_spans >= (int)spans.size()) return nullptr;
         EventSpan* s = &spans[n_spans++];
         s->kind = kind;
-        hipEventRecord(s->a, stream);
         return s;
     }
-    void end_span(EventSpan* s) { if (s) hipEventRecord(s->b, stream); }
 };
 
 namespace {
@@ -589,27 +588,30 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
         sa.visit_totals = s->d_visit_totals;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
-        EventSpan* sp = s->begin_span(1);
+        EventSpan* sp = s->new_span(1);
         const bool pretraced = b > 0 && s->bounce_refill && !tiny;
         if (pretraced) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
             qa.stack_entries = s->stack_entries; qa.sub_capacity = s->sub_capacity; qa.refill_min = s->refill_min; qa.tri_min = s->tri_min;
             qa.visit_totals = s->d_visit_totals;
+            if (sp) crt::set_launch_events(sp->a, nullptr);                 // span = both launches of the segment
             crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8, 1024), s->stream);
             sa.hits_in = s->d_qhits;
+            if (sp) crt::set_launch_events(nullptr, sp->b);
+        } else if (sp) {
+            crt::set_launch_events(sp->a, sp->b);
         }
         crt::launch_segment(sa, b == 0, pretraced, tiny, s->count_visits, s->trace_grid(P, 5), s->stream);
-        s->end_span(sp);
 
         if (tiny) continue;                          // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};
         sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = cnt + counter_index(b, 1, 0);
         sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = 0;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
-        sp = s->begin_span(2);
+        sp = s->new_span(2);
+        if (sp) crt::set_launch_events(sp->a, sp->b);
         crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->stream);
-        s->end_span(sp);
     }
     if (s->count_visits)
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
@@ -781,9 +783,10 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     ta.refill_min = s->refill_min;
     ta.tri_min = s->tri_min;
     s->n_spans = 0;
-    EventSpan* sp = s->begin_span(any_hit ? 2 : 1);
+    if ((mode & CRT_TRACE_BVH2) && !s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_trace: the scene was created without a BVH2 (desc.bvh)");
+    EventSpan* sp = s->new_span(any_hit ? 2 : 1);
+    if (sp) crt::set_launch_events(sp->a, sp->b);
     if (mode & CRT_TRACE_BVH2) {
-        if (!s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_trace: the scene was created without a BVH2 (desc.bvh)");
         crt::Bvh2Args ba{};
         ba.nodes = s->d_bvh2; ba.tris = s->d_tris2; ba.rays = ta.rays; ba.hits = ta.hits; ba.stats = ta.stats;
         ba.n = (uint32_t)n; ba.tie = (mode & CRT_TRACE_TIE_LOWEST_ID) ? 1u : 0u; ba.stack_entries = s->bvh2_stack;
@@ -794,7 +797,6 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     } else {
         crt::launch_trace(ta, any_hit ? 1 : 0, d_stats != nullptr, s->trace_grid(n, 8, 1024), s->stream);
     }
-    s->end_span(sp);
     HIPCHK(hipGetLastError());
     s->stats_pending = true;
     s->stats_from_frame = false;

@@ -7,6 +7,7 @@
 // (resolve).  One ray per lane, 64-lane wavefronts; traversal stack in LDS; queue compaction with
 // wave ballots.  No MFMA: this is pointer chasing, bounded by memory latency/bandwidth.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "rt_kernels.hpp"
@@ -961,6 +962,20 @@ __global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linea
 
 // ------------------------------------------------------------------ launchers --------
 
+// Timing events ride on the dispatch itself (hipExtLaunchKernelGGL): the events take the kernel's own start/stop
+// timestamps, with none of the marker packets a hipEventRecord pair puts between back-to-back kernels (~4 us per pair).
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+template <typename K, typename A>
+static inline void launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stream, const A& a) {
+    if (g_ev_start || g_ev_stop) {
+        hipExtLaunchKernelGGL(kernel, g, b, (uint32_t)lds, stream, g_ev_start, g_ev_stop, 0, a);
+        g_ev_start = g_ev_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kernel, g, b, lds, stream, a);
+    }
+}
+
 static uint32_t g_waves_per_group = 1;   // measured: 1 M mesh k_segment 0.246 -> 0.226 ms, Cornell 0.079 -> 0.074 ms
 void set_waves_per_workgroup(uint32_t n) { g_waves_per_group = n == 1u ? 1u : 4u; }
 static inline size_t stack_bytes(uint32_t entries) { return (size_t)g_waves_per_group * entries * 64 * sizeof(uint2); }
@@ -972,22 +987,22 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipSt
     const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
     if (mode == 1) {
-        if (stats) hipLaunchKernelGGL((k_trace<true, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_trace<true, false>), g, b, lds, stream, a);
+        if (stats) launch(k_trace<true, true>, g, b, lds, stream, a);
+        else       launch(k_trace<true, false>, g, b, lds, stream, a);
     } else {
-        if (stats) hipLaunchKernelGGL((k_trace<false, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_trace<false, false>), g, b, lds, stream, a);
+        if (stats) launch(k_trace<false, true>, g, b, lds, stream, a);
+        else       launch(k_trace<false, false>, g, b, lds, stream, a);
     }
 }
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = (size_t)g_waves_per_group * a.stack_entries * 64 * sizeof(int);
     if (any) {
-        if (stats) hipLaunchKernelGGL((k_trace_bvh2<true, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_trace_bvh2<true, false>), g, b, lds, stream, a);
+        if (stats) launch(k_trace_bvh2<true, true>, g, b, lds, stream, a);
+        else       launch(k_trace_bvh2<true, false>, g, b, lds, stream, a);
     } else {
-        if (stats) hipLaunchKernelGGL((k_trace_bvh2<false, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((k_trace_bvh2<false, false>), g, b, lds, stream, a);
+        if (stats) launch(k_trace_bvh2<false, true>, g, b, lds, stream, a);
+        else       launch(k_trace_bvh2<false, false>, g, b, lds, stream, a);
     }
 }
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
@@ -996,7 +1011,7 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny,
     const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
     const bool tex = a.textures != nullptr;
-#define CRT_LAUNCH_SEG(F, S, T, P, Y) hipLaunchKernelGGL((k_segment<F, S, T, P, Y>), g, b, lds, stream, a)
+#define CRT_LAUNCH_SEG(F, S, T, P, Y) launch(k_segment<F, S, T, P, Y>, g, b, lds, stream, a)
 #define CRT_LAUNCH_SEG_T(F, S, P, Y) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y); else CRT_LAUNCH_SEG(F, S, false, P, Y); } while (0)
 #define CRT_LAUNCH_SEG_S(F, P, Y) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y); else CRT_LAUNCH_SEG_T(F, false, P, Y); } while (0)
     if (pretraced) CRT_LAUNCH_SEG_T(false, false, true, false);          // shade-only: never tiny (the host falls back to lock-step)
@@ -1009,14 +1024,14 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny,
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
-    if (stats) hipLaunchKernelGGL((k_closest_queue<true>), g, b, lds, stream, a);
-    else       hipLaunchKernelGGL((k_closest_queue<false>), g, b, lds, stream, a);
+    if (stats) launch(k_closest_queue<true>, g, b, lds, stream, a);
+    else       launch(k_closest_queue<false>, g, b, lds, stream, a);
 }
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g = grid_dim(grid), b = block_dim();
     const size_t lds = stack_bytes(a.stack_entries);
-    if (stats) hipLaunchKernelGGL((k_shadow<true>), g, b, lds, stream, a);
-    else       hipLaunchKernelGGL((k_shadow<false>), g, b, lds, stream, a);
+    if (stats) launch(k_shadow<true>, g, b, lds, stream, a);
+    else       launch(k_shadow<false>, g, b, lds, stream, a);
 }
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_untile, dim3(grid), dim3(256), 0, stream, f, packed, linear);

@@ -113,6 +113,8 @@ void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hi
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 // 4 (256-thread workgroups) or 1 (every wave its own workgroup); process-wide
 void set_waves_per_workgroup(uint32_t n);
+// start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 

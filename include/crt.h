@@ -132,8 +132,8 @@ int crt_sync(crt_scene* s);
 /* knobs: "jitter" (0/1, tent-filter jitter of path_trace.fs:1030-1037; default 1),
  * "trace_occupancy" (persistent workgroups per CU for the traversal kernels),
  * "count_visits" (0/1: traversal launches also count node fetches / triangle tests),
- * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = around every launch (default), 1 = closest-hit
- * launches only, 0 = none), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
+ * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit
+ * launches only, 0 = none; the events are attached to the dispatches, so timing does not slow the stream down), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
  * restarting every frame — crt_frame_stats.ms_* are then sums over n_trace_launches launches; 0: per frame),
  * tuning: "tri_min" (vote ratio of the traversal loop; 0 = per-lane loop with the NEE shadow ray walked inside
  * the segment kernel, which trees under 64 nodes get anyway), "refill_min", "bounce_refill" (lane-refill pools for
