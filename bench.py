@@ -143,8 +143,8 @@ def main():
     scene.sync()
     if use_dist:    # warm the collective too
         read_back()
-    # HIP events around every closest-hit launch of the timed region, on the scene's own stream (the any-hit
-    # launches are timed in the untimed tail below: an event pair costs ~4 us of device idle time per launch)
+    # HIP events on every closest-hit launch of the timed region, on the scene's own stream (attached to the dispatch:
+    # they take the kernel's own start/stop timestamps); the any-hit launches are timed in the untimed tail below
     scene.set_option("timing", 1)
     scene.set_option("timing_accumulate", args.steps * max(1, args.depth))
     barrier()
