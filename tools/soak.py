@@ -1,0 +1,65 @@
+"""Randomised parity soak (run on the GPU box): random cameras, resolutions, depths, builders and scenes; the HIP path
+must match the oracle bit for bit (radiance sums, ray counts, visit counters) on every case.
+usage: python tools/soak.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import __graft_entry__ as g
+g.build()
+import caitlynrenderer_amd as cr
+from caitlynrenderer_amd.meshgen import tessellated_cornell
+from oracle import binding as ob
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+base, cam0 = g._cornell()
+meshes = {"cornell": base, "tess8": tessellated_cornell(base, 8), "tess24": tessellated_cornell(base, 24)}
+datas = {}
+bad = 0
+t_start = time.time()
+for case in range(n_cases):
+    name = list(meshes)[rng.integers(0, len(meshes))]
+    builder = "lbvh" if rng.random() < 0.3 else "sbvh"
+    convert = "device" if rng.random() < 0.5 else "host"
+    key = (name, builder, convert)
+    if key not in datas:
+        datas[key] = cr.SceneData.build(meshes[name], cam0, builder=builder, convert=convert)
+    data = datas[key]
+    W, H = int(rng.integers(40, 420)), int(rng.integers(30, 260))
+    depth = int(rng.integers(1, 5))
+    # camera: inside or outside the box (box spans roughly 0..5.6), any direction, fov 15..100 degrees
+    pos = rng.uniform(-3.0, 9.0, 3).astype(np.float32)
+    tgt = rng.uniform(0.0, 5.6, 3).astype(np.float32)
+    if rng.random() < 0.15:
+        tgt = pos + np.array([0, 0, -1], np.float32) * np.float32(rng.uniform(0.5, 3))      # axis-aligned view: zero components
+    cam = cr.Camera(tuple(float(x) for x in pos), tuple(float(x) for x in tgt), float(rng.uniform(15, 100)))
+    scene = cr.Scene(data, W, H, depth)
+    scene.update(cam)
+    jitter = 1                                   # the oracle's frame loop always jitters, like the shader
+    scene.set_option("count_visits", 1)
+    orc = ob.Oracle(data, W, H, depth, cam)
+    rnd = cr.Rnd()
+    for _ in range(int(rng.integers(0, 50))):
+        rnd.randf2()
+    ref = np.zeros((H, W, 3), np.float32)
+    ok = True
+    for frame in range(3):
+        rx, ry = rnd.randf2(), rnd.randf2()
+        scene.render_frame(rx, ry)
+        _, cnt = orc.render_frame(rx, ry, ref, threads=16)
+        st = scene.frame_stats()
+        out = scene.read_sum()
+        same = np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+        counts = (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
+        if not (same and counts):
+            ok = False
+            print(f"MISMATCH case {case} frame {frame}: {key} {W}x{H} depth {depth} jitter {jitter} pos {pos} tgt {tgt} "
+                  f"sum_equal {same} max|d| {np.abs(out - ref).max():.3g} n_diff {(out != ref).sum()} counts {counts}", flush=True)
+            break
+    bad += 0 if ok else 1
+    scene.close()
+    if case % 10 == 9:
+        print(f"case {case + 1}/{n_cases}: {bad} mismatching, {time.time() - t_start:.0f}s", flush=True)
+print(f"soak done: {n_cases} cases, {bad} mismatching")
+sys.exit(1 if bad else 0)
