@@ -122,7 +122,7 @@ struct crt_scene {
     bool stats_counted = false;
     uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
-    uint32_t trace_occupancy = 8;            // upper bound on persistent workgroups per CU (option/env)
+    uint32_t trace_occupancy = 8;            // persistent grids only (oversubscribe >= 1): workgroups per CU
     // 0: one chunk per workgroup, the hardware dispatcher hands chunks to CUs as they drain (measured 13 % faster than
     // a persistent grid on the 1 M mesh: per-chunk cost varies 10x between sky and grazing rays);
     // k >= 1: persistent grid of k x the resident workgroups, static schedule (rt_kernels.hip)
@@ -143,7 +143,7 @@ struct crt_scene {
         if (stream) hipStreamDestroy(stream);
     }
 
-    // persistent grid: workgroups per CU bounded by LDS (stack) and registers; always a multiple of 8
+    // grid of a traversal kernel (always a multiple of 8: one slice per XCD group); persistent variant bounded by LDS and registers
     // (the XCD-aware schedule in rt_kernels.hip groups workgroups by blockIdx & 7)
     // reg_cap = workgroups per CU the kernel's VGPR count admits (k_segment ~90 VGPRs -> 5, k_trace/k_shadow <= 64 -> 8)
     // chunk = items one workgroup pass covers: 256 (lock-step kernels) or 1024 (pool kernels)

@@ -5,7 +5,8 @@
 // SURVEY.md §8a defects corrected), Shader/path_trace.fs:322-374 (Moller-Trumbore), :414-489 (hit
 // attributes), :843-1024 (integrator), :1026-1060 (ray generation, accumulate), Shader/output.fs
 // (resolve).  One ray per lane, 64-lane wavefronts; traversal stack in LDS; queue compaction with
-// wave ballots.  No MFMA: this is pointer chasing, bounded by memory latency/bandwidth.
+// wave ballots.  No MFMA: this is pointer chasing; measured bound = VALU issue (primary / shadow rays) or L2-miss
+// latency (bounce rays), see DESIGN.md section 5.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -301,7 +302,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
 
 // ------------------------------------------------------------------ scheduling -------
 
-// Static, XCD-aware work distribution shared by all persistent kernels.
+// XCD-aware work distribution shared by all traversal kernels.  By default the host launches one (single-wave)
+// workgroup per batch, so `it` below only ever takes the value 0 and the hardware dispatcher balances the load; with a
+// smaller, persistent grid (option "oversubscribe" >= 1) the same mapping is a static round-robin schedule.
 //
 // Work is cut into 64-ray batches (one wave; one 8x8 pixel block for primary rays) and chunks of 4
 // batches (one workgroup pass, a 16x16 pixel patch).  Every chunk belongs to one of 8 *groups*:
@@ -393,7 +396,7 @@ __device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, u
     }
 }
 
-// Persistent-threads trace kernel over an explicit ray buffer (crt_trace / crt_trace_device).
+// Trace kernel over an explicit ray buffer (crt_trace / crt_trace_device): 256-ray pools with lane refill.
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]

@@ -130,7 +130,7 @@ int crt_render_frame(crt_scene* s, float rx, float ry);
 int crt_render_frame_async(crt_scene* s, float rx, float ry);
 int crt_sync(crt_scene* s);
 /* knobs: "jitter" (0/1, tent-filter jitter of path_trace.fs:1030-1037; default 1),
- * "trace_occupancy" (persistent workgroups per CU for the traversal kernels),
+ * "trace_occupancy" (workgroups per CU when a persistent grid is selected with "oversubscribe"),
  * "count_visits" (0/1: traversal launches also count node fetches / triangle tests),
  * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit
  * launches only, 0 = none; the events are attached to the dispatches, so timing does not slow the stream down), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
