@@ -740,6 +740,54 @@ int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
 
 // Debug/test hook: copy out one of the frame's ray queues as left by the last crt_render_frame.
 // which: 0/1 = path-ray queue written for an even/odd segment, 2 = shadow-ray queue of the last segment.
+int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint32_t reps, float* ms_stream, float* ms_graph) {
+    if (!s || !rxy || !ms_stream || !ms_graph || n_frames == 0 || (n_frames & 1u) || reps == 0)
+        return fail(CRT_ERR_INVALID, "crt_debug_time_graph: bad argument (n_frames must be even: the counter banks alternate)");
+    HIPCHK(hipSetDevice(s->device));
+    const uint32_t timing0 = s->timing;
+    s->timing = 0;                                         // event-carrying launches are not capturable
+    int rc = crt_render_frame(s, rxy[0], rxy[1]);          // allocates, clears the counter banks once
+    if (!rc) rc = crt_render_frame(s, rxy[0], rxy[1]);
+    if (rc) { s->timing = timing0; return rc; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    auto done = [&](int code) {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        s->timing = timing0;
+        return code;
+    };
+#define G_CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
+    G_CHK(hipEventCreate(&e0));
+    G_CHK(hipEventCreate(&e1));
+    G_CHK(hipEventRecord(e0, s->stream));
+    for (uint32_t r = 0; r < reps; ++r)
+        for (uint32_t f = 0; f < n_frames; ++f)
+            if ((rc = crt_render_frame_async(s, rxy[2 * f], rxy[2 * f + 1]))) return done(rc);
+    G_CHK(hipEventRecord(e1, s->stream));
+    G_CHK(hipStreamSynchronize(s->stream));
+    float ms = 0.f;
+    G_CHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_stream = ms / (float)(reps * n_frames);
+    G_CHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    for (uint32_t f = 0; f < n_frames; ++f)
+        if ((rc = crt_render_frame_async(s, rxy[2 * f], rxy[2 * f + 1]))) { (void)hipStreamEndCapture(s->stream, &graph); return done(rc); }
+    G_CHK(hipStreamEndCapture(s->stream, &graph));
+    G_CHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    G_CHK(hipGraphLaunch(exec, s->stream));                // warm
+    G_CHK(hipStreamSynchronize(s->stream));
+    G_CHK(hipEventRecord(e0, s->stream));
+    for (uint32_t r = 0; r < reps; ++r) G_CHK(hipGraphLaunch(exec, s->stream));
+    G_CHK(hipEventRecord(e1, s->stream));
+    G_CHK(hipStreamSynchronize(s->stream));
+    G_CHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_graph = ms / (float)(reps * n_frames);
+#undef G_CHK
+    return done(CRT_OK);
+}
+
 int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst, size_t cap, size_t* n_out) {
     if (!s || !n_out) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: null argument");
     HIPCHK(hipSetDevice(s->device));

@@ -158,6 +158,9 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
 /* test hook: read back a ray queue of the last rendered frame (which: 0 = path rays entering
  * `segment`, 2 = that segment's shadow rays).  dst may be NULL to query the count. */
 int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst, size_t cap, size_t* n_out);
+/* measurement aid: the same n_frames (rxy = n_frames pairs) queued `reps` times on the stream and replayed `reps`
+ * times as one captured hipGraph; device milliseconds per frame of either way ("hipGraph") */
+int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint32_t reps, float* ms_stream, float* ms_graph);
 
 /* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is
  * cut into tile x tile squares dealt round-robin in Morton order to `world` ranks;
