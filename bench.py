@@ -63,8 +63,8 @@ def frame_size(n_gpus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cornell")
     ap.add_argument("--depth", type=int, default=1, help="path segments per sample (1 = primary + shadow)")
     ap.add_argument("--tile", type=int, default=64)
