@@ -72,6 +72,9 @@ def main():
                     help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build)")
     ap.add_argument("--convert", default="host", choices=["host", "device"],
                     help="BVH2 -> CWBVH conversion on the host (default) or on the GPU (crt_cwbvh_convert_device, same bytes)")
+    ap.add_argument("--accel", default="cwbvh", choices=["cwbvh", "bvh2"],
+                    help="cwbvh = the 8-wide compressed BVH (default, the metric's configuration); bvh2 = frames through the "
+                         "reference's live BVH2 walk (path_trace.fs:511-819), for comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,6 +111,9 @@ def main():
     W, H = frame_size(world)
     scene = cr.Scene(data, W, H, args.depth)
     scene.set_shard(rank, world, args.tile)
+    if args.accel == "bvh2":
+        scene.set_option("accel", 1)
+        label = label.replace("CWBVH", "BVH2 walked as the shipped shader does")
     info = scene.bvh_info()
     if rank == 0:
         log(f"[bench] {label}; {W}x{H}, depth {args.depth}, {world} rank(s); BVH build {build_s:.1f}s; "
@@ -185,11 +191,12 @@ def main():
 
     if rank == 0:
         launches = max(1, args.depth)
-        alg_closest = (NODE_BYTES * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches
+        node_bytes = 96 if args.accel == "bvh2" else NODE_BYTES      # own 2 texels + 4 child texels per BVH2 visit
+        alg_closest = (node_bytes * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches
         # tiny trees: k_segment also walks the NEE shadow rays (no k_shadow launch), so their visits are this launch's bytes too
         fused_shadow = st["any_rays"] > 0 and float(np.median(any_ms)) == 0.0
         if fused_shadow:
-            alg_closest += (NODE_BYTES * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches
+            alg_closest += (node_bytes * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches
         t_closest = launch_ms_timed * 1e-3
         achieved = alg_closest / t_closest / 1e9 if t_closest > 0 else 0.0
         if fused_shadow:
@@ -228,7 +235,7 @@ def main():
                          "frame_device_ms": round(float(np.median(total_ms)), 4),
                          "note": "working set fits the 256 MiB Infinity Cache: measured HBM traffic << algorithmic bytes"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.accel == "cwbvh":
             out["cpu_baseline"] = cpu_baseline(data, cam, W, H, args.depth, rvs[0], cs)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

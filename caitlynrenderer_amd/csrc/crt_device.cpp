@@ -121,6 +121,7 @@ struct crt_scene {
     bool stats_from_frame = false;
     bool stats_counted = false;
     uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
+    uint32_t accel = 0;                      // frames: 0 CWBVH; 1 BVH2 walked as the shipped shader does (first visited wins); 2 BVH2, lowest id wins
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
     uint32_t trace_occupancy = 8;            // persistent grids only (oversubscribe >= 1): workgroups per CU
     // 0: one chunk per workgroup, the hardware dispatcher hands chunks to CUs as they drain (measured 13 % faster than
@@ -524,6 +525,11 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "waves_per_workgroup")) crt::set_waves_per_workgroup((uint32_t)value);
+    else if (!std::strcmp(name, "accel")) {
+        if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
+        if (value != 0 && !s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_set_option: the scene was created without a BVH2 (desc.bvh)");
+        s->accel = (uint32_t)value;
+    }
     else if (!std::strcmp(name, "timing")) s->timing = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "timing_accumulate")) {
         HIPCHK(hipSetDevice(s->device));
@@ -579,8 +585,10 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.f = f;
         sa.sub_capacity = s->sub_capacity;
         // tiny trees (or tri_min = 0): plain per-lane loop and the shadow ray traced inside k_segment, no k_shadow launch
-        const bool tiny = s->info.n_nodes8 < 64 || s->tri_min == 0u;
+        const bool bvh2 = s->accel != 0u;
+        const bool tiny = bvh2 || s->info.n_nodes8 < 64 || s->tri_min == 0u;
         sa.tri_min = s->tri_min;
+        sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
         sa.shadow = s->d_shadow; sa.count_shadow = cnt + counter_index(b, 1, 0);
@@ -602,7 +610,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         } else if (sp) {
             crt::set_launch_events(sp->a, sp->b);
         }
-        crt::launch_segment(sa, b == 0, pretraced, tiny, s->count_visits, s->trace_grid(P, 5), s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, tiny, bvh2, s->count_visits, s->trace_grid(P, 5), s->stream);
 
         if (tiny) continue;                          // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};

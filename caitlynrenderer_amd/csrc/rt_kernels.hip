@@ -11,6 +11,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "rt_kernels.hpp"
 #include "rt_math.hpp"
 
@@ -457,6 +459,72 @@ __device__ __forceinline__ float hit_bbox2(vec3 o, vec3 bmin, vec3 bmax, vec3 in
 // per-ray stack (path_trace.fs:511-652 closest hit, :669-819 any hit), on the FlatNode array as uploaded
 // (Scene.h:1057-1062).  Raw 1/d like the shader.  tie = 0 keeps the shader's first-visited rule (strict '<'),
 // tie = 1 is the lowest-original-id rule of the CWBVH path.  Lock-step 64-ray batches, int stack in LDS.
+// One ray through the BVH2.  best.tri = BVH2 leaf slot (index into the slot-ordered records), best.id = original id;
+// returns hit / occluded.  `stk` is this lane's column of an int stack, stk[level * 64].
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool traverse_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o, vec3 d,
+                                              float tmax_in, uint32_t tie, int* stk, int stack_entries, HitState& best,
+                                              uint32_t& nn, uint32_t& nt) {
+    const vec3 invdir = V3(rcp_ieee(d.x), rcp_ieee(d.y), rcp_ieee(d.z));
+    best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
+    int ptr = 0;
+    stk[0] = -1; ptr = 1;
+    int ind = 0;
+    while (ind > -1) {
+        const float4 bmin = nodes[2 * (size_t)ind], bmax = nodes[2 * (size_t)ind + 1];
+        if (STATS) ++nn;
+        const int left = (int)bmin.w;
+        if (bmax.w == 0.0f) {
+            const float4 amin = nodes[2 * (size_t)left], amax = nodes[2 * (size_t)left + 1];
+            const float4 cmin = nodes[2 * (size_t)left + 2], cmax = nodes[2 * (size_t)left + 3];
+            float tl1, tl2;
+            const float th1 = hit_bbox2(o, V3(amin.x, amin.y, amin.z), V3(amax.x, amax.y, amax.z), invdir, tl1);
+            const float th2 = hit_bbox2(o, V3(cmin.x, cmin.y, cmin.z), V3(cmax.x, cmax.y, cmax.z), invdir, tl2);
+            bool l, r;
+            if (ANY) {                                   // path_trace.fs:741-742
+                l = th1 >= 0 && th1 >= tl1 && tl1 <= best.t;
+                r = th2 >= 0 && th2 >= tl2 && tl2 <= best.t;
+            } else {                                     // path_trace.fs:562-563 ('<=' under the lowest-id rule)
+                l = th1 > 0 && th1 >= tl1 && (tie ? tl1 <= best.t : tl1 < best.t);
+                r = th2 > 0 && th2 >= tl2 && (tie ? tl2 <= best.t : tl2 < best.t);
+            }
+            if (l) {
+                ind = left;
+                if (r) {
+                    const int off = tl1 > tl2 ? 1 : 0;
+                    if (ptr < stack_entries) { stk[ptr * 64] = ind + 1 - off; ++ptr; }
+                    ind += off;
+                }
+                continue;
+            } else if (r) {
+                ind = left + 1;
+                continue;
+            }
+        } else {
+            const int range = (int)bmax.w;
+            for (int s = left; s < left + range; ++s) {
+                const float4* tp = tris + 3 * (size_t)s;
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                if (STATS) ++nt;
+                float u, vv, t;
+                if (mt_test(ta, tb, tc, o, d, u, vv, t)) {
+                    if (ANY) {
+                        if (t < best.t) { best.tri = s; return true; }
+                    } else {
+                        const int id = __float_as_int(ta.w);
+                        if (t < best.t || (tie && t == best.t && best.tri >= 0 && id < best.id)) {
+                            best.t = t; best.u = u; best.v = vv; best.tri = s; best.id = id;
+                        }
+                    }
+                }
+            }
+        }
+        --ptr;
+        ind = stk[ptr * 64];
+    }
+    return best.tri >= 0;
+}
+
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace_bvh2(Bvh2Args a) {
     extern __shared__ int s_stk2[];      // [wave][level][lane]
@@ -469,73 +537,15 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace_bvh2(Bvh2Args a) {
         const uint32_t i = dense_item(v, wave, lane);
         if (i >= a.n) continue;
         const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
-        const vec3 o = V3(r0.x, r0.y, r0.z), d = V3(r1.x, r1.y, r1.z);
-        const vec3 invdir = V3(rcp_ieee(d.x), rcp_ieee(d.y), rcp_ieee(d.z));
-        float best_t = r0.w, best_u = 0.f, best_v = 0.f;
-        int best_slot = -1, best_id = -1;
-        bool occluded = false;
+        HitState best;
         uint32_t nn = 0, nt = 0;
-        int ptr = 0;
-        stk[0] = -1; ptr = 1;
-        int ind = 0;
-        while (ind > -1) {
-            const float4 bmin = a.nodes[2 * (size_t)ind], bmax = a.nodes[2 * (size_t)ind + 1];
-            if (STATS) ++nn;
-            const int left = (int)bmin.w;
-            if (bmax.w == 0.0f) {
-                const float4 amin = a.nodes[2 * (size_t)left], amax = a.nodes[2 * (size_t)left + 1];
-                const float4 cmin = a.nodes[2 * (size_t)left + 2], cmax = a.nodes[2 * (size_t)left + 3];
-                float tl1, tl2;
-                const float th1 = hit_bbox2(o, V3(amin.x, amin.y, amin.z), V3(amax.x, amax.y, amax.z), invdir, tl1);
-                const float th2 = hit_bbox2(o, V3(cmin.x, cmin.y, cmin.z), V3(cmax.x, cmax.y, cmax.z), invdir, tl2);
-                bool l, r;
-                if (ANY) {                                   // path_trace.fs:741-742
-                    l = th1 >= 0 && th1 >= tl1 && tl1 <= best_t;
-                    r = th2 >= 0 && th2 >= tl2 && tl2 <= best_t;
-                } else {                                     // path_trace.fs:562-563 ('<=' under the lowest-id rule)
-                    l = th1 > 0 && th1 >= tl1 && (a.tie ? tl1 <= best_t : tl1 < best_t);
-                    r = th2 > 0 && th2 >= tl2 && (a.tie ? tl2 <= best_t : tl2 < best_t);
-                }
-                if (l) {
-                    ind = left;
-                    if (r) {
-                        const int off = tl1 > tl2 ? 1 : 0;
-                        if (ptr < (int)a.stack_entries) { stk[ptr * 64] = ind + 1 - off; ++ptr; }
-                        ind += off;
-                    }
-                    continue;
-                } else if (r) {
-                    ind = left + 1;
-                    continue;
-                }
-            } else {
-                const int range = (int)bmax.w;
-                for (int s = left; s < left + range; ++s) {
-                    const float4* tp = a.tris + 3 * (size_t)s;
-                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                    if (STATS) ++nt;
-                    float u, vv, t;
-                    if (mt_test(ta, tb, tc, o, d, u, vv, t)) {
-                        if (ANY) {
-                            if (t < best_t) { occluded = true; break; }
-                        } else {
-                            const int id = __float_as_int(ta.w);
-                            if (t < best_t || (a.tie && t == best_t && best_slot >= 0 && id < best_id)) {
-                                best_t = t; best_u = u; best_v = vv; best_slot = s; best_id = id;
-                            }
-                        }
-                    }
-                }
-                if (ANY && occluded) break;
-            }
-            --ptr;
-            ind = stk[ptr * 64];
-        }
+        const bool hit = traverse_bvh2<ANY, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, a.tie, stk,
+                                                   (int)a.stack_entries, best, nn, nt);
         float4 h;
-        h.x = ANY ? 0.f : (best_slot >= 0 ? best_t : 0.f);
-        h.y = ANY ? 0.f : best_u;
-        h.z = ANY ? 0.f : best_v;
-        h.w = __int_as_float(ANY ? (occluded ? 0 : -1) : best_id);
+        h.x = ANY ? 0.f : (hit ? best.t : 0.f);
+        h.y = ANY ? 0.f : best.u;
+        h.z = ANY ? 0.f : best.v;
+        h.w = __int_as_float(ANY ? (hit ? 0 : -1) : best.id);
         a.hits[i] = h;
         if (STATS) a.stats[i] = ((nt > 65535u ? 65535u : nt) << 16) | (nn > 65535u ? 65535u : nn);
     }
@@ -616,12 +626,16 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // (0.0755 vs 0.0816 ms) and the NEE shadow ray is traced right here instead of going through the shadow queue and
 // k_shadow — with ~1 node per ray the queue traffic (64 B written + read back per ray) and the second launch cost
 // more than the idle lanes of an in-place any-hit walk.
-template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool TINY>
+// BVH2 (with TINY's structure): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks
+// (path_trace.fs:511-819, traverse_bvh2) on the FlatNode array — the live path of the reference as a frame renderer.
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool TINY, bool BVH2 = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
+    int* stk2 = reinterpret_cast<int*>(s_lds) + (size_t)wid.lds_wave * a.stack_entries2 * 64u + lane;   // BVH2 mode
+    const float4* const recs = BVH2 ? a.tris2 : a.tris;   // intersection records the hit index refers to
     const FrameArgs& f = a.f;
     uint32_t nn = 0, nt = 0, nn_any = 0, nt_any = 0;
     // Queue counters are double-banked by frame parity: the first kernel of a frame clears the bank the next
@@ -694,6 +708,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                 const float4 h = a.hits_in[(size_t)g * a.sub_capacity + e];
                 hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = __float_as_int(h.w);
             }
+        } else if (BVH2) {
+            if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, hit, nn, nt);
         } else if (TINY) {
             if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, hit, nn, nt);
         } else {
@@ -711,7 +727,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, nx0 = sh0, nx1 = sh0;
         if (active && hit.tri >= 0) {
             const float t = hit.t, bu = hit.u, bv = hit.v;
-            const float4 tb = a.tris[3 * (size_t)hit.tri + 1], tc = a.tris[3 * (size_t)hit.tri + 2];
+            const float4 tb = recs[3 * (size_t)hit.tri + 1], tc = recs[3 * (size_t)hit.tri + 2];
             const int slot = __float_as_int(tb.w), mtl = __float_as_int(tc.w);
             const int4 vn = a.triangles[3 * (size_t)slot + 1];                    // path_trace.fs:440-454
             vec3 n;
@@ -791,8 +807,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                                 const unsigned long long m = __ballot(true);
                                 if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
                                 HitState sh;
-                                if (!traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, sh, nn_any, nt_any))
-                                    L = L + c;
+                                const bool occluded = BVH2
+                                    ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, sh, nn_any, nt_any)
+                                    : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, sh, nn_any, nt_any);
+                                if (!occluded) L = L + c;
                             } else {
                                 emit_shadow = true;
                             }
@@ -847,7 +865,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     }
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt);
     if (STATS && TINY) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any);
-    (void)stk;
+    (void)stk; (void)stk2;
 }
 
 // Closest hit for a device-written path-ray queue (segments >= 1): per-wave 256-ray pools with lane refill
@@ -1010,16 +1028,18 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hi
 }
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny, bool stats, uint32_t grid, hipStream_t stream) {
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny, bool bvh2, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g = grid_dim(grid), b = block_dim();
-    const size_t lds = stack_bytes(a.stack_entries);
+    // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
+    const size_t lds = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)g_waves_per_group * a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
     const bool tex = a.textures != nullptr;
-#define CRT_LAUNCH_SEG(F, S, T, P, Y) launch(k_segment<F, S, T, P, Y>, g, b, lds, stream, a)
-#define CRT_LAUNCH_SEG_T(F, S, P, Y) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y); else CRT_LAUNCH_SEG(F, S, false, P, Y); } while (0)
-#define CRT_LAUNCH_SEG_S(F, P, Y) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y); else CRT_LAUNCH_SEG_T(F, false, P, Y); } while (0)
-    if (pretraced) CRT_LAUNCH_SEG_T(false, false, true, false);          // shade-only: never tiny (the host falls back to lock-step)
-    else if (first) { if (tiny) CRT_LAUNCH_SEG_S(true, false, true); else CRT_LAUNCH_SEG_S(true, false, false); }
-    else            { if (tiny) CRT_LAUNCH_SEG_S(false, false, true); else CRT_LAUNCH_SEG_S(false, false, false); }
+#define CRT_LAUNCH_SEG(F, S, T, P, Y, B) launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a)
+#define CRT_LAUNCH_SEG_T(F, S, P, Y, B) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y, B); else CRT_LAUNCH_SEG(F, S, false, P, Y, B); } while (0)
+#define CRT_LAUNCH_SEG_S(F, P, Y, B) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y, B); else CRT_LAUNCH_SEG_T(F, false, P, Y, B); } while (0)
+    if (pretraced) CRT_LAUNCH_SEG_T(false, false, true, false, false);   // shade-only: never tiny (the host falls back to lock-step)
+    else if (bvh2) { if (first) CRT_LAUNCH_SEG_S(true, false, true, true); else CRT_LAUNCH_SEG_S(false, false, true, true); }
+    else if (first) { if (tiny) CRT_LAUNCH_SEG_S(true, false, true, false); else CRT_LAUNCH_SEG_S(true, false, false, false); }
+    else            { if (tiny) CRT_LAUNCH_SEG_S(false, false, true, false); else CRT_LAUNCH_SEG_S(false, false, false, false); }
 #undef CRT_LAUNCH_SEG_S
 #undef CRT_LAUNCH_SEG_T
 #undef CRT_LAUNCH_SEG

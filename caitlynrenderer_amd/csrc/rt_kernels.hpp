@@ -75,6 +75,10 @@ struct SegmentArgs {
     float* sum;                // packed tile-major RGB32F
     uint32_t last_segment;
     unsigned long long* visit_totals;   // STATS: [0] += nodes, [1] += tris
+    const float4* nodes2;      // BVH2 mode: FlatNode array and slot-ordered records (see Bvh2Args), int stack entries, tie rule
+    const float4* tris2;
+    uint32_t stack_entries2;
+    uint32_t tie;
     uint32_t* zero_counts;     // FIRST: the other frame's counter bank, cleared here for the next frame (no memset launch)
     uint32_t n_zero;
 };
@@ -108,7 +112,7 @@ struct ShadowArgs {
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream);
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny, bool stats, uint32_t grid, hipStream_t stream);
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny, bool bvh2, bool stats, uint32_t grid, hipStream_t stream);
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 // 4 (256-thread workgroups) or 1 (every wave its own workgroup); process-wide

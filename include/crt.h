@@ -132,6 +132,8 @@ int crt_sync(crt_scene* s);
 /* knobs: "jitter" (0/1, tent-filter jitter of path_trace.fs:1030-1037; default 1),
  * "trace_occupancy" (workgroups per CU when a persistent grid is selected with "oversubscribe"),
  * "count_visits" (0/1: traversal launches also count node fetches / triangle tests),
+ * "accel" (what crt_render_frame walks: 0 = the CWBVH (default); 1 = the BVH2 exactly as the shipped shader walks it,
+ * path_trace.fs:511-819, first visited triangle wins a tie; 2 = the BVH2 with the lowest-id tie rule; needs desc.bvh),
  * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit
  * launches only, 0 = none; the events are attached to the dispatches, so timing does not slow the stream down), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
  * restarting every frame — crt_frame_stats.ms_* are then sums over n_trace_launches launches; 0: per frame),

@@ -681,3 +681,46 @@ def test_scene_from_bvh2_only_converts_on_the_device(cr, tess40, scenes):
     _assert_hits_equal(got, want)
     assert np.array_equal(gst["nodes"], wst["nodes"]) and np.array_equal(gst["tris"], wst["tris"])   # same tree, same walk
     a.close()
+
+
+@pytest.mark.parametrize("name,depth", [("cornell", 3), ("tess8", 3), ("tess40", 2)])
+def test_frames_through_the_reference_bvh2_walk(cr, ob, cornell, scenes, name, depth):
+    """crt_set_option("accel", 1): whole frames rendered with the walk the reference ships (path_trace.fs:511-819 on the
+    FlatNode array, raw 1/d, first-visited tie rule) — the live shader as a frame renderer.  Radiance, ray counts and
+    visit counters bit-identical to the oracle's BVH2 integrator; accel 2 = same walk with the lowest-id tie rule."""
+    _, _, data = scenes[name]
+    W, H = 240, 136
+    for accel, tie in ((1, ob.TIE_FIRST_VISITED), (2, ob.TIE_LOWEST_ID)):
+        scene = cr.Scene(data, W, H, depth)
+        scene.set_option("accel", accel)
+        scene.set_option("count_visits", 1)
+        orc = ob.Oracle(data, W, H, depth, cornell[1])
+        rnd = cr.Rnd()
+        ref = np.zeros((H, W, 3), np.float32)
+        for frame in range(3):
+            rx, ry = rnd.randf2(), rnd.randf2()
+            scene.render_frame(rx, ry)
+            _, cnt = orc.render_frame(rx, ry, ref, accel=ob.BVH2, tie=tie, threads=8)
+            st = scene.frame_stats()
+            assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]), (accel, frame)
+            assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3], (accel, frame)
+            out = scene.read_sum()
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (accel, frame, float(np.abs(out - ref).max()))
+        if accel == 2:
+            # same tie rule as the CWBVH path: the two walks agree except where a zero direction component makes the
+            # shader's raw 1/d slab test drop a box (DESIGN.md section 3)
+            cw = cr.Scene(data, W, H, depth)
+            rnd = cr.Rnd()
+            for frame in range(3):
+                cw.render_frame(rnd.randf2(), rnd.randf2())
+            same = (cw.read_sum().view(np.uint32) == out.view(np.uint32)).all(axis=2).mean()
+            assert same > 0.995, same
+            cw.close()
+        scene.close()
+    # a scene without a BVH2 cannot switch
+    import copy
+    only8 = copy.copy(data); only8.bvh = None
+    s8 = cr.Scene(only8, 32, 32, 1)
+    with pytest.raises(cr.CrtError):
+        s8.set_option("accel", 1)
+    s8.close()
