@@ -121,6 +121,7 @@ struct crt_scene {
     bool stats_from_frame = false;
     bool stats_counted = false;
     uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
+    uint32_t inplace_shadow = 0;             // EXPERIMENT
     uint32_t accel = 0;                      // frames: 0 CWBVH; 1 BVH2 walked as the shipped shader does (first visited wins); 2 BVH2, lowest id wins
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
     uint32_t trace_occupancy = 8;            // persistent grids only (oversubscribe >= 1): workgroups per CU
@@ -389,7 +390,8 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_WAVES_PER_WG")) crt::set_waves_per_workgroup((uint32_t)std::atoi(e));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
+    if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
@@ -586,8 +588,9 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.sub_capacity = s->sub_capacity;
         // tiny trees (or tri_min = 0): plain per-lane loop and the shadow ray traced inside k_segment, no k_shadow launch
         const bool bvh2 = s->accel != 0u;
-        const bool tiny = bvh2 || s->info.n_nodes8 < 64 || s->tri_min == 0u;
-        sa.tri_min = s->tri_min;
+        const bool small_tree = s->info.n_nodes8 < 64;
+        const bool tiny = bvh2 || small_tree || s->tri_min == 0u || s->inplace_shadow;
+        sa.tri_min = small_tree ? 0u : s->tri_min;
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
