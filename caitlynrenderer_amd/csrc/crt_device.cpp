@@ -92,7 +92,9 @@ struct crt_scene {
     float4* d_rays[2] = {nullptr, nullptr};   // path-ray queues, only for max_depth > 1
     float4* d_shadow = nullptr;               // 3 x float4 per shadow ray: ray, ray, pending contribution C
     float4* d_qhits = nullptr;                // closest hits of the path-ray queue (max_depth > 1, refill tracing)
-    uint32_t bounce_refill = 1;               // segments >= 1: trace with lane refill + separate shading (0: fused lock-step)
+    // segments >= 1: 0 = fused lock-step k_segment (default: with the shadow rays walked in place it beats the pools,
+    // 1.87 vs 2.09 ms for 4 segments at 1 M triangles); 1 = closest hits through lane-refill pools (k_closest_queue) + shade-only pass
+    uint32_t bounce_refill = 0;
     crt::PathBuffers pb{};
     uint32_t stack_entries = CRT_STACK_ENTRIES;
     uint32_t sub_capacity = 0;                // entries per sub-queue (8 per queue)
@@ -121,7 +123,7 @@ struct crt_scene {
     bool stats_from_frame = false;
     bool stats_counted = false;
     uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
-    uint32_t inplace_shadow = 0;             // EXPERIMENT
+    uint32_t inplace_shadow = 1;             // NEE shadow rays walked inside k_segment (0: shadow queue + k_shadow)
     uint32_t accel = 0;                      // frames: 0 CWBVH; 1 BVH2 walked as the shipped shader does (first visited wins); 2 BVH2, lowest id wins
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
     uint32_t trace_occupancy = 8;            // persistent grids only (oversubscribe >= 1): workgroups per CU
@@ -527,6 +529,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "waves_per_workgroup")) crt::set_waves_per_workgroup((uint32_t)value);
+    else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "accel")) {
         if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
         if (value != 0 && !s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_set_option: the scene was created without a BVH2 (desc.bvh)");
@@ -546,7 +549,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
             s->spans.push_back(sp);
         }
     }
-    else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: per-lane loop + shadow rays walked in place (what tiny trees get)
+    else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: plain per-lane closest-hit loop (what trees of a few nodes get)
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
     return CRT_OK;
@@ -586,10 +589,10 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.tex_width = s->tex_width; sa.tex_height = s->tex_height; sa.n_textures = s->n_textures;
         sa.f = f;
         sa.sub_capacity = s->sub_capacity;
-        // tiny trees (or tri_min = 0): plain per-lane loop and the shadow ray traced inside k_segment, no k_shadow launch
         const bool bvh2 = s->accel != 0u;
+        // trees of a few nodes: plain per-lane closest-hit loop (tri_min = 0) and no bounce pools
         const bool small_tree = s->info.n_nodes8 < 64;
-        const bool tiny = bvh2 || small_tree || s->tri_min == 0u || s->inplace_shadow;
+        const bool inplace = bvh2 || s->inplace_shadow != 0u;   // shadow rays walked inside k_segment: no queue, no k_shadow launch
         sa.tri_min = small_tree ? 0u : s->tri_min;
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
@@ -600,7 +603,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.visit_totals = s->d_visit_totals;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
         EventSpan* sp = s->new_span(1);
-        const bool pretraced = b > 0 && s->bounce_refill && !tiny;
+        const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u;
         if (pretraced) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
@@ -613,9 +616,9 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         } else if (sp) {
             crt::set_launch_events(sp->a, sp->b);
         }
-        crt::launch_segment(sa, b == 0, pretraced, tiny, bvh2, s->count_visits, s->trace_grid(P, 5), s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->count_visits, s->trace_grid(P, 5), s->stream);
 
-        if (tiny) continue;                          // shadow rays were traced inside k_segment
+        if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};
         sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = cnt + counter_index(b, 1, 0);
         sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = 0;

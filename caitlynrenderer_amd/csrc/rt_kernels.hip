@@ -622,13 +622,17 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // under wave-granular dispatch: no change (0.225 vs 0.226 ms) with 56 bytes of scratch per lane.
 // PRETRACED: the closest hit of each queue entry was found by k_closest_queue (incoherent bounce rays are
 // traced with lane refill, which cannot be fused with lock-step shading); the kernel then only shades.
-// TINY (trees of a few nodes, e.g. the 32-triangle Cornell box): plain per-lane loop instead of the voting loop
-// (0.0755 vs 0.0816 ms) and the NEE shadow ray is traced right here instead of going through the shadow queue and
-// k_shadow — with ~1 node per ray the queue traffic (64 B written + read back per ray) and the second launch cost
-// more than the idle lanes of an in-place any-hit walk.
-// BVH2 (with TINY's structure): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks
+// INPLACE: the NEE shadow ray is walked right here (path_trace.fs:968, where the shader has it) instead of going
+// through the shadow queue and k_shadow.  The walk runs with only the lanes that have a shadow ray (39 % on average),
+// yet it is the faster arrangement at every scene size measured: the rays start where the closest-hit walk of the same
+// lanes just ended, so their first nodes and triangles are still in L1, and 48 B per ray of queue traffic, a launch
+// and a second kernel's tail disappear (1 M triangles: 0.214 + 0.158 ms as two kernels, 0.292 ms fused; Cornell
+// 0.104 -> 0.087 ms).  The queue + k_shadow path remains selectable (option "inplace_shadow" 0).
+// a.tri_min == 0 (trees of a few nodes, e.g. the 32-triangle Cornell box: 0.0755 vs 0.0816 ms) selects the plain
+// per-lane closest-hit loop instead of the voting loop.
+// BVH2 (INPLACE's structure): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks
 // (path_trace.fs:511-819, traverse_bvh2) on the FlatNode array — the live path of the reference as a frame renderer.
-template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool TINY, bool BVH2 = false>
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const WaveId wid = wave_id();
@@ -710,7 +714,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
             }
         } else if (BVH2) {
             if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, hit, nn, nt);
-        } else if (TINY && a.tri_min == 0u) {
+        } else if (a.tri_min == 0u) {
             if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, hit, nn, nt);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
@@ -802,7 +806,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                             const float w = __fdiv_rn(tt, bsdf_pdf * bsdf_pdf + tt);
                             vec3 c = ((T * le) * albedo) * w;
                             c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
-                            if (TINY) {
+                            if (INPLACE) {
                                 // the occlusion test of path_trace.fs:968 in place (what k_shadow does with a queue entry)
                                 const unsigned long long m = __ballot(true);
                                 if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
@@ -851,7 +855,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         }
         // a path that ends here with nothing pending adds its radiance to the running sum now
         if (finished && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, pix, L);
-        if (!TINY) {
+        if (!INPLACE) {
             const uint32_t si = wave_append(emit_shadow, count_shadow);
             if (emit_shadow) {
                 float4* q = shadow_q + 3 * (size_t)si;
@@ -864,7 +868,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
     }
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt);
-    if (STATS && TINY) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any);
+    if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any);
     (void)stk; (void)stk2;
 }
 
@@ -1028,7 +1032,7 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hi
 }
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny, bool bvh2, bool stats, uint32_t grid, hipStream_t stream) {
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool stats, uint32_t grid, hipStream_t stream) {
     const dim3 g = grid_dim(grid), b = block_dim();
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
     const size_t lds = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)g_waves_per_group * a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
@@ -1036,10 +1040,10 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny,
 #define CRT_LAUNCH_SEG(F, S, T, P, Y, B) launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a)
 #define CRT_LAUNCH_SEG_T(F, S, P, Y, B) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y, B); else CRT_LAUNCH_SEG(F, S, false, P, Y, B); } while (0)
 #define CRT_LAUNCH_SEG_S(F, P, Y, B) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y, B); else CRT_LAUNCH_SEG_T(F, false, P, Y, B); } while (0)
-    if (pretraced) CRT_LAUNCH_SEG_T(false, false, true, false, false);   // shade-only: never tiny (the host falls back to lock-step)
+    if (pretraced) { if (inplace) CRT_LAUNCH_SEG_S(false, true, true, false); else CRT_LAUNCH_SEG_S(false, true, false, false); }   // shade (+ shadow walk)
     else if (bvh2) { if (first) CRT_LAUNCH_SEG_S(true, false, true, true); else CRT_LAUNCH_SEG_S(false, false, true, true); }
-    else if (first) { if (tiny) CRT_LAUNCH_SEG_S(true, false, true, false); else CRT_LAUNCH_SEG_S(true, false, false, false); }
-    else            { if (tiny) CRT_LAUNCH_SEG_S(false, false, true, false); else CRT_LAUNCH_SEG_S(false, false, false, false); }
+    else if (first) { if (inplace) CRT_LAUNCH_SEG_S(true, false, true, false); else CRT_LAUNCH_SEG_S(true, false, false, false); }
+    else            { if (inplace) CRT_LAUNCH_SEG_S(false, false, true, false); else CRT_LAUNCH_SEG_S(false, false, false, false); }
 #undef CRT_LAUNCH_SEG_S
 #undef CRT_LAUNCH_SEG_T
 #undef CRT_LAUNCH_SEG

@@ -112,7 +112,7 @@ struct ShadowArgs {
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream);
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool tiny, bool bvh2, bool stats, uint32_t grid, hipStream_t stream);
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool stats, uint32_t grid, hipStream_t stream);
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
 // 4 (256-thread workgroups) or 1 (every wave its own workgroup); process-wide

@@ -137,9 +137,9 @@ int crt_sync(crt_scene* s);
  * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit
  * launches only, 0 = none; the events are attached to the dispatches, so timing does not slow the stream down), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
  * restarting every frame — crt_frame_stats.ms_* are then sums over n_trace_launches launches; 0: per frame),
- * tuning: "tri_min" (vote ratio of the traversal loop; 0 = per-lane loop with the NEE shadow ray walked inside
- * the segment kernel, which trees under 64 nodes get anyway), "refill_min", "bounce_refill" (lane-refill pools for
- * bounce rays), "oversubscribe" (0 = one 64-ray batch per workgroup, the hardware dispatcher balances; k >= 1 =
+ * tuning: "inplace_shadow" (1 = NEE shadow rays walked inside the segment kernel (default), 0 = shadow queue +
+ * k_shadow), "tri_min" (vote ratio of the closest-hit traversal loop; 0 = plain per-lane loop, which trees under 64
+ * nodes get anyway), "refill_min", "bounce_refill" (lane-refill pools for bounce rays), "oversubscribe" (0 = one 64-ray batch per workgroup, the hardware dispatcher balances; k >= 1 =
  * persistent grid of k x the resident workgroups with a static schedule), "waves_per_workgroup" (1 or 4, process-wide). */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */

@@ -188,21 +188,26 @@ def test_full_resolution_mesh_frame_with_visit_counters(cr, ob, cornell, tess40)
     scene.close()
 
 
-def test_async_frames_and_timing_options_do_not_change_results(cr, scenes):
+@pytest.mark.parametrize("inplace", [1, 0])
+def test_async_frames_and_timing_options_do_not_change_results(cr, scenes, inplace):
     """Frames queued back to back (counter banks alternate, the kernels clear the next frame's bank) with the
-    event spans reduced / accumulated give the same sum and ray counts as synchronous frames with full timing."""
+    event spans reduced / accumulated give the same sum and ray counts as synchronous frames with full timing.
+    inplace = 1: one launch per path segment; inplace = 0: the shadow queue + k_shadow pipeline, two launches."""
     _, _, data = scenes["tess8"]
     W, H, depth, frames = 320, 200, 3, 7
+    per_seg = 1 if inplace else 2
     rnd = cr.Rnd()
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(frames)]
     a = cr.Scene(data, W, H, depth)
+    a.set_option("inplace_shadow", inplace)
     for rx, ry in rvs:
         a.render_frame(rx, ry)
     want, want_st = a.read_sum(), a.frame_stats()
-    assert want_st["n_trace_launches"] == 2 * depth and want_st["ms_trace_closest"] > 0 and want_st["ms_trace_any"] > 0
+    assert want_st["n_trace_launches"] == per_seg * depth and want_st["ms_trace_closest"] > 0 and (want_st["ms_trace_any"] > 0) == (not inplace)
     a.close()
     for timing in (0, 1, 2):
         b = cr.Scene(data, W, H, depth)
+        b.set_option("inplace_shadow", inplace)
         b.set_option("timing", timing)
         b.set_option("timing_accumulate", frames * depth * 2)
         for rx, ry in rvs:
@@ -211,12 +216,12 @@ def test_async_frames_and_timing_options_do_not_change_results(cr, scenes):
         st = b.frame_stats()
         assert np.array_equal(b.read_sum().view(np.uint32), want.view(np.uint32)), timing
         assert (st["closest_rays"], st["any_rays"]) == (want_st["closest_rays"], want_st["any_rays"])
-        assert st["n_trace_launches"] == (0, frames * depth, 2 * frames * depth)[timing]
-        assert (st["ms_trace_closest"] > 0) == (timing > 0) and (st["ms_trace_any"] > 0) == (timing > 1)
+        assert st["n_trace_launches"] == (0, frames * depth, per_seg * frames * depth)[timing]
+        assert (st["ms_trace_closest"] > 0) == (timing > 0) and (st["ms_trace_any"] > 0) == (timing > 1 and not inplace)
         b.set_option("timing_accumulate", 0)
         b.set_option("timing", 2)
         b.render_frame(*rvs[0])
-        assert b.frame_stats()["n_trace_launches"] == 2 * depth
+        assert b.frame_stats()["n_trace_launches"] == per_seg * depth
         b.close()
 
 
@@ -244,7 +249,8 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
     assert want.max() > 0.1
     for options in ({"waves_per_workgroup": 4}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
                     {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5},
-                    {"bounce_refill": 0}, {"refill_min": 1}, {"refill_min": 40}):
+                    {"bounce_refill": 1}, {"bounce_refill": 1, "refill_min": 1}, {"bounce_refill": 1, "refill_min": 40}, {"inplace_shadow": 0},
+                    {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
         got, counts = run(options)
         assert counts == want_counts, options
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), options
@@ -396,6 +402,14 @@ def test_million_triangle_mesh_full_frame(cr, ob, cornell):
         assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
         out = scene.read_sum()
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
+    # the same frame through the shadow queue + k_shadow pipeline (inplace_shadow = 0): same sum, and its queue feeds the
+    # any-hit / closest-hit consistency check below
+    scene.set_option("inplace_shadow", 0)
+    scene.reset()
+    scene.render_frame(rx, ry)
+    last = np.zeros((H, W, 3), np.float32)
+    orc.render_frame(rx, ry, last, threads=16)
+    assert np.array_equal(scene.read_sum().view(np.uint32), last.view(np.uint32))
     shadow = scene.debug_read_queue(2, 1)
     assert len(shadow) > 100000
     occ = scene.trace(shadow, cr.CRT_TRACE_ANY)["tri"] >= 0
