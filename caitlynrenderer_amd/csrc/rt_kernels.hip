@@ -627,7 +627,9 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // yet it is the faster arrangement at every scene size measured: the rays start where the closest-hit walk of the same
 // lanes just ended, so their first nodes and triangles are still in L1, and 48 B per ray of queue traffic, a launch
 // and a second kernel's tail disappear (1 M triangles: 0.214 + 0.158 ms as two kernels, 0.292 ms fused; Cornell
-// 0.104 -> 0.087 ms).  The queue + k_shadow path remains selectable (option "inplace_shadow" 0).
+// 0.104 -> 0.087 ms).  The queue + k_shadow path remains selectable (option "inplace_shadow" 0).  Hoisting the walk
+// out of the shading branches so that it could use the voting loop was measured too: 0.310 / 0.304 / 0.302 ms at
+// ratios 1 / 2 / 3 against 0.297 ms for the plain loop in that arrangement and 0.293 ms as written here.
 // a.tri_min == 0 (trees of a few nodes, e.g. the 32-triangle Cornell box: 0.0755 vs 0.0816 ms) selects the plain
 // per-lane closest-hit loop instead of the voting loop.
 // BVH2 (INPLACE's structure): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks
