@@ -228,11 +228,11 @@ int alloc_frame_buffers(crt_scene* s) {
     // a workgroup group handles every 8th unit of 4096 pixels/rays, so it can emit at most this many rays per segment
     s->sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096);
     const size_t Q = 8 * (size_t)s->sub_capacity;
-    if ((rc = dev_alloc(&s->d_shadow, 3 * Q))) return rc;
+    // the shadow queue (inplace_shadow = 0) and the hit buffer of the bounce pools (bounce_refill = 1) are allocated
+    // by the first frame that needs them
     if (s->max_depth > 1) {                      // path state and ray queues exist only for multi-segment paths
         if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
         if ((rc = dev_alloc(&s->d_rays[1], 2 * Q))) return rc;
-        if ((rc = dev_alloc(&s->d_qhits, Q))) return rc;
         if ((rc = dev_alloc(&s->pb.L, P))) return rc;
         if ((rc = dev_alloc(&s->pb.T, P))) return rc;
         if ((rc = dev_alloc(&s->pb.seed, P))) return rc;
@@ -575,6 +575,11 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
     }
     // counter banks alternate per frame; k_segment<FIRST> clears the other bank for the frame after this one, so a
     // memset is only needed for the very first frame (or after a failed launch left the banks in an unknown state)
+    {
+        const size_t Q = 8 * (size_t)s->sub_capacity;
+        if (!s->inplace_shadow && s->accel == 0u && !s->d_shadow && (rc = dev_alloc(&s->d_shadow, 3 * Q))) return rc;
+        if (s->bounce_refill && s->max_depth > 1 && !s->d_qhits && (rc = dev_alloc(&s->d_qhits, Q))) return rc;
+    }
     s->bank ^= 1u;
     if (!s->counts_clean) HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * kCounters * sizeof(uint32_t), s->stream));
     s->counts_clean = false;
@@ -810,6 +815,7 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
     std::vector<uint32_t> counts(kCounters);
     HIPCHK(hipMemcpy(counts.data(), s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const float4* src = which == 2 ? s->d_shadow : s->d_rays[segment & 1];
+    if (!src) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: that queue does not exist (shadow queue: only with inplace_shadow = 0; path queues: max_depth > 1)");
     const size_t entry = which == 2 ? 3 * sizeof(float4) : sizeof(crt_ray);
     size_t total = 0;
     for (uint32_t g = 0; g < 8; ++g) total += counts[counter_index(segment, which == 2 ? 1 : 0, g)];
