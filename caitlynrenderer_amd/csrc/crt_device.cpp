@@ -246,6 +246,7 @@ crt::FrameArgs frame_args(const crt_scene* s, float rx, float ry) {
     f.tile_xy = s->d_tile_xy;
     f.n_local_pixels = s->n_local_pixels;
     f.tile = s->tile; f.width = s->width; f.height = s->height;
+    f.tile_log2 = (s->tile & (s->tile - 1u)) == 0u ? (uint32_t)__builtin_ctz(s->tile) : 0u;
     f.jitter = s->jitter;
     f.rv = rx * ry;
     const float W = (float)s->width, H = (float)s->height;

@@ -568,13 +568,22 @@ __device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
 // local pixel index -> frame pixel.  Pixels are laid out tile-major; inside a tile, 8x8 blocks
 // row-major, so one 64-lane wave covers an 8x8 pixel block (coherent primary rays).
 __device__ __forceinline__ bool pixel_of(const FrameArgs& f, uint32_t i, uint32_t& px, uint32_t& py) {
-    const uint32_t tile_px = f.tile * f.tile;
-    const uint32_t t = i / tile_px, j = i % tile_px;
-    const uint32_t blocks_per_row = f.tile >> 3;
-    const uint32_t blk = j >> 6, k = j & 63u;
+    uint32_t t, bx, by;
+    const uint32_t k = i & 63u;
+    if (f.tile_log2) {                                   // power-of-two tiles (the default 64): no integer division
+        const uint32_t s2 = 2u * f.tile_log2, sb = f.tile_log2 - 3u;
+        t = i >> s2;
+        const uint32_t blk = (i & ((1u << s2) - 1u)) >> 6;
+        bx = blk & ((1u << sb) - 1u); by = blk >> sb;
+    } else {
+        const uint32_t tile_px = f.tile * f.tile;
+        t = i / tile_px;
+        const uint32_t blk = (i % tile_px) >> 6, blocks_per_row = f.tile >> 3;
+        bx = blk % blocks_per_row; by = blk / blocks_per_row;
+    }
     const uint2 txy = f.tile_xy[t];
-    px = txy.x * f.tile + (blk % blocks_per_row) * 8u + (k & 7u);
-    py = txy.y * f.tile + (blk / blocks_per_row) * 8u + (k >> 3);
+    px = txy.x * f.tile + bx * 8u + (k & 7u);
+    py = txy.y * f.tile + by * 8u + (k >> 3);
     return px < f.width && py < f.height;
 }
 

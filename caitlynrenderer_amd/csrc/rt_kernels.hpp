@@ -45,6 +45,7 @@ struct FrameArgs {
     const uint2* tile_xy;      // local tile -> (tile x, tile y)
     uint32_t n_local_pixels;   // n_local_tiles * tile * tile
     uint32_t tile, width, height;
+    uint32_t tile_log2;        // log2(tile) when the tile is a power of two (shifts instead of integer divisions), else 0
     uint32_t jitter;
     float rv;                  // randomVector.x * randomVector.y (path_trace.fs:40)
     float tan_fov, aspect_tan; // tan(fov/2), W/H*tan(fov/2) (path_trace.fs:1041-1043)

@@ -256,10 +256,12 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), options
 
 
-def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data):
-    """world=3 shards rendered on one GPU: the union of the ranks' pixels is bit-identical to world=1."""
+@pytest.mark.parametrize("T", [16, 24])
+def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data, T):
+    """world=3 shards rendered on one GPU: the union of the ranks' pixels is bit-identical to world=1
+    (power-of-two tiles index pixels with shifts, other multiples of 8 with integer divisions)."""
     from caitlynrenderer_amd import tiles
-    W, H, T = 200, 120, 16
+    W, H = 200, 120
     full = cr.Scene(cornell_data, W, H, 3)
     full.set_shard(0, 1, T)
     full.render_frame(RX1, RY1)
