@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt.so")
+# CRT_LIB points the binding at another build of the same library (A/B measurements of kernel variants in one gpurun call)
+LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt.so")
 
 CRT_ABI_VERSION = 1
 CRT_OK, CRT_ERR_INVALID, CRT_ERR_NO_DEVICE, CRT_ERR_HIP, CRT_ERR_IO, CRT_ERR_LIMIT, CRT_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
