@@ -38,6 +38,15 @@ for case in range(n_cases):
     scene.update(cam)
     jitter = 1                                   # the oracle's frame loop always jitters, like the shader
     scene.set_option("count_visits", 1)
+    # pipeline variants: all must give the oracle's bits
+    accel = int(rng.choice([0, 0, 0, 1, 2]))
+    opts = {"accel": accel}
+    if accel == 0:
+        opts.update(inplace_shadow=int(rng.random() < 0.7), bounce_refill=int(rng.random() < 0.3),
+                    tri_min=int(rng.choice([0, 1, 2, 2, 3])), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])))
+    for k, v in opts.items():
+        scene.set_option(k, v)
+    o_accel, o_tie = (ob.BVH8, ob.TIE_LOWEST_ID) if accel == 0 else (ob.BVH2, ob.TIE_FIRST_VISITED if accel == 1 else ob.TIE_LOWEST_ID)
     orc = ob.Oracle(data, W, H, depth, cam)
     rnd = cr.Rnd()
     for _ in range(int(rng.integers(0, 50))):
@@ -47,14 +56,14 @@ for case in range(n_cases):
     for frame in range(3):
         rx, ry = rnd.randf2(), rnd.randf2()
         scene.render_frame(rx, ry)
-        _, cnt = orc.render_frame(rx, ry, ref, threads=16)
+        _, cnt = orc.render_frame(rx, ry, ref, accel=o_accel, tie=o_tie, threads=16)
         st = scene.frame_stats()
         out = scene.read_sum()
         same = np.array_equal(out.view(np.uint32), ref.view(np.uint32))
         counts = (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
         if not (same and counts):
             ok = False
-            print(f"MISMATCH case {case} frame {frame}: {key} {W}x{H} depth {depth} jitter {jitter} pos {pos} tgt {tgt} "
+            print(f"MISMATCH case {case} frame {frame}: {key} {opts} {W}x{H} depth {depth} jitter {jitter} pos {pos} tgt {tgt} "
                   f"sum_equal {same} max|d| {np.abs(out - ref).max():.3g} n_diff {(out != ref).sum()} counts {counts}", flush=True)
             break
     bad += 0 if ok else 1
