@@ -129,18 +129,29 @@ int crt_render_frame(crt_scene* s, float rx, float ry);
  * stream; crt_sync (or any read-back call) waits for them. */
 int crt_render_frame_async(crt_scene* s, float rx, float ry);
 int crt_sync(crt_scene* s);
-/* knobs: "jitter" (0/1, tent-filter jitter of path_trace.fs:1030-1037; default 1),
- * "trace_occupancy" (workgroups per CU when a persistent grid is selected with "oversubscribe"),
- * "count_visits" (0/1: traversal launches also count node fetches / triangle tests),
- * "accel" (what crt_render_frame walks: 0 = the CWBVH (default); 1 = the BVH2 exactly as the shipped shader walks it,
- * path_trace.fs:511-819, first visited triangle wins a tie; 2 = the BVH2 with the lowest-id tie rule; needs desc.bvh),
- * "timing" (HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit
- * launches only, 0 = none; the events are attached to the dispatches, so timing does not slow the stream down), "timing_accumulate" (n > 0: keep the spans of the next n launches instead of
- * restarting every frame — crt_frame_stats.ms_* are then sums over n_trace_launches launches; 0: per frame),
- * tuning: "inplace_shadow" (1 = NEE shadow rays walked inside the segment kernel (default), 0 = shadow queue +
- * k_shadow), "tri_min" (vote ratio of the closest-hit traversal loop; 0 = plain per-lane loop, which trees under 64
- * nodes get anyway), "refill_min", "bounce_refill" (lane-refill pools for bounce rays), "oversubscribe" (0 = one 64-ray batch per workgroup, the hardware dispatcher balances; k >= 1 =
- * persistent grid of k x the resident workgroups with a static schedule), "waves_per_workgroup" (1 or 4, process-wide). */
+/* Options (name, value).  Results never depend on the tuning options: every combination is bit-identical.
+ *   behaviour
+ *     "jitter"            0/1 tent-filter jitter of path_trace.fs:1030-1037 (default 1)
+ *     "accel"             what crt_render_frame walks: 0 = the CWBVH (default); 1 = the BVH2 exactly as the shipped
+ *                         shader walks it (path_trace.fs:511-819, first visited triangle wins a tie); 2 = the BVH2 with
+ *                         the lowest-id tie rule; 1 and 2 need desc.bvh
+ *   telemetry
+ *     "count_visits"      0/1: traversal launches also count node fetches / triangle tests (crt_frame_stats)
+ *     "timing"            HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit
+ *                         launches only, 0 = none.  The events ride on the dispatches; a timed dispatch costs ~5 us of
+ *                         stream time because it cannot overlap its neighbours
+ *     "timing_accumulate" n > 0: keep the spans of the next n launches instead of restarting every frame
+ *                         (crt_frame_stats.ms_* are then sums over n_trace_launches launches); 0: per frame
+ *   tuning
+ *     "inplace_shadow"    1 = NEE shadow rays walked inside the segment kernel (default), 0 = shadow queue + k_shadow
+ *     "tri_min"           vote ratio of the closest-hit traversal loop (default 2); 0 = plain per-lane loop, which
+ *                         trees under 64 nodes get anyway
+ *     "bounce_refill"     segments >= 1: 0 = lock-step segment kernel (default), 1 = closest hits through lane-refill
+ *                         pools (k_closest_queue) + shade-only pass; "refill_min" = idle lanes that trigger a refill
+ *     "oversubscribe"     0 = one 64-ray batch per workgroup, the hardware dispatcher balances (default); k >= 1 =
+ *                         persistent grid of k x the resident workgroups with a static schedule, then
+ *                         "trace_occupancy" = workgroups per CU
+ *     "waves_per_workgroup" 1 (default) or 4; process-wide */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);
