@@ -740,3 +740,29 @@ def test_frames_through_the_reference_bvh2_walk(cr, ob, cornell, scenes, name, d
     with pytest.raises(cr.CrtError):
         s8.set_option("accel", 1)
     s8.close()
+
+
+def test_graph_replay_measurement_aid(cr, scenes):
+    """crt_debug_time_graph: the frame loop is capturable as a hipGraph; replaying it accumulates exactly like queued frames."""
+    import ctypes as C
+    from caitlynrenderer_amd._lib import lib, check
+    _, _, data = scenes["tess8"]
+    W, H, depth, n, reps = 160, 96, 2, 4, 3
+    rnd = cr.Rnd()
+    rxy = np.array([rnd.randf2() for _ in range(2 * n)], np.float32)
+    s = cr.Scene(data, W, H, depth)
+    a, b = C.c_float(), C.c_float()
+    check(lib().crt_debug_time_graph(s._h, n, rxy.ctypes.data_as(C.c_void_p), reps, C.byref(a), C.byref(b)))
+    assert a.value > 0 and b.value > 0
+    got = s.read_sum()
+    # what ran: 2 set-up frames with the first vector, reps x n queued frames, (1 warm-up + reps) graph replays of n frames
+    ref = cr.Scene(data, W, H, depth)
+    for _ in range(2):
+        ref.render_frame(float(rxy[0]), float(rxy[1]))
+    for _ in range(reps + 1 + reps):
+        for f in range(n):
+            ref.render_frame(float(rxy[2 * f]), float(rxy[2 * f + 1]))
+    assert np.array_equal(got.view(np.uint32), ref.read_sum().view(np.uint32))
+    with pytest.raises(cr.CrtError):
+        check(lib().crt_debug_time_graph(s._h, 3, rxy.ctypes.data_as(C.c_void_p), 1, C.byref(a), C.byref(b)))   # odd frame count
+    s.close(); ref.close()
