@@ -766,3 +766,28 @@ def test_graph_replay_measurement_aid(cr, scenes):
     with pytest.raises(cr.CrtError):
         check(lib().crt_debug_time_graph(s._h, 3, rxy.ctypes.data_as(C.c_void_p), 1, C.byref(a), C.byref(b)))   # odd frame count
     s.close(); ref.close()
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints exactly one JSON line with the driver's fields, the roofline object and the CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, run.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mray/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["achieved"] > 0 and r["launch_ms"] > 0 and r["launches_timed"] == 6 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mray/s" and c["cores"] >= 1 and c["value"] > 0 and c["visit_counters_match_gpu"] is True
+    assert d["value"] > 1000 and abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) / d["value"] < 0.01
