@@ -233,7 +233,9 @@ def main():
                          "launch_ms": round(t_closest * 1e3, 4), "launches_timed": int(n_timed_launches),
                          "any_hit_launch_ms": round(float(np.median(any_ms)), 4),
                          "frame_device_ms": round(float(np.median(total_ms)), 4),
-                         "note": "working set fits the 256 MiB Infinity Cache: measured HBM traffic << algorithmic bytes"},
+                         "note": ("working set fits the 256 MiB Infinity Cache: measured HBM traffic << algorithmic bytes; the kernel is VALU-issue bound"
+                                  + ("; this tree of %d nodes lives in L1, so the algorithmic-bytes rate can exceed the HBM peak" % info["n_nodes8"]
+                                     if info["n_nodes8"] < 64 else ""))},
         }
         if not args.no_cpu_baseline and world == 1 and args.accel == "cwbvh":
             out["cpu_baseline"] = cpu_baseline(data, cam, W, H, args.depth, rvs[0], cs)
