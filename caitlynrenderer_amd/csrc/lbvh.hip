@@ -2,9 +2,9 @@
 //
 // A linear BVH in the FlatNode layout the path consumes (Caitlyn/FlatNode.h:34-40, BFS order, children
 // adjacent, one triangle per leaf like sbvh.h:285-324 leaves them): 30-bit Morton codes of the triangle
-// centroids, a device radix sort (rocPRIM), Karras' parallel binary radix tree, and a bottom-up refit in
-// which the second child to arrive at a node computes its box, then the renumbering into FlatNode BFS order
-// as one more radix sort of the nodes by (depth, first key of the node's range).  The result is handed back
+// centroids, a device radix sort (rocPRIM), Karras' parallel binary radix tree, the renumbering into FlatNode BFS
+// order as one more radix sort of the nodes by (depth, first key of the node's range), and a bottom-up refit
+// of that array, one small launch per level.  The result is handed back
 // as host arrays (crt_sbvh handle, interchangeable with crt_sbvh_build's).
 // This is NOT the reference's SBVH: no SAH, no spatial splits, hence a different (lower quality, ~100x
 // faster to build) tree; closest hits are identical by construction.
@@ -130,36 +130,6 @@ __global__ void k_radix_tree(const unsigned long long* __restrict__ keys, int n,
     if (i == 0) parent[0] = -1;
 }
 
-// Bottom-up refit.  One thread per leaf climbs; at every internal node the first arrival stops and the
-// second one — which is therefore ordered after both children's boxes — writes the union.  The arrival
-// counter is an agent-scope acq_rel RMW: it releases this thread's box stores and acquires the sibling's
-// (workgroups on different XCDs do not share an L2; see the cross-XCD rules in the CDNA4 notes).
-__global__ void k_refit(const unsigned long long* __restrict__ keys, const float* __restrict__ leaf_box, int n, const int2* __restrict__ child,
-                        const int* __restrict__ parent, float* __restrict__ node_box, uint32_t* __restrict__ arrivals) {
-    const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= n) return;
-    const uint32_t tri = (uint32_t)(keys[leaf] & 0xffffffffull);
-    float box[6];
-    for (int a = 0; a < 6; ++a) box[a] = leaf_box[6 * (size_t)tri + a];
-    float* mine = node_box + 6 * (size_t)((n - 1) + leaf);
-    for (int a = 0; a < 6; ++a) mine[a] = box[a];
-    int node = parent[(n - 1) + leaf];
-    while (node >= 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == 0u) return;
-        const int2 c = child[node];
-        const float* a0 = node_box + 6 * (size_t)c.x;
-        const float* a1 = node_box + 6 * (size_t)c.y;
-        for (int a = 0; a < 3; ++a) {
-            box[a] = fminf(__hip_atomic_load(&a0[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&a1[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            box[3 + a] = fmaxf(__hip_atomic_load(&a0[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&a1[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        float* out = node_box + 6 * (size_t)node;
-        for (int a = 0; a < 6; ++a) __hip_atomic_store(&out[a], box[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        node = parent[node];
-    }
-}
-
 // BFS renumbering into FlatNode order (sbvh.h:570-609: children adjacent, parents before children) without a
 // queue: nodes of one level own disjoint key ranges, so sorting all nodes by (depth, first key of the range) IS the
 // breadth-first order a queue would produce (left child before right, parents in order).
@@ -177,28 +147,54 @@ __global__ void k_bfs_pos(const uint32_t* __restrict__ order, uint32_t total, ui
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < total) pos[order[p]] = p;
 }
+// FlatNode array in BFS order: links for every node, boxes for the leaves (slot j = j-th triangle in Morton order).
 __global__ void k_flatten(const uint32_t* __restrict__ order, const uint32_t* __restrict__ pos, const int2* __restrict__ child,
-                          const float* __restrict__ node_box, int n, crt_flatnode* __restrict__ flat, uint32_t* __restrict__ bad) {
+                          const unsigned long long* __restrict__ sorted, const float* __restrict__ leaf_box, int n,
+                          crt_flatnode* __restrict__ flat, uint32_t* __restrict__ bad) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (uint32_t)(2 * n - 1)) return;
     const int id = (int)order[p];
-    const float* bx = node_box + 6 * (size_t)id;
     crt_flatnode f;
-    f.bmin[0] = bx[0]; f.bmin[1] = bx[1]; f.bmin[2] = bx[2];
-    f.bmax[0] = bx[3]; f.bmax[1] = bx[4]; f.bmax[2] = bx[5];
     if (id >= n - 1) {
-        f.bmin[3] = (float)(id - (n - 1));              // leaf slot = position in Morton order
+        const int leaf = id - (n - 1);
+        const float* bx = leaf_box + 6 * (size_t)(uint32_t)(sorted[leaf] & 0xffffffffull);
+        f.bmin[0] = bx[0]; f.bmin[1] = bx[1]; f.bmin[2] = bx[2];
+        f.bmax[0] = bx[3]; f.bmax[1] = bx[4]; f.bmax[2] = bx[5];
+        f.bmin[3] = (float)leaf;                        // leaf slot = position in Morton order
         f.bmax[3] = 1.0f;
     } else {
         const int2 c = child[id];
         const uint32_t l = pos[c.x], r = pos[c.y];
         if (r != l + 1u || l <= p) atomicOr(bad, 1u);   // children adjacent and after their parent
+        f.bmin[0] = f.bmin[1] = f.bmin[2] = 0.f; f.bmax[0] = f.bmax[1] = f.bmax[2] = 0.f;   // set by k_refit_level
         f.bmin[3] = (float)l;
         f.bmax[3] = 0.0f;
     }
     flat[p] = f;
 }
+// level_start[d] = first BFS position of depth d (the sorted keys carry the depth in their high word)
+__global__ void k_level_starts(const unsigned long long* __restrict__ sorted_keys, uint32_t total, uint32_t* __restrict__ level_start, uint32_t cap) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t d = (uint32_t)(sorted_keys[p] >> 32);
+    if ((p == 0u || (uint32_t)(sorted_keys[p - 1] >> 32) != d) && d < cap) level_start[d] = p;
+}
+// Bottom-up refit, one launch per level of the BFS-ordered array, deepest first: an interior node's children lie in
+// the next level, already final.  Plain loads and stores — the kernel boundary orders them.  (The first version
+// climbed from the leaves with an agent-scope acq_rel arrival counter per node: 3.3 ms of a 5 ms build at 1 M
+// triangles, against ~0.3 ms for ~30 small launches.)
+__global__ void k_refit_level(crt_flatnode* __restrict__ flat, uint32_t begin, uint32_t end) {
+    const uint32_t p = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= end) return;
+    crt_flatnode f = flat[p];
+    if (f.bmax[3] != 0.0f) return;                      // leaf
+    const uint32_t l = (uint32_t)f.bmin[3];
+    const crt_flatnode a = flat[l], b = flat[l + 1];
+    for (int k = 0; k < 3; ++k) { f.bmin[k] = fminf(a.bmin[k], b.bmin[k]); f.bmax[k] = fmaxf(a.bmax[k], b.bmax[k]); }
+    flat[p] = f;
+}
 
+constexpr size_t kMaxLevels = 4096;
 thread_local float g_last_device_ms = 0.f, g_last_total_ms = 0.f;
 
 }  // namespace
@@ -220,12 +216,12 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     const int n = (int)n_tris;
     int32_t* d_vidx = nullptr; float* d_verts = nullptr; float* d_leaf_box = nullptr; uint32_t* d_scene = nullptr;
     unsigned long long *d_keys = nullptr, *d_sorted = nullptr; void* d_tmp = nullptr;
-    int2* d_child = nullptr; int* d_parent = nullptr; float* d_node_box = nullptr; uint32_t* d_arrivals = nullptr;
+    int2* d_child = nullptr; int* d_parent = nullptr; uint32_t* d_levels = nullptr;
     int* d_first = nullptr; unsigned long long *d_bkeys = nullptr, *d_bkeys2 = nullptr; uint32_t *d_ids = nullptr, *d_order = nullptr, *d_pos = nullptr, *d_bad = nullptr;
     crt_flatnode* d_flat = nullptr; void* d_tmp2 = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = {d_vidx, d_verts, d_leaf_box, d_scene, d_keys, d_sorted, d_tmp, d_child, d_parent, d_node_box, d_arrivals,
+        void* ptrs[] = {d_vidx, d_verts, d_leaf_box, d_scene, d_keys, d_sorted, d_tmp, d_child, d_parent, d_levels,
                         d_first, d_bkeys, d_bkeys2, d_ids, d_order, d_pos, d_bad, d_flat, d_tmp2};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -243,13 +239,11 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     LB_HIPCHK(hipMalloc(&d_sorted, n_tris * 8));
     LB_HIPCHK(hipMalloc(&d_child, std::max<size_t>(n_tris - 1, 1) * sizeof(int2)));
     LB_HIPCHK(hipMalloc(&d_parent, n_nodes * 4));
-    LB_HIPCHK(hipMalloc(&d_node_box, n_nodes * 24));
-    LB_HIPCHK(hipMalloc(&d_arrivals, std::max<size_t>(n_tris - 1, 1) * 4));
+    LB_HIPCHK(hipMalloc(&d_levels, kMaxLevels * 4));
     LB_HIPCHK(hipMemcpy(d_vidx, vidx.data(), vidx.size() * 4, hipMemcpyHostToDevice));
     LB_HIPCHK(hipMemcpy(d_verts, vertices, n_vertices * 12, hipMemcpyHostToDevice));
     const uint32_t scene_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     LB_HIPCHK(hipMemcpy(d_scene, scene_init, sizeof scene_init, hipMemcpyHostToDevice));
-    LB_HIPCHK(hipMemset(d_arrivals, 0, std::max<size_t>(n_tris - 1, 1) * 4));
     size_t tmp_bytes = 0;
     LB_HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys, d_sorted, n_tris, 0, 64, (hipStream_t)0));
     LB_HIPCHK(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
@@ -275,12 +269,24 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     LB_HIPCHK(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, n_tris, 0, 64, (hipStream_t)0));
     if (n > 1) hipLaunchKernelGGL(k_radix_tree, dim3((uint32_t)((n_tris - 1 + 255) / 256)), dim3(256), 0, 0, d_sorted, n, d_child, d_parent, d_first);
     else { const int minus1 = -1; LB_HIPCHK(hipMemcpyAsync(d_parent, &minus1, 4, hipMemcpyHostToDevice, 0)); }
-    hipLaunchKernelGGL(k_refit, dim3(g), dim3(256), 0, 0, d_sorted, d_leaf_box, n, d_child, d_parent, d_node_box, d_arrivals);
     const dim3 gn((uint32_t)((n_nodes + 255) / 256));
     hipLaunchKernelGGL(k_bfs_keys, gn, dim3(256), 0, 0, d_parent, d_first, n, d_bkeys, d_ids);
     LB_HIPCHK(rocprim::radix_sort_pairs(d_tmp2, tmp2_bytes, d_bkeys, d_bkeys2, d_ids, d_order, n_nodes, 0, 64, (hipStream_t)0));
     hipLaunchKernelGGL(k_bfs_pos, gn, dim3(256), 0, 0, d_order, (uint32_t)n_nodes, d_pos);
-    hipLaunchKernelGGL(k_flatten, gn, dim3(256), 0, 0, d_order, d_pos, d_child, d_node_box, n, d_flat, d_bad);
+    hipLaunchKernelGGL(k_flatten, gn, dim3(256), 0, 0, d_order, d_pos, d_child, d_sorted, d_leaf_box, n, d_flat, d_bad);
+    hipLaunchKernelGGL(k_level_starts, gn, dim3(256), 0, 0, d_bkeys2, (uint32_t)n_nodes, d_levels, (uint32_t)kMaxLevels);
+    unsigned long long deepest_key = 0;
+    std::vector<uint32_t> level_start;
+    LB_HIPCHK(hipMemcpy(&deepest_key, d_bkeys2 + (n_nodes - 1), 8, hipMemcpyDeviceToHost));
+    const uint32_t n_levels = (uint32_t)(deepest_key >> 32) + 1u;
+    if (n_levels > kMaxLevels) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_lbvh_build: tree deeper than 4096 levels"); }
+    level_start.resize(n_levels + 1);
+    LB_HIPCHK(hipMemcpy(level_start.data(), d_levels, n_levels * 4, hipMemcpyDeviceToHost));
+    level_start[n_levels] = (uint32_t)n_nodes;
+    for (uint32_t l = n_levels; l-- > 0;) {
+        const uint32_t cnt = level_start[l + 1] - level_start[l];
+        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 255) / 256), dim3(256), 0, 0, d_flat, level_start[l], level_start[l + 1]);
+    }
     LB_HIPCHK(hipEventRecord(ev1, 0));
     LB_HIPCHK(hipDeviceSynchronize());
     LB_HIPCHK(hipGetLastError());
