@@ -4,9 +4,9 @@
 // arithmetic is the shared code of host/cwbvh_core.hpp, and what the host does with a reverse sweep and a
 // depth-first recursion is re-expressed as data-parallel passes:
 //   1. k_parents        parent links of the BFS-ordered FlatNode array
-//   2. k_costs          the 7-entry cost/decision table of every BVH2 node, bottom-up; one thread per leaf climbs,
-//                       the second arrival at a node (ordered after both children by an agent-scope acq_rel
-//                       counter: workgroups on different XCDs do not share an L2) combines the children's tables
+//   2. k_costs_level    the 7-entry cost/decision table of every BVH2 node, bottom-up, one launch per level of the
+//                       BFS-ordered array (k_depths / k_level_starts find the levels): plain loads and stores, the
+//                       kernel boundary orders a level after its children's
 //   3. k_discover       the node8 tree level by level: slot-ordered children of every node8, inner children
 //                       appended to the next level
 //   4. k_sizes          subtree sizes (node8 count, triangle count), deepest level first
@@ -37,17 +37,7 @@ using crt::fail;
 
 enum : uint32_t { ERR_LEAF_SIZE = 1u, ERR_LEAF_RANGE = 2u, ERR_LINK = 4u, ERR_COVER = 8u };
 
-union DecBits { Decision d; unsigned long long u; };
-static_assert(sizeof(Decision) == 8, "Decision travels as one 64-bit word");
-
-__device__ __forceinline__ void store_dec(unsigned long long* p, const Decision& d) {
-    DecBits b; b.u = 0ull; b.d = d;
-    __hip_atomic_store(p, b.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ Decision load_dec(const unsigned long long* p) {
-    DecBits b; b.u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return b.d;
-}
+static_assert(sizeof(Decision) == 8, "7 decisions per node are stored as 7 x 8 bytes");
 
 __global__ void k_parents(const crt_flatnode* __restrict__ bvh2, uint32_t n2, int32_t* __restrict__ parent, uint32_t* flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,34 +50,44 @@ __global__ void k_parents(const crt_flatnode* __restrict__ bvh2, uint32_t n2, in
     parent[left + 1] = (int32_t)i;
 }
 
-__global__ void k_costs(const crt_flatnode* __restrict__ bvh2, uint32_t n2, uint32_t n_slots, const int32_t* __restrict__ parent,
-                        uint32_t* __restrict__ arrivals, unsigned long long* __restrict__ dec, int32_t* __restrict__ nprims, uint32_t* flags) {
+// depth of every BVH2 node (root 0) by walking the parent links; in a BFS-ordered array it never decreases with the index
+__global__ void k_depths(const int32_t* __restrict__ parent, uint32_t n2, uint32_t* __restrict__ depth) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n2) return;
+    uint32_t d = 0;
+    for (int p = parent[i]; p >= 0; p = parent[p]) ++d;
+    depth[i] = d;
+}
+__global__ void k_level_starts(const uint32_t* __restrict__ depth, uint32_t n2, uint32_t* __restrict__ level_start, uint32_t cap, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const uint32_t d = depth[i];
+    if (i > 0u && depth[i - 1] > d) atomicOr(flags, ERR_LINK);          // not breadth-first
+    if ((i == 0u || depth[i - 1] != d) && d < cap) level_start[d] = i;
+}
+// The 7-entry cost/decision table of every node of one level (cwbvh.h:75-173); the children's tables are in the next
+// level, computed by the previous launch.  (First version: one thread per leaf climbing with an agent-scope acq_rel
+// arrival counter per node — 3.6 ms of the 4.6 ms conversion at 1 M triangles.)
+__global__ void k_costs_level(const crt_flatnode* __restrict__ bvh2, uint32_t begin, uint32_t end, uint32_t n_slots,
+                              Decision* __restrict__ dec, int32_t* __restrict__ nprims, uint32_t* flags) {
+    const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end) return;
     const crt_flatnode fn = bvh2[i];
-    if (!is_leaf(fn)) return;
-    const int np = (int)fn.bmax[3], start = (int)fn.bmin[3];
-    if (np < 1 || np > 3) { atomicOr(flags, ERR_LEAF_SIZE); return; }
-    if (start < 0 || (uint32_t)(start + np) > n_slots) { atomicOr(flags, ERR_LEAF_RANGE); return; }
     Decision d[7];
-    leaf_decisions(half_area(fn), np, d);
-    for (int k = 0; k < 7; ++k) store_dec(dec + (size_t)i * 7 + k, d[k]);
-    __hip_atomic_store(&nprims[i], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int node = parent[i];
-    while (node >= 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == 0u) return;                    // the sibling subtree is not finished: its thread will come by
-        const crt_flatnode pn = bvh2[node];
-        const int left = (int)pn.bmin[3];
-        Decision L[7], R[7];
-        for (int k = 0; k < 7; ++k) { L[k] = load_dec(dec + (size_t)left * 7 + k); R[k] = load_dec(dec + (size_t)(left + 1) * 7 + k); }
-        const int npn = __hip_atomic_load(&nprims[left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
-                        __hip_atomic_load(&nprims[left + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        inner_decisions(half_area(pn), npn, L, R, d);
-        for (int k = 0; k < 7; ++k) store_dec(dec + (size_t)node * 7 + k, d[k]);
-        __hip_atomic_store(&nprims[node], npn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        node = parent[node];
+    int np;
+    if (is_leaf(fn)) {
+        np = (int)fn.bmax[3];
+        const int start = (int)fn.bmin[3];
+        if (np < 1 || np > 3) { atomicOr(flags, ERR_LEAF_SIZE); return; }
+        if (start < 0 || (uint32_t)(start + np) > n_slots) { atomicOr(flags, ERR_LEAF_RANGE); return; }
+        leaf_decisions(half_area(fn), np, d);
+    } else {
+        const int left = (int)fn.bmin[3];
+        np = nprims[left] + nprims[left + 1];
+        inner_decisions(half_area(fn), np, dec + (size_t)left * 7, dec + (size_t)(left + 1) * 7, d);
     }
+    for (int k = 0; k < 7; ++k) dec[(size_t)i * 7 + k] = d[k];
+    nprims[i] = np;
 }
 
 // per node8 (temporary id = discovery order, level by level)
@@ -193,6 +193,7 @@ __global__ void k_cover(const uint32_t* __restrict__ seen, uint32_t n_slots, uin
     if (i < n_slots && seen[i] != 1u) atomicOr(flags, ERR_COVER);
 }
 
+constexpr size_t kMaxLevels = 4096;
 thread_local float g_device_ms = 0.f, g_total_ms = 0.f;
 
 inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256 ? (n + 255) / 256 : 1)); }
@@ -214,12 +215,13 @@ int crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_
     const uint32_t n2 = (uint32_t)n_nodes, ns = (uint32_t)n_slots;
     const uint32_t cap8 = n2 / 2u + 1u;            // every node8 stands for a distinct interior BVH2 node (or the root)
     crt_flatnode* d_bvh2 = nullptr; int32_t* d_parent = nullptr; uint32_t* d_arrivals = nullptr; unsigned long long* d_dec = nullptr;
+    uint32_t* d_levels = nullptr;
     int32_t* d_nprims = nullptr; uint32_t* d_flags = nullptr; uint32_t* d_ntmp = nullptr; uint32_t* d_seen = nullptr;
     crt_node8* d_nodes = nullptr; int32_t* d_tri_slots = nullptr; int32_t* d_child_bvh2 = nullptr;
     Tmp t{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = {d_bvh2, d_parent, d_arrivals, d_dec, d_nprims, d_flags, d_ntmp, d_seen, d_nodes, d_tri_slots, d_child_bvh2,
+        void* ptrs[] = {d_levels, d_bvh2, d_parent, d_arrivals, d_dec, d_nprims, d_flags, d_ntmp, d_seen, d_nodes, d_tri_slots, d_child_bvh2,
                         t.bvh2, t.children, t.first, t.n_inner, t.n_tris, t.S, t.T, t.idx, t.A, t.B};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (ev0) (void)hipEventDestroy(ev0);
@@ -231,6 +233,7 @@ int crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_
     CW_HIPCHK(hipMalloc(&d_dec, (size_t)n2 * 7 * 8));
     CW_HIPCHK(hipMalloc(&d_nprims, (size_t)n2 * 4));
     CW_HIPCHK(hipMalloc(&d_flags, 4));
+    CW_HIPCHK(hipMalloc(&d_levels, kMaxLevels * 4));
     CW_HIPCHK(hipMalloc(&d_ntmp, 4));
     CW_HIPCHK(hipMalloc(&d_seen, (size_t)ns * 4));
     CW_HIPCHK(hipMalloc(&d_tri_slots, (size_t)ns * 4));
@@ -250,11 +253,22 @@ int crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_
     CW_HIPCHK(hipMemcpy(d_bvh2, bvh2, (size_t)n2 * sizeof(crt_flatnode), hipMemcpyHostToDevice));
     CW_HIPCHK(hipEventRecord(ev0, 0));
     CW_HIPCHK(hipMemsetAsync(d_parent, 0xff, (size_t)n2 * 4, 0));
-    CW_HIPCHK(hipMemsetAsync(d_arrivals, 0, (size_t)n2 * 4, 0));
     CW_HIPCHK(hipMemsetAsync(d_flags, 0, 4, 0));
     CW_HIPCHK(hipMemsetAsync(d_seen, 0, (size_t)ns * 4, 0));
     hipLaunchKernelGGL(k_parents, grid_for(n2), dim3(256), 0, 0, d_bvh2, n2, d_parent, d_flags);
-    hipLaunchKernelGGL(k_costs, grid_for(n2), dim3(256), 0, 0, d_bvh2, n2, ns, d_parent, d_arrivals, d_dec, d_nprims, d_flags);
+    // levels of the BFS-ordered array, then the cost tables deepest level first
+    uint32_t* const d_depth = d_arrivals;           // one word per node
+    hipLaunchKernelGGL(k_depths, grid_for(n2), dim3(256), 0, 0, d_parent, n2, d_depth);
+    hipLaunchKernelGGL(k_level_starts, grid_for(n2), dim3(256), 0, 0, d_depth, n2, d_levels, (uint32_t)kMaxLevels, d_flags);
+    uint32_t deepest = 0;
+    CW_HIPCHK(hipMemcpy(&deepest, d_depth + (n2 - 1), 4, hipMemcpyDeviceToHost));
+    if (deepest + 1u > kMaxLevels) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: BVH2 deeper than 4096 levels"); }
+    std::vector<uint32_t> lv(deepest + 2u);
+    CW_HIPCHK(hipMemcpy(lv.data(), d_levels, (deepest + 1u) * 4, hipMemcpyDeviceToHost));
+    lv[deepest + 1u] = n2;
+    for (uint32_t l = deepest + 1u; l-- > 0;)
+        hipLaunchKernelGGL(k_costs_level, grid_for(lv[l + 1] - lv[l]), dim3(256), 0, 0, d_bvh2, lv[l], lv[l + 1], ns,
+                           reinterpret_cast<Decision*>(d_dec), d_nprims, d_flags);
 
     uint32_t flags = 0;
     Decision root0;
