@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -131,6 +132,8 @@ struct crt_scene {
     // a persistent grid on the 1 M mesh: per-chunk cost varies 10x between sky and grazing rays);
     // k >= 1: persistent grid of k x the resident workgroups, static schedule (rt_kernels.hip)
     uint32_t oversubscribe = 0;
+    uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 4 = 256-thread workgroups
+    uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
     bool timing_accumulate = false;          // spans pile up over frames (crt_frame_stats then holds sums) instead of per frame
 
@@ -139,7 +142,7 @@ struct crt_scene {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
-                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals};
+                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_counts) hipHostFree(h_counts);
         if (h_visit_totals) hipHostFree(h_visit_totals);
@@ -299,7 +302,19 @@ int crt_device_count(void) {
     return n;
 }
 
+static int scene_create_impl(const crt_scene_desc* d, crt_scene** out);
+
 int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
+    // nothing may unwind through the C ABI: the vectors built during upload can throw bad_alloc / length_error
+    try {
+        return scene_create_impl(d, out);
+    } catch (const std::exception& e) {
+        if (out) *out = nullptr;
+        return fail(CRT_ERR_NOMEM, std::string("crt_scene_create: ") + e.what());
+    }
+}
+
+static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
     if (!out) return fail(CRT_ERR_INVALID, "crt_scene_create: null out");
     *out = nullptr;
     if (!d) return fail(CRT_ERR_INVALID, "crt_scene_create: null desc");
@@ -382,16 +397,17 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
                 return fail(CRT_ERR_INVALID, "crt_scene_create: bvh8_tri_slots entry out of range");
     }
 
-    crt_scene* s = new (std::nothrow) crt_scene;
+    std::unique_ptr<crt_scene> owner(new (std::nothrow) crt_scene);   // freed on every early return and on a throw
+    crt_scene* s = owner.get();
     if (!s) return fail(CRT_ERR_NOMEM, "crt_scene_create: out of memory");
-    auto bail = [&](int code) { delete s; return code; };
+    auto bail = [&](int code) { return code; };
     if (hipGetDevice(&s->device) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipGetDevice failed"));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) crt::set_waves_per_workgroup((uint32_t)std::atoi(e));
+    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) s->waves_per_workgroup = std::atoi(e) == 1 ? 1u : 4u;
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
@@ -447,8 +463,18 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         std::vector<uint32_t> level(d->n_bvh, 0);
         uint32_t depth2 = 0;
         for (size_t i = 0; i < d->n_bvh; ++i) {
-            if (d->bvh[i].bmax[3] != 0.0f) { depth2 = std::max(depth2, level[i]); continue; }
-            const size_t l = (size_t)d->bvh[i].bmin[3];
+            if (d->bvh[i].bmax[3] != 0.0f) {
+                // leaf: traverse_bvh2 loops over [start, start + range) of the slot-ordered records, so the range must lie
+                // inside the triangle array (range <= 255 is the builder's own bit-field cap, FlatNode.h:24-25)
+                const float fs = d->bvh[i].bmin[3], fr = d->bvh[i].bmax[3];
+                if (!(fr >= 1.0f && fr <= 255.0f) || !(fs >= 0.0f && fs < 16777216.0f) || (size_t)fs + (size_t)fr > d->n_triangles)
+                    return bail(fail(CRT_ERR_INVALID, "crt_scene_create: BVH2 leaf range outside the triangle array"));
+                depth2 = std::max(depth2, level[i]);
+                continue;
+            }
+            const float fl = d->bvh[i].bmin[3];
+            if (!(fl >= 0.0f && fl < 16777216.0f)) return bail(fail(CRT_ERR_INVALID, "crt_scene_create: BVH2 child link out of order"));
+            const size_t l = (size_t)fl;
             if (l <= i || l + 1 >= d->n_bvh) return bail(fail(CRT_ERR_INVALID, "crt_scene_create: BVH2 child link out of order"));
             level[l] = level[l + 1] = level[i] + 1;
         }
@@ -474,6 +500,8 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         if (hipMemcpy(s->d_tris2, rec2.data(), rec2.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));
     }
+    if ((rc = dev_alloc(&s->d_overflow, 1))) return bail(rc);
+    if (hipMemset(s->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipMemset failed"));
     if ((rc = dev_alloc(&s->d_counts, 2 * kCounters))) return bail(rc);
     if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
         return bail(fail(CRT_ERR_NOMEM, "hipHostMalloc failed"));
@@ -481,7 +509,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     for (EventSpan& sp : s->spans)
         if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)
             return bail(fail(CRT_ERR_HIP, "hipEventCreate failed"));
-    *out = s;
+    *out = owner.release();
     return CRT_OK;
 }
 
@@ -529,7 +557,10 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
-    else if (!std::strcmp(name, "waves_per_workgroup")) crt::set_waves_per_workgroup((uint32_t)value);
+    else if (!std::strcmp(name, "waves_per_workgroup")) {
+        if (value != 1 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: waves_per_workgroup is 1 or 4");
+        s->waves_per_workgroup = (uint32_t)value;
+    }
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "accel")) {
         if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
@@ -607,6 +638,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.pb = s->pb; sa.sum = s->d_sum;
         sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
         sa.visit_totals = s->d_visit_totals;
+        sa.overflow = s->d_overflow;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
         EventSpan* sp = s->new_span(1);
         const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u;
@@ -614,24 +646,25 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
             qa.stack_entries = s->stack_entries; qa.sub_capacity = s->sub_capacity; qa.refill_min = s->refill_min; qa.tri_min = s->tri_min;
-            qa.visit_totals = s->d_visit_totals;
+            qa.visit_totals = s->d_visit_totals; qa.overflow = s->d_overflow;
             if (sp) crt::set_launch_events(sp->a, nullptr);                 // span = both launches of the segment
-            crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8, 1024), s->stream);
+            crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8, 1024), s->waves_per_workgroup, s->stream);
             sa.hits_in = s->d_qhits;
             if (sp) crt::set_launch_events(nullptr, sp->b);
         } else if (sp) {
             crt::set_launch_events(sp->a, sp->b);
         }
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->count_visits, s->trace_grid(P, 5), s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};
         sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = cnt + counter_index(b, 1, 0);
         sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = 0;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
+        sh.overflow = s->d_overflow;
         sp = s->new_span(2);
         if (sp) crt::set_launch_events(sp->a, sp->b);
-        crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->stream);
+        crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->waves_per_workgroup, s->stream);
     }
     if (s->count_visits)
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
@@ -676,6 +709,7 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
         }
         int rc = collect_stats(s);
         if (rc) return rc;
+        HIPCHK(hipMemcpy(&s->stats.stack_overflows, s->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     *out = s->stats;
     return CRT_OK;
@@ -851,6 +885,7 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     ta.stack_entries = s->stack_entries;
     ta.refill_min = s->refill_min;
     ta.tri_min = s->tri_min;
+    ta.overflow = s->d_overflow;
     s->n_spans = 0;
     if ((mode & CRT_TRACE_BVH2) && !s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_trace: the scene was created without a BVH2 (desc.bvh)");
     EventSpan* sp = s->new_span(any_hit ? 2 : 1);
@@ -858,13 +893,13 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     if (mode & CRT_TRACE_BVH2) {
         crt::Bvh2Args ba{};
         ba.nodes = s->d_bvh2; ba.tris = s->d_tris2; ba.rays = ta.rays; ba.hits = ta.hits; ba.stats = ta.stats;
-        ba.n = (uint32_t)n; ba.tie = (mode & CRT_TRACE_TIE_LOWEST_ID) ? 1u : 0u; ba.stack_entries = s->bvh2_stack;
+        ba.n = (uint32_t)n; ba.tie = (mode & CRT_TRACE_TIE_LOWEST_ID) ? 1u : 0u; ba.stack_entries = s->bvh2_stack; ba.overflow = s->d_overflow;
         const uint64_t lds = (uint64_t)(CRT_TRACE_BLOCK / 64) * ba.stack_entries * 64 * 4;
         uint64_t g = std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cu * std::max<uint64_t>(1, std::min<uint64_t>(8, 160 * 1024 / lds)));
         g = (std::max<uint64_t>(g, 8) + 7) / 8 * 8;
-        crt::launch_trace_bvh2(ba, any_hit, d_stats != nullptr, (uint32_t)g, s->stream);
+        crt::launch_trace_bvh2(ba, any_hit, d_stats != nullptr, (uint32_t)g, s->waves_per_workgroup, s->stream);
     } else {
-        crt::launch_trace(ta, any_hit ? 1 : 0, d_stats != nullptr, s->trace_grid(n, 8, 1024), s->stream);
+        crt::launch_trace(ta, any_hit ? 1 : 0, d_stats != nullptr, s->trace_grid(n, 8, 1024), s->waves_per_workgroup, s->stream);
     }
     HIPCHK(hipGetLastError());
     s->stats_pending = true;

@@ -103,7 +103,14 @@ int crt_load_obj(const char* path, float camera_position[3], crt_mesh** out) {
     *out = nullptr;
     crt_mesh* h = new (std::nothrow) crt_mesh;
     if (!h) return fail(CRT_ERR_NOMEM, "crt_load_obj: out of memory");
-    if (!h->mesh.read_object(path)) {
+    bool ok = false;
+    try {
+        ok = h->mesh.read_object(path);
+    } catch (const std::exception& e) {   // bad_alloc / length_error from the loader's or a texture decoder's vectors
+        delete h;
+        return fail(CRT_ERR_NOMEM, std::string("crt_load_obj: ") + e.what());
+    }
+    if (!ok) {
         std::string msg = "crt_load_obj: " + h->mesh.error;
         delete h;
         return fail(CRT_ERR_IO, msg);

@@ -68,7 +68,7 @@ __global__ void k_level_starts(const uint32_t* __restrict__ depth, uint32_t n2, 
 // The 7-entry cost/decision table of every node of one level (cwbvh.h:75-173); the children's tables are in the next
 // level, computed by the previous launch.  (First version: one thread per leaf climbing with an agent-scope acq_rel
 // arrival counter per node — 3.6 ms of the 4.6 ms conversion at 1 M triangles.)
-__global__ void k_costs_level(const crt_flatnode* __restrict__ bvh2, uint32_t begin, uint32_t end, uint32_t n_slots,
+__global__ void k_costs_level(const crt_flatnode* __restrict__ bvh2, uint32_t begin, uint32_t end, uint32_t n2, uint32_t n_slots,
                               Decision* __restrict__ dec, int32_t* __restrict__ nprims, uint32_t* flags) {
     const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= end) return;
@@ -83,6 +83,8 @@ __global__ void k_costs_level(const crt_flatnode* __restrict__ bvh2, uint32_t be
         leaf_decisions(half_area(fn), np, d);
     } else {
         const int left = (int)fn.bmin[3];
+        // the host bails out on ERR_LINK before the first cost pass; this check keeps the kernel in bounds on its own
+        if (left <= (int)i || (uint32_t)left + 1u >= n2) { atomicOr(flags, ERR_LINK); return; }
         np = nprims[left] + nprims[left + 1];
         inner_decisions(half_area(fn), np, dec + (size_t)left * 7, dec + (size_t)(left + 1) * 7, d);
     }
@@ -261,16 +263,23 @@ int crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_
     hipLaunchKernelGGL(k_depths, grid_for(n2), dim3(256), 0, 0, d_parent, n2, d_depth);
     hipLaunchKernelGGL(k_level_starts, grid_for(n2), dim3(256), 0, 0, d_depth, n2, d_levels, (uint32_t)kMaxLevels, d_flags);
     uint32_t deepest = 0;
+    uint32_t flags = 0;
     CW_HIPCHK(hipMemcpy(&deepest, d_depth + (n2 - 1), 4, hipMemcpyDeviceToHost));
+    // a link that is out of order, out of range, negative or NaN was flagged by k_parents / k_level_starts: stop before
+    // any pass follows the links (host/cwbvh.cpp returns CRT_ERR_INVALID at the same point)
+    CW_HIPCHK(hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost));
+    if (flags) {
+        cleanup();
+        return fail(CRT_ERR_INVALID, "crt_cwbvh_convert_device: BVH2 child link out of order");
+    }
     if (deepest + 1u > kMaxLevels) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: BVH2 deeper than 4096 levels"); }
     std::vector<uint32_t> lv(deepest + 2u);
     CW_HIPCHK(hipMemcpy(lv.data(), d_levels, (deepest + 1u) * 4, hipMemcpyDeviceToHost));
     lv[deepest + 1u] = n2;
     for (uint32_t l = deepest + 1u; l-- > 0;)
-        hipLaunchKernelGGL(k_costs_level, grid_for(lv[l + 1] - lv[l]), dim3(256), 0, 0, d_bvh2, lv[l], lv[l + 1], ns,
+        hipLaunchKernelGGL(k_costs_level, grid_for(lv[l + 1] - lv[l]), dim3(256), 0, 0, d_bvh2, lv[l], lv[l + 1], n2, ns,
                            reinterpret_cast<Decision*>(d_dec), d_nprims, d_flags);
 
-    uint32_t flags = 0;
     Decision root0;
     CW_HIPCHK(hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost));
     auto input_error = [&](uint32_t f) -> int {

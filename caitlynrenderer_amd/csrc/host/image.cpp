@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 
 namespace crt {
@@ -128,6 +129,12 @@ bool decode_tga(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
         r.skip(bytes);
     }
     const uint32_t px_bytes = bpp / 8;
+    // bound the allocation by what the file can hold: raw data needs w*h*px_bytes input bytes, and a run-length
+    // packet of 1 + px_bytes bytes expands to at most 128 pixels
+    {
+        const size_t left = n - std::min(n, r.at), want = (size_t)w * h * px_bytes;
+        if (rle ? want / 128 > left : want > left) return fail(error, "tga: truncated pixel data");
+    }
     std::vector<uint8_t> raw((size_t)w * h * px_bytes);
     if (!rle) {
         if (r.at + raw.size() > n) return fail(error, "tga: truncated pixel data");
@@ -200,6 +207,8 @@ bool decode_png(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))) || (ctype == 3 && depth == 16))
         return fail(error, "png: bad bit depth");
     const size_t bits_pp = (size_t)channels * depth, stride = ((size_t)w * bits_pp + 7) / 8, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+    // deflate expands by at most ~1032 : 1, so a header of a few bytes cannot ask for gigabytes
+    if ((stride + 1) * (size_t)h / 1032 > idat.size() + 1) return fail(error, "png: bad compressed data");
     std::vector<uint8_t> raw((stride + 1) * (size_t)h);
     uLongf raw_len = (uLongf)raw.size();
     const int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());

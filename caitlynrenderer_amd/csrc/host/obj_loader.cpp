@@ -187,7 +187,8 @@ bool Mesh::read_object(const std::string& file_name) {
                 for (const auto& kv : mtl_map) if (kv.first == name) mtl_ind = kv.second;
             }
         } else if (t[0] == 'm' && !read_mtl_done) {                    // Scene.h:890-899 (first `m…` line = mtllib)
-            if (std::sscanf(t + 6, "%255s", name) == 1) {
+            // the reference skips 6 characters of whatever `m…` line comes first; a line shorter than that has no name
+            if (std::strlen(t) > 6 && std::sscanf(t + 6, "%255s", name) == 1) {
                 if (!read_mtl(dir + name, dir, mtl_map)) return false;
                 read_mtl_done = true;
             }

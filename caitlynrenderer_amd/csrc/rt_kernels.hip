@@ -114,7 +114,7 @@ __device__ __forceinline__ bool mt_test(const float4 a, const float4 b, const fl
 // CWBVH's depth at scene creation so shallow trees leave more LDS for occupancy.
 template <bool ANY, bool STATS>
 __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o,
-                                         vec3 d, float tmax_in, uint2* stk, int stack_entries, HitState& best,
+                                         vec3 d, float tmax_in, uint2* stk, int stack_entries, uint32_t* overflow, HitState& best,
                                          uint32_t& n_nodes, uint32_t& n_tris) {
     best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
     // a non-finite origin makes every slab NaN (all children pass): such a ray can hit nothing
@@ -137,7 +137,9 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const uint32_t base = cur.x;
             cur.y &= ~(1u << off);
             if (cur.y & 0xff000000u) {
-                if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; }
+                // crt_scene_create sizes the stack from the validated depth of the tree, so a push always fits; if a
+                // caller-supplied tree ever got past the validator the dropped push is counted, not silent
+                if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u);
             }
             const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
@@ -192,7 +194,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
 // The pool is [pool_begin, pool_end); refill happens when at least `refill_min` lanes are idle (or none is busy).
 template <bool ANY, bool STATS, typename Load, typename Done>
 __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* stk,
-                                              int stack_entries, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
+                                              int stack_entries, uint32_t* overflow, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
                                               uint32_t tri_min, Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t next = pool_begin;                     // wave-uniform
@@ -257,7 +259,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 const uint32_t base = cur.x;
                 cur.y &= ~(1u << off);
                 if (cur.y & 0xff000000u) {
-                    if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; }
+                    // crt_scene_create sizes the stack from the validated depth of the tree, so a push always fits; if a
+                // caller-supplied tree ever got past the validator the dropped push is counted, not silent
+                if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u);
                 }
                 const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
                 const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
@@ -436,7 +440,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
                     a.stats[i] = ((dt > 65535u ? 65535u : dt) << 16) | (dn > 65535u ? 65535u : dn);
                 }
             };
-        traverse_pool<ANY, STATS>(a.nodes, a.tris, stk, (int)a.stack_entries, first, last, a.refill_min, a.tri_min, load, done, nn, nt);
+        traverse_pool<ANY, STATS>(a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, load, done, nn, nt);
         nn_total += nn; nt_total += nt;
     }
     (void)nn_total; (void)nt_total; (void)lane;
@@ -463,7 +467,7 @@ __device__ __forceinline__ float hit_bbox2(vec3 o, vec3 bmin, vec3 bmax, vec3 in
 // returns hit / occluded.  `stk` is this lane's column of an int stack, stk[level * 64].
 template <bool ANY, bool STATS>
 __device__ __forceinline__ bool traverse_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o, vec3 d,
-                                              float tmax_in, uint32_t tie, int* stk, int stack_entries, HitState& best,
+                                              float tmax_in, uint32_t tie, int* stk, int stack_entries, uint32_t* overflow, HitState& best,
                                               uint32_t& nn, uint32_t& nt) {
     const vec3 invdir = V3(rcp_ieee(d.x), rcp_ieee(d.y), rcp_ieee(d.z));
     best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
@@ -492,7 +496,7 @@ __device__ __forceinline__ bool traverse_bvh2(const float4* __restrict__ nodes, 
                 ind = left;
                 if (r) {
                     const int off = tl1 > tl2 ? 1 : 0;
-                    if (ptr < stack_entries) { stk[ptr * 64] = ind + 1 - off; ++ptr; }
+                    if (ptr < stack_entries) { stk[ptr * 64] = ind + 1 - off; ++ptr; } else atomicAdd(overflow, 1u);
                     ind += off;
                 }
                 continue;
@@ -540,7 +544,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace_bvh2(Bvh2Args a) {
         HitState best;
         uint32_t nn = 0, nt = 0;
         const bool hit = traverse_bvh2<ANY, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, a.tie, stk,
-                                                   (int)a.stack_entries, best, nn, nt);
+                                                   (int)a.stack_entries, a.overflow, best, nn, nt);
         float4 h;
         h.x = ANY ? 0.f : (hit ? best.t : 0.f);
         h.y = ANY ? 0.f : best.u;
@@ -724,15 +728,15 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                 hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = __float_as_int(h.w);
             }
         } else if (BVH2) {
-            if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, hit, nn, nt);
+            if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, a.overflow, hit, nn, nt);
         } else if (a.tri_min == 0u) {
-            if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, hit, nn, nt);
+            if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray get a non-finite origin, which finishes immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             const float qnan = __uint_as_float(0x7fc00000u);
             traverse_pool<false, STATS>(
-                a.nodes, a.tris, stk, (int)a.stack_entries, 0u, 64u, 65u, a.tri_min,
+                a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
                 [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = active ? o : V3(qnan, qnan, qnan); rd = d; tmax = CRT_INF; },
                 [&](uint32_t, const HitState& best, bool) { hit = best; },
                 nn, nt);
@@ -809,7 +813,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                         ldir = ldir * ilen;
                         const float cos_mtl = dot(ldir, original_n);
                         const float cos_light = dot(ldir, V3(Lt[9], Lt[10], Lt[11]));
-                        if (cos_mtl > 0.0f && cos_light < 0.0f) {                 // :968 (the occlusion test runs in k_shadow)
+                        if (cos_mtl > 0.0f && cos_light < 0.0f) {                 // :968 (the occlusion test follows: in place, or in k_shadow with inplace_shadow = 0)
                             const vec3 le = V3(Lt[12], Lt[13], Lt[14]);
                             const float pdf_light = __fdiv_rn(len * len, Lt[15] * -cos_light) * Lt[16];
                             const float bsdf_pdf = __fdiv_rn(dot(ldir, n) * 1.0f, CRT_PI);
@@ -823,8 +827,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                                 if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
                                 HitState sh;
                                 const bool occluded = BVH2
-                                    ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, sh, nn_any, nt_any)
-                                    : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, sh, nn_any, nt_any);
+                                    ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
+                                    : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any);
                                 if (!occluded) L = L + c;
                             } else {
                                 emit_shadow = true;
@@ -903,7 +907,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
         const float4* const rays = a.rays + 2 * (size_t)g * a.sub_capacity;
         float4* const hits = a.hits + (size_t)g * a.sub_capacity;
         traverse_pool<false, STATS>(
-            a.nodes, a.tris, stk, (int)a.stack_entries, first, last, a.refill_min, a.tri_min,
+            a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min,
             [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
                 const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
                 o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
@@ -942,7 +946,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
         // (0.180 ms) on these short, fairly coherent rays; re-measured with single-wave workgroups: voting at
         // ratio 1/2/3 0.164/0.163/0.164 vs 0.154 ms (and it costs 93 instead of 64 VGPRs)
         const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
-                                                    (int)a.stack_entries, hit, nn, nt);
+                                                    (int)a.stack_entries, a.overflow, hit, nn, nt);
         const uint32_t tag = __float_as_uint(r1.w);
         const uint32_t pix = tag & 0x7fffffffu;
         if (tag & 0x80000000u) {                             // the path ended with this segment
@@ -1012,16 +1016,24 @@ static inline void launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stre
     }
 }
 
-static uint32_t g_waves_per_group = 1;   // measured: 1 M mesh k_segment 0.246 -> 0.226 ms, Cornell 0.079 -> 0.074 ms
-void set_waves_per_workgroup(uint32_t n) { g_waves_per_group = n == 1u ? 1u : 4u; }
-static inline size_t stack_bytes(uint32_t entries) { return (size_t)g_waves_per_group * entries * 64 * sizeof(uint2); }
+// Workgroup shape of the traversal kernels: `waves` = 1 (every wave its own workgroup: the hardware dispatcher refills
+// SIMDs wave by wave; measured 1 M mesh k_segment 0.246 -> 0.226 ms, Cornell 0.079 -> 0.074 ms) or 4 (256 threads).
+// It is a per-scene setting handed to every launcher.  A request whose LDS stacks would not fit the 64 KB a kernel may
+// ask for without raising its dynamic-LDS limit (only the BVH2 stack of a very deep tree at 4 waves gets there) falls
+// back to single-wave workgroups, which the kernels' index mapping (wave_id) supports for any grid.
+static inline uint32_t fit_waves(uint32_t waves, size_t lds_per_wave) {
+    waves = waves == 1u ? 1u : 4u;
+    return (size_t)waves * lds_per_wave > 64u * 1024u ? 1u : waves;
+}
+static inline size_t stack_bytes(uint32_t entries) { return (size_t)entries * 64 * sizeof(uint2); }
 // `grid` counts 4-wave chunks; with single-wave workgroups each of them becomes 4 workgroups
-static inline dim3 grid_dim(uint32_t grid) { return dim3(g_waves_per_group == 1u ? grid * 4u : grid); }
-static inline dim3 block_dim() { return dim3(g_waves_per_group * 64u); }
+static inline dim3 grid_dim(uint32_t grid, uint32_t waves) { return dim3(waves == 1u ? grid * 4u : grid); }
+static inline dim3 block_dim(uint32_t waves) { return dim3(waves * 64u); }
 
-void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g = grid_dim(grid), b = block_dim();
-    const size_t lds = stack_bytes(a.stack_entries);
+void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+    waves = fit_waves(waves, stack_bytes(a.stack_entries));
+    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
+    const size_t lds = waves * stack_bytes(a.stack_entries);
     if (mode == 1) {
         if (stats) launch(k_trace<true, true>, g, b, lds, stream, a);
         else       launch(k_trace<true, false>, g, b, lds, stream, a);
@@ -1030,9 +1042,11 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipSt
         else       launch(k_trace<false, false>, g, b, lds, stream, a);
     }
 }
-void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g = grid_dim(grid), b = block_dim();
-    const size_t lds = (size_t)g_waves_per_group * a.stack_entries * 64 * sizeof(int);
+void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+    const size_t per_wave = (size_t)a.stack_entries * 64 * sizeof(int);
+    waves = fit_waves(waves, per_wave);
+    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
+    const size_t lds = waves * per_wave;
     if (any) {
         if (stats) launch(k_trace_bvh2<true, true>, g, b, lds, stream, a);
         else       launch(k_trace_bvh2<true, false>, g, b, lds, stream, a);
@@ -1043,10 +1057,12 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hi
 }
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g = grid_dim(grid), b = block_dim();
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
-    const size_t lds = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)g_waves_per_group * a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
+    const size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
+    waves = fit_waves(waves, per_wave);
+    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
+    const size_t lds = waves * per_wave;
     const bool tex = a.textures != nullptr;
 #define CRT_LAUNCH_SEG(F, S, T, P, Y, B) launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a)
 #define CRT_LAUNCH_SEG_T(F, S, P, Y, B) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y, B); else CRT_LAUNCH_SEG(F, S, false, P, Y, B); } while (0)
@@ -1059,15 +1075,17 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
 #undef CRT_LAUNCH_SEG_T
 #undef CRT_LAUNCH_SEG
 }
-void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g = grid_dim(grid), b = block_dim();
-    const size_t lds = stack_bytes(a.stack_entries);
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+    waves = fit_waves(waves, stack_bytes(a.stack_entries));
+    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
+    const size_t lds = waves * stack_bytes(a.stack_entries);
     if (stats) launch(k_closest_queue<true>, g, b, lds, stream, a);
     else       launch(k_closest_queue<false>, g, b, lds, stream, a);
 }
-void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream) {
-    const dim3 g = grid_dim(grid), b = block_dim();
-    const size_t lds = stack_bytes(a.stack_entries);
+void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+    waves = fit_waves(waves, stack_bytes(a.stack_entries));
+    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
+    const size_t lds = waves * stack_bytes(a.stack_entries);
     if (stats) launch(k_shadow<true>, g, b, lds, stream, a);
     else       launch(k_shadow<false>, g, b, lds, stream, a);
 }

@@ -22,6 +22,7 @@ struct TraceArgs {
     uint32_t stack_entries;
     uint32_t refill_min;       // idle lanes that trigger a pool refill (traverse_pool)
     uint32_t tri_min;          // vote ratio of traverse_pool: node step while node-ready lanes >= tri_min x triangle-waiting lanes
+    uint32_t* overflow;        // += 1 per dropped stack push (never happens for a tree crt_scene_create accepted)
 };
 
 struct Bvh2Args {               // the reference's live BVH2 walk (path_trace.fs:511-819) for crt_trace
@@ -33,6 +34,7 @@ struct Bvh2Args {               // the reference's live BVH2 walk (path_trace.fs
     uint32_t n;
     uint32_t tie;              // 0: first visited wins (path_trace.fs:363), 1: lowest original id
     uint32_t stack_entries;    // >= BVH2 depth + 1
+    uint32_t* overflow;
 };
 
 struct PathBuffers {           // indexed by local pixel; touched only by paths longer than one segment
@@ -82,6 +84,7 @@ struct SegmentArgs {
     uint32_t tie;
     uint32_t* zero_counts;     // FIRST: the other frame's counter bank, cleared here for the next frame (no memset launch)
     uint32_t n_zero;
+    uint32_t* overflow;        // += 1 per dropped stack push
 };
 
 struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-written path-ray queue
@@ -95,6 +98,7 @@ struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-writ
     uint32_t refill_min;
     uint32_t tri_min;
     unsigned long long* visit_totals;
+    uint32_t* overflow;
 };
 
 struct ShadowArgs {
@@ -109,15 +113,15 @@ struct ShadowArgs {
     uint32_t refill_min;
     uint32_t tri_min;
     unsigned long long* visit_totals;
+    uint32_t* overflow;
 };
 
-void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, hipStream_t stream);
-void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, hipStream_t stream);
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool stats, uint32_t grid, hipStream_t stream);
-void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, hipStream_t stream);
-void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, hipStream_t stream);
-// 4 (256-thread workgroups) or 1 (every wave its own workgroup); process-wide
-void set_waves_per_workgroup(uint32_t n);
+// waves = waves per workgroup: 1 (every wave its own workgroup) or 4 (256 threads); a per-scene setting
+void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);

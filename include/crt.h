@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 1
+#define CRT_ABI_VERSION 2   /* 2: crt_frame_stats.stack_overflows */
 
 typedef enum crt_status {
     CRT_OK = 0,
@@ -151,7 +151,8 @@ int crt_sync(crt_scene* s);
  *     "oversubscribe"     0 = one 64-ray batch per workgroup, the hardware dispatcher balances (default); k >= 1 =
  *                         persistent grid of k x the resident workgroups with a static schedule, then
  *                         "trace_occupancy" = workgroups per CU
- *     "waves_per_workgroup" 1 (default) or 4; process-wide */
+ *     "waves_per_workgroup" 1 (default) or 4, per scene; a launch whose LDS stacks would exceed 64 KB at 4 waves
+ *                         (a BVH2 deeper than ~60 levels) runs with 1 */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);
@@ -195,6 +196,9 @@ typedef struct crt_frame_stats {
     /* visit totals of the frame's traversal launches; filled only when the option
      * "count_visits" is on (the counting kernels are slower: never time such a frame) */
     uint64_t nodes_closest, tris_closest, nodes_any, tris_any;
+    /* traversal-stack pushes dropped since the scene was created.  crt_scene_create sizes the LDS stack from the
+     * validated depth of the tree, so this is 0 for every scene it accepts; the GPU tests assert it */
+    uint32_t stack_overflows;
 } crt_frame_stats;
 int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out);
 /* structural facts about the device-resident CWBVH */

@@ -241,19 +241,27 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
         for rx, ry in rvs:
             s.render_frame(rx, ry)
         out, st = s.read_sum(), s.frame_stats()
-        s.set_option("waves_per_workgroup", 1)          # process-wide knob: back to the default
+        assert st["stack_overflows"] == 0
         s.close()
         return out, (st["closest_rays"], st["any_rays"])
 
     want, want_counts = run({})
     assert want.max() > 0.1
-    for options in ({"waves_per_workgroup": 4}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
+    # waves_per_workgroup is a per-scene setting: a 4-wave scene next to a 1-wave scene leaves the latter alone
+    other = cr.Scene(data, 64, 64, 1)
+    other.set_option("waves_per_workgroup", 4)
+    got, counts = run({})
+    other.close()
+    assert counts == want_counts and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for options in ({"waves_per_workgroup": 4}, {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
                     {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5},
                     {"bounce_refill": 1}, {"bounce_refill": 1, "refill_min": 1}, {"bounce_refill": 1, "refill_min": 40}, {"inplace_shadow": 0},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
+        ref_opts = options.pop("_ref", None)             # a variant compared with another baseline (the BVH2 frame mode)
+        w, wc = (want, want_counts) if ref_opts is None else run(ref_opts)
         got, counts = run(options)
-        assert counts == want_counts, options
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), options
+        assert counts == wc, options
+        assert np.array_equal(got.view(np.uint32), w.view(np.uint32)), options
 
 
 @pytest.mark.parametrize("T", [16, 24])
@@ -400,7 +408,7 @@ def test_million_triangle_mesh_full_frame(cr, ob, cornell):
         scene.render_frame(rx, ry)
         _, cnt = orc.render_frame(rx, ry, ref, threads=16)
         st = scene.frame_stats()
-        assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1])
+        assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["stack_overflows"] == 0
         assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
         out = scene.read_sum()
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
@@ -513,6 +521,16 @@ def test_scene_input_variants(cr, ob, cornell, cornell_data, scenes):
                 s.trace(rays, cr.CRT_TRACE_BVH2)
             assert e.value.code == _lib.CRT_ERR_INVALID
         s.close()
+    # a corrupted BVH2 leaf is refused even when a valid bvh8 comes with it: the BVH2 walk (accel 1/2, CRT_TRACE_BVH2)
+    # loops over the leaf's slot range
+    leaf = int(np.nonzero(cornell_data.bvh[:, 7] != 0)[0][3])
+    for col, val in ((7, 200.0), (3, float(cornell_data.triangles.shape[0])), (3, -4.0), (7, np.nan), (3, np.nan), (7, 1e30)):
+        bad2 = copy.copy(cornell_data)
+        bad2.bvh = cornell_data.bvh.copy()
+        bad2.bvh[leaf, col] = val
+        with pytest.raises(cr.CrtError) as e:
+            cr.Scene(bad2, 64, 64, 1)
+        assert e.value.code == _lib.CRT_ERR_INVALID and "BVH2" in str(e.value), (col, val)
     # a corrupted caller-supplied CWBVH is refused instead of being walked
     bad = copy.copy(cornell_data)
     bad.bvh8 = cornell_data.bvh8.copy()
@@ -614,7 +632,13 @@ def test_device_cwbvh_conversion_edge_cases_and_errors(cr, cornell):
     bad_link = sb.flat_nodes.copy(); bad_link[1, 3] = 0
     out_of_range = sb.flat_nodes.copy(); out_of_range[np.nonzero(out_of_range[:, 7] != 0)[0][0], 3] = n_slots + 5
     twice = sb.flat_nodes.copy(); leaves = np.nonzero(twice[:, 7] != 0)[0]; twice[leaves[0], 3] = twice[leaves[1], 3]
-    for flat in (big_leaf, bad_link, out_of_range, twice):
+    # links that point outside the array, are negative or NaN: an out-of-bounds read if a pass followed them
+    inner = np.nonzero(sb.flat_nodes[:, 7] == 0)[0]
+    far_link = sb.flat_nodes.copy(); far_link[inner[2], 3] = sb.flat_nodes.shape[0] + 1000
+    neg_link = sb.flat_nodes.copy(); neg_link[inner[1], 3] = -5
+    nan_link = sb.flat_nodes.copy(); nan_link[inner[3], 3] = np.nan
+    huge_link = sb.flat_nodes.copy(); huge_link[inner[0], 3] = 3e38
+    for flat in (big_leaf, bad_link, out_of_range, twice, far_link, neg_link, nan_link, huge_link):
         for device in (False, True):
             with pytest.raises(cr.CrtError) as e:
                 cr.CWBVH().convert_arrays(flat, n_slots, device=device)

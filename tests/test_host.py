@@ -83,6 +83,16 @@ def test_loader_semantics_on_handwritten_obj(cr, tmp_path):
     np.testing.assert_allclose(L[15:18], [np.sqrt(68.0), 1.0, 0.0], rtol=1e-6)   # |u x v|, pdf = area / sum
 
 
+def test_loader_short_m_lines_are_not_read_past_their_end(cr, tmp_path):
+    """Scene.h:890-899 takes the first line that starts with 'm' as `mtllib` and skips six characters; a shorter line
+    has nothing behind them (no read past the terminator)."""
+    (tmp_path / "m.mtl").write_text("newmtl A\nKd 0.5 0.25 0.125\nKe 0 0 0\n")
+    (tmp_path / "s.obj").write_text("m\nmtl\nmtllib\nmtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nusemtl A\nf 1//1 2//1 3//1\n")
+    m = cr.Mesh.read_object(str(tmp_path / "s.obj"))
+    assert m.triangles.shape[0] == 1 and m.materials.shape[0] == 1
+    np.testing.assert_allclose(m.materials[0][:3], [0.5, 0.25, 0.125])
+
+
 def test_sbvh_cornell_known_answers(cr, cornell, survey):
     mesh, _ = cornell
     b = cr.SBVH(mesh.triangles, mesh.vertices)

@@ -75,6 +75,15 @@ def test_refused_and_damaged_files(host):
         with pytest.raises(cr.CrtError) as e:
             host.decode_image(data)
         assert e.value.code == _lib.CRT_ERR_INVALID
+    # headers of a few bytes that claim gigabytes of pixels are refused before anything is allocated
+    import struct
+    huge_png = bytearray(png); huge_png[16:24] = struct.pack(">II", 30000, 30000)
+    huge_tga = bytearray(T.write_tga(rgb)); huge_tga[12:16] = struct.pack("<HH", 30000, 30000)
+    huge_rle = bytearray(huge_tga); huge_rle[2] = 10
+    for data in (bytes(huge_png), bytes(huge_tga), bytes(huge_rle)):
+        with pytest.raises(cr.CrtError) as e:
+            host.decode_image(data)
+        assert e.value.code == _lib.CRT_ERR_INVALID
 
 
 @pytest.mark.parametrize("size", [(256, 256), (300, 300), (512, 384), (100, 70), (256, 100), (64, 512), (1, 1), (257, 255), (3, 1000)])
