@@ -1,24 +1,42 @@
 #!/usr/bin/env python3
 """bench.py — Mray/s of the HIP ray/BVH-traversal hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|mesh1m|meshN] [--depth D]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--workload auto|cornell|mesh1m|meshN] [--depth D] [--resolution WxH] [--spp S] [--scaling strong|weak]
 
-One step = one pass of the hot path over one batch: one sample per pixel of this rank's tiles
-(ray generation -> CWBVH closest-hit -> shade/NEE -> CWBVH any-hit -> accumulate), everything
-resident in HBM.  Default workload = BASELINE.json configs[1]: Cornell box, CWBVH, 1 spp,
-primary + shadow, 1920x1080 on one GPU.  N > 1 (launched by torch.distributed.run, one rank per
-GPU, RCCL) shards framebuffer tiles over the ranks with no data-path collective (weak scaling: the
-frame grows with N so every rank keeps ~1920x1080 pixels) and gathers the per-tile radiance to rank 0
-once, inside the timed region, at read-back.
+One step = one pass of the hot path over one batch of the workload: `spp_per_step` samples per pixel of this rank's
+tiles (ray generation -> CWBVH closest hit -> shading / NEE -> CWBVH any hit -> accumulate), everything resident in HBM.
 
-Prints ONE JSON line on rank 0 with the driver's keys plus "roofline" (dominant kernel = the
-closest-hit traversal: algorithmic bytes of SURVEY §8d / hipEvent launch time on the kernel's own
-stream) and "cpu_baseline" (the CPU oracle on the same workload, bounded sample, rank 0, N = 1).
+Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
+  N = 1, --workload auto (the default):
+    value / roofline / cpu_baseline  = configs[1]: Cornell box, CWBVH, 1 spp primary + shadow, 1920x1080;
+    "north_star"                     = configs[2]: the 1,004,672-triangle mesh, 4 spp per step, 1920x1080, primary + shadow —
+                                       the workload BASELINE.json's targets are quoted on, with its own roofline and cpu_baseline;
+    "incoherent"                     = configs[3]: same mesh, 4 path segments (incoherent bounce rays);
+    "scale_base"                     = configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines
+                                       divide by).
+  N > 1, --workload auto: configs[4]: ONE fixed 3840x2160 frame of the 1 M-triangle mesh, 4 spp per step, its 64x64 tiles dealt
+    to the N ranks (strong scaling, no data-path collective), one RCCL gather of the per-tile radiance to rank 0 inside the timed
+    region; "n1_same_workload" is the same frame rendered by rank 0 alone in the same job.  `--scaling weak` keeps the round-1
+    behaviour (the frame grows with N, ~1920x1080 pixels per rank).
+  An explicit --workload measures just that one (used by the profiling scripts).
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts its N ranks itself, as fresh child processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE anything touches the GPU,
+forwards rank 0's JSON line and exits with the children's status; launched under torch.distributed.run by someone else it
+simply is one of the ranks.
+
+Prints ONE JSON line on rank 0 with the driver's keys plus "roofline" (dominant kernel = the fused segment kernel:
+algorithmic bytes of SURVEY §8d / HIP-event launch time on the kernel's own stream; the committed --pmc pass supplies the
+L2<->fabric traffic and the VALU-issue fraction, which is the real ceiling of this kernel) and "cpu_baseline" (the CPU oracle on
+the same workload, bounded sample, rank 0, N = 1).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,14 +45,77 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, MI355X_MICROARCH.md "Chip-level parameters"
 NODE_BYTES, TRI_BYTES, FB_BYTES = 80, 52, 24   # SURVEY.md §8d algorithmic bytes per node fetch / triangle test / pixel-sample
+METRIC = "Mray/s (primary+1 bounce) at 1920x1080"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(name, builder="sbvh", convert="host"):
-    import numpy as np
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="auto", help="auto (see the module docstring), cornell, mesh1m or meshN (tessellation n)")
+    ap.add_argument("--depth", type=int, default=1, help="path segments per sample (1 = primary + shadow)")
+    ap.add_argument("--resolution", default=None, help="WxH; default 1920x1080 (3840x2160 for N > 1 strong scaling)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (default: 1 for cornell, 4 for the mesh workloads)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = one fixed frame split over the ranks (configs[4], default); weak = the frame grows with N")
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--builder", default="sbvh", choices=["sbvh", "lbvh"],
+                    help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build)")
+    ap.add_argument("--convert", default="host", choices=["host", "device"],
+                    help="BVH2 -> CWBVH conversion on the host (default) or on the GPU (crt_cwbvh_convert_device, same bytes)")
+    ap.add_argument("--accel", default="cwbvh", choices=["cwbvh", "bvh2"],
+                    help="cwbvh = the 8-wide compressed BVH (default, the metric's configuration); bvh2 = frames through the "
+                         "reference's live BVH2 walk (path_trace.fs:511-819), for comparison")
+    ap.add_argument("--materials", default="lambert", choices=["lambert", "disney"],
+                    help="mesh workloads: lambert = the reference's only BSDF (default); disney = the boxes get the GGX / Disney-diffuse "
+                         "material of configs[3] (oracle-defined, no reference code)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="crt_set_option passthrough (tuning experiments)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="auto workload: only the headline block")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
+                         "(what the CPU tests exercise); the line says dry_run and reports no throughput")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+
+def self_launch(args):
+    """Plain `python bench.py --gpus N`: start the N ranks as fresh children before this process has made a single GPU call
+    (a process that initialised the GPU must never be replaced or forked), forward rank 0's line, return the exit status."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}")
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    if run.returncode == 0 and len(lines) != 1:
+        log(f"[bench] expected one JSON line from rank 0, got {len(lines)}")
+        return 1
+    for l in lines:
+        print(l, flush=True)
+    return run.returncode
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+
+_SCENE_CACHE = {}
+
+
+def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
+    key = (name, builder, convert, materials)
+    if key in _SCENE_CACHE:
+        return _SCENE_CACHE[key]
     import __graft_entry__ as g
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd.meshgen import tessellated_cornell
@@ -44,207 +125,234 @@ def build_workload(name, builder="sbvh", convert="host"):
         n = 183 if name == "mesh1m" else int(name[4:])
         mesh = tessellated_cornell(mesh, n)
         label = f"procedural tessellated Cornell n={n}: {mesh.triangles.shape[0]} tris, CWBVH"
+    if materials == "disney":
+        from caitlynrenderer_amd.meshgen import with_disney_materials
+        mesh = with_disney_materials(mesh)
+        label += ", GGX/Disney-diffuse boxes"
     t0 = time.time()
     data = cr.SceneData.build(mesh, cam, builder=builder, convert=convert)
     if builder == "lbvh":
         label += " over a GPU-built LBVH"
     if convert == "device":
         label += ", CWBVH converted on the GPU"
-    return data, cam, label, time.time() - t0
+    _SCENE_CACHE[key] = (data, cam, label, time.time() - t0)
+    return _SCENE_CACHE[key]
 
 
-def frame_size(n_gpus):
+def weak_frame_size(n_gpus):
     if n_gpus == 1:
         return 1920, 1080
     w = int(round(1920 * math.sqrt(n_gpus) / 16.0)) * 16
     return w, int(round(w * 9 / 16))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cornell")
-    ap.add_argument("--depth", type=int, default=1, help="path segments per sample (1 = primary + shadow)")
-    ap.add_argument("--tile", type=int, default=64)
-    ap.add_argument("--builder", default="sbvh", choices=["sbvh", "lbvh"],
-                    help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build)")
-    ap.add_argument("--convert", default="host", choices=["host", "device"],
-                    help="BVH2 -> CWBVH conversion on the host (default) or on the GPU (crt_cwbvh_convert_device, same bytes)")
-    ap.add_argument("--accel", default="cwbvh", choices=["cwbvh", "bvh2"],
-                    help="cwbvh = the 8-wide compressed BVH (default, the metric's configuration); bvh2 = frames through the "
-                         "reference's live BVH2 walk (path_trace.fs:511-819), for comparison")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Ctx:
+    """Rank / world / collective plumbing shared by every block of one run."""
 
-    # stdout carries exactly ONE JSON line: anything a library prints there (RCCL's version banner at
-    # communicator creation, for one) is sent to stderr instead
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.use_dist = "RANK" in os.environ       # launched by torch.distributed.run (also at N = 1: same code path)
+        self.device = "cpu" if args.dry_run else "cuda"
 
+    def init(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        if not self.args.dry_run:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU: the traversal path has no CPU fallback")
+            torch.cuda.set_device(self.local_rank)
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.args.dry_run:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+
+    def barrier(self, scene=None):
+        if self.use_dist:
+            self.dist.barrier()
+        if not self.args.dry_run:
+            self.torch.cuda.synchronize()
+        if scene is not None:
+            scene.sync()
+
+    def max_over_ranks(self, x):
+        if not self.use_dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if not self.use_dist:
+            return x
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.use_dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def pmc_entry(workload, depth):
+    """What the committed rocprofv3 --pmc passes say about this workload's dominant kernel (tools/pmc_traffic.py)."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(tpath)).get(f"{workload}_d{depth}", {})
+    except Exception:
+        return {}
+
+
+def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling):
+    """Measure one workload: returns the dict of the bench line for it (rank 0) or None (other ranks)."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the traversal path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also at N = 1: same code path)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    import __graft_entry__ as g
-    g.build()
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd import tiles
+    args, torch = ctx.args, ctx.torch
+    rank, world = (ctx.rank, ctx.world) if sharded else (0, 1)
+    takes_part = sharded or ctx.rank == 0
+    use_dist = ctx.use_dist and sharded
+    K, Wu = args.steps, args.warmup
 
-    data, cam, label, build_s = build_workload(args.workload, args.builder, args.convert)
-    W, H = frame_size(world)
-    scene = cr.Scene(data, W, H, args.depth)
-    scene.set_shard(rank, world, args.tile)
-    if args.accel == "bvh2":
-        scene.set_option("accel", 1)
-        label = label.replace("CWBVH", "BVH2 walked as the shipped shader does")
-    info = scene.bvh_info()
-    if rank == 0:
-        log(f"[bench] {label}; {W}x{H}, depth {args.depth}, {world} rank(s); BVH build {build_s:.1f}s; "
-            f"{info['n_nodes8']} node8, {info['n_tris8']} tris, depth {info['max_depth8']}")
+    out = None
+    if takes_part:
+        data, cam, label, build_s = build_workload(name, args.builder, args.convert, args.materials)
+        scene = cr.Scene(data, W, H, depth)
+        scene.set_shard(rank, world, args.tile)
+        for kv in args.option:
+            k, v = kv.split("=")
+            scene.set_option(k, int(v))
+        if args.accel == "bvh2":
+            scene.set_option("accel", 1)
+            label = label.replace("CWBVH", "BVH2 walked as the shipped shader does")
+        info = scene.bvh_info()
+        if ctx.rank == 0:
+            log(f"[bench] {label}; {W}x{H}, depth {depth}, {spp} spp/step, {world} rank(s); BVH build {build_s:.1f}s; "
+                f"{info['n_nodes8']} node8, {info['n_tris8']} tris, depth {info['max_depth8']}")
+        rnd = cr.Rnd()
+        rvs = [(rnd.randf2(), rnd.randf2()) for _ in range((Wu + K) * spp + 1)]
 
-    rnd = cr.Rnd()
-    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(args.warmup + args.steps + 1)]
+        # ---- untimed: algorithmic bytes of one frame (visit counters from the counting kernels) ----
+        scene.set_option("count_visits", 1)
+        scene.render_frame(*rvs[0])
+        cs = scene.frame_stats()
+        scene.set_option("count_visits", 0)
+        scene.reset()
 
-    # ---- untimed: algorithmic bytes of one step (visit counters from the counting kernels) ----
-    scene.set_option("count_visits", 1)
-    scene.render_frame(*rvs[0])
-    cs = scene.frame_stats()
-    scene.set_option("count_visits", 0)
-    scene.reset()
-
-    _, tile, n_floats = scene.packed_info()
-    gather_buf = torch.zeros(tiles.max_local_tiles(W, H, tile, world) * tile * tile * 3, dtype=torch.float32, device="cuda")
-    recv = torch.empty(world * gather_buf.numel(), dtype=torch.float32, device="cuda") if (use_dist and rank == 0) else None
-
-    def barrier():
+        _, tile, n_floats = scene.packed_info()
+        gather_buf = recv = None
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+            gather_buf = torch.zeros(tiles.max_local_tiles(W, H, tile, world) * tile * tile * 3, dtype=torch.float32, device="cuda")
+            recv = torch.empty(world * gather_buf.numel(), dtype=torch.float32, device="cuda") if rank == 0 else None
+
+        def read_back():
+            """RCCL gather over xGMI of the per-tile radiance to rank 0 (at read-back only)."""
+            scene.copy_packed_device(gather_buf.data_ptr(), n_floats)
+            tiles.gather_packed_to_root(gather_buf, recv, world)
+
+        for i in range(Wu * spp):
+            scene.render_frame(*rvs[1 + i], sync=False)
         scene.sync()
+        if use_dist:    # warm the collective too
+            read_back()
+        # HIP events on every segment launch of the timed region, on the scene's own stream (attached to the dispatch:
+        # they take the kernel's own start/stop timestamps)
+        scene.set_option("timing", 1)
+        scene.set_option("timing_accumulate", K * spp * max(1, depth))
+    if sharded:
+        ctx.barrier(scene)
+    elif takes_part:
+        torch.cuda.synchronize(); scene.sync()
+    if takes_part:
+        t0 = time.perf_counter()
+        for i in range(K * spp):
+            scene.render_frame(*rvs[1 + Wu * spp + i], sync=False)
+        scene.sync()
+        if use_dist:
+            read_back()
+    if sharded:
+        ctx.barrier(scene)
+    if takes_part:
+        if not sharded:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if sharded:
+            dt = ctx.max_over_ranks(dt)
 
-    def read_back():
-        """RCCL gather over xGMI of the per-tile radiance to rank 0 (at read-back only)."""
-        scene.copy_packed_device(gather_buf.data_ptr(), n_floats)
-        tiles.gather_packed_to_root(gather_buf, recv, world)
+        # ray counts of the LAST timed frame (every frame does identical work up to the per-frame random vector) and
+        # the mean launch time over the timed region; then a short event-timed tail for the per-kernel split
+        st = scene.frame_stats()
+        launch_ms_timed = st["ms_trace_closest"] / max(1, st["n_trace_launches"])
+        n_timed_launches = st["n_trace_launches"]
+        scene.set_option("timing_accumulate", 0)
+        scene.set_option("timing", 2)
+        any_ms, total_ms = [], []
+        for i in range(min(10, K * spp)):
+            scene.render_frame(*rvs[1 + Wu * spp + i])
+            s = scene.frame_stats()
+            any_ms.append(s["ms_trace_any"] / max(1, depth))
+            total_ms.append(s["ms_total"])
+        rays_frame = st["closest_rays"] + st["any_rays"]
+        rays_all = ctx.sum_over_ranks(rays_frame) if sharded else float(rays_frame)
+        value = rays_all * K * spp / dt / 1e6
 
-    for i in range(args.warmup):
-        scene.render_frame(*rvs[1 + i], sync=False)
-    scene.sync()
-    if use_dist:    # warm the collective too
-        read_back()
-    # HIP events on every closest-hit launch of the timed region, on the scene's own stream (attached to the dispatch:
-    # they take the kernel's own start/stop timestamps); the any-hit launches are timed in the untimed tail below
-    scene.set_option("timing", 1)
-    scene.set_option("timing_accumulate", args.steps * max(1, args.depth))
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        scene.render_frame(*rvs[1 + args.warmup + i], sync=False)
-    scene.sync()
-    if use_dist:
-        read_back()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # per-step ray counts and per-kernel device time of the LAST timed step (all steps do identical work
-    # up to the per-frame random vector); then a short event-timed tail for a stable launch average
-    st = scene.frame_stats()
-    launch_ms_timed = st["ms_trace_closest"] / max(1, st["n_trace_launches"])   # mean over the timed region's launches
-    n_timed_launches = st["n_trace_launches"]
-    scene.set_option("timing_accumulate", 0)
-    scene.set_option("timing", 2)
-    any_ms, total_ms = [], []
-    for i in range(min(10, args.steps)):
-        scene.render_frame(*rvs[1 + args.warmup + i])
-        s = scene.frame_stats()
-        any_ms.append(s["ms_trace_any"] / max(1, args.depth))
-        total_ms.append(s["ms_total"])
-    rays_step = st["closest_rays"] + st["any_rays"]
-    if use_dist:
-        t = torch.tensor([float(rays_step)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        rays_all = float(t.item())
-    else:
-        rays_all = float(rays_step)
-    value = rays_all * args.steps / dt / 1e6
-
-    if rank == 0:
-        launches = max(1, args.depth)
+    if takes_part and ctx.rank == 0:
+        launches = max(1, depth)
         node_bytes = 96 if args.accel == "bvh2" else NODE_BYTES      # SURVEY 8a-1: own 2 texels + 4 child texels per BVH2 visit
-        alg_closest = (node_bytes * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches
-        # tiny trees: k_segment also walks the NEE shadow rays (no k_shadow launch), so their visits are this launch's bytes too
+        alg = (node_bytes * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches
+        # the segment kernel also walks the NEE shadow rays in place (no k_shadow launch): their visits are this launch's bytes too
         fused_shadow = st["any_rays"] > 0 and float(np.median(any_ms)) == 0.0
         if fused_shadow:
-            alg_closest += (node_bytes * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches
-        t_closest = launch_ms_timed * 1e-3
-        achieved = alg_closest / t_closest / 1e9 if t_closest > 0 else 0.0
+            alg += (node_bytes * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches
+        t_launch = launch_ms_timed * 1e-3
+        achieved = alg / t_launch / 1e9 if t_launch > 0 else 0.0
         if fused_shadow:
-            kernel_label = "k_segment (raygen + CWBVH closest hit + shading + in-place NEE any-hit walk)"
-        elif args.depth > 1:
-            kernel_label = ("closest-hit launches, mean per path segment: k_segment (raygen + closest hit + shading + queue emission) "
-                            "for segment 0, k_closest_queue (lane-refill pools) + k_segment<PRETRACED> (shading) for bounce segments")
+            kernel_label = "k_segment (raygen / queue fetch + CWBVH closest hit + shading + in-place NEE any-hit walk), mean per path segment"
         else:
-            kernel_label = "k_segment (raygen + CWBVH closest hit + shading + queue emission)"
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from a separate rocprofv3 --pmc pass
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}_d{args.depth}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "Mray/s (primary+1 bounce) at 1920x1080",
-            "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": 1, "path_segments": args.depth,
-                       "rays_per_step": int(rays_all), "closest_rays_rank0": int(st["closest_rays"]),
-                       "any_rays_rank0": int(st["any_rays"]), "tile": tile, "parallelism": f"tiles/{world}",
-                       "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
-            "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg_closest),
-                         "bytes_per_ray": round(alg_closest / max(1, (cs["closest_rays"] + (cs["any_rays"] if fused_shadow else 0)) / launches), 2),
-                         "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3),
-                         "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
-                         "any_hit_nodes_per_ray": round(cs["nodes_any"] / max(1, cs["any_rays"]), 3),
-                         "any_hit_tris_per_ray": round(cs["tris_any"] / max(1, cs["any_rays"]), 3),
-                         "launch_ms": round(t_closest * 1e3, 4), "launches_timed": int(n_timed_launches),
-                         "any_hit_launch_ms": round(float(np.median(any_ms)), 4),
-                         "frame_device_ms": round(float(np.median(total_ms)), 4),
-                         "note": ("working set fits the 256 MiB Infinity Cache: measured HBM traffic << algorithmic bytes; the kernel is VALU-issue bound"
-                                  + ("; this tree of %d nodes lives in L1, so the algorithmic-bytes rate can exceed the HBM peak" % info["n_nodes8"]
-                                     if info["n_nodes8"] < 64 else ""))},
+            kernel_label = "k_segment (raygen / queue fetch + CWBVH closest hit + shading + queue emission), mean per path segment"
+        pmc = pmc_entry(name, depth)
+        traffic = pmc.get("l2_fabric_bytes_per_launch", pmc.get("hbm_bytes_per_launch"))
+        roofline = {
+            "bound": "hbm", "kernel": kernel_label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "traffic_is": "L2<->fabric bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the committed --pmc passes of this "
+                          "workload (profiles/pmc_traffic.json); the scene sits in the 256 MiB Infinity Cache, so true HBM bytes are lower still",
+            "limiter": "valu_issue",
+            "valu_issue": pmc.get("valu_issue"),
+            "algorithmic_bytes_per_launch": int(alg),
+            "bytes_per_ray": round(alg / max(1, (cs["closest_rays"] + (cs["any_rays"] if fused_shadow else 0)) / launches), 2),
+            "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3),
+            "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
+            "any_hit_nodes_per_ray": round(cs["nodes_any"] / max(1, cs["any_rays"]), 3),
+            "any_hit_tris_per_ray": round(cs["tris_any"] / max(1, cs["any_rays"]), 3),
+            "launch_ms": round(t_launch * 1e3, 4), "launches_timed": int(n_timed_launches),
+            "any_hit_launch_ms": round(float(np.median(any_ms)), 4),
+            "frame_device_ms": round(float(np.median(total_ms)), 4),
+            "note": ("frac = SURVEY §8d algorithmic bytes / launch time / HBM peak; the kernel itself is bound by VALU issue (valu_issue.frac = "
+                     "issue slots busy x lanes enabled, from the PMC pass), not by HBM"
+                     + ("; this tree of %d nodes lives in L1, so the algorithmic-bytes rate says nothing about the memory system" % info["n_nodes8"]
+                        if info["n_nodes8"] < 64 else "")),
         }
-        if not args.no_cpu_baseline and world == 1 and args.accel == "cwbvh":
-            out["cpu_baseline"] = cpu_baseline(data, cam, W, H, args.depth, rvs[0], cs)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    scene.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        out = {
+            "value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling,
+            "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": spp, "path_segments": depth,
+                       "rays_per_step": int(rays_all) * spp, "closest_rays_rank0": int(st["closest_rays"]),
+                       "any_rays_rank0": int(st["any_rays"]), "tile": tile, "parallelism": f"tiles/{world}",
+                       "stack_overflows": int(st["stack_overflows"]),
+                       "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
+            "roofline": roofline,
+        }
+        if cpu_base and not args.no_cpu_baseline and args.accel == "cwbvh":
+            out["cpu_baseline"] = cpu_baseline(data, cam, W, H, depth, rvs[0], cs)
+    if takes_part:
+        scene.close()
+    return out
 
 
 def cpu_baseline(data, cam, W, H, depth, rv, cs):
@@ -287,6 +395,108 @@ def cpu_baseline(data, cam, W, H, depth, rv, cs):
             "single_thread_value": round(rate / 1e6, 3),          # one thread, 8 pixel rows through the image centre
             "sample": f"rows {y0}..{y1} of {H} ({rays} rays, same frame and CWBVH as the GPU step)",
             "visit_counters_match_gpu": check}
+
+
+def dry_block(ctx, W, H, spp, scaling):
+    """--dry-run: everything around the rendering — shard bookkeeping, the gather of packed tile buffers of the real
+    size over the process group, barrier + max-over-ranks timing — with no GPU and no rendering."""
+    from caitlynrenderer_amd import tiles
+    torch, args = ctx.torch, ctx.args
+    tile = args.tile
+    cap = tiles.max_local_tiles(W, H, tile, ctx.world) * tile * tile * 3
+    mine = tiles.local_tiles(W, H, tile, ctx.rank, ctx.world)
+    send = torch.full((cap,), float(ctx.rank + 1), dtype=torch.float32)
+    recv = torch.empty(ctx.world * cap, dtype=torch.float32) if ctx.rank == 0 else None
+    ctx.barrier()
+    t0 = time.perf_counter()
+    if ctx.use_dist:
+        tiles.gather_packed_to_root(send, recv, ctx.world)
+    ctx.barrier()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
+    n_tiles = ctx.sum_over_ranks(len(mine))
+    if ctx.rank != 0:
+        return None
+    if ctx.use_dist:
+        got = recv.view(ctx.world, cap)
+        assert all(float(got[r][0]) == r + 1 and float(got[r][-1]) == r + 1 for r in range(ctx.world)), "gather delivered the wrong slices"
+    assert int(n_tiles) == len(tiles.tile_order(W, H, tile)), "the shards do not cover the frame exactly once"
+    return {"value": 0.0, "unit": "Mray/s", "ms_per_step": round(dt * 1e3, 4), "scaling": scaling, "dry_run": True,
+            "config": {"workload": "dry run: no rendering", "resolution": f"{W}x{H}", "spp_per_step": spp, "tile": tile,
+                       "tiles": int(n_tiles), "parallelism": f"tiles/{ctx.world}", "gather_floats_per_rank": cap},
+            "roofline": None}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+
+    # stdout carries exactly ONE JSON line: anything a library prints there (RCCL's version banner at
+    # communicator creation, for one) is sent to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    ctx = Ctx(args)
+    if ctx.world != args.gpus:
+        args.gpus = ctx.world
+    ctx.init()
+    if not args.dry_run:
+        import __graft_entry__ as g
+        g.build()
+
+    N = ctx.world
+    auto = args.workload == "auto"
+    if N == 1:
+        name = "cornell" if auto else args.workload
+        scaling = "weak"              # one GPU: per-GPU work is what it is
+        W, H = 1920, 1080
+    elif args.scaling == "strong":
+        name = "mesh1m" if auto else args.workload
+        scaling = "strong"
+        W, H = 3840, 2160
+    else:
+        name = "cornell" if auto else args.workload
+        scaling = "weak"
+        W, H = weak_frame_size(N)
+    if args.resolution:
+        W, H = (int(x) for x in args.resolution.lower().split("x"))
+    spp = args.spp or (1 if name == "cornell" else 4)
+
+    if args.dry_run:
+        head = dry_block(ctx, W, H, spp, scaling)
+        extra = {}
+    else:
+        head = run_block(ctx, name, W, H, args.depth, spp, True, N == 1, scaling)
+        extra = {}
+        if auto and not args.no_extra and args.accel == "cwbvh":
+            if N == 1:
+                extra["north_star"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, True, "weak")
+                extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak")
+                extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
+            elif args.scaling == "strong":
+                ctx.barrier()
+                extra["n1_same_workload"] = run_block(ctx, name, W, H, args.depth, spp, False, False, "strong")
+                ctx.barrier()
+
+    if ctx.rank == 0:
+        out = {"metric": METRIC, "value": head["value"], "unit": head["unit"], "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if head.get("dry_run"):
+            out["dry_run"] = True
+        descr = {"north_star": "BASELINE.json configs[2] — the workload its targets (>= 1 Gray/s, >= 50 % HBM roofline) are quoted on",
+                 "incoherent": "BASELINE.json configs[3] — 4 path segments on the same mesh",
+                 "scale_base": "BASELINE.json configs[4] at N = 1: what the N > 1 lines of `bench.py --gpus N` divide by",
+                 "n1_same_workload": "the same frame rendered by rank 0 alone in this job (strong-scaling base)"}
+        for k, v in extra.items():
+            if v is not None:
+                v["what"] = descr[k]
+                out[k] = v
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -384,15 +384,21 @@ def test_cpp_host_scene_matches_python_path(cr, ob, cornell, tmp_path):
     scene.close()
 
 
-def test_million_triangle_mesh_full_frame(cr, ob, cornell):
-    """BASELINE config 3 geometry (1,004,672 triangles, 4 frames = 4 spp) at 1920x1080, 2 segments: radiance
-    bit-identical to the oracle after every frame, ray counts and visit counters equal; plus the
-    size-independent property that any-hit agrees with closest-hit on every shadow ray of the last frame."""
+@pytest.fixture(scope="module")
+def mesh1m(cr, cornell):
+    """BASELINE configs[2..4] geometry: the 1,004,672-triangle tessellated Cornell box, built once."""
     from caitlynrenderer_amd.meshgen import tessellated_cornell
     mesh, cam = cornell
     big = tessellated_cornell(mesh, 183)
     assert big.triangles.shape[0] == 1004672 and big.vertices.shape[0] == 507844
-    data = cr.SceneData.build(big, cam)
+    return big, cr.SceneData.build(big, cam), cam
+
+
+def test_million_triangle_mesh_full_frame(cr, ob, mesh1m):
+    """BASELINE config 3 geometry (1,004,672 triangles, 4 frames = 4 spp) at 1920x1080, 2 segments: radiance
+    bit-identical to the oracle after every frame, ray counts and visit counters equal; plus the
+    size-independent property that any-hit agrees with closest-hit on every shadow ray of the last frame."""
+    big, data, cam = mesh1m
     dev = cr.CWBVH().convert_arrays(data.bvh, data.triangles.shape[0], device=True)    # the device converter at full size
     assert np.array_equal(dev.nodes, data.bvh8) and np.array_equal(dev.tri_slots, data.bvh8_tri_slots)
     W, H = 1920, 1080
@@ -427,6 +433,63 @@ def test_million_triangle_mesh_full_frame(cr, ob, cornell):
     c = scene.trace(far, cr.CRT_TRACE_CLOSEST)
     assert np.array_equal(occ, (c["tri"] >= 0) & (c["t"] < shadow["tmax"]))
     scene.close()
+
+
+def test_config4_million_triangles_four_segments(cr, ob, mesh1m):
+    """BASELINE configs[3] at full size: the 1,004,672-triangle CWBVH, 4 path segments (incoherent bounce rays), 1920x1080.
+    Two frames; after each the accumulated radiance is bit-identical to the oracle's, the closest / any-hit ray counts and the
+    node / triangle visit totals are equal, and no stack push was dropped.  (The reference has no BSDF but Lambert —
+    path_trace.fs:274-310 — so this is its integrator run one segment longer than the shader's hard-coded 3, :867.)"""
+    _, data, cam = mesh1m
+    W, H, depth = 1920, 1080, 4
+    scene = cr.Scene(data, W, H, depth)
+    orc = ob.Oracle(data, W, H, depth, cam)
+    scene.set_option("count_visits", 1)
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    for frame in range(2):
+        rx, ry = rnd.randf2(), rnd.randf2()
+        scene.render_frame(rx, ry)
+        _, cnt = orc.render_frame(rx, ry, ref, threads=16)
+        st = scene.frame_stats()
+        assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and cnt[0] > 5_000_000 and st["stack_overflows"] == 0
+        assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
+        out = scene.read_sum()
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
+    scene.close()
+
+
+def test_config5_4k_frame_of_the_million_triangle_mesh(cr, ob, mesh1m):
+    """BASELINE configs[4]'s workload: the 3840x2160 frame (2,040 tiles of 64x64) of the 1,004,672-triangle mesh.  The whole
+    frame on one rank and ranks 0, 3 and 7 of 8 are each bit-identical to the oracle on their pixels (ray counts included for the
+    full frame); the eight shards are disjoint and cover the frame, so composing them is the single-GPU frame."""
+    from caitlynrenderer_amd import tiles
+    _, data, cam = mesh1m
+    W, H = 3840, 2160
+    orc = ob.Oracle(data, W, H, 1, cam)
+    ref, cnt = orc.render_frame(RX1, RY1, threads=16)
+    full = cr.Scene(data, W, H, 1)
+    full.render_frame(RX1, RY1)
+    st = full.frame_stats()
+    assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and cnt[0] == W * H and st["stack_overflows"] == 0
+    assert np.array_equal(full.read_sum().view(np.uint32), ref.view(np.uint32))
+    full.close()
+    covered = np.zeros((H, W), np.int32)
+    for r in range(8):
+        for tx, ty in tiles.local_tiles(W, H, 64, r, 8):
+            covered[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] += 1
+    assert (covered == 1).all()
+    for r in (0, 3, 7):
+        shard = cr.Scene(data, W, H, 1)
+        shard.set_shard(r, 8, 64)
+        shard.render_frame(RX1, RY1)
+        part = shard.read_sum()
+        mine = np.zeros((H, W), bool)
+        for tx, ty in tiles.local_tiles(W, H, 64, r, 8):
+            mine[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = True
+        assert np.array_equal(part[mine].view(np.uint32), ref[mine].view(np.uint32)) and not part[~mine].any(), r
+        assert shard.packed_info()[0] == len(tiles.local_tiles(W, H, 64, r, 8)) == 255
+        shard.close()
 
 
 @pytest.mark.parametrize("name", ["cornell", "tess40"])
@@ -793,7 +856,8 @@ def test_graph_replay_measurement_aid(cr, scenes):
 
 
 def test_bench_line_contract(tmp_path):
-    """bench.py prints exactly one JSON line with the driver's fields, the roofline object and the CPU baseline."""
+    """`python bench.py` (N = 1): exactly one JSON line with the driver's fields for configs[1], the roofline object, the CPU
+    baseline, and the blocks for the 1 M-triangle workloads (configs[2], [3], [4] at N = 1) each with their own roofline."""
     import json
     import os
     import subprocess
@@ -808,10 +872,42 @@ def test_bench_line_contract(tmp_path):
         assert k in d, k
     assert d["unit"] == "Mray/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["achieved"] > 0 and r["launch_ms"] > 0 and r["launches_timed"] == 6 and (r["traffic"] is None or r["traffic"] > 0)
+    assert "cornell-box 32 tris" in d["config"]["workload"] and "model" not in d["config"] and d["config"]["stack_overflows"] == 0
+
+    def check_roofline(r, launches):
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["achieved"] > 0 and r["launch_ms"] > 0 and r["launches_timed"] == launches and (r["traffic"] is None or r["traffic"] > 0)
+        assert r["limiter"] == "valu_issue" and (r["valu_issue"] is None or 0 < r["valu_issue"]["frac"] <= 1)
+    check_roofline(d["roofline"], 6)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mray/s" and c["cores"] >= 1 and c["value"] > 0 and c["visit_counters_match_gpu"] is True
     assert d["value"] > 1000 and abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) / d["value"] < 0.01
+    # the north-star workload rides in the same line
+    ns = d["north_star"]
+    assert "1004672 tris" in ns["config"]["workload"] and ns["config"]["resolution"] == "1920x1080" and ns["config"]["spp_per_step"] == 4
+    assert ns["value"] > 1000 and ns["cpu_baseline"]["value"] > 0 and ns["config"]["stack_overflows"] == 0
+    assert abs(ns["value"] - ns["config"]["rays_per_step"] / ns["ms_per_step"] / 1e3) / ns["value"] < 0.01
+    check_roofline(ns["roofline"], 24)
+    assert d["incoherent"]["config"]["path_segments"] == 4 and d["incoherent"]["value"] > 500
+    check_roofline(d["incoherent"]["roofline"], 24)
+    sb = d["scale_base"]
+    assert sb["config"]["resolution"] == "3840x2160" and sb["scaling"] == "strong" and sb["value"] > 1000
+
+
+def test_bench_self_launch_under_rccl_on_one_gpu(tmp_path):
+    """The N > 1 code path (process group over RCCL, sharding, gather inside the timed region, the rank-0-alone base) at the only
+    world size a 1-GPU box allows: launched under torch.distributed.run with one rank, configs[4]'s workload requested explicitly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "mesh40", "--resolution", "3840x2160",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["resolution"] == "3840x2160" and d["config"]["spp_per_step"] == 4
+    assert "RCCL gather" in d["config"]["gather"] and d["value"] > 1000
