@@ -5,6 +5,16 @@ cuts each of the 15 non-light quads into n x n cells of two triangles (v00,v10,v
 keeps the light quad as 2 triangles, displaces interior grid vertices along the quad normal by
 0.02*(pcg_hash(vertex_index ^ 0x1234)/2^32 - 0.5), and gives every vertex the quad normal
 (vn.w = 1).  n = 183 gives 1,004,672 triangles / 507,844 vertices; n = 8 gives 1,922 triangles.
+
+SURVEY §8d leaves two things open that the displacement (a hash of the vertex index) and therefore the
+SBVH's spatial splits depend on; both are fixed here to what reproduces the survey's own probe of the
+reference builder on this mesh (appendix A / §8: n = 8 -> 1,945 leaf slots, 3,889 nodes, depth 15;
+n = 183 -> 1,006,286 slots, 2,012,571 nodes, depth 25 — asserted in tests/test_host.py):
+  * vertex numbering inside a quad: vertex (i, j) — i along P00->P10, j along P00->P01 — has index
+    base + j*(n+1) + i (rows of constant j); quads in OBJ order, the light quad's 4 vertices in sequence;
+  * grid positions by bilinear interpolation in float32.
+(Round 1 numbered i-major and interpolated in float64: 1,928 / 3,855 and 1,006,291 / 2,012,581 — a different
+mesh, not a different builder.)
 """
 import numpy as np
 
@@ -40,18 +50,23 @@ def tessellated_cornell(base, n):
                 out_t.append(np.array([[base_i + i0, base_i + i1, base_i + i2, mtl, vn[0], vn[1], vn[2], vn[3], -1, -1, -1, 0]], np.int32))
             n_vertices += 4
             continue
-        s = (np.arange(n + 1, dtype=np.float64) / n)
+        f32 = np.float32
+        s = (np.arange(n + 1, dtype=f32) / f32(n))
         S, T = np.meshgrid(s, s, indexing="ij")           # S: i (P00->P10), T: j (P00->P01)
         S, T = S[..., None], T[..., None]
-        P = (1 - S) * (1 - T) * P00 + S * (1 - T) * P10 + S * T * P11 + (1 - S) * T * P01
-        idx = n_vertices + np.arange((n + 1) * (n + 1), dtype=np.int64).reshape(n + 1, n + 1)
+        p00, p10, p11, p01 = (v.astype(f32) for v in (P00, P10, P11, P01))
+        one = f32(1)
+        P = (one - S) * (one - T) * p00 + S * (one - T) * p10 + S * T * p11 + (one - S) * T * p01     # float32 throughout
+        idx = n_vertices + np.arange((n + 1) * (n + 1), dtype=np.int64).reshape(n + 1, n + 1).T   # idx[i, j] = base + j*(n+1) + i
         h = pcg_hash_np((idx.astype(np.uint64) ^ np.uint64(0x1234)) & np.uint64(0xFFFFFFFF)).astype(np.float64)
         disp = 0.02 * (h / 4294967296.0 - 0.5)
         interior = np.zeros((n + 1, n + 1), bool)
         interior[1:n, 1:n] = True
         N = base.normals[int(vn[0])].astype(np.float64) if vn[3] == 1 else np.cross(P10 - P00, P01 - P00)
-        P = P + (disp * interior)[..., None] * N
-        out_v.append(P.reshape(-1, 3).astype(np.float32))
+        P = P.astype(np.float64) + (disp * interior)[..., None] * N
+        grid = np.empty(((n + 1) * (n + 1), 3), np.float32)
+        grid[(idx - n_vertices).reshape(-1)] = P.reshape(-1, 3).astype(np.float32)          # stored in index order
+        out_v.append(grid)
         i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
         v00, v10, v11, v01 = idx[i, j], idx[i + 1, j], idx[i + 1, j + 1], idx[i, j + 1]
         cells = np.empty((n, n, 2, 12), np.int32)
