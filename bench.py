@@ -120,15 +120,16 @@ def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd.meshgen import tessellated_cornell
     mesh, cam = g._cornell()
+    if materials == "disney":
+        from caitlynrenderer_amd.meshgen import with_disney_materials
+        mesh = with_disney_materials(mesh)
     label = "cornell-box 32 tris (Models/cornell-box.obj), CWBVH"
     if name != "cornell":
         n = 183 if name == "mesh1m" else int(name[4:])
         mesh = tessellated_cornell(mesh, n)
         label = f"procedural tessellated Cornell n={n}: {mesh.triangles.shape[0]} tris, CWBVH"
     if materials == "disney":
-        from caitlynrenderer_amd.meshgen import with_disney_materials
-        mesh = with_disney_materials(mesh)
-        label += ", GGX/Disney-diffuse boxes"
+        label += ", mirror tall box + GGX/Disney-diffuse short box and floor (oracle-defined materials)"
     t0 = time.time()
     data = cr.SceneData.build(mesh, cam, builder=builder, convert=convert)
     if builder == "lbvh":

@@ -132,6 +132,7 @@ struct crt_scene {
     // a persistent grid on the 1 M mesh: per-chunk cost varies 10x between sky and grazing rays);
     // k >= 1: persistent grid of k x the resident workgroups, static schedule (rt_kernels.hip)
     uint32_t oversubscribe = 0;
+    bool special_materials = false;          // some material is Mirror_type / Disney_type (albedo.w, Scene.h:111-132): k_segment<MAT>
     uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 4 = 256-thread workgroups
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
@@ -414,6 +415,8 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
+    for (size_t m = 0; m < d->n_materials; ++m)
+        s->special_materials = s->special_materials || d->materials[m].albedo[3] == 1.0f || d->materials[m].albedo[3] == 17.0f;
     s->stack_entries = std::min<uint32_t>(CRT_STACK_ENTRIES, std::max<uint32_t>(2, depth8));
     s->info.n_nodes8 = n_nodes8; s->info.n_tris8 = n_tris8; s->info.n_bvh2_nodes = d->n_bvh; s->info.max_depth8 = depth8;
 
@@ -565,6 +568,8 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "accel")) {
         if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
         if (value != 0 && !s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_set_option: the scene was created without a BVH2 (desc.bvh)");
+        if (value != 0 && s->special_materials)
+            return fail(CRT_ERR_INVALID, "crt_set_option: the BVH2 frame mode is the shipped shader, which is Lambert only; this scene has Mirror / Disney materials");
         s->accel = (uint32_t)value;
     }
     else if (!std::strcmp(name, "timing")) s->timing = (uint32_t)std::max(0, value);
@@ -641,7 +646,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.overflow = s->d_overflow;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
         EventSpan* sp = s->new_span(1);
-        const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u;
+        const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u && !s->special_materials;
         if (pretraced) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
@@ -654,7 +659,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         } else if (sp) {
             crt::set_launch_events(sp->a, sp->b);
         }
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};

@@ -95,8 +95,17 @@ bool Mesh::read_mtl(const std::string& file_name, const std::string& directory, 
         } else if (cur < 0 || (size_t)cur >= mats.size()) {
             continue;
         } else if (std::strncmp(t, "type", 4) == 0) {                  // Scene.h:576-582
-            if (std::sscanf(t + 4, "%255s", name) == 1 && std::strncmp(name, "Mirror", 6) == 0)
-                mats[cur].albedo[3] = 1.0f;   // Mirror_type, Scene.h:114
+            if (std::sscanf(t + 4, "%255s", name) == 1) {
+                if (std::strncmp(name, "Mirror", 6) == 0) mats[cur].albedo[3] = 1.0f;         // Mirror_type, Scene.h:114
+                // extension (no reference code, DESIGN.md "materials"): the enum's Disney_type (Scene.h:131) for the
+                // README's Disney BSDF; its parameters come from the PBR lines `Pm` / `Pr` below
+                else if (std::strncmp(name, "Disney", 6) == 0) mats[cur].albedo[3] = 17.0f;
+            }
+        } else if (t[0] == 'P' && (t[1] == 'm' || t[1] == 'r') && (t[2] == ' ' || t[2] == '\t')) {
+            // extension: `Pm metallic` / `Pr roughness` (the usual PBR additions to .mtl) -> specular.x / specular.y,
+            // read by the Disney lobe only; the reference ignores these lines (no branch matches them)
+            float v = 0.f;
+            if (std::sscanf(t + 2, "%f", &v) == 1) mats[cur].specular[t[1] == 'm' ? 0 : 1] = v;
         } else if (t[0] == 'K') {                                      // Scene.h:583-596
             float e[4] = {-1.f, -1.f, -1.f, -1.f};
             if (t[1] == 'd') std::sscanf(t + 2, "%f %f %f", &mats[cur].albedo[0], &mats[cur].albedo[1], &mats[cur].albedo[2]);

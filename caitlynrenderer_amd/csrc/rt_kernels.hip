@@ -624,6 +624,96 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
     s[2] = L.z + s[2];
 }
 
+// ------------------------------------------------------------------ materials ---------
+
+// path_trace.fs:44-60
+__device__ __forceinline__ void onb(vec3 n, vec3& ou, vec3& ov) {
+    if (n.z < -0.9999999f) { ou = V3(0.f, -1.f, 0.f); ov = V3(-1.f, 0.f, 0.f); }
+    else {
+        const float aa = rcp_ieee(1.0f + n.z);
+        const float bb = -n.x * n.y * aa;
+        ou = V3(1.0f + bb, bb, -n.x);
+        ov = V3(bb, 1.0f + bb, -n.y);
+    }
+}
+
+// Mirror and the GGX / Disney-diffuse lobe: NO REFERENCE CODE exists for these (the reference has the MaterialType enum,
+// `albedo.w = Mirror_type` in its loader and the shader's specular.w / is_specular plumbing, README.md:23 promises a Disney
+// BSDF).  They are defined by oracle/oracle.c ("materials beyond Lambert"); every function below restates the oracle's
+// operation for operation, so frames with such materials stay bit-identical to it.
+#define CRT_MIRROR_TYPE 1.0f    // Scene.h:114
+#define CRT_DISNEY_TYPE 17.0f   // Scene.h:131
+
+struct Disney { vec3 base; float metallic, rough, a2, p_spec; };
+
+__device__ __forceinline__ float schlick5(float c) {
+    float m = 1.0f - c;
+    if (m < 0.0f) m = 0.0f;
+    if (m > 1.0f) m = 1.0f;
+    const float m2 = m * m;
+    return (m2 * m2) * m;
+}
+__device__ __forceinline__ float smith_g1(float c, float a2) { return __fdiv_rn(2.0f * c, c + sqrt_ieee(a2 + (1.0f - a2) * (c * c))); }
+
+__device__ __forceinline__ Disney disney_params(vec3 base, float me, float ro) {
+    Disney m;
+    m.base = base;
+    m.metallic = me < 0.0f ? 0.0f : me > 1.0f ? 1.0f : me;
+    m.rough = ro < 0.03f ? 0.03f : ro > 1.0f ? 1.0f : ro;
+    const float al = m.rough * m.rough;
+    m.a2 = al * al;
+    m.p_spec = 0.5f + 0.5f * m.metallic;
+    return m;
+}
+
+// f(wo, wi) without the cosine and the solid-angle pdf of disney_sample; both 0 below the horizon
+__device__ __forceinline__ void disney_eval(const Disney& m, vec3 n, vec3 wo, vec3 wi, vec3& f, float& pdf) {
+    f = V3(0.f, 0.f, 0.f);
+    pdf = 0.f;
+    const float nl = dot(n, wi), nv = dot(n, wo);
+    if (!(nl > 0.0f && nv > 0.0f)) return;
+    const vec3 hs = wi + wo;
+    const float hh = dot(hs, hs);
+    if (!(hh > 0.0f)) return;
+    const vec3 h = hs * __fdiv_rn(1.0f, sqrt_ieee(hh));
+    const float nh = dot(n, h), lh = dot(wi, h);
+    if (!(nh > 0.0f && lh > 0.0f)) return;
+    const float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(lh);
+    const float fd90m1 = (0.5f + (2.0f * (lh * lh)) * m.rough) - 1.0f;
+    const float fd = (1.0f + fd90m1 * fl) * (1.0f + fd90m1 * fv);
+    const float kd = __fdiv_rn((1.0f - m.metallic) * fd, CRT_PI);
+    const float t = (nh * nh) * (m.a2 - 1.0f) + 1.0f;
+    const float D = __fdiv_rn(m.a2, (CRT_PI * t) * t);
+    const float G = smith_g1(nl, m.a2) * smith_g1(nv, m.a2);
+    const float spec = __fdiv_rn(D * G, (4.0f * nl) * nv);
+    const float dmm = 0.04f * (1.0f - m.metallic);
+    const vec3 F0 = V3(dmm + m.base.x * m.metallic, dmm + m.base.y * m.metallic, dmm + m.base.z * m.metallic);
+    const vec3 F = V3(F0.x + (1.0f - F0.x) * fh, F0.y + (1.0f - F0.y) * fh, F0.z + (1.0f - F0.z) * fh);
+    f = m.base * kd + F * spec;
+    const float pdf_d = __fdiv_rn(nl, CRT_PI);
+    const float pdf_s = __fdiv_rn(D * nh, 4.0f * lh);
+    pdf = m.p_spec * pdf_s + (1.0f - m.p_spec) * pdf_d;
+}
+
+__device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, float u0, float u1, float u2) {
+    vec3 ou, ov;
+    onb(n, ou, ov);
+    const float phi = CRT_PI2 * u2;
+    if (u0 < m.p_spec) {                                 // GGX normal distribution -> half vector -> reflect wo
+        const float c2 = __fdiv_rn(1.0f - u1, 1.0f + (m.a2 - 1.0f) * u1);
+        float s2 = 1.0f - c2;
+        if (s2 < 0.0f) s2 = 0.0f;
+        const float ch = sqrt_ieee(c2), sh = sqrt_ieee(s2);
+        const vec3 hl = V3(sh * pinned_cos(phi), sh * pinned_sin(phi), ch);
+        const vec3 h = (ou * hl.x + ov * hl.y) + n * hl.z;
+        const float vh = dot(wo, h);
+        return h * (2.0f * vh) - wo;
+    }
+    const float r = sqrt_ieee(u1);                       // path_trace.fs:257-270
+    const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), sqrt_ieee(1.0f - u1));
+    return (ou * dl.x + ov * dl.y) + n * dl.z;
+}
+
 // ------------------------------------------------------------------ path segment -----
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
@@ -647,7 +737,7 @@ __device__ __forceinline__ void add_to_sum(float* __restrict__ sum, uint32_t pix
 // per-lane closest-hit loop instead of the voting loop.
 // BVH2 (INPLACE's structure): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks
 // (path_trace.fs:511-819, traverse_bvh2) on the FlatNode array — the live path of the reference as a frame renderer.
-template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false>
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const WaveId wid = wave_id();
@@ -682,7 +772,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
         vec3 L = V3(0.f, 0.f, 0.f), T = V3(1.f, 1.f, 1.f);
         float prev_pdf = 1.0f, sx = 0.f, sy = 0.f;
-        bool is_specular = true;
+        bool is_specular = true, true_area = false;
         if (FIRST) {                                        // path_trace.fs:1026-1047
             uint32_t px = 0, py = 0;
             pix = e;
@@ -716,7 +806,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
             const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
             const float2 sd = a.pb.seed[pix];
             L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w;
-            T = V3(Tp.x, Tp.y, Tp.z); is_specular = __float_as_uint(Tp.w) != 0u;
+            T = V3(Tp.x, Tp.y, Tp.z);
+            is_specular = (__float_as_uint(Tp.w) & 1u) != 0u;
+            true_area = (__float_as_uint(Tp.w) & 2u) != 0u;
             sx = sd.x; sy = sd.y;
         }
 
@@ -775,7 +867,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                     const float len2 = len * len;
                     const int li = (int)m_emission.w;
                     const float* ap = a.lights + 18 * (size_t)li + 15;
-                    const float pdf_light = __fdiv_rn(len2, ap[0] * cos_light) * ap[1];
+                    float pdf_light = __fdiv_rn(len2, ap[0] * cos_light) * ap[1];
+                    if (MAT && true_area) pdf_light = 2.0f * pdf_light;           // the previous vertex was a Disney one (below)
                     const float tt = prev_pdf * prev_pdf;                         // power_heuristic :214-218
                     const float w = __fdiv_rn(tt, pdf_light * pdf_light + tt);
                     L = L + (T * em) * w;
@@ -796,75 +889,125 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                                     (float)pow((double)c.z, (double)2.2f));
                     }
                 }
-                if (m_specular.w == 0.0f) {
-                    if (a.n_lights <= 0) {
-                        shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv);
-                    } else {
-                        int li = (int)(shader_rand(sx, sy, f.rv) * (float)a.n_lights);
-                        if (li > a.n_lights - 1) li = a.n_lights - 1;
-                        const float* Lt = a.lights + 18 * (size_t)li;
-                        const float sq = sqrt_ieee(shader_rand(sx, sy, f.rv));    // :843-855
-                        const float b0 = 1.0f - sq;
-                        const float b1 = shader_rand(sx, sy, f.rv) * sq;
-                        const vec3 lp = (V3(Lt[0], Lt[1], Lt[2]) + V3(Lt[3], Lt[4], Lt[5]) * b0) + V3(Lt[6], Lt[7], Lt[8]) * b1;
-                        vec3 ldir = lp - hit_point;
-                        const float len = length(ldir);
-                        const float ilen = rcp_ieee(len);
-                        ldir = ldir * ilen;
-                        const float cos_mtl = dot(ldir, original_n);
-                        const float cos_light = dot(ldir, V3(Lt[9], Lt[10], Lt[11]));
-                        if (cos_mtl > 0.0f && cos_light < 0.0f) {                 // :968 (the occlusion test follows: in place, or in k_shadow with inplace_shadow = 0)
-                            const vec3 le = V3(Lt[12], Lt[13], Lt[14]);
-                            const float pdf_light = __fdiv_rn(len * len, Lt[15] * -cos_light) * Lt[16];
-                            const float bsdf_pdf = __fdiv_rn(dot(ldir, n) * 1.0f, CRT_PI);
-                            const float tt = pdf_light * pdf_light;
-                            const float w = __fdiv_rn(tt, bsdf_pdf * bsdf_pdf + tt);
-                            vec3 c = ((T * le) * albedo) * w;
-                            c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
-                            if (INPLACE) {
-                                // the occlusion test of path_trace.fs:968 in place (what k_shadow does with a queue entry)
-                                const unsigned long long m = __ballot(true);
-                                if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
-                                HitState sh;
-                                const bool occluded = BVH2
-                                    ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
-                                    : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any);
-                                if (!occluded) L = L + c;
-                            } else {
-                                emit_shadow = true;
+                // Materials beyond Lambert (MAT scenes only; oracle-defined, oracle.c "materials beyond Lambert" — the reference
+                // has the hooks but no code): albedo.w = MaterialType, 1 = Mirror_type (Scene.h:114, :576-582), 17 = Disney_type (:131)
+                const float mtype = m_albedo.w;
+                if (MAT && mtype == CRT_MIRROR_TYPE) {
+                    // perfect reflection: no NEE, no RNG draws, the next emitter hit takes the is_specular branch (:896)
+                    const vec3 ns = normalize(n);
+                    const float dn = dot(d, ns);
+                    T = T * albedo;
+                    if (!a.last_segment) {
+                        const vec3 rdir = d - ns * (2.0f * dn);
+                        a.pb.L[pix] = make_float4(L.x, L.y, L.z, prev_pdf);
+                        a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(1u));
+                        a.pb.seed[pix] = make_float2(sx, sy);
+                        emit_next = true;
+                        finished = false;
+                        nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
+                        nx1 = make_float4(rdir.x, rdir.y, rdir.z, __uint_as_float(pix));
+                    }
+                } else {
+                    const bool disney = MAT && mtype == CRT_DISNEY_TYPE;
+                    vec3 ns = n;
+                    const vec3 wo = -d;
+                    Disney dm;
+                    if (disney) { ns = normalize(n); dm = disney_params(albedo, m_specular.x, m_specular.y); }
+                    if (m_specular.w == 0.0f) {
+                        if (a.n_lights <= 0) {
+                            shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv); shader_rand(sx, sy, f.rv);
+                        } else {
+                            int li = (int)(shader_rand(sx, sy, f.rv) * (float)a.n_lights);
+                            if (li > a.n_lights - 1) li = a.n_lights - 1;
+                            const float* Lt = a.lights + 18 * (size_t)li;
+                            const float sq = sqrt_ieee(shader_rand(sx, sy, f.rv));    // :843-855
+                            const float b0 = 1.0f - sq;
+                            const float b1 = shader_rand(sx, sy, f.rv) * sq;
+                            const vec3 lp = (V3(Lt[0], Lt[1], Lt[2]) + V3(Lt[3], Lt[4], Lt[5]) * b0) + V3(Lt[6], Lt[7], Lt[8]) * b1;
+                            vec3 ldir = lp - hit_point;
+                            const float len = length(ldir);
+                            const float ilen = rcp_ieee(len);
+                            ldir = ldir * ilen;
+                            const float cos_mtl = dot(ldir, original_n);
+                            const float cos_light = dot(ldir, V3(Lt[9], Lt[10], Lt[11]));
+                            bool lit = cos_mtl > 0.0f && cos_light < 0.0f;            // :968 (the occlusion test follows: in place, or in k_shadow with inplace_shadow = 0)
+                            if (disney) lit = lit && dot(ns, ldir) > 0.0f;            // the lobe is zero below the shading horizon: no ray
+                            if (lit) {
+                                const vec3 le = V3(Lt[12], Lt[13], Lt[14]);
+                                float pdf_light = __fdiv_rn(len * len, Lt[15] * -cos_light) * Lt[16];
+                                vec3 c;
+                                if (disney) {
+                                    pdf_light = 2.0f * pdf_light;                     // true triangle area: Light.area is |u x v| (Scene.h:865-875)
+                                    vec3 fr; float pdf_b;
+                                    disney_eval(dm, ns, wo, ldir, fr, pdf_b);
+                                    const float tt = pdf_light * pdf_light;
+                                    const float w = __fdiv_rn(tt, pdf_b * pdf_b + tt);
+                                    c = ((T * le) * fr) * (dot(ns, ldir) * w);
+                                } else {
+                                    const float bsdf_pdf = __fdiv_rn(dot(ldir, n) * 1.0f, CRT_PI);
+                                    const float tt = pdf_light * pdf_light;
+                                    const float w = __fdiv_rn(tt, bsdf_pdf * bsdf_pdf + tt);
+                                    c = ((T * le) * albedo) * w;
+                                }
+                                c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
+                                if (INPLACE) {
+                                    // the occlusion test of path_trace.fs:968 in place (what k_shadow does with a queue entry)
+                                    const unsigned long long m = __ballot(true);
+                                    if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
+                                    HitState sh;
+                                    const bool occluded = BVH2
+                                        ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
+                                        : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any);
+                                    if (!occluded) L = L + c;
+                                } else {
+                                    emit_shadow = true;
+                                }
+                                sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
+                                sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix));
+                                sh2 = make_float4(c.x, c.y, c.z, 0.f);
                             }
-                            sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
-                            sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix | (a.last_segment ? 0x80000000u : 0u)));
-                            sh2 = make_float4(c.x, c.y, c.z, 0.f);
                         }
                     }
-                }
-                if (!a.last_segment) {
-                    vec3 ou, ov;                                                  // path_trace.fs:44-60
-                    if (n.z < -0.9999999f) { ou = V3(0.f, -1.f, 0.f); ov = V3(-1.f, 0.f, 0.f); }
-                    else {
-                        const float aa = rcp_ieee(1.0f + n.z);
-                        const float bb = -n.x * n.y * aa;
-                        ou = V3(1.0f + bb, bb, -n.x);
-                        ov = V3(bb, 1.0f + bb, -n.y);
+                    if (!a.last_segment) {
+                        vec3 sdir;
+                        float bsdf_pdf;
+                        bool go_on = true;
+                        if (disney) {
+                            const float u0 = shader_rand(sx, sy, f.rv);
+                            const float u1 = shader_rand(sx, sy, f.rv);
+                            const float u2 = shader_rand(sx, sy, f.rv);
+                            sdir = disney_sample(dm, ns, wo, u0, u1, u2);
+                            vec3 fr;
+                            disney_eval(dm, ns, wo, sdir, fr, bsdf_pdf);
+                            go_on = bsdf_pdf > 0.0f;                                 // sampled below the horizon: the path ends
+                            if (go_on) T = T * (fr * __fdiv_rn(dot(ns, sdir), bsdf_pdf));
+                        } else {
+                            vec3 ou, ov;                                              // path_trace.fs:44-60
+                            onb(n, ou, ov);
+                            const float u1 = shader_rand(sx, sy, f.rv);               // :257-270
+                            const float u2 = shader_rand(sx, sy, f.rv);
+                            const float r = sqrt_ieee(u1);
+                            const float phi = CRT_PI2 * u2;
+                            const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), sqrt_ieee(1.0f - u1));
+                            sdir = (ou * dl.x + ov * dl.y) + n * dl.z;
+                            bsdf_pdf = __fdiv_rn(dot(sdir, n) * 1.0f, CRT_PI);
+                            T = T * albedo;
+                        }
+                        if (go_on) {
+                            a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
+                            a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(disney ? 2u : 0u));   // bit 0 is_specular, bit 1 true_area
+                            a.pb.seed[pix] = make_float2(sx, sy);
+                            emit_next = true;
+                            finished = false;
+                            nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
+                            nx1 = make_float4(sdir.x, sdir.y, sdir.z, __uint_as_float(pix));
+                        }
                     }
-                    const float u1 = shader_rand(sx, sy, f.rv);                   // :257-270
-                    const float u2 = shader_rand(sx, sy, f.rv);
-                    const float r = sqrt_ieee(u1);
-                    const float phi = CRT_PI2 * u2;
-                    const vec3 dl = V3(r * pinned_cos(phi), r * pinned_sin(phi), sqrt_ieee(1.0f - u1));
-                    const vec3 sdir = (ou * dl.x + ov * dl.y) + n * dl.z;
-                    const float bsdf_pdf = __fdiv_rn(dot(sdir, n) * 1.0f, CRT_PI);
-                    T = T * albedo;
-                    a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
-                    a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(0u));
-                    a.pb.seed[pix] = make_float2(sx, sy);
-                    emit_next = true;
-                    finished = false;
-                    nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
-                    nx1 = make_float4(sdir.x, sdir.y, sdir.z, __uint_as_float(pix));
-                } else if (emit_shadow) {
-                    finished = false;                                             // k_shadow finishes this path
+                    if (emit_shadow && !emit_next) {
+                        // the path ends with this segment and its shadow ray is still in the queue: k_shadow finishes it
+                        finished = false;
+                        sh1.w = __uint_as_float(pix | 0x80000000u);
+                    }
                 }
             }
         }
@@ -876,7 +1019,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                 float4* q = shadow_q + 3 * (size_t)si;
                 q[0] = sh0; q[1] = sh1; q[2] = sh2;
                 // the radiance gathered so far waits in the path state (a 1-segment path has gathered none)
-                if (a.last_segment && a.pb.L) a.pb.L[pix] = make_float4(L.x, L.y, L.z, 0.f);
+                if (!emit_next && a.pb.L) a.pb.L[pix] = make_float4(L.x, L.y, L.z, 0.f);
             }
         }
         const uint32_t ni = wave_append(emit_next, count_next);
@@ -1057,14 +1200,15 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 }
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
     const size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
     waves = fit_waves(waves, per_wave);
     const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
     const size_t lds = waves * per_wave;
     const bool tex = a.textures != nullptr;
-#define CRT_LAUNCH_SEG(F, S, T, P, Y, B) launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a)
+#define CRT_LAUNCH_SEG(F, S, T, P, Y, B) do { if (mat && !(P) && !(B)) launch(k_segment<F, S, T, false, Y, false, true>, g, b, lds, stream, a); \
+                                              else launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a); } while (0)
 #define CRT_LAUNCH_SEG_T(F, S, P, Y, B) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y, B); else CRT_LAUNCH_SEG(F, S, false, P, Y, B); } while (0)
 #define CRT_LAUNCH_SEG_S(F, P, Y, B) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y, B); else CRT_LAUNCH_SEG_T(F, false, P, Y, B); } while (0)
     if (pretraced) { if (inplace) CRT_LAUNCH_SEG_S(false, true, true, false); else CRT_LAUNCH_SEG_S(false, true, false, false); }   // shade (+ shadow walk)

@@ -80,3 +80,29 @@ def tessellated_cornell(base, n):
         n_vertices += (n + 1) * (n + 1)
     return Mesh(np.concatenate(out_v), base.normals, base.texcoords, np.concatenate(out_t), base.materials,
                 base.lights, base.vertex_min)
+
+
+MIRROR_TYPE, DISNEY_TYPE = 1.0, 17.0          # Caitlyn/Scene.h:111-132 MaterialType (albedo.w, Scene.h:576-582)
+
+
+def with_disney_materials(base):
+    """The Cornell box of BASELINE configs[3] ("4-bounce Disney BSDF"): the tall box becomes a mirror (material `tallBox`
+    of the .mtl, `type Mirror`), the short box brushed metal and the floor a glossy dielectric (Disney_type: specular.x =
+    metallic, specular.y = roughness).  Apply to the 32-triangle base mesh BEFORE tessellated_cornell — quads are
+    identified by their position in Models/cornell-box.obj: tall box = quads 0-4, short box = 5-9, floor = quad 14.
+    The material model itself has no reference code (oracle-defined)."""
+    assert base.triangles.shape[0] == 32 and base.materials.shape[0] == 6, "expects the base Cornell mesh"
+    tris = base.triangles.copy()
+    mats = base.materials.copy()
+    mats[5, 0:4] = (0.95, 0.95, 0.95, MIRROR_TYPE)                       # tallBox: mirror
+    mats[4, 0:4] = (0.955, 0.638, 0.538, DISNEY_TYPE)                    # shortBox: copper-like metal
+    mats[4, 8:12] = (1.0, 0.35, 0.0, 0.0)                                # metallic, roughness, -, specular.w = 0 (NEE on)
+    floor = np.array([[0.75, 0.75, 0.75, DISNEY_TYPE, 0, 0, 0, -1, 0.0, 0.25, 0, 0, -1, -1, -1, -1]], np.float32)
+    mats = np.concatenate([mats, floor])                                 # material 6: glossy grey dielectric
+    tris[0:10, 3] = 5
+    tris[10:20, 3] = 4
+    tris[28:30, 3] = 6
+    m = Mesh(base.vertices, base.normals, base.texcoords, tris, mats, base.lights, base.vertex_min)
+    if getattr(base, "albedo_textures", None) is not None:
+        m.albedo_textures = base.albedo_textures
+    return m

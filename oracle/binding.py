@@ -67,6 +67,11 @@ def lib():
         l.orc_resolve.restype = None
         l.orc_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
         l.orc_hardware_threads.restype = C.c_int
+        fp = C.POINTER(C.c_float)
+        l.orc_disney_eval_test.restype = None
+        l.orc_disney_eval_test.argtypes = [fp, fp, fp, fp, fp, fp]
+        l.orc_disney_sample_test.restype = None
+        l.orc_disney_sample_test.argtypes = [fp, fp, fp, fp, fp]
         _lib = l
     return _lib
 
@@ -161,6 +166,23 @@ def resolve(sum_buf, inv_count):
 def rand_sequence(px, py, rx, ry, n):
     seed = (C.c_float * 2)(px + 0.5, py + 0.5)
     return [float(lib().orc_rand(seed, float(np.float32(rx)), float(np.float32(ry)))) for _ in range(n)]
+
+
+def _f(*xs):
+    return (C.c_float * len(xs))(*[float(np.float32(x)) for x in xs])
+
+
+def disney_eval(base, metallic, roughness, n, wo, wi):
+    """(f rgb, pdf) of the oracle-defined Disney lobe for one direction pair."""
+    f, pdf = _f(0, 0, 0), C.c_float()
+    lib().orc_disney_eval_test(_f(*base, metallic, roughness), _f(*n), _f(*wo), _f(*wi), f, C.byref(pdf))
+    return np.array(f[:], np.float32), float(pdf.value)
+
+
+def disney_sample(base, metallic, roughness, n, wo, u):
+    wi = _f(0, 0, 0)
+    lib().orc_disney_sample_test(_f(*base, metallic, roughness), _f(*n), _f(*wo), _f(*u), wi)
+    return np.array(wi[:], np.float32)
 
 
 def hardware_threads():

@@ -603,12 +603,133 @@ static void hit_attributes(const orc_scene* s, const rec_t* rec, v3* n, const fl
 /* path_trace.fs:214-218 */
 static inline float power_heuristic(float a, float b) { float t = a * a; return t / (b * b + t); }
 
-/* path_trace.fs:857-1024; loop bound is max_depth (the shader hard-codes 3, :867). */
+/* path_trace.fs:44-60 */
+static inline void onb(v3 n, v3* bu, v3* bv) {
+    if (n.z < -0.9999999f) { *bu = V(0.f, -1.f, 0.f); *bv = V(-1.f, 0.f, 0.f); }
+    else {
+        float a = 1.0f / (1.0f + n.z);
+        float b = -n.x * n.y * a;
+        *bu = V(1.0f + b, b, -n.x);
+        *bv = V(b, 1.0f + b, -n.y);
+    }
+}
+
+/* ------------------------------------------------ materials beyond Lambert --
+ * NO REFERENCE CODE EXISTS for this block: the reference has the hooks only — the loader writes
+ * albedo.w = Mirror_type for `type Mirror` (Scene.h:576-582), the enum names Mirror_type = 1 and Disney_type = 17
+ * (Scene.h:111-132), the shader gates NEE on `specular.w == 0` (path_trace.fs:938) and tracks is_specular
+ * (:865, :896, :1016), README.md:23 promises a "Disney BSDF" — and both shaders implement Lambert alone
+ * (path_trace.fs:274-310).  What follows is THIS PROJECT'S definition (oracle-defined; parity with the reference is
+ * unpinned by construction); the HIP kernel restates it operation for operation.
+ *
+ *   albedo.w == 1 (Mirror_type): perfect reflection d' = d - 2 (d.n) n about the normalised shading normal, throughput
+ *       *= albedo.xyz, no NEE (a delta lobe cannot be light-sampled; this is what `specular.w` gates in the shader), no RNG
+ *       draws, is_specular = true so that an emitter seen through the mirror takes the :896 branch.
+ *   albedo.w == 17 (Disney_type): base colour = albedo.xyz (or the albedo texture), specular.x = metallic,
+ *       specular.y = roughness.  Two lobes of Burley's 2012 model: the retro-reflective diffuse term weighted by
+ *       (1 - metallic), and a GGX microfacet lobe (alpha = roughness^2, separable Smith G, Schlick Fresnel with
+ *       F0 = lerp(0.04, base, metallic)).  One-sample MIS over the lobes: the specular lobe is picked with probability
+ *       p = 0.5 + 0.5 metallic (GGX normal-distribution sampling), else cosine sampling; the pdf is the mixture.
+ *       Unlike the reference's Lambert NEE (whose `diffuse_bsdf` returns the bare albedo, path_trace.fs:296-308), NEE here
+ *       carries f * cos.  RNG draws per hit: 3 (NEE) + 3 (lobe pick, two for the direction). */
+#define ORC_MIRROR_TYPE 1.0f
+#define ORC_DISNEY_TYPE 17.0f
+
+typedef struct { v3 base; float metallic, rough, a2, p_spec; } disney_t;
+
+static inline float schlick5(float c) {
+    float m = 1.0f - c;
+    if (m < 0.0f) m = 0.0f;
+    if (m > 1.0f) m = 1.0f;
+    float m2 = m * m;
+    return (m2 * m2) * m;
+}
+static inline float smith_g1(float c, float a2) { return (2.0f * c) / (c + sqrtf(a2 + (1.0f - a2) * (c * c))); }
+
+static disney_t disney_params(v3 base, const float* specular) {
+    disney_t m;
+    m.base = base;
+    float me = specular[0], ro = specular[1];
+    m.metallic = me < 0.0f ? 0.0f : me > 1.0f ? 1.0f : me;
+    m.rough = ro < 0.03f ? 0.03f : ro > 1.0f ? 1.0f : ro;      /* alpha >= 9e-4: D stays finite in fp32 */
+    float a = m.rough * m.rough;
+    m.a2 = a * a;
+    m.p_spec = 0.5f + 0.5f * m.metallic;
+    return m;
+}
+
+/* f(wo, wi) without the cosine, and the solid-angle pdf with which disney_sample picks wi; both 0 below the horizon.
+ * n: unit shading normal on wo's side; wo = -ray direction. */
+static void orc_disney_eval(const disney_t* m, v3 n, v3 wo, v3 wi, v3* f, float* pdf) {
+    *f = V(0.f, 0.f, 0.f);
+    *pdf = 0.f;
+    float nl = dot3(n, wi), nv = dot3(n, wo);
+    if (!(nl > 0.0f && nv > 0.0f)) return;
+    v3 hs = add(wi, wo);
+    float hh = dot3(hs, hs);
+    if (!(hh > 0.0f)) return;
+    v3 h = scl(hs, 1.0f / sqrtf(hh));
+    float nh = dot3(n, h), lh = dot3(wi, h);
+    if (!(nh > 0.0f && lh > 0.0f)) return;
+    float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(lh);
+    float fd90m1 = (0.5f + (2.0f * (lh * lh)) * m->rough) - 1.0f;
+    float fd = (1.0f + fd90m1 * fl) * (1.0f + fd90m1 * fv);
+    float kd = ((1.0f - m->metallic) * fd) / ORC_PI;
+    float t = (nh * nh) * (m->a2 - 1.0f) + 1.0f;
+    float D = m->a2 / ((ORC_PI * t) * t);
+    float G = smith_g1(nl, m->a2) * smith_g1(nv, m->a2);
+    float spec = (D * G) / ((4.0f * nl) * nv);
+    float dm = 0.04f * (1.0f - m->metallic);
+    v3 F0 = V(dm + m->base.x * m->metallic, dm + m->base.y * m->metallic, dm + m->base.z * m->metallic);
+    v3 F = V(F0.x + (1.0f - F0.x) * fh, F0.y + (1.0f - F0.y) * fh, F0.z + (1.0f - F0.z) * fh);
+    *f = add(scl(m->base, kd), scl(F, spec));
+    float pdf_d = nl / ORC_PI;
+    float pdf_s = (D * nh) / (4.0f * lh);
+    *pdf = m->p_spec * pdf_s + (1.0f - m->p_spec) * pdf_d;
+}
+
+static v3 orc_disney_sample(const disney_t* m, v3 n, v3 wo, float u0, float u1, float u2) {
+    v3 bu, bv;
+    onb(n, &bu, &bv);
+    float phi = ORC_PI2 * u2;
+    if (u0 < m->p_spec) {                              /* GGX normal distribution -> half vector -> reflect wo */
+        float c2 = (1.0f - u1) / (1.0f + (m->a2 - 1.0f) * u1);
+        float s2 = 1.0f - c2;
+        if (s2 < 0.0f) s2 = 0.0f;
+        float ch = sqrtf(c2), sh = sqrtf(s2);
+        v3 hl = V(sh * orc_cos(phi), sh * orc_sin(phi), ch);
+        v3 h = add(add(scl(bu, hl.x), scl(bv, hl.y)), scl(n, hl.z));
+        float vh = dot3(wo, h);
+        return sub(scl(h, 2.0f * vh), wo);
+    }
+    float r = sqrtf(u1);                               /* path_trace.fs:257-270 */
+    v3 dl = V(r * orc_cos(phi), r * orc_sin(phi), sqrtf(1.0f - u1));
+    return add(add(scl(bu, dl.x), scl(bv, dl.y)), scl(n, dl.z));
+}
+
+/* test hooks (tests/test_materials.py: furnace / sampling-consistency checks of the lobe): params = base rgb, metallic, roughness */
+void orc_disney_eval_test(const float params[5], const float n[3], const float wo[3], const float wi[3], float f[3], float* pdf) {
+    float sp[2] = {params[3], params[4]};
+    disney_t m = disney_params(ld3(params), sp);
+    v3 fv;
+    orc_disney_eval(&m, ld3(n), ld3(wo), ld3(wi), &fv, pdf);
+    f[0] = fv.x; f[1] = fv.y; f[2] = fv.z;
+}
+void orc_disney_sample_test(const float params[5], const float n[3], const float wo[3], const float u[3], float wi[3]) {
+    float sp[2] = {params[3], params[4]};
+    disney_t m = disney_params(ld3(params), sp);
+    v3 w = orc_disney_sample(&m, ld3(n), ld3(wo), u[0], u[1], u[2]);
+    wi[0] = w.x; wi[1] = w.y; wi[2] = w.z;
+}
+
+/* path_trace.fs:857-1024; loop bound is max_depth (the shader hard-codes 3, :867).  The Mirror / Disney branches are the
+ * oracle-defined extension above; a scene without such materials never enters them. */
 static v3 path_trace(const orc_scene* s, int accel, int tie, v3 o, v3 d, float seed[2], float rx, float ry,
                      uint64_t counters[4]) {
     v3 L = V(0.f, 0.f, 0.f), T = V(1.f, 1.f, 1.f);
     float prev_pdf = 1.0f;
     int is_specular = 1;
+    int true_area = 0;      /* the previous vertex was a Disney one: light pdfs use the triangle's true area (see below) */
     for (int i = 0; i < s->max_depth; ++i) {
         rec_t rec;
         cnt_t c = {0, 0};
@@ -631,11 +752,26 @@ static v3 path_trace(const orc_scene* s, int accel, int tie, v3 o, v3 d, float s
             int li = (int)emission[3];
             const float* ap = s->lights + 18 * (size_t)li + 15;
             float pdf_light = length2 / (ap[0] * cos_light) * ap[1];
+            if (true_area) pdf_light = 2.0f * pdf_light;
             float w = power_heuristic(prev_pdf, pdf_light);
             return add(L, scl(mul(T, ld3(emission)), w));
         }
         v3 hit_point = add(add(o, scl(d, rec.t)), scl(n, 0.0002f));
         const float* specular = mat + 8;
+        const float type = mat[3];                                 /* albedo.w = MaterialType (Scene.h:111-132, :581) */
+        if (type == ORC_MIRROR_TYPE) {
+            v3 ns = norm3(n);
+            float dn = dot3(d, ns);
+            T = mul(T, albedo);
+            is_specular = 1;
+            o = hit_point;
+            d = sub(d, scl(ns, 2.0f * dn));
+            continue;
+        }
+        const int disney = type == ORC_DISNEY_TYPE;
+        v3 ns = n, wo = neg(d);
+        disney_t dm;
+        if (disney) { ns = norm3(n); dm = disney_params(albedo, specular); }
         if (specular[3] == 0.0f && s->n_lights <= 0) {
             /* the shader would read light 0 of an empty buffer; keep the RNG stream, skip NEE */
             orc_rand(seed, rx, ry); orc_rand(seed, rx, ry); orc_rand(seed, rx, ry);
@@ -653,30 +789,55 @@ static v3 path_trace(const orc_scene* s, int accel, int tie, v3 o, v3 d, float s
             ldir = scl(ldir, ilength);
             float cos_mtl = dot3(ldir, original_n);
             float cos_light = dot3(ldir, ld3(Lt + 9));
-            if (cos_mtl > 0.0f && cos_light < 0.0f) {
+            int lit = cos_mtl > 0.0f && cos_light < 0.0f;
+            if (disney) lit = lit && dot3(ns, ldir) > 0.0f;        /* the lobe is zero below the shading horizon: no ray */
+            if (lit) {
                 cnt_t cs = {0, 0};
                 int occ = occluded(s, accel, hit_point, ldir, length - ORC_EPS, &cs);
                 counters[1]++; counters[2] += cs.nodes; counters[3] += cs.tris;
                 if (!occ) {
                     v3 le = ld3(Lt + 12);
                     float pdf_light = (length * length) / (Lt[15] * -cos_light) * Lt[16];
-                    float bsdf_pdf = dot3(ldir, n) * 1.0f / ORC_PI;   /* `cos * ipi`, ipi = `1.0f / pi` unparenthesised (:18, :294) */
-                    float w = power_heuristic(pdf_light, bsdf_pdf);
-                    v3 contrib = scl(mul(mul(T, le), albedo), w);
+                    v3 contrib;
+                    if (disney) {
+                        /* Light.area_pdf.x is |u x v| = TWICE the triangle's area (Scene.h:865-875) while the sample point is
+                         * uniform on the triangle, so the reference's pdf_light is half the true density; the Lambert path keeps
+                         * that (it is the reference's image), the Disney lobe uses the true one — here and in the MIS weight of
+                         * the emitter hit that follows a Disney bounce — so that NEE + BSDF sampling add up (furnace test) */
+                        pdf_light = 2.0f * pdf_light;
+                        v3 f; float pdf_b;
+                        orc_disney_eval(&dm, ns, wo, ldir, &f, &pdf_b);
+                        float w = power_heuristic(pdf_light, pdf_b);
+                        contrib = scl(mul(mul(T, le), f), dot3(ns, ldir) * w);
+                    } else {
+                        float bsdf_pdf = dot3(ldir, n) * 1.0f / ORC_PI;   /* `cos * ipi`, ipi = `1.0f / pi` unparenthesised (:18, :294) */
+                        float w = power_heuristic(pdf_light, bsdf_pdf);
+                        contrib = scl(mul(mul(T, le), albedo), w);
+                    }
                     contrib = V(contrib.x / pdf_light, contrib.y / pdf_light, contrib.z / pdf_light);
                     L = add(L, contrib);
                 }
             }
         }
+        if (disney) {
+            float u0 = orc_rand(seed, rx, ry);
+            float u1 = orc_rand(seed, rx, ry);
+            float u2 = orc_rand(seed, rx, ry);
+            v3 wi = orc_disney_sample(&dm, ns, wo, u0, u1, u2);
+            v3 f; float pdf;
+            orc_disney_eval(&dm, ns, wo, wi, &f, &pdf);
+            if (!(pdf > 0.0f)) return L;                           /* sampled below the horizon: the path ends */
+            T = mul(T, scl(f, dot3(ns, wi) / pdf));
+            prev_pdf = pdf;
+            is_specular = 0;
+            true_area = 1;
+            o = hit_point;
+            d = wi;
+            continue;
+        }
         /* path_trace.fs:44-60 onb, :257-270 cosine sample, :274-289 diffuse_sample */
         v3 bu, bv;
-        if (n.z < -0.9999999f) { bu = V(0.f, -1.f, 0.f); bv = V(-1.f, 0.f, 0.f); }
-        else {
-            float a = 1.0f / (1.0f + n.z);
-            float b = -n.x * n.y * a;
-            bu = V(1.0f + b, b, -n.x);
-            bv = V(b, 1.0f + b, -n.y);
-        }
+        onb(n, &bu, &bv);
         float u1 = orc_rand(seed, rx, ry);
         float u2 = orc_rand(seed, rx, ry);
         float r = sqrtf(u1);
@@ -687,6 +848,7 @@ static v3 path_trace(const orc_scene* s, int accel, int tie, v3 o, v3 d, float s
         T = mul(T, albedo);
         prev_pdf = bsdf_pdf;
         is_specular = 0;
+        true_area = 0;
         o = hit_point;
         d = sdir;
     }

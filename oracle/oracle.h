@@ -30,7 +30,7 @@ typedef struct orc_scene {
     const float*   texcoords;       /* uv (unused: no textures)                    */
     const int32_t* triangles;       /* 12 ints per triangle, BVH2 leaf order       */
     const int32_t* tri_orig_ids;    /* slot -> original id, may be NULL            */
-    const float*   materials;       /* 16 floats per material                      */
+    const float*   materials;       /* 16 floats per material; albedo.w = MaterialType (0 Lambert, 1 Mirror, 17 Disney), specular.xy = metallic, roughness */
     const float*   lights;          /* 18 floats per light                         */
     const float*   bvh2;            /* 8 floats per FlatNode                       */
     const uint8_t* bvh8;            /* 80 bytes per node8, may be NULL             */
@@ -72,6 +72,12 @@ void orc_render_rows(const orc_scene* s, int accel, int tie, float rx, float ry,
 
 /* Shader/output.fs:9-20 */
 void orc_resolve(const float* sum, size_t n_pixels, float inv_count, uint8_t* rgba);
+
+/* Test hooks of the oracle-defined Disney lobe (oracle.c "materials beyond Lambert"; no reference code exists for it):
+ * params = base r, g, b, metallic, roughness; n = unit normal on wo's side.  eval: f(wo, wi) without the cosine and the
+ * sampling pdf; sample: the direction disney_sample picks for the uniform triple u. */
+void orc_disney_eval_test(const float params[5], const float n[3], const float wo[3], const float wi[3], float f[3], float* pdf);
+void orc_disney_sample_test(const float params[5], const float n[3], const float wo[3], const float u[3], float wi[3]);
 
 int orc_hardware_threads(void);
 

@@ -492,6 +492,99 @@ def test_config5_4k_frame_of_the_million_triangle_mesh(cr, ob, mesh1m):
         shard.close()
 
 
+@pytest.fixture(scope="module")
+def disney_scenes(cr, cornell):
+    """Cornell box with a mirror tall box, a brushed-metal short box and a glossy floor (meshgen.with_disney_materials),
+    plain and tessellated; the material model is oracle-defined (no reference code), so parity here is HIP == oracle."""
+    from caitlynrenderer_amd.meshgen import tessellated_cornell, with_disney_materials
+    mesh, cam = cornell
+    base = with_disney_materials(mesh)
+    out = {"cornell": cr.SceneData.build(base, cam)}
+    for n in (8, 40):
+        out[f"tess{n}"] = cr.SceneData.build(tessellated_cornell(base, n), cam)
+    return out, cam
+
+
+@pytest.mark.parametrize("name,depth,inplace", [("cornell", 1, 1), ("cornell", 4, 1), ("cornell", 4, 0), ("tess8", 3, 1), ("tess8", 5, 0),
+                                                ("tess40", 4, 1), ("tess40", 4, 0)])
+def test_mirror_and_disney_materials_match_the_oracle(cr, ob, disney_scenes, name, depth, inplace):
+    """f3: perfect mirror + GGX / Disney-diffuse lobe.  Three frames: accumulated radiance bit-identical to
+    the oracle, ray counts and visit totals equal — in place and through the shadow queue (where a Disney path that samples
+    below the horizon ends mid-path with its shadow ray still queued)."""
+    datas, cam = disney_scenes
+    data = datas[name]
+    W, H = 320, 180
+    scene = cr.Scene(data, W, H, depth)
+    scene.set_option("inplace_shadow", inplace)
+    scene.set_option("count_visits", 1)
+    orc = ob.Oracle(data, W, H, depth, cam)
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    for frame in range(3):
+        rx, ry = rnd.randf2(), rnd.randf2()
+        scene.render_frame(rx, ry)
+        _, cnt = orc.render_frame(rx, ry, ref, threads=8)
+        st = scene.frame_stats()
+        assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["stack_overflows"] == 0
+        assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
+        out = scene.read_sum()
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
+    assert np.isfinite(ref).all() and ref.max() > 0.5
+    scene.close()
+
+
+def test_special_materials_restrictions_and_options(cr, ob, disney_scenes):
+    """The BVH2 frame mode is the shipped (Lambert-only) shader: refused for a scene with Mirror / Disney materials; the
+    bounce pools fall back to the lock-step segment; scheduling options leave the image untouched."""
+    from caitlynrenderer_amd import _lib
+    datas, cam = disney_scenes
+    data = datas["tess8"]
+    W, H, depth = 200, 120, 4
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(2)]
+
+    def run(options):
+        s = cr.Scene(data, W, H, depth)
+        for k, v in options.items():
+            s.set_option(k, v)
+        for rx, ry in rvs:
+            s.render_frame(rx, ry)
+        out = s.read_sum()
+        s.close()
+        return out
+
+    want = run({})
+    for options in ({"bounce_refill": 1}, {"waves_per_workgroup": 4}, {"oversubscribe": 2}, {"tri_min": 0}, {"inplace_shadow": 0, "tri_min": 3}):
+        assert np.array_equal(run(options).view(np.uint32), want.view(np.uint32)), options
+    s = cr.Scene(data, W, H, depth)
+    with pytest.raises(cr.CrtError) as e:
+        s.set_option("accel", 1)
+    assert e.value.code == _lib.CRT_ERR_INVALID and "Lambert" in str(e.value)
+    s.close()
+
+
+def test_textured_disney_material(cr, ob, textured):
+    """The albedo texture feeds the Disney lobe's base colour exactly as it feeds Lambert's albedo (path_trace.fs:471-483)."""
+    mesh, _, cam = textured
+    mats = mesh.materials.copy()
+    mats[3, 3] = 17.0; mats[3, 8:10] = (0.2, 0.45)          # the textured Khaki material becomes a Disney one
+    mats[2, 3] = 1.0                                          # the textured red wall a (tinted) mirror
+    m = cr.Mesh(mesh.vertices, mesh.normals, mesh.texcoords, mesh.triangles, mats, mesh.lights, mesh.vertex_min)
+    m.albedo_textures = mesh.albedo_textures
+    data = cr.SceneData.build(m, cam)
+    W, H, depth = 256, 144, 3
+    scene = cr.Scene(data, W, H, depth)
+    orc = ob.Oracle(data, W, H, depth, cam)
+    rnd = cr.Rnd()
+    ref = np.zeros((H, W, 3), np.float32)
+    for _ in range(2):
+        rx, ry = rnd.randf2(), rnd.randf2()
+        scene.render_frame(rx, ry)
+        orc.render_frame(rx, ry, ref, threads=8)
+    assert np.array_equal(scene.read_sum().view(np.uint32), ref.view(np.uint32))
+    scene.close()
+
+
 @pytest.mark.parametrize("name", ["cornell", "tess40"])
 def test_bvh2_reference_order_walk_on_device(cr, ob, cornell, tess40, scenes, name):
     """CRT_TRACE_BVH2: the shipped shader's own walk (path_trace.fs:511-819) on the FlatNode array, bit-exact

@@ -1,0 +1,160 @@
+"""Materials beyond Lambert: mirror reflection and the GGX / Disney-diffuse lobe.
+
+The reference has no code for either (only `albedo.w = Mirror_type` in the loader, the MaterialType enum and the shader's
+`specular.w` / `is_specular` plumbing), so the ORACLE DEFINES them (oracle.c "materials beyond Lambert") and nothing here can be
+pinned against the reference.  What can be checked without it is physics: reciprocity, energy conservation, that the sampling
+pdf is the pdf of the sampler, a known-answer mirror image, and a furnace test of the whole NEE + MIS machinery.  The GPU side
+(bit-identical to the oracle) is in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+N = (0.0, 0.0, 1.0)
+
+
+def _dirs(n, seed):
+    """Uniform directions on the upper hemisphere."""
+    rng = np.random.default_rng(seed)
+    z = rng.random(n)
+    phi = 2 * np.pi * rng.random(n)
+    r = np.sqrt(1 - z * z)
+    return np.stack([r * np.cos(phi), r * np.sin(phi), z], 1)
+
+
+@pytest.mark.parametrize("metallic,rough", [(0.0, 1.0), (0.0, 0.3), (1.0, 0.35), (0.5, 0.6), (1.0, 0.25)])
+def test_disney_lobe_reciprocity_energy_and_pdf(ob, metallic, rough):
+    base = (0.9, 0.7, 0.5)
+    wo = np.array([np.sin(0.9), 0.0, np.cos(0.9)])
+    # reciprocity f(wo, wi) == f(wi, wo)
+    for wi in _dirs(50, 1):
+        f1, _ = ob.disney_eval(base, metallic, rough, N, wo, wi)
+        f2, _ = ob.disney_eval(base, metallic, rough, N, wi, wo)
+        np.testing.assert_allclose(f1, f2, rtol=2e-4, atol=1e-7)
+    # uniform-hemisphere estimates of the directional albedo and of the pdf's mass
+    n = 40000 if rough > 0.3 else 300000
+    W = _dirs(n, 2)
+    fs, ps = zip(*(ob.disney_eval(base, metallic, rough, N, wo, w) for w in W))
+    fs, ps = np.array(fs), np.array(ps)
+    albedo_uniform = (fs * W[:, 2:3]).mean(0) * 2 * np.pi
+    mass = ps.mean() * 2 * np.pi
+    assert (albedo_uniform < 1.0).all() and (albedo_uniform > 0.02).all()        # energy is never created
+    assert 0.60 < mass <= 1.02                                                   # the rest is sampled below the horizon (plain NDF sampling)
+    # the sampler's own estimate of the same integral: mean of f cos / pdf over its samples (zero weight below the horizon)
+    rng = np.random.default_rng(3)
+    acc, below = np.zeros(3), 0
+    m = 20000
+    for u in rng.random((m, 3)):
+        wi = ob.disney_sample(base, metallic, rough, N, wo, u)
+        assert abs(np.linalg.norm(wi) - 1) < 1e-4
+        f, p = ob.disney_eval(base, metallic, rough, N, wo, wi)
+        if p > 0:
+            acc += f * wi[2] / p
+        else:
+            below += 1
+    albedo_sampled = acc / m
+    tol = 0.03 if rough > 0.3 else 0.06
+    np.testing.assert_allclose(albedo_sampled, albedo_uniform, rtol=tol, atol=5e-3)
+    assert abs((1 - below / m) - mass) < 0.03                                    # mass of the pdf == fraction of samples above the horizon
+
+
+def test_disney_sharp_metal_keeps_energy_below_one(ob):
+    """roughness 0.08 (alpha 0.0064): too sharp for a uniform quadrature, so only the sampler's own estimate is checked —
+    close to the Fresnel-weighted base colour and never above 1."""
+    base = (0.9, 0.7, 0.5)
+    wo = np.array([np.sin(0.6), 0.0, np.cos(0.6)])
+    rng = np.random.default_rng(11)
+    acc, m = np.zeros(3), 20000
+    for u in rng.random((m, 3)):
+        wi = ob.disney_sample(base, 1.0, 0.08, N, wo, u)
+        f, p = ob.disney_eval(base, 1.0, 0.08, N, wo, wi)
+        if p > 0:
+            acc += f * wi[2] / p
+    a = acc / m
+    assert (a < 1.0).all() and (a > 0.85 * np.array(base)).all() and (a < 1.12 * np.array(base)).all()
+
+
+def test_disney_rough_dielectric_is_close_to_lambert(ob):
+    """metallic 0, roughness 1: Burley's diffuse term is albedo / pi up to its grazing-angle retro-reflection factor, plus a 4 % lobe."""
+    f, pdf = ob.disney_eval((0.5, 0.5, 0.5), 0.0, 1.0, N, N, N)
+    assert abs(f[0] - (0.5 / np.pi * (1 + 1.5 * 0) ** 2 + 0.04 / (4 * np.pi))) < 2e-3 and pdf > 0
+
+
+def _write_scene(tmp_path, mtl, quads):
+    """quads: (material name, 4 corner points); normals from the winding (u x v), written as vn so the loader keeps them."""
+    v, vn, f = [], [], []
+    for name, P in quads:
+        P = np.asarray(P, float)
+        n = np.cross(P[1] - P[0], P[3] - P[0]); n /= np.linalg.norm(n)
+        vn.append("vn %.9g %.9g %.9g" % tuple(n))
+        b = len(v)
+        v += ["v %.9g %.9g %.9g" % tuple(p) for p in P]
+        f += [f"usemtl {name}", "f " + " ".join(f"{b + k + 1}//{len(vn)}" for k in range(4))]
+    (tmp_path / "s.mtl").write_text(mtl)
+    (tmp_path / "s.obj").write_text("mtllib s.mtl\n" + "\n".join(v + vn + f) + "\n")
+    return str(tmp_path / "s.obj")
+
+
+def test_loader_reads_mirror_and_disney_materials(cr, tmp_path):
+    path = _write_scene(tmp_path, "newmtl A\ntype Mirror\nKd 0.5 0.5 0.5\nKe 0 0 0\n"
+                                  "newmtl B\ntype Disney\nKd 0.9 0.6 0.3\nPm 0.75\nPr 0.4\nKe 0 0 0\n"
+                                  "newmtl C\nKd 1 1 1\nPr 0.9\nKe 0 0 0\n",
+                        [("A", [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)]), ("B", [(0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)])])
+    m = cr.Mesh.read_object(path)
+    assert m.materials[0][3] == 1.0 and m.materials[1][3] == 17.0 and m.materials[2][3] == 0.0     # Scene.h:114, :131
+    np.testing.assert_allclose(m.materials[1][8:12], [0.75, 0.4, 0, 0])                              # metallic, roughness; specular.w = 0: NEE on
+    np.testing.assert_allclose(m.materials[2][8:12], [0, 0.9, 0, 0])                                 # parsed, ignored by a Lambert material
+
+
+def test_mirror_known_answer(cr, ob, tmp_path):
+    """A floor mirror (tint 0.5) under a ceiling lamp (Ke 3): a pixel whose reflected ray reaches the lamp shows exactly
+    0.5 * 3 through the is_specular branch (path_trace.fs:896) — no MIS weight, no NEE at the mirror — and nothing at depth 1."""
+    path = _write_scene(tmp_path, "newmtl M\ntype Mirror\nKd 0.5 0.5 0.5\nKe 0 0 0\nnewmtl L\nKd 0 0 0\nKe 3 3 3\n",
+                        [("M", [(-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)]),           # floor, normal +y
+                         ("L", [(-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1)])])          # lamp, normal -y
+    cam = cr.Camera((0.0, 2.0, 6.0), (0.0, 0.0, 4.0), 30.0)      # aimed at the lamp's mirror image (0, -4, 0) through the floor
+    data = cr.SceneData.from_obj(path, cam)
+    img = {}
+    for depth in (1, 2):
+        orc = ob.Oracle(data, 64, 64, depth, cam)
+        img[depth], cnt = orc.render_frame(0.3, 0.7)
+        assert cnt[1] == 0                                                                 # a mirror casts no shadow rays
+    assert not img[1].any()
+    lit = img[2][..., 0] > 0
+    assert 40 < lit.sum() < 3000 and np.array_equal(img[2][lit], np.full((lit.sum(), 3), 1.5, np.float32))
+    # the image of the lamp is where geometry says: centred on the view axis
+    ys, xs = np.nonzero(lit)
+    assert abs(xs.mean() - 31.5) < 1.5 and abs(ys.mean() - 31.5) < 2.5
+
+
+@pytest.mark.parametrize("metallic,rough", [(0.0, 0.8), (1.0, 0.4)])
+def test_furnace_nee_plus_bsdf_sampling_sum_to_the_directional_albedo(cr, ob, tmp_path, metallic, rough):
+    """A Disney patch inside a closed box whose six walls all emit 1: whatever the patch reflects is gathered by NEE (12 light
+    triangles, area pdf) and by BSDF sampling with the power heuristic; their sum must be the directional albedo of the lobe,
+    which a quadrature of orc_disney_eval gives independently."""
+    base = (0.8, 0.8, 0.8)
+    c = [(-4, -4, -4), (4, -4, -4), (4, 4, -4), (-4, 4, -4), (-4, -4, 4), (4, -4, 4), (4, 4, 4), (-4, 4, 4)]
+    walls = [[c[0], c[1], c[2], c[3]], [c[5], c[4], c[7], c[6]], [c[4], c[0], c[3], c[7]],
+             [c[1], c[5], c[6], c[2]], [c[4], c[5], c[1], c[0]], [c[3], c[2], c[6], c[7]]]      # all normals point inwards
+    for wq in walls:
+        n = np.cross(np.subtract(wq[1], wq[0]), np.subtract(wq[3], wq[0]))
+        assert np.dot(n, -np.mean(wq, 0)) > 0
+    quads = [("W", wq) for wq in walls] + [("D", [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)])]     # patch, normal +z
+    mtl = ("newmtl W\nKd 0 0 0\nKe 1 1 1\n"
+           f"newmtl D\ntype Disney\nKd {base[0]} {base[1]} {base[2]}\nPm {metallic}\nPr {rough}\nKe 0 0 0\n")
+    path = _write_scene(tmp_path, mtl, quads)
+    cam_pos = np.array([1.5, 0.0, 2.0])
+    cam = cr.Camera(tuple(cam_pos), (0.0, 0.0, 0.0), 6.0)
+    data = cr.SceneData.from_obj(path, cam)
+    W = H = 16
+    orc = ob.Oracle(data, W, H, 2, cam)
+    rnd = cr.Rnd()
+    acc = np.zeros((H, W, 3), np.float32)
+    frames = 600
+    for _ in range(frames):
+        orc.render_frame(rnd.randf2(), rnd.randf2(), acc, threads=8)
+    got = acc[4:12, 4:12].reshape(-1, 3).mean(0) / frames
+    wo = cam_pos / np.linalg.norm(cam_pos)
+    Wd = _dirs(60000, 5)
+    fs = np.array([ob.disney_eval(base, metallic, rough, N, wo, w)[0] for w in Wd])
+    want = (fs * Wd[:, 2:3]).mean(0) * 2 * np.pi
+    np.testing.assert_allclose(got, want, rtol=0.04)
+    assert (got < 1.0).all()
