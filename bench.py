@@ -12,7 +12,8 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
     value / roofline / cpu_baseline  = configs[1]: Cornell box, CWBVH, 1 spp primary + shadow, 1920x1080;
     "north_star"                     = configs[2]: the 1,004,672-triangle mesh, 4 spp per step, 1920x1080, primary + shadow —
                                        the workload BASELINE.json's targets are quoted on, with its own roofline and cpu_baseline;
-    "incoherent"                     = configs[3]: same mesh, 4 path segments (incoherent bounce rays);
+    "incoherent" / "incoherent_disney" = configs[3]: same mesh, 4 path segments (incoherent bounce rays), with the reference's
+                                       Lambert integrator and with the oracle-defined mirror + GGX/Disney-diffuse materials;
     "scale_base"                     = configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines
                                        divide by).
   N > 1, --workload auto: configs[4]: ONE fixed 3840x2160 frame of the 1 M-triangle mesh, 4 spp per step, its 64x64 tiles dealt
@@ -116,6 +117,7 @@ def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
     key = (name, builder, convert, materials)
     if key in _SCENE_CACHE:
         return _SCENE_CACHE[key]
+    import copy
     import __graft_entry__ as g
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd.meshgen import tessellated_cornell
@@ -123,6 +125,19 @@ def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
     if materials == "disney":
         from caitlynrenderer_amd.meshgen import with_disney_materials
         mesh = with_disney_materials(mesh)
+        lam = _SCENE_CACHE.get((name, builder, convert, "lambert"))
+        if lam is not None:
+            # same geometry, same tree: only the material table and the triangles' material ids change
+            data0, cam0, label0, build_s = lam
+            if name != "cornell":
+                mesh = tessellated_cornell(mesh, 183 if name == "mesh1m" else int(name[4:]))
+            data = copy.copy(data0)
+            data.materials = mesh.materials
+            data.triangles = data0.triangles.copy()
+            data.triangles[:, 3] = mesh.triangles[data0.tri_orig_ids, 3]
+            label = label0 + ", mirror tall box + GGX/Disney-diffuse short box and floor (oracle-defined materials)"
+            _SCENE_CACHE[key] = (data, cam0, label, build_s)
+            return _SCENE_CACHE[key]
     label = "cornell-box 32 tris (Models/cornell-box.obj), CWBVH"
     if name != "cornell":
         n = 183 if name == "mesh1m" else int(name[4:])
@@ -210,7 +225,7 @@ def pmc_entry(workload, depth):
         return {}
 
 
-def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling):
+def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials=None):
     """Measure one workload: returns the dict of the bench line for it (rank 0) or None (other ranks)."""
     import numpy as np
     import caitlynrenderer_amd as cr
@@ -223,7 +238,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling):
 
     out = None
     if takes_part:
-        data, cam, label, build_s = build_workload(name, args.builder, args.convert, args.materials)
+        data, cam, label, build_s = build_workload(name, args.builder, args.convert, materials or args.materials)
         scene = cr.Scene(data, W, H, depth)
         scene.set_shard(rank, world, args.tile)
         for kv in args.option:
@@ -473,6 +488,7 @@ def main():
             if N == 1:
                 extra["north_star"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, True, "weak")
                 extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak")
+                extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak", materials="disney")
                 extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
             elif args.scaling == "strong":
                 ctx.barrier()
@@ -488,7 +504,9 @@ def main():
         if head.get("dry_run"):
             out["dry_run"] = True
         descr = {"north_star": "BASELINE.json configs[2] — the workload its targets (>= 1 Gray/s, >= 50 % HBM roofline) are quoted on",
-                 "incoherent": "BASELINE.json configs[3] — 4 path segments on the same mesh",
+                 "incoherent": "BASELINE.json configs[3] ray mix with the reference's own (Lambert-only) integrator — 4 path segments on the same mesh",
+                 "incoherent_disney": "BASELINE.json configs[3] as worded: 4 path segments with a mirror tall box and GGX / Disney-diffuse short "
+                                      "box and floor (the material model has no reference code: oracle-defined, HIP == oracle bit for bit)",
                  "scale_base": "BASELINE.json configs[4] at N = 1: what the N > 1 lines of `bench.py --gpus N` divide by",
                  "n1_same_workload": "the same frame rendered by rank 0 alone in this job (strong-scaling base)"}
         for k, v in extra.items():

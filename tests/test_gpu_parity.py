@@ -982,6 +982,7 @@ def test_bench_line_contract(tmp_path):
     assert abs(ns["value"] - ns["config"]["rays_per_step"] / ns["ms_per_step"] / 1e3) / ns["value"] < 0.01
     check_roofline(ns["roofline"], 24)
     assert d["incoherent"]["config"]["path_segments"] == 4 and d["incoherent"]["value"] > 500
+    assert "Disney" in d["incoherent_disney"]["config"]["workload"] and d["incoherent_disney"]["value"] > 500
     check_roofline(d["incoherent"]["roofline"], 24)
     sb = d["scale_base"]
     assert sb["config"]["resolution"] == "3840x2160" and sb["scaling"] == "strong" and sb["value"] > 1000
