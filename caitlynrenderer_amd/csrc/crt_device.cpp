@@ -133,7 +133,8 @@ struct crt_scene {
     // k >= 1: persistent grid of k x the resident workgroups, static schedule (rt_kernels.hip)
     uint32_t oversubscribe = 0;
     bool special_materials = false;          // some material is Mirror_type / Disney_type (albedo.w, Scene.h:111-132): k_segment<MAT>
-    uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 4 = 256-thread workgroups
+    uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 2, or 4 = 256-thread workgroups
+    uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
     bool timing_accumulate = false;          // spans pile up over frames (crt_frame_stats then holds sums) instead of per frame
@@ -408,7 +409,8 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) s->waves_per_workgroup = std::atoi(e) == 1 ? 1u : 4u;
+    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
+    if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
@@ -561,9 +563,10 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "waves_per_workgroup")) {
-        if (value != 1 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: waves_per_workgroup is 1 or 4");
+        if (value != 1 && value != 2 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: waves_per_workgroup is 1, 2 or 4");
         s->waves_per_workgroup = (uint32_t)value;
     }
+    else if (!std::strcmp(name, "compact_shadow")) s->compact_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "accel")) {
         if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
@@ -659,7 +662,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         } else if (sp) {
             crt::set_launch_events(sp->a, sp->b);
         }
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};

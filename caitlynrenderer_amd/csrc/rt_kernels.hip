@@ -337,21 +337,19 @@ __device__ __forceinline__ uint32_t dense_chunks_of_group(uint32_t n_items, uint
 __device__ __forceinline__ uint32_t queue_chunks(uint32_t n) { return (((n + 63u) >> 6) + 3u) >> 2; }
 
 // (group << 28 | chunk) for iteration `it` of this workgroup, or CRT_NO_WORK; uniform over the workgroup.
-// A workgroup is either 4 waves (256 threads) or a single wave (64 threads): with one wave per workgroup, 4
-// consecutive workgroups of the same XCD stand for one chunk, so the dispatcher refills CUs wave by wave.
+// A workgroup is 4 waves (256 threads), 2 waves or a single wave: with fewer than 4 waves per workgroup, 4 / W
+// consecutive workgroups of the same XCD stand for one chunk, so the dispatcher refills CUs (half-)wave-pair by wave.
 struct WaveId { uint32_t lane, wave, lds_wave, vblock, vgrid; };
 __device__ __forceinline__ WaveId wave_id() {
     WaveId w;
     w.lane = threadIdx.x & 63u;
     w.lds_wave = threadIdx.x >> 6;
-    if (blockDim.x == 64u) {
-        const uint32_t q = blockIdx.x >> 3;
-        w.wave = q & 3u;
-        w.vblock = ((q >> 2) << 3) | (blockIdx.x & 7u);
-        w.vgrid = gridDim.x >> 2;
-    } else {
-        w.wave = w.lds_wave; w.vblock = blockIdx.x; w.vgrid = gridDim.x;
-    }
+    // W = 1, 2 or 4 waves per workgroup: 4 / W consecutive workgroups of the same XCD slice stand for one 4-batch chunk
+    const uint32_t W = blockDim.x >> 6, per_log2 = W == 1u ? 2u : W == 2u ? 1u : 0u;
+    const uint32_t q = blockIdx.x >> 3;
+    w.wave = (q & ((1u << per_log2) - 1u)) * W + w.lds_wave;
+    w.vblock = ((q >> per_log2) << 3) | (blockIdx.x & 7u);
+    w.vgrid = gridDim.x >> per_log2;
     return w;
 }
 
@@ -737,12 +735,19 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // per-lane closest-hit loop instead of the voting loop.
 // BVH2 (INPLACE's structure): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks
 // (path_trace.fs:511-819, traverse_bvh2) on the FlatNode array — the live path of the reference as a frame renderer.
-template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false>
+// COMPACT (with INPLACE, workgroups of 2 or 4 waves): the NEE shadow rays of the workgroup's waves — 39 % of the lanes on
+// average, so a wave walking only its own runs the ~200-instruction node step with most lanes masked off — are first
+// gathered through LDS (ballot + prefix over the waves) into full waves: wave w of the workgroup walks rays [64 w, 64 w + 64)
+// of the compacted list and finishes those paths itself (L + C into the sum buffer or the path state), a wave left without
+// rays retires at once.  Each ray is walked exactly as before, by another lane: sums and counters stay bit-identical.
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
-    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
+    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
-    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
+    // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
+    const uint32_t wave_stride = (COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) * 64u;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * wave_stride + lane;
     int* stk2 = reinterpret_cast<int*>(s_lds) + (size_t)wid.lds_wave * a.stack_entries2 * 64u + lane;   // BVH2 mode
     const float4* const recs = BVH2 ? a.tris2 : a.tris;   // intersection records the hit index refers to
     const FrameArgs& f = a.f;
@@ -834,7 +839,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                 nn, nt);
         }
 
-        bool emit_shadow = false, emit_next = false, finished = active;
+        bool emit_shadow = false, emit_next = false, finished = active, pending = false;
+        float pend_pdf = 0.f;
         float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, nx0 = sh0, nx1 = sh0;
         if (active && hit.tri >= 0) {
             const float t = hit.t, bu = hit.u, bv = hit.v;
@@ -954,11 +960,15 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                                     // the occlusion test of path_trace.fs:968 in place (what k_shadow does with a queue entry)
                                     const unsigned long long m = __ballot(true);
                                     if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
-                                    HitState sh;
-                                    const bool occluded = BVH2
-                                        ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
-                                        : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any);
-                                    if (!occluded) L = L + c;
+                                    if (COMPACT) {
+                                        pending = true;                               // walked after the workgroup-wide compaction below
+                                    } else {
+                                        HitState sh;
+                                        const bool occluded = BVH2
+                                            ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
+                                            : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any);
+                                        if (!occluded) L = L + c;
+                                    }
                                 } else {
                                     emit_shadow = true;
                                 }
@@ -994,7 +1004,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                             T = T * albedo;
                         }
                         if (go_on) {
-                            a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
+                            if (COMPACT && pending) pend_pdf = bsdf_pdf;              // the lane that walks the shadow ray writes L (+ C) and this pdf
+                            else a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
                             a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(disney ? 2u : 0u));   // bit 0 is_specular, bit 1 true_area
                             a.pb.seed[pix] = make_float2(sx, sy);
                             emit_next = true;
@@ -1012,7 +1023,50 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
             }
         }
         // a path that ends here with nothing pending adds its radiance to the running sum now
-        if (finished && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, pix, L);
+        if (finished && !pending && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, pix, L);
+        if (COMPACT) {
+            // ---- gather the workgroup's shadow rays into full waves (LDS), walk them, finish their paths ----
+            const uint32_t W = blockDim.x >> 6;
+            uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_lds + (size_t)W * wave_stride);
+            float4* const s_rec = reinterpret_cast<float4*>(s_lds);                  // [4][W * 64], aliases the stacks
+            const unsigned long long pm = __ballot(pending);
+            if (lane == 0u) s_cnt[wid.lds_wave] = (uint32_t)__builtin_popcountll(pm);
+            __syncthreads();                                                          // every wave is done with its stack
+            uint32_t base = 0u, total = 0u;
+            for (uint32_t w = 0; w < W; ++w) {
+                const uint32_t cw = s_cnt[w];
+                base += w < wid.lds_wave ? cw : 0u;
+                total += cw;
+            }
+            const uint32_t cap = W * 64u;
+            if (pending) {
+                const uint32_t slot = base + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                s_rec[slot] = sh0;
+                s_rec[cap + slot] = make_float4(sh1.x, sh1.y, sh1.z, __uint_as_float(pix | (emit_next ? 0u : 0x80000000u)));
+                s_rec[2u * cap + slot] = make_float4(sh2.x, sh2.y, sh2.z, pend_pdf);
+                s_rec[3u * cap + slot] = make_float4(L.x, L.y, L.z, 0.f);
+            }
+            __syncthreads();
+            const uint32_t r = wid.lds_wave * 64u + lane;
+            const bool have = r < total;
+            float4 r0 = sh0, r1 = sh0, r2 = sh0, r3 = sh0;
+            if (have) { r0 = s_rec[r]; r1 = s_rec[cap + r]; r2 = s_rec[2u * cap + r]; r3 = s_rec[3u * cap + r]; }
+            __syncthreads();                                                          // records are in registers: the stacks may be written again
+            if (have) {
+                HitState shh;
+                const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
+                                                            (int)a.stack_entries, a.overflow, shh, nn_any, nt_any);
+                vec3 L2 = V3(r3.x, r3.y, r3.z);
+                if (!occluded) L2 = L2 + V3(r2.x, r2.y, r2.z);
+                const uint32_t tag = __float_as_uint(r1.w), spix = tag & 0x7fffffffu;
+                if (tag & 0x80000000u) {                                              // the path ended with this segment
+                    if (L2.x != 0.f || L2.y != 0.f || L2.z != 0.f) add_to_sum(a.sum, spix, L2);
+                } else {
+                    a.pb.L[spix] = make_float4(L2.x, L2.y, L2.z, r2.w);
+                }
+            }
+            __syncthreads();                                                          // persistent grids: the next pass reuses the region
+        }
         if (!INPLACE) {
             const uint32_t si = wave_append(emit_shadow, count_shadow);
             if (emit_shadow) {
@@ -1165,12 +1219,12 @@ static inline void launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stre
 // ask for without raising its dynamic-LDS limit (only the BVH2 stack of a very deep tree at 4 waves gets there) falls
 // back to single-wave workgroups, which the kernels' index mapping (wave_id) supports for any grid.
 static inline uint32_t fit_waves(uint32_t waves, size_t lds_per_wave) {
-    waves = waves == 1u ? 1u : 4u;
+    waves = waves == 1u ? 1u : waves == 2u ? 2u : 4u;
     return (size_t)waves * lds_per_wave > 64u * 1024u ? 1u : waves;
 }
 static inline size_t stack_bytes(uint32_t entries) { return (size_t)entries * 64 * sizeof(uint2); }
 // `grid` counts 4-wave chunks; with single-wave workgroups each of them becomes 4 workgroups
-static inline dim3 grid_dim(uint32_t grid, uint32_t waves) { return dim3(waves == 1u ? grid * 4u : grid); }
+static inline dim3 grid_dim(uint32_t grid, uint32_t waves) { return dim3(grid * (4u / waves)); }
 static inline dim3 block_dim(uint32_t waves) { return dim3(waves * 64u); }
 
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
@@ -1200,15 +1254,20 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 }
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
-    const size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
+    size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
     waves = fit_waves(waves, per_wave);
+    compact = compact && inplace && !pretraced && !bvh2 && waves > 1u;      // shadow-ray compaction needs partner waves
+    if (compact) per_wave = std::max(per_wave, (size_t)4096);                // 64 B of ray record per lane alias the stacks
     const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
-    const size_t lds = waves * per_wave;
+    const size_t lds = waves * per_wave + (compact ? 16 : 0);
     const bool tex = a.textures != nullptr;
-#define CRT_LAUNCH_SEG(F, S, T, P, Y, B) do { if (mat && !(P) && !(B)) launch(k_segment<F, S, T, false, Y, false, true>, g, b, lds, stream, a); \
-                                              else launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a); } while (0)
+#define CRT_LAUNCH_SEG(F, S, T, P, Y, B) do { \
+        if (compact) { if (mat) launch(k_segment<F, S, T, false, true, false, true, true>, g, b, lds, stream, a); \
+                       else launch(k_segment<F, S, T, false, true, false, false, true>, g, b, lds, stream, a); } \
+        else if (mat && !(P) && !(B)) launch(k_segment<F, S, T, false, Y, false, true>, g, b, lds, stream, a); \
+        else launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a); } while (0)
 #define CRT_LAUNCH_SEG_T(F, S, P, Y, B) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y, B); else CRT_LAUNCH_SEG(F, S, false, P, Y, B); } while (0)
 #define CRT_LAUNCH_SEG_S(F, P, Y, B) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y, B); else CRT_LAUNCH_SEG_T(F, false, P, Y, B); } while (0)
     if (pretraced) { if (inplace) CRT_LAUNCH_SEG_S(false, true, true, false); else CRT_LAUNCH_SEG_S(false, true, false, false); }   // shade (+ shadow walk)

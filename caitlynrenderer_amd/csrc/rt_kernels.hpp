@@ -116,11 +116,12 @@ struct ShadowArgs {
     uint32_t* overflow;
 };
 
-// waves = waves per workgroup: 1 (every wave its own workgroup) or 4 (256 threads); a per-scene setting
+// waves = waves per workgroup: 1 (every wave its own workgroup), 2 or 4 (256 threads); a per-scene setting
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 // mat: the scene has Mirror / Disney materials (CWBVH lock-step segments only: not with pretraced or bvh2)
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+// compact: gather the in-place shadow rays of a 2- or 4-wave workgroup into full waves before walking them
+void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it

@@ -151,8 +151,10 @@ int crt_sync(crt_scene* s);
  *     "oversubscribe"     0 = one 64-ray batch per workgroup, the hardware dispatcher balances (default); k >= 1 =
  *                         persistent grid of k x the resident workgroups with a static schedule, then
  *                         "trace_occupancy" = workgroups per CU
- *     "waves_per_workgroup" 1 (default) or 4, per scene; a launch whose LDS stacks would exceed 64 KB at 4 waves
- *                         (a BVH2 deeper than ~60 levels) runs with 1 */
+ *     "waves_per_workgroup" 1, 2 or 4, per scene; a launch whose LDS stacks would exceed 64 KB (a BVH2 deeper than ~60
+ *                         levels at 4 waves) runs with 1
+ *     "compact_shadow"    1 (default): with 2 or 4 waves per workgroup and in-place shadows, the workgroup's NEE shadow rays
+ *                         are gathered through LDS into full waves before they are walked; 0: every wave walks its own */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);

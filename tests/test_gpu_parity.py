@@ -253,7 +253,9 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
     got, counts = run({})
     other.close()
     assert counts == want_counts and np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    for options in ({"waves_per_workgroup": 4}, {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
+    for options in ({"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
+                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
+                    {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
                     {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5},
                     {"bounce_refill": 1}, {"bounce_refill": 1, "refill_min": 1}, {"bounce_refill": 1, "refill_min": 40}, {"inplace_shadow": 0},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
@@ -554,7 +556,8 @@ def test_special_materials_restrictions_and_options(cr, ob, disney_scenes):
         return out
 
     want = run({})
-    for options in ({"bounce_refill": 1}, {"waves_per_workgroup": 4}, {"oversubscribe": 2}, {"tri_min": 0}, {"inplace_shadow": 0, "tri_min": 3}):
+    for options in ({"bounce_refill": 1}, {"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
+                    {"oversubscribe": 2}, {"tri_min": 0}, {"inplace_shadow": 0, "tri_min": 3}):
         assert np.array_equal(run(options).view(np.uint32), want.view(np.uint32)), options
     s = cr.Scene(data, W, H, depth)
     with pytest.raises(cr.CrtError) as e:
