@@ -32,42 +32,43 @@ __device__ __forceinline__ vec3 normalize(vec3 a) {
 }
 __device__ __forceinline__ float rcp_ieee(float x) { return __fdiv_rn(1.0f, x); }
 
-// ---- pinned sin/cos: Cody-Waite by pi in double, Taylor polynomial (Horner), one rounding to float.
-// Same constants and the same sequence of fused multiply-adds as oracle/oracle.c orc_sin / orc_cos (v_fma_f64 here, fma()
-// there: one IEEE operation either way).  Double-precision VALU instructions issue at half rate on gfx950 (8 cycles per
-// wave64, scratch/ubench measurements in DESIGN.md), so the fused form — 18 instead of 32 of them per call — matters.
+// ---- pinned sin/cos: Cody-Waite by pi in double, Taylor polynomial, one rounding to float.
+// Same constants and the same sequence of +,-,* as oracle/oracle.c orc_sin / orc_cos.  (Written as fused multiply-adds —
+// 18 instead of 32 half-rate double-precision instructions per call, same float results on every fixture — it was 8 % SLOWER
+// on the 1 M-triangle frame: hipcc turns the chain into v_fmac_f64 with the coefficients parked in VGPR pairs, and the
+// kernel, already at its 96-register budget, spills 144 bytes per lane; the mul + add form takes them as SGPR operands.)
 __device__ __forceinline__ double reduce_pi(double x, double& k) {
     k = __builtin_rint(x * 0x1.45f306dc9c883p-2);
-    return __builtin_fma(-k, 0x1.3198a2ep-68, __builtin_fma(-k, 0x1.0b4611a6p-33, __builtin_fma(-k, 0x1.921fb544p+1, x)));
+    return ((x - k * 0x1.921fb544p+1) - k * 0x1.0b4611a6p-33) - k * 0x1.3198a2ep-68;
 }
 __device__ __forceinline__ double sin_poly(double r) {
     double z = r * r;
     double p = 1.0 / 51090942171709440000.0;
-    p = __builtin_fma(p, z, (-1.0 / 121645100408832000.0));
-    p = __builtin_fma(p, z, (1.0 / 355687428096000.0));
-    p = __builtin_fma(p, z, (-1.0 / 1307674368000.0));
-    p = __builtin_fma(p, z, (1.0 / 6227020800.0));
-    p = __builtin_fma(p, z, (-1.0 / 39916800.0));
-    p = __builtin_fma(p, z, (1.0 / 362880.0));
-    p = __builtin_fma(p, z, (-1.0 / 5040.0));
-    p = __builtin_fma(p, z, (1.0 / 120.0));
-    p = __builtin_fma(p, z, (-1.0 / 6.0));
-    return __builtin_fma(r * z, p, r);
+    p = p * z + (-1.0 / 121645100408832000.0);
+    p = p * z + (1.0 / 355687428096000.0);
+    p = p * z + (-1.0 / 1307674368000.0);
+    p = p * z + (1.0 / 6227020800.0);
+    p = p * z + (-1.0 / 39916800.0);
+    p = p * z + (1.0 / 362880.0);
+    p = p * z + (-1.0 / 5040.0);
+    p = p * z + (1.0 / 120.0);
+    p = p * z + (-1.0 / 6.0);
+    return r + (r * z) * p;
 }
 __device__ __forceinline__ double cos_poly(double r) {
     double z = r * r;
     double p = 1.0 / 1124000727777607680000.0;
-    p = __builtin_fma(p, z, (-1.0 / 2432902008176640000.0));
-    p = __builtin_fma(p, z, (1.0 / 6402373705728000.0));
-    p = __builtin_fma(p, z, (-1.0 / 20922789888000.0));
-    p = __builtin_fma(p, z, (1.0 / 87178291200.0));
-    p = __builtin_fma(p, z, (-1.0 / 479001600.0));
-    p = __builtin_fma(p, z, (1.0 / 3628800.0));
-    p = __builtin_fma(p, z, (-1.0 / 40320.0));
-    p = __builtin_fma(p, z, (1.0 / 720.0));
-    p = __builtin_fma(p, z, (-1.0 / 24.0));
-    p = __builtin_fma(p, z, 0.5);
-    return __builtin_fma(-z, p, 1.0);
+    p = p * z + (-1.0 / 2432902008176640000.0);
+    p = p * z + (1.0 / 6402373705728000.0);
+    p = p * z + (-1.0 / 20922789888000.0);
+    p = p * z + (1.0 / 87178291200.0);
+    p = p * z + (-1.0 / 479001600.0);
+    p = p * z + (1.0 / 3628800.0);
+    p = p * z + (-1.0 / 40320.0);
+    p = p * z + (1.0 / 720.0);
+    p = p * z + (-1.0 / 24.0);
+    p = p * z + 0.5;
+    return 1.0 - z * p;
 }
 __device__ __forceinline__ float pinned_sin(float xf) {
     double x = (double)xf;

@@ -35,10 +35,8 @@
  *     IEEE correctly rounded operations;
  *   - min/max = fminf/fmaxf (IEEE minNum/maxNum: a NaN operand is ignored), which is also
  *     what v_min_f32/v_max_f32 do on gfx950;
- *   - sin/cos are evaluated in double by a fixed sequence of fused multiply-adds (orc_sin/orc_cos: fma() here,
- *     v_fma_f64 on the device — IEEE fma is uniquely defined, so both give the same bits; the fused form halves the
- *     double-precision instruction count of the kernels' RNG) and rounded once to float; tan(fov/2) is computed once per
- *     frame on the host with tanf.
+ *   - sin/cos are evaluated in double by a fixed sequence of +,-,* (orc_sin/orc_cos) and
+ *     rounded once to float; tan(fov/2) is computed once per frame on the host with tanf.
  */
 #include "oracle.h"
 
@@ -72,44 +70,44 @@ static inline v3 norm3(v3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return scl(
 /* ------------------------------------------------------------ pinned sin/cos -- */
 
 /* Cody-Waite reduction by pi in three 33-bit pieces (the fdlibm pio2 constants doubled),
- * exact for |k| < 2^20, then a Taylor polynomial in double (Horner, one fma per step); error << 1 float ulp. */
+ * exact for |k| < 2^20, then a Taylor polynomial in double; error << 1 float ulp. */
 static const double PI_1 = 0x1.921fb544p+1, PI_2 = 0x1.0b4611a6p-33, PI_3 = 0x1.3198a2ep-68;
 static const double INV_PI = 0x1.45f306dc9c883p-2;
 
 static inline double reduce_pi(double x, double* k_out) {
     double k = rint(x * INV_PI);
-    double r = fma(-k, PI_3, fma(-k, PI_2, fma(-k, PI_1, x)));
+    double r = ((x - k * PI_1) - k * PI_2) - k * PI_3;
     *k_out = k;
     return r;
 }
 static inline double sin_poly(double r) {
     double z = r * r;
     double p = 1.0 / 51090942171709440000.0;          /*  1/21! */
-    p = fma(p, z, (-1.0 / 121645100408832000.0));        /* -1/19! */
-    p = fma(p, z, (1.0 / 355687428096000.0));            /*  1/17! */
-    p = fma(p, z, (-1.0 / 1307674368000.0));             /* -1/15! */
-    p = fma(p, z, (1.0 / 6227020800.0));                 /*  1/13! */
-    p = fma(p, z, (-1.0 / 39916800.0));                  /* -1/11! */
-    p = fma(p, z, (1.0 / 362880.0));                     /*  1/9!  */
-    p = fma(p, z, (-1.0 / 5040.0));                      /* -1/7!  */
-    p = fma(p, z, (1.0 / 120.0));                        /*  1/5!  */
-    p = fma(p, z, (-1.0 / 6.0));                         /* -1/3!  */
-    return fma(r * z, p, r);
+    p = p * z + (-1.0 / 121645100408832000.0);        /* -1/19! */
+    p = p * z + (1.0 / 355687428096000.0);            /*  1/17! */
+    p = p * z + (-1.0 / 1307674368000.0);             /* -1/15! */
+    p = p * z + (1.0 / 6227020800.0);                 /*  1/13! */
+    p = p * z + (-1.0 / 39916800.0);                  /* -1/11! */
+    p = p * z + (1.0 / 362880.0);                     /*  1/9!  */
+    p = p * z + (-1.0 / 5040.0);                      /* -1/7!  */
+    p = p * z + (1.0 / 120.0);                        /*  1/5!  */
+    p = p * z + (-1.0 / 6.0);                         /* -1/3!  */
+    return r + (r * z) * p;
 }
 static inline double cos_poly(double r) {
     double z = r * r;
     double p = 1.0 / 1124000727777607680000.0;        /*  1/22! */
-    p = fma(p, z, (-1.0 / 2432902008176640000.0));       /* -1/20! */
-    p = fma(p, z, (1.0 / 6402373705728000.0));           /*  1/18! */
-    p = fma(p, z, (-1.0 / 20922789888000.0));            /* -1/16! */
-    p = fma(p, z, (1.0 / 87178291200.0));                /*  1/14! */
-    p = fma(p, z, (-1.0 / 479001600.0));                 /* -1/12! */
-    p = fma(p, z, (1.0 / 3628800.0));                    /*  1/10! */
-    p = fma(p, z, (-1.0 / 40320.0));                     /* -1/8!  */
-    p = fma(p, z, (1.0 / 720.0));                        /*  1/6!  */
-    p = fma(p, z, (-1.0 / 24.0));                        /* -1/4!  */
-    p = fma(p, z, 0.5);                                  /*  1/2!  */
-    return fma(-z, p, 1.0);
+    p = p * z + (-1.0 / 2432902008176640000.0);       /* -1/20! */
+    p = p * z + (1.0 / 6402373705728000.0);           /*  1/18! */
+    p = p * z + (-1.0 / 20922789888000.0);            /* -1/16! */
+    p = p * z + (1.0 / 87178291200.0);                /*  1/14! */
+    p = p * z + (-1.0 / 479001600.0);                 /* -1/12! */
+    p = p * z + (1.0 / 3628800.0);                    /*  1/10! */
+    p = p * z + (-1.0 / 40320.0);                     /* -1/8!  */
+    p = p * z + (1.0 / 720.0);                        /*  1/6!  */
+    p = p * z + (-1.0 / 24.0);                        /* -1/4!  */
+    p = p * z + 0.5;                                  /*  1/2!  */
+    return 1.0 - z * p;
 }
 float orc_sin(float xf) {
     double x = (double)xf;
