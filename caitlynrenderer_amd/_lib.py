@@ -50,7 +50,9 @@ class crt_frame_stats(C.Structure):
                 ("ms_trace_closest", C.c_float), ("ms_trace_any", C.c_float), ("ms_shade", C.c_float),
                 ("ms_raygen", C.c_float), ("n_trace_launches", C.c_uint32),
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("tris_any", C.c_uint64),
-                ("stack_overflows", C.c_uint32)]
+                ("stack_overflows", C.c_uint32),
+                ("wave_steps_closest_nodes", C.c_uint64), ("wave_steps_closest_tris", C.c_uint64),
+                ("wave_steps_any_nodes", C.c_uint64), ("wave_steps_any_tris", C.c_uint64)]
 
 
 class crt_bvh_info(C.Structure):

@@ -110,7 +110,7 @@ struct crt_scene {
     bool have_camera = false;
     uint32_t jitter = 1;
     bool count_visits = false;
-    unsigned long long* d_visit_totals = nullptr;   // closest nodes/tris, any nodes/tris
+    unsigned long long* d_visit_totals = nullptr;   // [0..3] lane visits: closest nodes/tris, any nodes/tris; [4..7] wave-level steps of the same blocks
     unsigned long long* h_visit_totals = nullptr;   // pinned
 
     // scratch for crt_trace (host rays)
@@ -288,6 +288,8 @@ int collect_stats(crt_scene* s) {
         st.nodes_closest = s->h_visit_totals[0];
         st.tris_closest = s->h_visit_totals[1];
         st.nodes_any = s->h_visit_totals[2]; st.tris_any = s->h_visit_totals[3];
+        st.wave_steps_closest_nodes = s->h_visit_totals[4]; st.wave_steps_closest_tris = s->h_visit_totals[5];
+        st.wave_steps_any_nodes = s->h_visit_totals[6]; st.wave_steps_any_tris = s->h_visit_totals[7];
     }
     s->stats = st;
     s->stats_pending = false;
@@ -608,10 +610,10 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
     if (!s->timing_accumulate) s->n_spans = 0;
     if (s->count_visits) {
         if (!s->d_visit_totals) {
-            if ((rc = dev_alloc(&s->d_visit_totals, 4))) return rc;
-            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 4 * sizeof(unsigned long long)));
+            if ((rc = dev_alloc(&s->d_visit_totals, 8))) return rc;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 8 * sizeof(unsigned long long)));
         }
-        HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 4 * sizeof(unsigned long long), s->stream));
+        HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 8 * sizeof(unsigned long long), s->stream));
     }
     // counter banks alternate per frame; k_segment<FIRST> clears the other bank for the frame after this one, so a
     // memset is only needed for the very first frame (or after a failed launch left the banks in an unknown state)
@@ -675,7 +677,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->waves_per_workgroup, s->stream);
     }
     if (s->count_visits)
-        HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     s->stats_counted = s->count_visits;
     HIPCHK(hipGetLastError());
     s->counts_clean = true;

@@ -82,6 +82,13 @@ __device__ __forceinline__ float clamp_dir(float d) {
     return __builtin_fabsf(d) > eps ? d : __builtin_copysignf(eps, d);
 }
 
+// counting kernels only: +1 on exactly one lane each time the wave executes the enclosing block (wave-level step counter;
+// lane visits / (64 x wave steps) = the lane utilisation of that block)
+__device__ __forceinline__ void count_wave_step(uint32_t& c) {
+    const unsigned long long m = __ballot(true);
+    if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) ++c;
+}
+
 struct HitState {
     float t, u, v;
     int tri;   // index into the CWBVH-ordered triangle array, -1 = none
@@ -115,7 +122,7 @@ __device__ __forceinline__ bool mt_test(const float4 a, const float4 b, const fl
 template <bool ANY, bool STATS>
 __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o,
                                          vec3 d, float tmax_in, uint2* stk, int stack_entries, uint32_t* overflow, HitState& best,
-                                         uint32_t& n_nodes, uint32_t& n_tris) {
+                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
     best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
     // a non-finite origin makes every slab NaN (all children pass): such a ray can hit nothing
     if (!(__builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z))) return false;
@@ -145,7 +152,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
             const uint4* np = nodes + (size_t)(base + rel) * 5;
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            if (STATS) ++n_nodes;
+            if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
             const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
             cur.x = n1.x;
             tg.x = n1.y;
@@ -161,7 +168,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const uint32_t ti = tg.x + (uint32_t)b;
             const float4* tp = tris + (size_t)ti * 3;
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            if (STATS) ++n_tris;
+            if (STATS) { ++n_tris; count_wave_step(w_tris); }
             float u, v, t;
             if (mt_test(ta, tb, tc, o, d, u, v, t)) {
                 if (ANY) {
@@ -195,7 +202,8 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
 template <bool ANY, bool STATS, typename Load, typename Done>
 __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* stk,
                                               int stack_entries, uint32_t* overflow, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
-                                              uint32_t tri_min, Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
+                                              uint32_t tri_min, Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris,
+                                              uint32_t& w_nodes, uint32_t& w_tris) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t next = pool_begin;                     // wave-uniform
     bool busy = false;
@@ -267,7 +275,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 const uint4* np = nodes + (size_t)nidx * 5;
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) ++n_nodes;
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
                 cur.x = n1.x;
                 tg.x = n1.y;
@@ -280,7 +288,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             const uint32_t ti = tg.x + (uint32_t)b;
             const float4* tp = tris + (size_t)ti * 3;
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            if (STATS) ++n_tris;
+            if (STATS) { ++n_tris; count_wave_step(w_tris); }
             float u, v, t;
             if (mt_test(ta, tb, tc, o, d, u, v, t)) {
                 if (ANY) {
@@ -388,15 +396,20 @@ __device__ __forceinline__ uint32_t dense_item(uint32_t v, uint32_t wave, uint32
     return (unit * 64u + (c & 15u) * 4u + wave) * 64u + lane;
 }
 
-__device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, uint32_t nn, uint32_t nt) {
-    unsigned long long a = nn, b = nt;
+// totals[0], [1] += lane visits (nodes, triangles); totals[4], [5] += wave-level steps of the same blocks
+__device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, uint32_t nn, uint32_t nt, uint32_t wn = 0u, uint32_t wt = 0u) {
+    unsigned long long a = nn, b = nt, c = wn, d = wt;
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_down(a, off);
         b += __shfl_down(b, off);
+        c += __shfl_down(c, off);
+        d += __shfl_down(d, off);
     }
     if ((threadIdx.x & 63u) == 0) {
         if (a) atomicAdd(&totals[0], a);
         if (b) atomicAdd(&totals[1], b);
+        if (c) atomicAdd(&totals[4], c);
+        if (d) atomicAdd(&totals[5], d);
     }
 }
 
@@ -415,7 +428,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
         const uint32_t first = dense_pool_first(v, wave);
         if (first >= n) continue;
         const uint32_t last = first + 256u < n ? first + 256u : n;
-        uint32_t nn = 0, nt = 0;
+        uint32_t nn = 0, nt = 0, wn_unused = 0, wt_unused = 0;
         // per-ray counters need the count of ONE ray: sample the running totals at load and at completion
         uint32_t nn0 = 0, nt0 = 0;
         auto load = [&](uint32_t i, vec3& o, vec3& d, float& tmax) {
@@ -438,7 +451,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
                     a.stats[i] = ((dt > 65535u ? 65535u : dt) << 16) | (dn > 65535u ? 65535u : dn);
                 }
             };
-        traverse_pool<ANY, STATS>(a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, load, done, nn, nt);
+        traverse_pool<ANY, STATS>(a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, load, done, nn, nt, wn_unused, wt_unused);
         nn_total += nn; nt_total += nt;
     }
     (void)nn_total; (void)nt_total; (void)lane;
@@ -752,6 +765,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     const float4* const recs = BVH2 ? a.tris2 : a.tris;   // intersection records the hit index refers to
     const FrameArgs& f = a.f;
     uint32_t nn = 0, nt = 0, nn_any = 0, nt_any = 0;
+    uint32_t wn = 0, wt = 0, wn_any = 0, wt_any = 0;     // wave-level step counts of the same blocks (counting kernels)
     // Queue counters are double-banked by frame parity: the first kernel of a frame clears the bank the next
     // frame will append to (last touched by the previous frame, which stream order has retired).
     if (FIRST && a.zero_counts && blockIdx.x == 0)   // 64 or 256 threads, either works
@@ -827,7 +841,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         } else if (BVH2) {
             if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, a.overflow, hit, nn, nt);
         } else if (a.tri_min == 0u) {
-            if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt);
+            if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray get a non-finite origin, which finishes immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
@@ -836,7 +850,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                 a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
                 [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = active ? o : V3(qnan, qnan, qnan); rd = d; tmax = CRT_INF; },
                 [&](uint32_t, const HitState& best, bool) { hit = best; },
-                nn, nt);
+                nn, nt, wn, wt);
         }
 
         bool emit_shadow = false, emit_next = false, finished = active, pending = false;
@@ -966,7 +980,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                                         HitState sh;
                                         const bool occluded = BVH2
                                             ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
-                                            : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any);
+                                            : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any);
                                         if (!occluded) L = L + c;
                                     }
                                 } else {
@@ -1055,7 +1069,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
             if (have) {
                 HitState shh;
                 const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
-                                                            (int)a.stack_entries, a.overflow, shh, nn_any, nt_any);
+                                                            (int)a.stack_entries, a.overflow, shh, nn_any, nt_any, wn_any, wt_any);
                 vec3 L2 = V3(r3.x, r3.y, r3.z);
                 if (!occluded) L2 = L2 + V3(r2.x, r2.y, r2.z);
                 const uint32_t tag = __float_as_uint(r1.w), spix = tag & 0x7fffffffu;
@@ -1079,8 +1093,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         const uint32_t ni = wave_append(emit_next, count_next);
         if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
     }
-    if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt);
-    if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any);
+    if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
+    if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any, wn_any, wt_any);
     (void)stk; (void)stk2;
 }
 
@@ -1092,7 +1106,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
-    uint32_t nn = 0, nt = 0;
+    uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
     for (uint32_t it = 0;; ++it) {
         const uint32_t v = static_pool_chunk<false>(wid, a.count, 0u, it);
         if (v == CRT_NO_WORK) break;
@@ -1112,10 +1126,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
             [&](uint32_t e, const HitState& best, bool hit) {
                 hits[e] = make_float4(best.t, best.u, best.v, __int_as_float(hit ? best.tri : -1));
             },
-            nn, nt);
+            nn, nt, wn, wt);
     }
     (void)lane;
-    if (STATS) flush_visit_totals(a.visit_totals, nn, nt);
+    if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
 }
 
 // NEE occlusion test (path_trace.fs:968) fused with its resolve: an unoccluded ray adds its pending
@@ -1129,7 +1143,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
-    uint32_t nn = 0, nt = 0;
+    uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
     for (uint32_t it = 0;; ++it) {
         const uint32_t v = static_chunk<false>(wid, a.count, 0u, it);
         if (v == CRT_NO_WORK) break;
@@ -1143,7 +1157,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
         // (0.180 ms) on these short, fairly coherent rays; re-measured with single-wave workgroups: voting at
         // ratio 1/2/3 0.164/0.163/0.164 vs 0.154 ms (and it costs 93 instead of 64 VGPRs)
         const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
-                                                    (int)a.stack_entries, a.overflow, hit, nn, nt);
+                                                    (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt);
         const uint32_t tag = __float_as_uint(r1.w);
         const uint32_t pix = tag & 0x7fffffffu;
         if (tag & 0x80000000u) {                             // the path ended with this segment
@@ -1159,7 +1173,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
             a.L[pix] = L;
         }
     }
-    if (STATS) flush_visit_totals(a.visit_totals, nn, nt);
+    if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
 }
 
 // packed tile-major -> linear frame (bottom row first); pixels of other ranks stay untouched.

@@ -201,6 +201,10 @@ typedef struct crt_frame_stats {
     /* traversal-stack pushes dropped since the scene was created.  crt_scene_create sizes the LDS stack from the
      * validated depth of the tree, so this is 0 for every scene it accepts; the GPU tests assert it */
     uint32_t stack_overflows;
+    /* with "count_visits": how many times a WAVE executed the node block / the triangle block of the closest-hit and the
+     * any-hit walks (each execution offers 64 lane slots), so nodes_closest / (64 * wave_steps_closest_nodes) is the lane
+     * utilisation of that block — the quantity the traversal loops are tuned for */
+    uint64_t wave_steps_closest_nodes, wave_steps_closest_tris, wave_steps_any_nodes, wave_steps_any_tris;
 } crt_frame_stats;
 int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out);
 /* structural facts about the device-resident CWBVH */

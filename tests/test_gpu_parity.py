@@ -456,6 +456,10 @@ def test_config4_million_triangles_four_segments(cr, ob, mesh1m):
         st = scene.frame_stats()
         assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and cnt[0] > 4_500_000 and st["stack_overflows"] == 0
         assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
+        # wave-level step counters of the counting kernels: every block execution offers 64 lane slots
+        for v, w in (("nodes_closest", "wave_steps_closest_nodes"), ("tris_closest", "wave_steps_closest_tris"),
+                     ("nodes_any", "wave_steps_any_nodes"), ("tris_any", "wave_steps_any_tris")):
+            assert 0 < st[w] and st[w] <= st[v] <= 64 * st[w], (v, st[v], st[w])
         out = scene.read_sum()
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
     scene.close()
