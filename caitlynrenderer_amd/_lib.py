@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt.so")
 CRT_ABI_VERSION = 2
 CRT_OK, CRT_ERR_INVALID, CRT_ERR_NO_DEVICE, CRT_ERR_HIP, CRT_ERR_IO, CRT_ERR_LIMIT, CRT_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 CRT_TRACE_CLOSEST, CRT_TRACE_ANY, CRT_TRACE_BVH2, CRT_TRACE_TIE_LOWEST_ID = 0, 1, 2, 4
+CRT_BUILD_LBVH_ON_DEVICE = 1
 
 
 class CrtError(RuntimeError):
@@ -41,7 +42,7 @@ class crt_scene_desc(C.Structure):
         ("bvh8", C.c_void_p), ("n_bvh8", C.c_size_t),
         ("bvh8_tri_slots", C.c_void_p), ("n_bvh8_tris", C.c_size_t),
         ("albedo_textures", C.c_void_p), ("tex_width", C.c_uint32), ("tex_height", C.c_uint32), ("n_textures", C.c_uint32),
-        ("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32),
+        ("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32), ("build_flags", C.c_uint32),
     ]
 
 
@@ -56,7 +57,9 @@ class crt_frame_stats(C.Structure):
 
 
 class crt_bvh_info(C.Structure):
-    _fields_ = [("n_nodes8", C.c_uint64), ("n_tris8", C.c_uint64), ("n_bvh2_nodes", C.c_uint64), ("max_depth8", C.c_uint64)]
+    _fields_ = [("n_nodes8", C.c_uint64), ("n_tris8", C.c_uint64), ("n_bvh2_nodes", C.c_uint64), ("max_depth8", C.c_uint64),
+                ("built_on_device", C.c_uint32), ("bvh2_depth", C.c_uint32), ("build_wall_ms", C.c_float), ("build_upload_ms", C.c_float),
+                ("build_lbvh_device_ms", C.c_float), ("build_convert_device_ms", C.c_float)]
 
 
 # every symbol include/crt.h declares: name -> (restype, argtypes)

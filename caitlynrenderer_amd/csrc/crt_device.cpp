@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 
 #include "../../include/crt.h"
 #include "crt_error.hpp"
+#include "device_build.hpp"
 #include "host/cwbvh.hpp"
 #include "rt_kernels.hpp"
 
@@ -298,6 +300,41 @@ int collect_stats(crt_scene* s) {
 
 }  // namespace
 
+// device, stream, environment overrides and the descriptor's scalars: shared by both ways of creating a scene
+static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
+    if (hipGetDevice(&s->device) != hipSuccess) return (fail(CRT_ERR_HIP, "hipGetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
+    if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
+    if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return (fail(CRT_ERR_HIP, "hipStreamCreate failed"));
+    s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
+    for (size_t m = 0; m < d->n_materials; ++m)
+        s->special_materials = s->special_materials || d->materials[m].albedo[3] == 1.0f || d->materials[m].albedo[3] == 17.0f;
+    return CRT_OK;
+}
+
+static int finish_scene_setup(crt_scene* s) {
+    int rc;
+    if ((rc = dev_alloc(&s->d_overflow, 1))) return rc;
+    if (hipMemset(s->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) return fail(CRT_ERR_HIP, "hipMemset failed");
+    if ((rc = dev_alloc(&s->d_counts, 2 * kCounters))) return rc;
+    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
+        return fail(CRT_ERR_NOMEM, "hipHostMalloc failed");
+    s->spans.resize(kMaxEvents);
+    for (EventSpan& sp : s->spans)
+        if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)
+            return fail(CRT_ERR_HIP, "hipEventCreate failed");
+    return CRT_OK;
+}
+
 extern "C" {
 
 int crt_device_count(void) {
@@ -307,6 +344,7 @@ int crt_device_count(void) {
 }
 
 static int scene_create_impl(const crt_scene_desc* d, crt_scene** out);
+static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out);
 
 int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     // nothing may unwind through the C ABI: the vectors built during upload can throw bad_alloc / length_error
@@ -327,14 +365,20 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
         return fail(CRT_ERR_INVALID, "crt_scene_create: vertices/triangles missing");
     if (!d->materials || d->n_materials == 0) return fail(CRT_ERR_INVALID, "crt_scene_create: materials missing");
     if (d->n_lights && !d->lights) return fail(CRT_ERR_INVALID, "crt_scene_create: lights missing");
-    if (!d->bvh && !d->bvh8) return fail(CRT_ERR_INVALID, "crt_scene_create: neither bvh nor bvh8 given");
+    if (!d->bvh && !d->bvh8 && !(d->build_flags & CRT_BUILD_LBVH_ON_DEVICE))
+        return fail(CRT_ERR_INVALID, "crt_scene_create: neither bvh nor bvh8 given (and build_flags does not ask for a build on the device)");
+    if ((d->build_flags & CRT_BUILD_LBVH_ON_DEVICE) && (d->bvh || d->bvh8 || d->tri_orig_ids))
+        return fail(CRT_ERR_INVALID, "crt_scene_create: CRT_BUILD_LBVH_ON_DEVICE takes the triangles in source order, without bvh / bvh8 / tri_orig_ids");
+    if (d->build_flags & ~(uint32_t)CRT_BUILD_LBVH_ON_DEVICE) return fail(CRT_ERR_INVALID, "crt_scene_create: unknown build_flags");
     if (d->width == 0 || d->height == 0 || d->width > 65535u * 8u || d->height > 65535u * 8u)
         return fail(CRT_ERR_INVALID, "crt_scene_create: bad resolution");
     if (d->max_depth == 0 || d->max_depth > 16) return fail(CRT_ERR_INVALID, "crt_scene_create: max_depth must be 1..16");
     if (d->n_triangles >= (1ull << 31) || d->n_vertices >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_scene_create: too many elements");
 
-    // index validation: a bad index would be an out-of-bounds device access
-    for (size_t i = 0; i < d->n_triangles; ++i) {
+    // index validation: a bad index would be an out-of-bounds device access (build-on-device scenes run the same checks
+    // as a kernel over the uploaded array, scene_create_device_built)
+    const bool host_checks = !(d->build_flags & CRT_BUILD_LBVH_ON_DEVICE);
+    for (size_t i = 0; host_checks && i < d->n_triangles; ++i) {
         const crt_triangle& t = d->triangles[i];
         for (int j = 0; j < 3; ++j)
             if (t.v[j] < 0 || (size_t)t.v[j] >= d->n_vertices) return fail(CRT_ERR_INVALID, "crt_scene_create: vertex index out of range");
@@ -354,7 +398,7 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
             if (!d->texcoords) return fail(CRT_ERR_INVALID, "crt_scene_create: textured material but no texcoords");
         }
     }
-    if (have_tex)
+    if (have_tex && host_checks)
         for (size_t i = 0; i < d->n_triangles; ++i) {
             const crt_triangle& t = d->triangles[i];
             const float tx = d->materials[t.v[3] < 0 || (size_t)t.v[3] >= d->n_materials ? 0 : t.v[3]].tex_ind[0];
@@ -369,6 +413,7 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
     }
     int rc = require_device();
     if (rc) return rc;
+    if (d->build_flags & CRT_BUILD_LBVH_ON_DEVICE) return scene_create_device_built(d, out);
 
     // CWBVH: take the caller's, or convert the BVH2 (cwbvh.h:58)
     crt::CWBVH conv;
@@ -405,22 +450,7 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
     crt_scene* s = owner.get();
     if (!s) return fail(CRT_ERR_NOMEM, "crt_scene_create: out of memory");
     auto bail = [&](int code) { return code; };
-    if (hipGetDevice(&s->device) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipGetDevice failed"));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
-    if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
-    if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
-    if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
-    if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
-    if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
-    if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipStreamCreate failed"));
-    s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
-    for (size_t m = 0; m < d->n_materials; ++m)
-        s->special_materials = s->special_materials || d->materials[m].albedo[3] == 1.0f || d->materials[m].albedo[3] == 17.0f;
+    if ((rc = init_scene_common(s, d))) return bail(rc);
     s->stack_entries = std::min<uint32_t>(CRT_STACK_ENTRIES, std::max<uint32_t>(2, depth8));
     s->info.n_nodes8 = n_nodes8; s->info.n_tris8 = n_tris8; s->info.n_bvh2_nodes = d->n_bvh; s->info.max_depth8 = depth8;
 
@@ -507,15 +537,104 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
         if (hipMemcpy(s->d_tris2, rec2.data(), rec2.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));
     }
-    if ((rc = dev_alloc(&s->d_overflow, 1))) return bail(rc);
-    if (hipMemset(s->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) return bail(fail(CRT_ERR_HIP, "hipMemset failed"));
-    if ((rc = dev_alloc(&s->d_counts, 2 * kCounters))) return bail(rc);
-    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
-        return bail(fail(CRT_ERR_NOMEM, "hipHostMalloc failed"));
-    s->spans.resize(kMaxEvents);
-    for (EventSpan& sp : s->spans)
-        if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)
-            return bail(fail(CRT_ERR_HIP, "hipEventCreate failed"));
+    if ((rc = finish_scene_setup(s))) return bail(rc);
+    *out = owner.release();
+    return CRT_OK;
+}
+
+// CRT_BUILD_LBVH_ON_DEVICE: upload the seven input arrays once, then LBVH -> CWBVH -> leaf-order triangles and intersection
+// records without anything leaving HBM (the host-array entry points crt_lbvh_build / crt_cwbvh_convert_device moved 64 MB
+// of FlatNodes over PCIe twice at 1 M triangles).  Temporaries of both builders come from one arena allocation.
+static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (d->n_triangles >= (1u << 21)) return fail(CRT_ERR_LIMIT, "crt_scene_create: more than 2^21 triangles (FlatNode.h:24 start field)");
+    const bool have_tex = d->albedo_textures && d->n_textures > 0;
+    std::unique_ptr<crt_scene> owner(new (std::nothrow) crt_scene);
+    crt_scene* s = owner.get();
+    if (!s) return fail(CRT_ERR_NOMEM, "crt_scene_create: out of memory");
+    int rc = init_scene_common(s, d);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)d->n_triangles, n2 = 2u * n - 1u;
+    hipStream_t st = s->stream;
+
+    crt::DeviceArena arena;                       // input-order triangles + both builders' temporaries; gone when this returns
+    auto P = crt::DeviceArena::padded;
+    const size_t tmp_bytes = std::max(crt::lbvh_tmp_bytes(n), crt::cwbvh_tmp_bytes(n2, n));
+    hipError_t he = arena.reserve(P((size_t)n * sizeof(crt_triangle)) + P(4) + P((size_t)n * 4) + P((size_t)n * 4) + tmp_bytes);
+    if (he != hipSuccess) return fail(CRT_ERR_NOMEM, std::string("crt_scene_create: hipMalloc: ") + hipGetErrorString(he));
+    crt_triangle* d_in = arena.take<crt_triangle>(n);
+    uint32_t* d_flag = arena.take<uint32_t>(1);
+    uint32_t* d_tri_order = arena.take<uint32_t>(n);
+    int32_t* d_tri_slots = arena.take<int32_t>(n);
+    const size_t persistent_mark = arena.used;
+
+#define UPA(dst, src, count, T)                                                                                      \
+    do {                                                                                                             \
+        if ((rc = dev_alloc(&(dst), (count)))) return rc;                                                            \
+        if ((count) && hipMemcpyAsync((dst), (src), (count) * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess)   \
+            return fail(CRT_ERR_HIP, "hipMemcpy H2D failed");                                                        \
+    } while (0)
+    float* d_verts = nullptr;
+    struct Guard { void* p = nullptr; ~Guard() { if (p) (void)hipFree(p); } } verts_guard, nodes_guard;
+    UPA(d_verts, d->vertices, d->n_vertices * 3, float);
+    verts_guard.p = d_verts;                      // only the builders and the gather kernels read the vertices
+    if (hipMemcpyAsync(d_in, d->triangles, (size_t)n * sizeof(crt_triangle), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(CRT_ERR_HIP, "hipMemcpy H2D failed");
+    UPA(s->d_normals, d->normals, d->n_normals * 3, float);
+    UPA(s->d_materials, reinterpret_cast<const float4*>(d->materials), d->n_materials * 4, float4);
+    UPA(s->d_lights, reinterpret_cast<const float*>(d->lights), d->n_lights * 18, float);
+    if (have_tex) {
+        UPA(s->d_texcoords, reinterpret_cast<const float2*>(d->texcoords), d->n_texcoords, float2);
+        const size_t n_tex = (size_t)d->tex_width * d->tex_height * d->n_textures * 3;
+        std::vector<float> texf(n_tex);
+        for (size_t i = 0; i < n_tex; ++i) texf[i] = (float)d->albedo_textures[i] / 255.0f;
+        if ((rc = dev_alloc(&s->d_textures, n_tex))) return rc;
+        if (hipMemcpy(s->d_textures, texf.data(), n_tex * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(CRT_ERR_HIP, "hipMemcpy H2D failed");
+        s->tex_width = (int32_t)d->tex_width; s->tex_height = (int32_t)d->tex_height; s->n_textures = (int32_t)d->n_textures;
+    }
+#undef UPA
+    if (hipMemsetAsync(d_flag, 0, 4, st) != hipSuccess) return fail(CRT_ERR_HIP, "hipMemset failed");
+    crt::launch_validate_triangles(d_in, n, (uint32_t)d->n_vertices, (uint32_t)d->n_materials, d->normals ? (uint32_t)d->n_normals : 0u,
+                                   (uint32_t)d->n_texcoords, reinterpret_cast<const float*>(s->d_materials), have_tex ? 1 : 0, d_flag, st);
+    uint32_t flag = 0;
+    if (hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(CRT_ERR_HIP, "crt_scene_create: triangle validation failed to run");
+    const float upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (flag)
+        return fail(CRT_ERR_INVALID, std::string("crt_scene_create: ") + ((flag & 1u) ? "vertex" : (flag & 2u) ? "material" : (flag & 4u) ? "normal" : "texcoord") +
+                                         " index out of range");
+
+    // BVH2 (kept: it is the FlatNode array the BVH2 frame mode and CRT_TRACE_BVH2 walk) -> CWBVH
+    if ((rc = dev_alloc(&s->d_bvh2, (size_t)n2 * 2))) return rc;
+    uint32_t depth2 = 0, n8 = 0, depth8 = 0;
+    float lbvh_ms = 0.f, conv_ms = 0.f;
+    rc = crt::lbvh_build_on_device(reinterpret_cast<const int32_t*>(d_in), 12, d_verts, n, arena, reinterpret_cast<crt_flatnode*>(s->d_bvh2), d_tri_order,
+                                   &depth2, &lbvh_ms, st);
+    if (rc) return fail(rc, std::string("crt_scene_create: LBVH build failed: ") + crt_last_error());
+    arena.used = persistent_mark;                 // the LBVH temporaries are dead: the converter reuses the space
+    crt_node8* d_nodes8 = nullptr;
+    rc = crt::cwbvh_convert_on_device(reinterpret_cast<const crt_flatnode*>(s->d_bvh2), n2, n, arena, d_tri_slots, &d_nodes8, nullptr, &n8, &depth8,
+                                      &conv_ms, st);
+    if (rc) return fail(rc, std::string("crt_scene_create: BVH2 -> CWBVH failed: ") + crt_last_error());
+    s->d_nodes = reinterpret_cast<uint4*>(d_nodes8);
+    if (depth8 > CRT_STACK_ENTRIES) return fail(CRT_ERR_LIMIT, "crt_scene_create: CWBVH rejected: CWBVH deeper than the traversal stack");
+
+    // leaf-order triangle array (what sbvh.h:130-139 leaves behind), records for both walks
+    if ((rc = dev_alloc(&s->d_triangles, (size_t)n * 3))) return rc;
+    if ((rc = dev_alloc(&s->d_tris, (size_t)n * 3))) return rc;
+    const bool keep_bvh2 = depth2 + 2u <= 96u;    // the BVH2 walk's LDS stack bound (crt_scene_create: "BVH2 deeper than 94 levels")
+    if (keep_bvh2 && (rc = dev_alloc(&s->d_tris2, (size_t)n * 3))) return rc;
+    crt::launch_gather_slots(d_in, d_tri_order, d_verts, n, reinterpret_cast<crt_triangle*>(s->d_triangles), keep_bvh2 ? s->d_tris2 : nullptr, st);
+    crt::launch_gather_records(d_in, d_tri_order, d_tri_slots, d_verts, n, s->d_tris, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(CRT_ERR_HIP, "crt_scene_create: scene assembly kernels failed");
+    if (!keep_bvh2) { (void)hipFree(s->d_bvh2); s->d_bvh2 = nullptr; }
+    s->bvh2_stack = keep_bvh2 ? depth2 + 2u : 0u;
+    s->stack_entries = std::min<uint32_t>(CRT_STACK_ENTRIES, std::max<uint32_t>(2, depth8));
+    s->info.n_nodes8 = n8; s->info.n_tris8 = n; s->info.n_bvh2_nodes = n2; s->info.max_depth8 = depth8;
+    s->info.built_on_device = 1u; s->info.bvh2_depth = depth2;
+    s->info.build_upload_ms = upload_ms; s->info.build_lbvh_device_ms = lbvh_ms; s->info.build_convert_device_ms = conv_ms;
+    if ((rc = finish_scene_setup(s))) return rc;
+    s->info.build_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     *out = owner.release();
     return CRT_OK;
 }

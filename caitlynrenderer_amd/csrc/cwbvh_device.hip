@@ -22,6 +22,7 @@
 
 #include "crt_error.hpp"
 #include "crt_handles.hpp"
+#include "device_build.hpp"
 #include "host/cwbvh_core.hpp"
 
 #define CW_HIPCHK(expr)                                                                          \
@@ -177,7 +178,7 @@ __global__ void k_emit(const crt_flatnode* __restrict__ bvh2, const Decision* __
     nodes[idx] = node;
     uint32_t off = 0;
     for (int s = 0; s < 8; ++s) {
-        child_bvh2[(size_t)idx * 8 + s] = children[s];
+        if (child_bvh2) child_bvh2[(size_t)idx * 8 + s] = children[s];
         if (children[s] == -1 || dec[(size_t)children[s] * 7].type != LEAF) continue;
         int32_t slots[3];
         const int cnt = collect_slots(bvh2, children[s], slots);
@@ -202,6 +203,145 @@ inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256 ? (n +
 
 }  // namespace
 
+namespace crt {
+
+size_t cwbvh_tmp_bytes(size_t n2, size_t ns) {
+    auto P = DeviceArena::padded;
+    const size_t cap8 = n2 / 2 + 1;
+    return 3 * P(n2 * 4) + P(n2 * 7 * 8) + 2 * P(4) + P(kMaxLevels * 4) + P(ns * 4) + 7 * P(cap8 * 4) + P(cap8 * 8 * 4) + 2 * P(cap8) + 4096;
+}
+
+int cwbvh_convert_on_device(const crt_flatnode* d_bvh2, uint32_t n2, uint32_t ns, DeviceArena& tmp, int32_t* d_tri_slots,
+                            crt_node8** d_nodes_out, int32_t** d_child_bvh2_out, uint32_t* n8_out, uint32_t* depth_out, float* device_ms,
+                            hipStream_t st) {
+    *d_nodes_out = nullptr;
+    if (d_child_bvh2_out) *d_child_bvh2_out = nullptr;
+    const uint32_t cap8 = n2 / 2u + 1u;            // every node8 stands for a distinct interior BVH2 node (or the root)
+    crt_node8* d_nodes = nullptr; int32_t* d_child_bvh2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto cleanup = [&]() {
+        if (d_nodes) (void)hipFree(d_nodes);
+        if (d_child_bvh2) (void)hipFree(d_child_bvh2);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    };
+    int32_t* d_parent = tmp.take<int32_t>(n2);
+    uint32_t* d_depth = tmp.take<uint32_t>(n2);
+    unsigned long long* d_dec = tmp.take<unsigned long long>((size_t)n2 * 7);
+    int32_t* d_nprims = tmp.take<int32_t>(n2);
+    uint32_t* d_flags = tmp.take<uint32_t>(1);
+    uint32_t* d_levels = tmp.take<uint32_t>(kMaxLevels);
+    uint32_t* d_ntmp = tmp.take<uint32_t>(1);
+    uint32_t* d_seen = tmp.take<uint32_t>(ns);
+    Tmp t{};
+    t.bvh2 = tmp.take<int32_t>(cap8);
+    t.children = tmp.take<int32_t>((size_t)cap8 * 8);
+    t.first = tmp.take<int32_t>(cap8);
+    t.n_inner = tmp.take<uint8_t>(cap8);
+    t.n_tris = tmp.take<uint8_t>(cap8);
+    t.S = tmp.take<uint32_t>(cap8);
+    t.T = tmp.take<uint32_t>(cap8);
+    t.idx = tmp.take<uint32_t>(cap8);
+    t.A = tmp.take<uint32_t>(cap8);
+    t.B = tmp.take<uint32_t>(cap8);
+    if (!d_parent || !d_depth || !d_dec || !d_nprims || !d_flags || !d_levels || !d_ntmp || !d_seen || !t.bvh2 || !t.children || !t.first ||
+        !t.n_inner || !t.n_tris || !t.S || !t.T || !t.idx || !t.A || !t.B)
+        return fail(CRT_ERR_NOMEM, "cwbvh: temporary arena too small");
+    CW_HIPCHK(hipEventCreate(&ev0));
+    CW_HIPCHK(hipEventCreate(&ev1));
+
+    CW_HIPCHK(hipEventRecord(ev0, st));
+    CW_HIPCHK(hipMemsetAsync(d_parent, 0xff, (size_t)n2 * 4, st));
+    CW_HIPCHK(hipMemsetAsync(d_flags, 0, 4, st));
+    CW_HIPCHK(hipMemsetAsync(d_seen, 0, (size_t)ns * 4, st));
+    hipLaunchKernelGGL(k_parents, grid_for(n2), dim3(256), 0, st, d_bvh2, n2, d_parent, d_flags);
+    // levels of the BFS-ordered array, then the cost tables deepest level first
+    hipLaunchKernelGGL(k_depths, grid_for(n2), dim3(256), 0, st, d_parent, n2, d_depth);
+    hipLaunchKernelGGL(k_level_starts, grid_for(n2), dim3(256), 0, st, d_depth, n2, d_levels, (uint32_t)kMaxLevels, d_flags);
+    uint32_t deepest = 0;
+    uint32_t flags = 0;
+    CW_HIPCHK(hipMemcpyAsync(&deepest, d_depth + (n2 - 1), 4, hipMemcpyDeviceToHost, st));
+    // a link that is out of order, out of range, negative or NaN was flagged by k_parents / k_level_starts: stop before
+    // any pass follows the links (host/cwbvh.cpp returns CRT_ERR_INVALID at the same point)
+    CW_HIPCHK(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, st));
+    CW_HIPCHK(hipStreamSynchronize(st));
+    if (flags) {
+        cleanup();
+        return fail(CRT_ERR_INVALID, "crt_cwbvh_convert_device: BVH2 child link out of order");
+    }
+    if (deepest + 1u > kMaxLevels) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: BVH2 deeper than 4096 levels"); }
+    std::vector<uint32_t> lv(deepest + 2u);
+    CW_HIPCHK(hipMemcpyAsync(lv.data(), d_levels, (deepest + 1u) * 4, hipMemcpyDeviceToHost, st));
+    CW_HIPCHK(hipStreamSynchronize(st));
+    lv[deepest + 1u] = n2;
+    for (uint32_t l = deepest + 1u; l-- > 0;)
+        hipLaunchKernelGGL(k_costs_level, grid_for(lv[l + 1] - lv[l]), dim3(256), 0, st, d_bvh2, lv[l], lv[l + 1], n2, ns,
+                           reinterpret_cast<Decision*>(d_dec), d_nprims, d_flags);
+
+    Decision root0;
+    CW_HIPCHK(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, st));
+    CW_HIPCHK(hipMemcpyAsync(&root0, d_dec, 8, hipMemcpyDeviceToHost, st));
+    CW_HIPCHK(hipStreamSynchronize(st));
+    auto input_error = [&](uint32_t f) -> int {
+        cleanup();
+        const char* msg = (f & ERR_LINK) ? "BVH2 child link out of order"
+                        : (f & ERR_LEAF_SIZE) ? "BVH2 leaf with more than 3 triangles cannot be encoded"
+                        : (f & ERR_LEAF_RANGE) ? "BVH2 leaf range outside the triangle array"
+                        : "BVH2 leaves do not cover the triangle array exactly once";
+        return fail(CRT_ERR_INVALID, std::string("crt_cwbvh_convert_device: ") + msg);
+    };
+    if (flags) return input_error(flags);
+    const int root_is_leaf = root0.type == LEAF;
+    const Decision* dec = reinterpret_cast<const Decision*>(d_dec);
+
+    // node8 tree, level by level (the root stands for BVH2 node 0)
+    const int32_t zero = 0; const uint32_t one = 1;
+    CW_HIPCHK(hipMemcpyAsync(t.bvh2, &zero, 4, hipMemcpyHostToDevice, st));
+    CW_HIPCHK(hipMemcpyAsync(d_ntmp, &one, 4, hipMemcpyHostToDevice, st));
+    std::vector<uint32_t> level_begin{0u};
+    uint32_t begin = 0, end = 1;
+    while (begin < end) {
+        if (level_begin.size() > 64) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: CWBVH deeper than 64 levels"); }
+        hipLaunchKernelGGL(k_discover, grid_for(end - begin), dim3(256), 0, st, d_bvh2, dec, d_nprims, t, begin, end, d_ntmp, root_is_leaf);
+        uint32_t n_tmp = 0;
+        CW_HIPCHK(hipMemcpyAsync(&n_tmp, d_ntmp, 4, hipMemcpyDeviceToHost, st));
+        CW_HIPCHK(hipStreamSynchronize(st));
+        if (n_tmp > cap8) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: node8 count exceeds its bound"); }
+        begin = end; end = n_tmp;
+        level_begin.push_back(begin);
+    }
+    const uint32_t n8 = end;
+    const uint32_t depth = (uint32_t)level_begin.size() - 1u;      // level_begin = starts of levels 0..depth-1, then n8
+    for (uint32_t l = depth; l-- > 0;)
+        hipLaunchKernelGGL(k_sizes, grid_for(level_begin[l + 1] - level_begin[l]), dim3(256), 0, st, t, level_begin[l], level_begin[l + 1]);
+    const uint32_t root_place[3] = {0u, 1u, 0u};
+    CW_HIPCHK(hipMemcpyAsync(t.idx, &root_place[0], 4, hipMemcpyHostToDevice, st));
+    CW_HIPCHK(hipMemcpyAsync(t.A, &root_place[1], 4, hipMemcpyHostToDevice, st));
+    CW_HIPCHK(hipMemcpyAsync(t.B, &root_place[2], 4, hipMemcpyHostToDevice, st));
+    for (uint32_t l = 0; l < depth; ++l)
+        hipLaunchKernelGGL(k_place, grid_for(level_begin[l + 1] - level_begin[l]), dim3(256), 0, st, t, level_begin[l], level_begin[l + 1]);
+    CW_HIPCHK(hipMalloc(&d_nodes, (size_t)n8 * sizeof(crt_node8)));
+    if (d_child_bvh2_out) CW_HIPCHK(hipMalloc(&d_child_bvh2, (size_t)n8 * 8 * 4));
+    hipLaunchKernelGGL(k_emit, grid_for(n8), dim3(256), 0, st, d_bvh2, dec, d_nprims, t, n8, ns, d_nodes, d_tri_slots, d_child_bvh2, d_seen, d_flags);
+    hipLaunchKernelGGL(k_cover, grid_for(ns), dim3(256), 0, st, d_seen, ns, d_flags);
+    CW_HIPCHK(hipEventRecord(ev1, st));
+    CW_HIPCHK(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, st));
+    CW_HIPCHK(hipStreamSynchronize(st));
+    CW_HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    CW_HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    if (flags) return input_error(flags);
+    if (device_ms) *device_ms = ms;
+    *d_nodes_out = d_nodes; d_nodes = nullptr;
+    if (d_child_bvh2_out) { *d_child_bvh2_out = d_child_bvh2; d_child_bvh2 = nullptr; }
+    *n8_out = n8;
+    *depth_out = depth;
+    cleanup();
+    return CRT_OK;
+}
+
+}  // namespace crt
+
 extern "C" {
 
 int crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_slots, crt_cwbvh** out) {
@@ -215,121 +355,22 @@ int crt_cwbvh_convert_device(const crt_flatnode* bvh2, size_t n_nodes, size_t n_
 
     const auto t_begin = std::chrono::steady_clock::now();
     const uint32_t n2 = (uint32_t)n_nodes, ns = (uint32_t)n_slots;
-    const uint32_t cap8 = n2 / 2u + 1u;            // every node8 stands for a distinct interior BVH2 node (or the root)
-    crt_flatnode* d_bvh2 = nullptr; int32_t* d_parent = nullptr; uint32_t* d_arrivals = nullptr; unsigned long long* d_dec = nullptr;
-    uint32_t* d_levels = nullptr;
-    int32_t* d_nprims = nullptr; uint32_t* d_flags = nullptr; uint32_t* d_ntmp = nullptr; uint32_t* d_seen = nullptr;
-    crt_node8* d_nodes = nullptr; int32_t* d_tri_slots = nullptr; int32_t* d_child_bvh2 = nullptr;
-    Tmp t{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    crt::DeviceArena arena;
+    crt_node8* d_nodes = nullptr; int32_t* d_child_bvh2 = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = {d_levels, d_bvh2, d_parent, d_arrivals, d_dec, d_nprims, d_flags, d_ntmp, d_seen, d_nodes, d_tri_slots, d_child_bvh2,
-                        t.bvh2, t.children, t.first, t.n_inner, t.n_tris, t.S, t.T, t.idx, t.A, t.B};
-        for (void* p : ptrs) if (p) (void)hipFree(p);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+        arena.release();
+        if (d_nodes) (void)hipFree(d_nodes);
+        if (d_child_bvh2) (void)hipFree(d_child_bvh2);
     };
-    CW_HIPCHK(hipMalloc(&d_bvh2, (size_t)n2 * sizeof(crt_flatnode)));
-    CW_HIPCHK(hipMalloc(&d_parent, (size_t)n2 * 4));
-    CW_HIPCHK(hipMalloc(&d_arrivals, (size_t)n2 * 4));
-    CW_HIPCHK(hipMalloc(&d_dec, (size_t)n2 * 7 * 8));
-    CW_HIPCHK(hipMalloc(&d_nprims, (size_t)n2 * 4));
-    CW_HIPCHK(hipMalloc(&d_flags, 4));
-    CW_HIPCHK(hipMalloc(&d_levels, kMaxLevels * 4));
-    CW_HIPCHK(hipMalloc(&d_ntmp, 4));
-    CW_HIPCHK(hipMalloc(&d_seen, (size_t)ns * 4));
-    CW_HIPCHK(hipMalloc(&d_tri_slots, (size_t)ns * 4));
-    CW_HIPCHK(hipMalloc(&t.bvh2, (size_t)cap8 * 4));
-    CW_HIPCHK(hipMalloc(&t.children, (size_t)cap8 * 8 * 4));
-    CW_HIPCHK(hipMalloc(&t.first, (size_t)cap8 * 4));
-    CW_HIPCHK(hipMalloc(&t.n_inner, cap8));
-    CW_HIPCHK(hipMalloc(&t.n_tris, cap8));
-    CW_HIPCHK(hipMalloc(&t.S, (size_t)cap8 * 4));
-    CW_HIPCHK(hipMalloc(&t.T, (size_t)cap8 * 4));
-    CW_HIPCHK(hipMalloc(&t.idx, (size_t)cap8 * 4));
-    CW_HIPCHK(hipMalloc(&t.A, (size_t)cap8 * 4));
-    CW_HIPCHK(hipMalloc(&t.B, (size_t)cap8 * 4));
-    CW_HIPCHK(hipEventCreate(&ev0));
-    CW_HIPCHK(hipEventCreate(&ev1));
-
+    auto P = crt::DeviceArena::padded;
+    CW_HIPCHK(arena.reserve(crt::cwbvh_tmp_bytes(n2, ns) + P((size_t)n2 * sizeof(crt_flatnode)) + P((size_t)ns * 4)));
+    crt_flatnode* d_bvh2 = arena.take<crt_flatnode>(n2);
+    int32_t* d_tri_slots = arena.take<int32_t>(ns);
+    if (!d_bvh2 || !d_tri_slots) { cleanup(); return fail(CRT_ERR_NOMEM, "crt_cwbvh_convert_device: arena"); }
     CW_HIPCHK(hipMemcpy(d_bvh2, bvh2, (size_t)n2 * sizeof(crt_flatnode), hipMemcpyHostToDevice));
-    CW_HIPCHK(hipEventRecord(ev0, 0));
-    CW_HIPCHK(hipMemsetAsync(d_parent, 0xff, (size_t)n2 * 4, 0));
-    CW_HIPCHK(hipMemsetAsync(d_flags, 0, 4, 0));
-    CW_HIPCHK(hipMemsetAsync(d_seen, 0, (size_t)ns * 4, 0));
-    hipLaunchKernelGGL(k_parents, grid_for(n2), dim3(256), 0, 0, d_bvh2, n2, d_parent, d_flags);
-    // levels of the BFS-ordered array, then the cost tables deepest level first
-    uint32_t* const d_depth = d_arrivals;           // one word per node
-    hipLaunchKernelGGL(k_depths, grid_for(n2), dim3(256), 0, 0, d_parent, n2, d_depth);
-    hipLaunchKernelGGL(k_level_starts, grid_for(n2), dim3(256), 0, 0, d_depth, n2, d_levels, (uint32_t)kMaxLevels, d_flags);
-    uint32_t deepest = 0;
-    uint32_t flags = 0;
-    CW_HIPCHK(hipMemcpy(&deepest, d_depth + (n2 - 1), 4, hipMemcpyDeviceToHost));
-    // a link that is out of order, out of range, negative or NaN was flagged by k_parents / k_level_starts: stop before
-    // any pass follows the links (host/cwbvh.cpp returns CRT_ERR_INVALID at the same point)
-    CW_HIPCHK(hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost));
-    if (flags) {
-        cleanup();
-        return fail(CRT_ERR_INVALID, "crt_cwbvh_convert_device: BVH2 child link out of order");
-    }
-    if (deepest + 1u > kMaxLevels) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: BVH2 deeper than 4096 levels"); }
-    std::vector<uint32_t> lv(deepest + 2u);
-    CW_HIPCHK(hipMemcpy(lv.data(), d_levels, (deepest + 1u) * 4, hipMemcpyDeviceToHost));
-    lv[deepest + 1u] = n2;
-    for (uint32_t l = deepest + 1u; l-- > 0;)
-        hipLaunchKernelGGL(k_costs_level, grid_for(lv[l + 1] - lv[l]), dim3(256), 0, 0, d_bvh2, lv[l], lv[l + 1], n2, ns,
-                           reinterpret_cast<Decision*>(d_dec), d_nprims, d_flags);
-
-    Decision root0;
-    CW_HIPCHK(hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost));
-    auto input_error = [&](uint32_t f) -> int {
-        cleanup();
-        const char* msg = (f & ERR_LINK) ? "BVH2 child link out of order"
-                        : (f & ERR_LEAF_SIZE) ? "BVH2 leaf with more than 3 triangles cannot be encoded"
-                        : (f & ERR_LEAF_RANGE) ? "BVH2 leaf range outside the triangle array"
-                        : "BVH2 leaves do not cover the triangle array exactly once";
-        return fail(CRT_ERR_INVALID, std::string("crt_cwbvh_convert_device: ") + msg);
-    };
-    if (flags) return input_error(flags);
-    CW_HIPCHK(hipMemcpy(&root0, d_dec, 8, hipMemcpyDeviceToHost));
-    const int root_is_leaf = root0.type == LEAF;
-    const Decision* dec = reinterpret_cast<const Decision*>(d_dec);
-
-    // node8 tree, level by level (the root stands for BVH2 node 0)
-    const int32_t zero = 0; const uint32_t one = 1;
-    CW_HIPCHK(hipMemcpy(t.bvh2, &zero, 4, hipMemcpyHostToDevice));
-    CW_HIPCHK(hipMemcpy(d_ntmp, &one, 4, hipMemcpyHostToDevice));
-    std::vector<uint32_t> level_begin{0u};
-    uint32_t begin = 0, end = 1;
-    while (begin < end) {
-        if (level_begin.size() > 64) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: CWBVH deeper than 64 levels"); }
-        hipLaunchKernelGGL(k_discover, grid_for(end - begin), dim3(256), 0, 0, d_bvh2, dec, d_nprims, t, begin, end, d_ntmp, root_is_leaf);
-        uint32_t n_tmp = 0;
-        CW_HIPCHK(hipMemcpy(&n_tmp, d_ntmp, 4, hipMemcpyDeviceToHost));
-        if (n_tmp > cap8) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_cwbvh_convert_device: node8 count exceeds its bound"); }
-        begin = end; end = n_tmp;
-        level_begin.push_back(begin);
-    }
-    const uint32_t n8 = end;
-    const uint32_t depth = (uint32_t)level_begin.size() - 1u;      // level_begin = starts of levels 0..depth-1, then n8
-    for (uint32_t l = depth; l-- > 0;)
-        hipLaunchKernelGGL(k_sizes, grid_for(level_begin[l + 1] - level_begin[l]), dim3(256), 0, 0, t, level_begin[l], level_begin[l + 1]);
-    const uint32_t root_place[3] = {0u, 1u, 0u};
-    CW_HIPCHK(hipMemcpyAsync(t.idx, &root_place[0], 4, hipMemcpyHostToDevice, 0));
-    CW_HIPCHK(hipMemcpyAsync(t.A, &root_place[1], 4, hipMemcpyHostToDevice, 0));
-    CW_HIPCHK(hipMemcpyAsync(t.B, &root_place[2], 4, hipMemcpyHostToDevice, 0));
-    for (uint32_t l = 0; l < depth; ++l)
-        hipLaunchKernelGGL(k_place, grid_for(level_begin[l + 1] - level_begin[l]), dim3(256), 0, 0, t, level_begin[l], level_begin[l + 1]);
-    CW_HIPCHK(hipMalloc(&d_nodes, (size_t)n8 * sizeof(crt_node8)));
-    CW_HIPCHK(hipMalloc(&d_child_bvh2, (size_t)n8 * 8 * 4));
-    hipLaunchKernelGGL(k_emit, grid_for(n8), dim3(256), 0, 0, d_bvh2, dec, d_nprims, t, n8, ns, d_nodes, d_tri_slots, d_child_bvh2, d_seen, d_flags);
-    hipLaunchKernelGGL(k_cover, grid_for(ns), dim3(256), 0, 0, d_seen, ns, d_flags);
-    CW_HIPCHK(hipEventRecord(ev1, 0));
-    CW_HIPCHK(hipDeviceSynchronize());
-    CW_HIPCHK(hipGetLastError());
-    CW_HIPCHK(hipEventElapsedTime(&g_device_ms, ev0, ev1));
-    CW_HIPCHK(hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost));
-    if (flags) return input_error(flags);
+    uint32_t n8 = 0, depth = 0;
+    int rc = crt::cwbvh_convert_on_device(d_bvh2, n2, ns, arena, d_tri_slots, &d_nodes, &d_child_bvh2, &n8, &depth, &g_device_ms, (hipStream_t)0);
+    if (rc) { cleanup(); return rc; }
 
     crt_cwbvh* h = new (std::nothrow) crt_cwbvh;
     if (!h) { cleanup(); return fail(CRT_ERR_NOMEM, "crt_cwbvh_convert_device: out of memory"); }

@@ -20,6 +20,7 @@
 #include "../../include/crt.h"
 #include "crt_error.hpp"
 #include "crt_handles.hpp"
+#include "device_build.hpp"
 
 using crt::fail;
 
@@ -31,6 +32,12 @@ namespace {
         if (e_ != hipSuccess) { cleanup(); return fail(CRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
     } while (0)
 
+// leaf slot j <-> j-th triangle in Morton order: the low word of the sorted key
+__global__ void k_tri_order(const unsigned long long* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ order) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = (uint32_t)(sorted[i] & 0xffffffffull);
+}
+
 // order-preserving float <-> uint mapping for atomicMin/atomicMax on floats
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
@@ -38,14 +45,14 @@ __device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u &
 // Triangle boxes + the bounds of their centroids.  Grid-stride over the triangles with at most 1024 workgroups, the
 // centroid bounds reduced per lane, per wave and per workgroup before they touch the six global words: one atomic
 // per wave and component (94 k atomics on one cache line) made this kernel 1.07 ms of a 5 ms build.
-__global__ void __launch_bounds__(256) k_tri_bounds(const int32_t* __restrict__ vidx, const float* __restrict__ verts, uint32_t n,
+__global__ void __launch_bounds__(256) k_tri_bounds(const int32_t* __restrict__ vidx, uint32_t stride, const float* __restrict__ verts, uint32_t n,
                                                     float* __restrict__ leaf_box, uint32_t* __restrict__ scene_box) {
     __shared__ float s_red[4][6];
     float cmn[3] = {1e30f, 1e30f, 1e30f}, cmx[3] = {-1e30f, -1e30f, -1e30f};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
         for (int k = 0; k < 3; ++k) {
-            const float* p = verts + 3 * (size_t)vidx[3 * (size_t)i + k];
+            const float* p = verts + 3 * (size_t)vidx[(size_t)stride * i + k];
             for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
         }
         for (int a = 0; a < 3; ++a) {
@@ -199,6 +206,103 @@ thread_local float g_last_device_ms = 0.f, g_last_total_ms = 0.f;
 
 }  // namespace
 
+namespace crt {
+
+size_t lbvh_tmp_bytes(size_t n_tris) {
+    const size_t n_nodes = 2 * n_tris - 1;
+    size_t sort1 = 0, sort2 = 0;
+    (void)rocprim::radix_sort_keys(nullptr, sort1, (unsigned long long*)nullptr, (unsigned long long*)nullptr, n_tris, 0, 64, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs(nullptr, sort2, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, n_nodes, 0, 64, (hipStream_t)0);
+    auto P = DeviceArena::padded;
+    return P(n_tris * 24) + P(24) + 2 * P(n_tris * 8) + P(std::max<size_t>(n_tris - 1, 1) * sizeof(int2)) + P(n_nodes * 4) + P(kMaxLevels * 4) +
+           P(std::max<size_t>(n_tris - 1, 1) * 4) + 2 * P(n_nodes * 8) + 3 * P(n_nodes * 4) + P(4) + P(std::max<size_t>(sort1, 16)) +
+           P(std::max<size_t>(sort2, 16)) + 4096;
+}
+
+int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_verts, uint32_t n_tris_u, DeviceArena& tmp,
+                         crt_flatnode* d_flat, uint32_t* d_tri_order, uint32_t* depth_out, float* device_ms, hipStream_t stream) {
+    const size_t n_tris = n_tris_u;
+    const int n = (int)n_tris;
+    const size_t n_nodes = 2 * n_tris - 1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto cleanup = [&]() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    };
+    size_t tmp_bytes = 0, tmp2_bytes = 0;
+    LB_HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, n_tris, 0, 64, stream));
+    LB_HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp2_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
+                                        (uint32_t*)nullptr, n_nodes, 0, 64, stream));
+    float* d_leaf_box = tmp.take<float>(n_tris * 6);
+    uint32_t* d_scene = tmp.take<uint32_t>(6);
+    unsigned long long* d_keys = tmp.take<unsigned long long>(n_tris);
+    unsigned long long* d_sorted = tmp.take<unsigned long long>(n_tris);
+    int2* d_child = tmp.take<int2>(std::max<size_t>(n_tris - 1, 1));
+    int* d_parent = tmp.take<int>(n_nodes);
+    uint32_t* d_levels = tmp.take<uint32_t>(kMaxLevels);
+    int* d_first = tmp.take<int>(std::max<size_t>(n_tris - 1, 1));
+    unsigned long long* d_bkeys = tmp.take<unsigned long long>(n_nodes);
+    unsigned long long* d_bkeys2 = tmp.take<unsigned long long>(n_nodes);
+    uint32_t* d_ids = tmp.take<uint32_t>(n_nodes);
+    uint32_t* d_order = tmp.take<uint32_t>(n_nodes);
+    uint32_t* d_pos = tmp.take<uint32_t>(n_nodes);
+    uint32_t* d_bad = tmp.take<uint32_t>(1);
+    void* d_tmp = tmp.take<char>(std::max<size_t>(tmp_bytes, 16));
+    void* d_tmp2 = tmp.take<char>(std::max<size_t>(tmp2_bytes, 16));
+    if (!d_leaf_box || !d_scene || !d_keys || !d_sorted || !d_child || !d_parent || !d_levels || !d_first || !d_bkeys || !d_bkeys2 || !d_ids ||
+        !d_order || !d_pos || !d_bad || !d_tmp || !d_tmp2)
+        return fail(CRT_ERR_NOMEM, "lbvh: temporary arena too small");
+    const uint32_t scene_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    LB_HIPCHK(hipEventCreate(&ev0));
+    LB_HIPCHK(hipEventCreate(&ev1));
+    LB_HIPCHK(hipMemcpyAsync(d_scene, scene_init, sizeof scene_init, hipMemcpyHostToDevice, stream));
+    LB_HIPCHK(hipMemsetAsync(d_bad, 0, 4, stream));
+
+    const uint32_t g = (uint32_t)((n_tris + 255) / 256);
+    LB_HIPCHK(hipEventRecord(ev0, stream));
+    hipLaunchKernelGGL(k_tri_bounds, dim3(std::min<uint32_t>(g, 1024u)), dim3(256), 0, stream, d_vidx, stride, d_verts, (uint32_t)n, d_leaf_box, d_scene);
+    hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, stream, d_leaf_box, d_scene, (uint32_t)n, d_keys);
+    LB_HIPCHK(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, n_tris, 0, 64, stream));
+    hipLaunchKernelGGL(k_tri_order, dim3(g), dim3(256), 0, stream, d_sorted, (uint32_t)n, d_tri_order);
+    if (n > 1) hipLaunchKernelGGL(k_radix_tree, dim3((uint32_t)((n_tris - 1 + 255) / 256)), dim3(256), 0, stream, d_sorted, n, d_child, d_parent, d_first);
+    else { const int minus1 = -1; LB_HIPCHK(hipMemcpyAsync(d_parent, &minus1, 4, hipMemcpyHostToDevice, stream)); LB_HIPCHK(hipStreamSynchronize(stream)); }
+    const dim3 gn((uint32_t)((n_nodes + 255) / 256));
+    hipLaunchKernelGGL(k_bfs_keys, gn, dim3(256), 0, stream, d_parent, d_first, n, d_bkeys, d_ids);
+    LB_HIPCHK(rocprim::radix_sort_pairs(d_tmp2, tmp2_bytes, d_bkeys, d_bkeys2, d_ids, d_order, n_nodes, 0, 64, stream));
+    hipLaunchKernelGGL(k_bfs_pos, gn, dim3(256), 0, stream, d_order, (uint32_t)n_nodes, d_pos);
+    hipLaunchKernelGGL(k_flatten, gn, dim3(256), 0, stream, d_order, d_pos, d_child, d_sorted, d_leaf_box, n, d_flat, d_bad);
+    hipLaunchKernelGGL(k_level_starts, gn, dim3(256), 0, stream, d_bkeys2, (uint32_t)n_nodes, d_levels, (uint32_t)kMaxLevels);
+    unsigned long long deepest_key = 0;
+    std::vector<uint32_t> level_start;
+    LB_HIPCHK(hipMemcpyAsync(&deepest_key, d_bkeys2 + (n_nodes - 1), 8, hipMemcpyDeviceToHost, stream));
+    LB_HIPCHK(hipStreamSynchronize(stream));
+    const uint32_t n_levels = (uint32_t)(deepest_key >> 32) + 1u;
+    if (n_levels > kMaxLevels) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_lbvh_build: tree deeper than 4096 levels"); }
+    level_start.resize(n_levels + 1);
+    LB_HIPCHK(hipMemcpyAsync(level_start.data(), d_levels, n_levels * 4, hipMemcpyDeviceToHost, stream));
+    LB_HIPCHK(hipStreamSynchronize(stream));
+    level_start[n_levels] = (uint32_t)n_nodes;
+    for (uint32_t l = n_levels; l-- > 0;) {
+        const uint32_t cnt = level_start[l + 1] - level_start[l];
+        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_flat, level_start[l], level_start[l + 1]);
+    }
+    LB_HIPCHK(hipEventRecord(ev1, stream));
+    uint32_t bad = 0;
+    LB_HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
+    LB_HIPCHK(hipStreamSynchronize(stream));
+    LB_HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    LB_HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    cleanup();
+    if (bad) return fail(CRT_ERR_HIP, "crt_lbvh_build: breadth-first renumbering is inconsistent");
+    if (device_ms) *device_ms = ms;
+    if (depth_out) *depth_out = n_levels - 1u;           // the deepest level holds leaves only
+    return CRT_OK;
+}
+
+}  // namespace crt
+
 extern "C" {
 
 int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertices, size_t n_vertices, uint32_t /*flags*/, crt_sbvh** out) {
@@ -213,115 +317,45 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(CRT_ERR_NO_DEVICE, "crt_lbvh_build: no HIP device visible");
 
     const auto t_begin = std::chrono::steady_clock::now();
-    const int n = (int)n_tris;
-    int32_t* d_vidx = nullptr; float* d_verts = nullptr; float* d_leaf_box = nullptr; uint32_t* d_scene = nullptr;
-    unsigned long long *d_keys = nullptr, *d_sorted = nullptr; void* d_tmp = nullptr;
-    int2* d_child = nullptr; int* d_parent = nullptr; uint32_t* d_levels = nullptr;
-    int* d_first = nullptr; unsigned long long *d_bkeys = nullptr, *d_bkeys2 = nullptr; uint32_t *d_ids = nullptr, *d_order = nullptr, *d_pos = nullptr, *d_bad = nullptr;
-    crt_flatnode* d_flat = nullptr; void* d_tmp2 = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    auto cleanup = [&]() {
-        void* ptrs[] = {d_vidx, d_verts, d_leaf_box, d_scene, d_keys, d_sorted, d_tmp, d_child, d_parent, d_levels,
-                        d_first, d_bkeys, d_bkeys2, d_ids, d_order, d_pos, d_bad, d_flat, d_tmp2};
-        for (void* p : ptrs) if (p) (void)hipFree(p);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-    };
-
-    std::vector<int32_t> vidx(3 * n_tris);
-    for (size_t i = 0; i < n_tris; ++i) for (int j = 0; j < 3; ++j) vidx[3 * i + j] = tris[i].v[j];
     const size_t n_nodes = 2 * n_tris - 1;
-    LB_HIPCHK(hipMalloc(&d_vidx, vidx.size() * 4));
-    LB_HIPCHK(hipMalloc(&d_verts, n_vertices * 12));
-    LB_HIPCHK(hipMalloc(&d_leaf_box, n_tris * 24));
-    LB_HIPCHK(hipMalloc(&d_scene, 6 * 4));
-    LB_HIPCHK(hipMalloc(&d_keys, n_tris * 8));
-    LB_HIPCHK(hipMalloc(&d_sorted, n_tris * 8));
-    LB_HIPCHK(hipMalloc(&d_child, std::max<size_t>(n_tris - 1, 1) * sizeof(int2)));
-    LB_HIPCHK(hipMalloc(&d_parent, n_nodes * 4));
-    LB_HIPCHK(hipMalloc(&d_levels, kMaxLevels * 4));
-    LB_HIPCHK(hipMemcpy(d_vidx, vidx.data(), vidx.size() * 4, hipMemcpyHostToDevice));
-    LB_HIPCHK(hipMemcpy(d_verts, vertices, n_vertices * 12, hipMemcpyHostToDevice));
-    const uint32_t scene_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    LB_HIPCHK(hipMemcpy(d_scene, scene_init, sizeof scene_init, hipMemcpyHostToDevice));
-    size_t tmp_bytes = 0;
-    LB_HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys, d_sorted, n_tris, 0, 64, (hipStream_t)0));
-    LB_HIPCHK(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-    LB_HIPCHK(hipMalloc(&d_first, std::max<size_t>(n_tris - 1, 1) * 4));
-    LB_HIPCHK(hipMalloc(&d_bkeys, n_nodes * 8));
-    LB_HIPCHK(hipMalloc(&d_bkeys2, n_nodes * 8));
-    LB_HIPCHK(hipMalloc(&d_ids, n_nodes * 4));
-    LB_HIPCHK(hipMalloc(&d_order, n_nodes * 4));
-    LB_HIPCHK(hipMalloc(&d_pos, n_nodes * 4));
-    LB_HIPCHK(hipMalloc(&d_bad, 4));
-    LB_HIPCHK(hipMalloc(&d_flat, n_nodes * sizeof(crt_flatnode)));
-    LB_HIPCHK(hipMemset(d_bad, 0, 4));
-    size_t tmp2_bytes = 0;
-    LB_HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp2_bytes, d_bkeys, d_bkeys2, d_ids, d_order, n_nodes, 0, 64, (hipStream_t)0));
-    LB_HIPCHK(hipMalloc(&d_tmp2, std::max<size_t>(tmp2_bytes, 16)));
-    LB_HIPCHK(hipEventCreate(&ev0));
-    LB_HIPCHK(hipEventCreate(&ev1));
-
-    const uint32_t g = (uint32_t)((n_tris + 255) / 256);
-    LB_HIPCHK(hipEventRecord(ev0, 0));
-    hipLaunchKernelGGL(k_tri_bounds, dim3(std::min<uint32_t>(g, 1024u)), dim3(256), 0, 0, d_vidx, d_verts, (uint32_t)n, d_leaf_box, d_scene);
-    hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, 0, d_leaf_box, d_scene, (uint32_t)n, d_keys);
-    LB_HIPCHK(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, n_tris, 0, 64, (hipStream_t)0));
-    if (n > 1) hipLaunchKernelGGL(k_radix_tree, dim3((uint32_t)((n_tris - 1 + 255) / 256)), dim3(256), 0, 0, d_sorted, n, d_child, d_parent, d_first);
-    else { const int minus1 = -1; LB_HIPCHK(hipMemcpyAsync(d_parent, &minus1, 4, hipMemcpyHostToDevice, 0)); }
-    const dim3 gn((uint32_t)((n_nodes + 255) / 256));
-    hipLaunchKernelGGL(k_bfs_keys, gn, dim3(256), 0, 0, d_parent, d_first, n, d_bkeys, d_ids);
-    LB_HIPCHK(rocprim::radix_sort_pairs(d_tmp2, tmp2_bytes, d_bkeys, d_bkeys2, d_ids, d_order, n_nodes, 0, 64, (hipStream_t)0));
-    hipLaunchKernelGGL(k_bfs_pos, gn, dim3(256), 0, 0, d_order, (uint32_t)n_nodes, d_pos);
-    hipLaunchKernelGGL(k_flatten, gn, dim3(256), 0, 0, d_order, d_pos, d_child, d_sorted, d_leaf_box, n, d_flat, d_bad);
-    hipLaunchKernelGGL(k_level_starts, gn, dim3(256), 0, 0, d_bkeys2, (uint32_t)n_nodes, d_levels, (uint32_t)kMaxLevels);
-    unsigned long long deepest_key = 0;
-    std::vector<uint32_t> level_start;
-    LB_HIPCHK(hipMemcpy(&deepest_key, d_bkeys2 + (n_nodes - 1), 8, hipMemcpyDeviceToHost));
-    const uint32_t n_levels = (uint32_t)(deepest_key >> 32) + 1u;
-    if (n_levels > kMaxLevels) { cleanup(); return fail(CRT_ERR_LIMIT, "crt_lbvh_build: tree deeper than 4096 levels"); }
-    level_start.resize(n_levels + 1);
-    LB_HIPCHK(hipMemcpy(level_start.data(), d_levels, n_levels * 4, hipMemcpyDeviceToHost));
-    level_start[n_levels] = (uint32_t)n_nodes;
-    for (uint32_t l = n_levels; l-- > 0;) {
-        const uint32_t cnt = level_start[l + 1] - level_start[l];
-        hipLaunchKernelGGL(k_refit_level, dim3((cnt + 255) / 256), dim3(256), 0, 0, d_flat, level_start[l], level_start[l + 1]);
-    }
-    LB_HIPCHK(hipEventRecord(ev1, 0));
-    LB_HIPCHK(hipDeviceSynchronize());
-    LB_HIPCHK(hipGetLastError());
-    LB_HIPCHK(hipEventElapsedTime(&g_last_device_ms, ev0, ev1));
-
-    crt_sbvh* h = new (std::nothrow) crt_sbvh;
-    if (!h) { cleanup(); return fail(CRT_ERR_NOMEM, "crt_lbvh_build: out of memory"); }
-    crt::SBVH& b = h->bvh;
-    std::vector<unsigned long long> sorted;
-    uint32_t bad = 0;
-    unsigned long long last_key = 0;
+    crt::DeviceArena arena;
+    auto cleanup = [&]() { arena.release(); };
+    auto P = crt::DeviceArena::padded;
+    LB_HIPCHK(arena.reserve(crt::lbvh_tmp_bytes(n_tris) + P(n_tris * 12) + P(n_vertices * 12) + P(n_nodes * sizeof(crt_flatnode)) + P(n_tris * 4)));
+    std::vector<int32_t> vidx;
+    crt_sbvh* h = nullptr;
     try {
-        sorted.resize(n_tris);
-        b.flat_nodes.resize(n_nodes);
-        b.triangle_indices.resize(n_tris);
-        b.triangles.resize(n_tris);
+        vidx.resize(3 * n_tris);
+        h = new crt_sbvh;
+        h->bvh.flat_nodes.resize(n_nodes);
+        h->bvh.triangle_indices.resize(n_tris);
+        h->bvh.triangles.resize(n_tris);
     } catch (const std::exception& e) {
         delete h; cleanup();
         return fail(CRT_ERR_NOMEM, std::string("crt_lbvh_build: ") + e.what());
     }
-    if (hipMemcpy(sorted.data(), d_sorted, n_tris * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(b.flat_nodes.data(), d_flat, n_nodes * sizeof(crt_flatnode), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&last_key, d_bkeys2 + (n_nodes - 1), 8, hipMemcpyDeviceToHost) != hipSuccess) {
+    for (size_t i = 0; i < n_tris; ++i) for (int j = 0; j < 3; ++j) vidx[3 * i + j] = tris[i].v[j];
+    int32_t* d_vidx = arena.take<int32_t>(3 * n_tris);
+    float* d_verts = arena.take<float>(3 * n_vertices);
+    crt_flatnode* d_flat = arena.take<crt_flatnode>(n_nodes);
+    uint32_t* d_tri_order = arena.take<uint32_t>(n_tris);
+    if (!d_vidx || !d_verts || !d_flat || !d_tri_order) { delete h; cleanup(); return fail(CRT_ERR_NOMEM, "crt_lbvh_build: arena"); }
+    hipError_t e = hipMemcpy(d_vidx, vidx.data(), vidx.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_verts, vertices, n_vertices * 12, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete h; cleanup(); return fail(CRT_ERR_HIP, std::string("crt_lbvh_build: upload: ") + hipGetErrorString(e)); }
+    uint32_t depth = 0;
+    int rc = crt::lbvh_build_on_device(d_vidx, 3, d_verts, (uint32_t)n_tris, arena, d_flat, d_tri_order, &depth, &g_last_device_ms, (hipStream_t)0);
+    if (rc) { delete h; cleanup(); return rc; }
+    crt::SBVH& b = h->bvh;
+    static_assert(sizeof(int32_t) == sizeof(uint32_t), "");
+    if (hipMemcpy(b.flat_nodes.data(), d_flat, n_nodes * sizeof(crt_flatnode), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(b.triangle_indices.data(), d_tri_order, n_tris * 4, hipMemcpyDeviceToHost) != hipSuccess) {
         delete h; cleanup();
         return fail(CRT_ERR_HIP, "crt_lbvh_build: copy back failed");
     }
     cleanup();
-    if (bad) { delete h; return fail(CRT_ERR_HIP, "crt_lbvh_build: breadth-first renumbering is inconsistent"); }
-    b.depth = (int)(last_key >> 32);                     // the deepest level holds leaves only
-    // leaf slot j <-> j-th triangle in Morton order
-    for (size_t jx = 0; jx < n_tris; ++jx) {
-        b.triangle_indices[jx] = (int32_t)(sorted[jx] & 0xffffffffull);
-        b.triangles[jx] = tris[b.triangle_indices[jx]];
-    }
+    b.depth = (int)depth;
+    for (size_t jx = 0; jx < n_tris; ++jx) b.triangles[jx] = tris[b.triangle_indices[jx]];
     g_last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     *out = h;
     return CRT_OK;

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (CRT_ABI_VERSION, CRT_TRACE_ANY, CRT_TRACE_CLOSEST, check, crt_bvh_info, crt_frame_stats,
+from ._lib import (CRT_ABI_VERSION, CRT_BUILD_LBVH_ON_DEVICE, CRT_TRACE_ANY, CRT_TRACE_CLOSEST, check, crt_bvh_info, crt_frame_stats,
                    crt_scene_desc, lib)
 from .host import CWBVH, SBVH, Camera, Mesh, Rnd, _ptr
 
@@ -31,6 +31,7 @@ class SceneData:
         self.camera = camera
         self.albedo_textures = getattr(mesh, "albedo_textures", None)   # (layers, H, W, 3) uint8 or None (Scene.h:1065-1078)
         self.n_source_triangles = int(mesh.triangles.shape[0])
+        self.build_flags = 0
 
     @staticmethod
     def build(mesh, camera, sbvh_flags=0, with_cwbvh=True, builder="sbvh", convert="host"):
@@ -40,6 +41,16 @@ class SceneData:
         sbvh = SBVH(mesh.triangles, mesh.vertices, sbvh_flags, builder=builder)
         cw = CWBVH().convert(sbvh, device=(convert == "device")) if with_cwbvh else None
         return SceneData(mesh, sbvh, cw, camera)
+
+    @staticmethod
+    def for_device_build(mesh, camera):
+        """The seven input arrays only (triangles in source order): Scene() then builds LBVH, CWBVH and the intersection
+        records in HBM (crt_scene_desc.build_flags = CRT_BUILD_LBVH_ON_DEVICE) — nothing but these arrays crosses PCIe."""
+        class _NoBvh:
+            triangles, triangle_indices, flat_nodes = mesh.triangles, None, None
+        data = SceneData(mesh, _NoBvh, None, camera)
+        data.build_flags = CRT_BUILD_LBVH_ON_DEVICE
+        return data
 
     @staticmethod
     def from_obj(path, camera):
@@ -83,6 +94,7 @@ class Scene:
             d.albedo_textures = _ptr(tex)
             d.n_textures, d.tex_height, d.tex_width = tex.shape[0], tex.shape[1], tex.shape[2]
         d.width, d.height, d.max_depth = self.width, self.height, self.max_depth
+        d.build_flags = int(getattr(data, "build_flags", 0))
         check(lib().crt_scene_create(C.byref(d), C.byref(self._h)))
         if data.camera is not None:
             self.update(data.camera)
@@ -186,4 +198,4 @@ class Scene:
 
 
 __all__ = ["Scene", "SceneData", "Camera", "Mesh", "SBVH", "CWBVH", "RAY_DT", "HIT_DT", "STATS_DT",
-           "CRT_TRACE_CLOSEST", "CRT_TRACE_ANY"]
+           "CRT_TRACE_CLOSEST", "CRT_TRACE_ANY", "CRT_BUILD_LBVH_ON_DEVICE"]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 2   /* 2: crt_frame_stats.stack_overflows */
+#define CRT_ABI_VERSION 2   /* 2: crt_frame_stats.stack_overflows + wave_steps_*, crt_scene_desc.build_flags, crt_bvh_info build times */
 
 typedef enum crt_status {
     CRT_OK = 0,
@@ -94,7 +94,8 @@ enum { CRT_TRACE_CLOSEST = 0, CRT_TRACE_ANY = 1, CRT_TRACE_BVH2 = 2, CRT_TRACE_T
  * buffer.  All pointers are HOST memory and are COPIED (the reference frees its CPU
  * vectors right after upload, Scene.h:503).  `triangles` are in BVH2 leaf order with
  * spatial-split duplicates (sbvh.h:130-139).  Either `bvh` (BVH2; converted to CWBVH
- * on the host) or `bvh8` + `bvh8_tri_slots` must be given; both may be. */
+ * on the host) or `bvh8` + `bvh8_tri_slots` must be given; both may be — or neither, with
+ * build_flags = CRT_BUILD_LBVH_ON_DEVICE (below). */
 typedef struct crt_scene_desc {
     uint32_t abi_version;               /* CRT_ABI_VERSION */
     const float*        vertices;   size_t n_vertices;   /* xyz, 12 B   Scene.h:1015-1020 */
@@ -110,7 +111,16 @@ typedef struct crt_scene_desc {
     const uint8_t*      albedo_textures; uint32_t tex_width, tex_height, n_textures; /* RGB8 array, Scene.h:1065-1078 */
     uint32_t width, height;             /* screenResolution, Scene.h:1151 */
     uint32_t max_depth;                 /* path segments; the shader hard-codes 3 (path_trace.fs:867) */
+    uint32_t build_flags;               /* CRT_BUILD_*: 0 unless neither bvh nor bvh8 is given */
 } crt_scene_desc;
+
+/* crt_scene_desc.build_flags.  With CRT_BUILD_LBVH_ON_DEVICE (bvh == bvh8 == NULL) `triangles` come in SOURCE order
+ * (tri_orig_ids must be NULL: a triangle's id is its index) and everything Scene::build_bvh (Scene.h:929-958) and the
+ * intended CWBVH::convert would have produced on the host is produced in HBM instead: linear BVH (crt_lbvh_build's
+ * kernels), CWBVH conversion (crt_cwbvh_convert_device's kernels: same bytes as the host converter), leaf-order
+ * triangle array and intersection records.  Only the seven input arrays cross PCIe, once.  The tree is the LBVH, not
+ * the reference's SBVH; frames are bit-identical to a scene created from crt_lbvh_build's host arrays. */
+enum { CRT_BUILD_LBVH_ON_DEVICE = 1 };
 
 typedef struct crt_scene crt_scene;
 
@@ -208,7 +218,13 @@ typedef struct crt_frame_stats {
 } crt_frame_stats;
 int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out);
 /* structural facts about the device-resident CWBVH */
-typedef struct crt_bvh_info { uint64_t n_nodes8, n_tris8, n_bvh2_nodes, max_depth8; } crt_bvh_info;
+typedef struct crt_bvh_info {
+    uint64_t n_nodes8, n_tris8, n_bvh2_nodes, max_depth8;
+    /* build-on-device scenes (CRT_BUILD_LBVH_ON_DEVICE): wall milliseconds of crt_scene_create and of its parts (upload of
+     * the input arrays; LBVH and CWBVH conversion as device time); zero for scenes created from host-built arrays */
+    uint32_t built_on_device, bvh2_depth;
+    float build_wall_ms, build_upload_ms, build_lbvh_device_ms, build_convert_device_ms;
+} crt_bvh_info;
 int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out);
 int crt_device_count(void);
 

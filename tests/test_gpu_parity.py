@@ -867,6 +867,53 @@ def test_hip_bvh2_walk_reproduces_the_survey_census(cr, ob, cornell_data, survey
     scene.close()
 
 
+@pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
+def test_scene_built_entirely_on_the_device(cr, ob, cornell, tess8, tess40, name):
+    """crt_scene_desc.build_flags = CRT_BUILD_LBVH_ON_DEVICE: only the input arrays are uploaded; LBVH, CWBVH conversion,
+    leaf-order triangles and intersection records are produced in HBM.  Frames, hits, ray counts and visit counters are
+    identical to a scene created from crt_lbvh_build's host arrays (the same tree going the long way round), hits agree with
+    the oracle on that tree, and the BVH2 it keeps serves the BVH2 walks."""
+    from caitlynrenderer_amd import _lib
+    mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
+    cam = cornell[1]
+    W, H, depth = 256, 144, 3
+    dev = cr.Scene(cr.SceneData.for_device_build(mesh, cam), W, H, depth)
+    info = dev.bvh_info()
+    assert info["built_on_device"] == 1 and info["n_tris8"] == mesh.triangles.shape[0] and info["n_bvh2_nodes"] == 2 * mesh.triangles.shape[0] - 1
+    assert info["build_wall_ms"] > 0 and info["build_lbvh_device_ms"] > 0 and info["build_convert_device_ms"] > 0
+    data = cr.SceneData.build(mesh, cam, builder="lbvh", convert="device")
+    ref = cr.Scene(data, W, H, depth)
+    assert ref.bvh_info()["n_nodes8"] == info["n_nodes8"] and ref.bvh_info()["max_depth8"] == info["max_depth8"]
+    rnd = cr.Rnd()
+    for s in (dev, ref):
+        s.set_option("count_visits", 1)
+    for _ in range(2):
+        rx, ry = rnd.randf2(), rnd.randf2()
+        dev.render_frame(rx, ry); ref.render_frame(rx, ry)
+        a, b = dev.frame_stats(), ref.frame_stats()
+        for k in ("closest_rays", "any_rays", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert a[k] == b[k], k
+        assert a["stack_overflows"] == 0
+    assert np.array_equal(dev.read_sum().view(np.uint32), ref.read_sum().view(np.uint32))
+    rays = seeded_rays(mesh, 20000, 5, cr.RAY_DT)
+    orc = ob.Oracle(data, W, H, depth, cam)
+    want = orc.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=8)
+    _assert_hits_equal(dev.trace(rays), want)
+    got2 = dev.trace(rays, cr.CRT_TRACE_BVH2 | cr.CRT_TRACE_TIE_LOWEST_ID)      # the BVH2 stayed on the device
+    assert np.array_equal(got2["tri"], want["tri"]) and np.array_equal(got2["t"].view(np.uint32), want["t"].view(np.uint32))
+    dev.close(); ref.close()
+    # refused inputs: the same classes of error as the host checks, found by a kernel over the uploaded array
+    bad = cr.SceneData.for_device_build(mesh, cam)
+    bad.triangles = mesh.triangles.copy(); bad.triangles[3, 1] = mesh.vertices.shape[0] + 7
+    with pytest.raises(cr.CrtError) as e:
+        cr.Scene(bad, 64, 64, 1)
+    assert e.value.code == _lib.CRT_ERR_INVALID and "vertex index" in str(e.value)
+    bad.triangles = mesh.triangles.copy(); bad.triangles[5, 3] = 99
+    with pytest.raises(cr.CrtError) as e:
+        cr.Scene(bad, 64, 64, 1)
+    assert e.value.code == _lib.CRT_ERR_INVALID and "material index" in str(e.value)
+
+
 def test_scene_from_bvh2_only_converts_on_the_device(cr, tess40, scenes):
     """crt_scene_create with a BVH2 and no CWBVH converts internally — on the GPU for trees of 4096+ nodes; since the
     device converter is byte-identical to the host one, the scene behaves exactly like the one given both."""
