@@ -65,8 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = one fixed frame split over the ranks (configs[4], default); weak = the frame grows with N")
     ap.add_argument("--tile", type=int, default=64)
-    ap.add_argument("--builder", default="sbvh", choices=["sbvh", "lbvh"],
-                    help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build)")
+    ap.add_argument("--builder", default="sbvh",
+                    help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build); "
+                         "ploc / ploc<radius> = GPU parallel locally-ordered clustering")
     ap.add_argument("--convert", default="host", choices=["host", "device"],
                     help="BVH2 -> CWBVH conversion on the host (default) or on the GPU (crt_cwbvh_convert_device, same bytes)")
     ap.add_argument("--accel", default="cwbvh", choices=["cwbvh", "bvh2"],
@@ -149,6 +150,8 @@ def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
     data = cr.SceneData.build(mesh, cam, builder=builder, convert=convert)
     if builder == "lbvh":
         label += " over a GPU-built LBVH"
+    elif builder.startswith("ploc"):
+        label += f" over a GPU-built PLOC tree ({builder})"
     if convert == "device":
         label += ", CWBVH converted on the GPU"
     _SCENE_CACHE[key] = (data, cam, label, time.time() - t0)

@@ -41,8 +41,9 @@ struct DeviceArena {
 // d_vidx: vertex indices of triangle i at d_vidx[stride * i + 0..2] (stride 3 = packed, 12 = the crt_triangle array itself).
 // d_flat (2n - 1 nodes, BFS order, one triangle per leaf) and d_tri_order (leaf slot -> input triangle) are caller-owned
 // device buffers; temporaries come from `tmp` (lbvh_tmp_bytes).  Synchronises the stream twice (level table).
-size_t lbvh_tmp_bytes(size_t n_tris);
-int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_verts, uint32_t n_tris, DeviceArena& tmp,
+// flags: CRT_GPU_BUILD_* of include/crt.h (0 = linear BVH; CRT_GPU_BUILD_PLOC | radius << 8 = PLOC, whose boxes need no refit).
+size_t lbvh_tmp_bytes(size_t n_tris, uint32_t flags);
+int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_verts, uint32_t n_tris, uint32_t flags, DeviceArena& tmp,
                          crt_flatnode* d_flat, uint32_t* d_tri_order, uint32_t* depth_out, float* device_ms, hipStream_t stream);
 
 // ---- BVH2 -> CWBVH (cwbvh_device.hip) ----

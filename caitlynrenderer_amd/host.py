@@ -135,15 +135,20 @@ class SBVH:
     NO_SPATIAL_SPLITS = 1
 
     def __init__(self, triangles, vertices, flags=0, builder="sbvh"):
-        """builder="sbvh": the reference's split-BVH on the host; builder="lbvh": GPU linear BVH (crt_lbvh_build)."""
+        """builder="sbvh": the reference's split-BVH on the host; "lbvh": GPU linear BVH (crt_lbvh_build); "ploc" / "ploc<radius>":
+        GPU parallel locally-ordered clustering (crt_lbvh_build with CRT_GPU_BUILD_PLOC)."""
         L = lib()
         tris = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 12)
         verts = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         h = C.c_void_p()
-        build = L.crt_lbvh_build if builder == "lbvh" else L.crt_sbvh_build
+        gpu = builder in ("lbvh", "ploc") or builder.startswith("ploc")
+        if builder.startswith("ploc"):                  # "ploc" or "ploc<radius>": crt_lbvh_build with CRT_GPU_BUILD_PLOC | radius << 8
+            radius = int(builder[4:]) if len(builder) > 4 else 0
+            flags = 2 | (radius << 8)
+        build = L.crt_lbvh_build if gpu else L.crt_sbvh_build
         check(build(_ptr(tris), tris.shape[0], _ptr(verts), verts.shape[0], int(flags), C.byref(h)))
         self.build_ms = None
-        if builder == "lbvh":
+        if gpu:
             dev, tot = C.c_float(), C.c_float()
             L.crt_lbvh_last_build_ms(C.byref(dev), C.byref(tot))
             self.build_ms = (dev.value, tot.value)

@@ -43,13 +43,16 @@ class SceneData:
         return SceneData(mesh, sbvh, cw, camera)
 
     @staticmethod
-    def for_device_build(mesh, camera):
-        """The seven input arrays only (triangles in source order): Scene() then builds LBVH, CWBVH and the intersection
-        records in HBM (crt_scene_desc.build_flags = CRT_BUILD_LBVH_ON_DEVICE) — nothing but these arrays crosses PCIe."""
+    def for_device_build(mesh, camera, builder="lbvh"):
+        """The seven input arrays only (triangles in source order): Scene() then builds the BVH2 (builder "lbvh", or "ploc" /
+        "ploc<radius>"), the CWBVH and the intersection records in HBM (crt_scene_desc.build_flags =
+        CRT_BUILD_LBVH_ON_DEVICE [| CRT_BUILD_PLOC | radius << 8]) — nothing but these arrays crosses PCIe."""
         class _NoBvh:
             triangles, triangle_indices, flat_nodes = mesh.triangles, None, None
         data = SceneData(mesh, _NoBvh, None, camera)
         data.build_flags = CRT_BUILD_LBVH_ON_DEVICE
+        if builder.startswith("ploc"):
+            data.build_flags |= 2 | ((int(builder[4:]) if len(builder) > 4 else 0) << 8)
         return data
 
     @staticmethod

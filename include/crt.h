@@ -120,7 +120,10 @@ typedef struct crt_scene_desc {
  * kernels), CWBVH conversion (crt_cwbvh_convert_device's kernels: same bytes as the host converter), leaf-order
  * triangle array and intersection records.  Only the seven input arrays cross PCIe, once.  The tree is the LBVH, not
  * the reference's SBVH; frames are bit-identical to a scene created from crt_lbvh_build's host arrays. */
-enum { CRT_BUILD_LBVH_ON_DEVICE = 1 };
+enum { CRT_BUILD_LBVH_ON_DEVICE = 1,
+       /* with CRT_BUILD_LBVH_ON_DEVICE: build the tree by PLOC (CRT_GPU_BUILD_PLOC of crt_lbvh_build) instead of the linear
+        * BVH; bits 8..15 = search radius, 0 = 16 */
+       CRT_BUILD_PLOC = 2 };
 
 typedef struct crt_scene crt_scene;
 
@@ -254,6 +257,10 @@ void crt_sbvh_free(crt_sbvh*);
  * radix tree, bottom-up refit) in the same FlatNode/leaf-order layout, returned through the same handle as
  * crt_sbvh_build so either builder can feed crt_scene_desc.bvh / crt_cwbvh_convert.  Not the reference's
  * SBVH: no SAH and no spatial splits — a different, lower-quality tree built ~100x faster. */
+/* flags = 0: linear BVH.  flags = CRT_GPU_BUILD_PLOC | (radius << 8): parallel locally-ordered clustering (Meister & Bittner
+ * 2018) over the same Morton order — mutual nearest neighbours within `radius` cluster positions (1..64, 0 = 16) merge
+ * bottom-up; a SAH-quality tree for a few more milliseconds of device time. */
+enum { CRT_GPU_BUILD_PLOC = 2 };
 int  crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertices, size_t n_vertices,
                     uint32_t flags, crt_sbvh** out);
 void crt_lbvh_last_build_ms(float* device_ms, float* total_ms);

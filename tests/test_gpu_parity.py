@@ -719,17 +719,19 @@ def _check_lbvh(flat, tris, verts):
     assert np.array_equal(lo[inner], np.minimum(lo[left], lo[left + 1])) and np.array_equal(hi[inner], np.maximum(hi[left], hi[left + 1]))
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "ploc4", "ploc64"])
 @pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
-def test_gpu_lbvh_builder(cr, ob, cornell, tess8, tess40, scenes, name):
-    """crt_lbvh_build: Morton sort + Karras tree + device refit.  The tree is valid, the scene
-    built on it (LBVH -> host CWBVH conversion) returns exactly the hits of the reference-builder scene."""
+def test_gpu_lbvh_builder(cr, ob, cornell, tess8, tess40, scenes, name, builder):
+    """crt_lbvh_build: Morton sort, then Karras' radix tree + device refit (lbvh) or parallel locally-ordered
+    clustering (ploc, search radius 16 / 4 / 64).  The tree is valid, the scene built on it (-> host CWBVH conversion)
+    returns exactly the hits of the reference-builder scene."""
     mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
-    sb = cr.SBVH(mesh.triangles, mesh.vertices, builder="lbvh")
+    sb = cr.SBVH(mesh.triangles, mesh.vertices, builder=builder)
     assert sb.build_ms is not None and sb.build_ms[0] > 0
     _check_lbvh(sb.flat_nodes, sb.triangles, mesh.vertices)
     assert sorted(sb.triangle_indices.tolist()) == list(range(mesh.triangles.shape[0]))       # no duplicates: a permutation
     assert np.array_equal(sb.triangles, mesh.triangles[sb.triangle_indices])
-    data = cr.SceneData.build(mesh, cornell[1], builder="lbvh")
+    data = cr.SceneData.build(mesh, cornell[1], builder=builder)
     scene_l = cr.Scene(data, 64, 64, 1)
     scene_s, orc, _ = scenes[name]
     rays = np.concatenate([seeded_rays(mesh, 40000, 31, cr.RAY_DT), orc.primary_rays(RX1, RY1, jitter=True).astype(cr.RAY_DT)])
@@ -738,9 +740,17 @@ def test_gpu_lbvh_builder(cr, ob, cornell, tess8, tess40, scenes, name):
     _assert_hits_equal(got, ob.Oracle(data, 64, 64, 1, cornell[1]).trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=8))
     _assert_hits_equal(scene_l.trace(rays, cr.CRT_TRACE_BVH2 | cr.CRT_TRACE_TIE_LOWEST_ID), got)
     # deterministic: same tree on a second build
-    sb2 = cr.SBVH(mesh.triangles, mesh.vertices, builder="lbvh")
+    sb2 = cr.SBVH(mesh.triangles, mesh.vertices, builder=builder)
     assert np.array_equal(sb2.flat_nodes.view(np.uint32), sb.flat_nodes.view(np.uint32)) and np.array_equal(sb2.triangle_indices, sb.triangle_indices)
     scene_l.close()
+    if builder == "ploc" and name != "cornell":
+        # the point of PLOC: a better tree than the spatial-median LBVH — fewer node visits on the same rays
+        lb = cr.Scene(cr.SceneData.build(mesh, cornell[1], builder="lbvh"), 64, 64, 1)
+        pl = cr.Scene(data, 64, 64, 1)
+        _, st_l = lb.trace(rays, stats=True)
+        _, st_p = pl.trace(rays, stats=True)
+        assert st_p["nodes"].astype(np.int64).sum() < st_l["nodes"].astype(np.int64).sum()
+        lb.close(); pl.close()
 
 
 def test_gpu_lbvh_edge_cases(cr):
@@ -867,8 +877,9 @@ def test_hip_bvh2_walk_reproduces_the_survey_census(cr, ob, cornell_data, survey
     scene.close()
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
 @pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
-def test_scene_built_entirely_on_the_device(cr, ob, cornell, tess8, tess40, name):
+def test_scene_built_entirely_on_the_device(cr, ob, cornell, tess8, tess40, name, builder):
     """crt_scene_desc.build_flags = CRT_BUILD_LBVH_ON_DEVICE: only the input arrays are uploaded; LBVH, CWBVH conversion,
     leaf-order triangles and intersection records are produced in HBM.  Frames, hits, ray counts and visit counters are
     identical to a scene created from crt_lbvh_build's host arrays (the same tree going the long way round), hits agree with
@@ -877,11 +888,11 @@ def test_scene_built_entirely_on_the_device(cr, ob, cornell, tess8, tess40, name
     mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
     cam = cornell[1]
     W, H, depth = 256, 144, 3
-    dev = cr.Scene(cr.SceneData.for_device_build(mesh, cam), W, H, depth)
+    dev = cr.Scene(cr.SceneData.for_device_build(mesh, cam, builder=builder), W, H, depth)
     info = dev.bvh_info()
     assert info["built_on_device"] == 1 and info["n_tris8"] == mesh.triangles.shape[0] and info["n_bvh2_nodes"] == 2 * mesh.triangles.shape[0] - 1
     assert info["build_wall_ms"] > 0 and info["build_lbvh_device_ms"] > 0 and info["build_convert_device_ms"] > 0
-    data = cr.SceneData.build(mesh, cam, builder="lbvh", convert="device")
+    data = cr.SceneData.build(mesh, cam, builder=builder, convert="device")
     ref = cr.Scene(data, W, H, depth)
     assert ref.bvh_info()["n_nodes8"] == info["n_nodes8"] and ref.bvh_info()["max_depth8"] == info["max_depth8"]
     rnd = cr.Rnd()
