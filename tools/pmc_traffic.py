@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from the two --pmc passes of tools/profile_round.sh.
+"""profiles/pmc_traffic.json from the --pmc passes of tools/profile_round.sh.
 
 usage: tools/pmc_traffic.py <round dir> <out json>
-HBM bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts half of
-the fetched bytes (MI355X_MICROARCH.md, HBM section); both counters are in KiB.  Only the non-counting variant of
-k_segment<FIRST> (second template argument false) is aggregated, i.e. the launches of the timed region.
+Per workload (cornell_d1, mesh1m_d1, mesh1m_d4), over the non-counting k_segment launches of the timed region:
+  l2_fabric_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts half of the fetched bytes
+      (MI355X_MICROARCH.md, HBM section); both counters are in KiB.  These are bytes crossing L2 <-> Infinity Fabric; with the
+      scene resident in the 256 MiB Infinity Cache the bytes that reach HBM are fewer still.
+  valu_issue: busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8)   (SQ_* count quad-cycles; a wave64 VALU instruction
+      holds its SIMD's issue port ~4 cycles — measured, scratch/ubench in DESIGN.md §5; GRBM_GUI_ACTIVE is summed over the 8 XCDs);
+      lane_util = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); frac = busy * lane_util = the share of the chip's
+      lane-cycles doing enabled VALU work.  This, not HBM, is what bounds the kernel.
 """
 import collections, csv, glob, json, os, sys
+
+N_SIMD = 256 * 4
+
 
 def per_kernel(dirname):
     agg = collections.defaultdict(list)
@@ -15,26 +23,46 @@ def per_kernel(dirname):
             agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return agg
 
+
 def main(round_dir, out):
     res = {}
-    for wl in ("cornell", "mesh1m"):
+    for wl in ("cornell_d1", "mesh1m_d1", "mesh1m_d4"):
         agg = {}
-        for kind in ("fetch", "write"):
+        for kind in ("fetch", "write", "sq", "grbm"):
             agg.update(per_kernel(os.path.join(round_dir, f"pmc_{kind}_{wl}")))
-        names = sorted({k for k, _ in agg if "k_segment<true, false" in k})
+        names = sorted({k for k, _ in agg if k.startswith("void crt::k_segment<") and k.split(",")[1].strip() == "false"})
         if not names:
             continue
-        k = names[0]
-        mean = lambda c: sum(agg[(k, c)]) / len(agg[(k, c)])
-        fetch, write, hit, miss = mean("FETCH_SIZE"), mean("WRITE_SIZE"), mean("TCC_HIT_sum"), mean("TCC_MISS_sum")
-        res[f"{wl}_d1"] = {
-            "kernel": k, "FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
-            "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
-            "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of the fetched bytes (MI355X_MICROARCH.md, HBM)",
-            "l2_hit_rate": round(hit / (hit + miss), 3), "dispatches": len(agg[(k, "FETCH_SIZE")]),
-        }
+
+        def total(c):       # summed over the segment kernels (first + bounce), per launch
+            vals = [v for k in names for v in agg.get((k, c), [])]
+            return sum(vals), len(vals)
+        fetch, n_l = total("FETCH_SIZE")
+        write, _ = total("WRITE_SIZE")
+        hit, _ = total("TCC_HIT_sum")
+        miss, _ = total("TCC_MISS_sum")
+        e = {"kernels": names, "dispatches": n_l}
+        if n_l:
+            e.update({"FETCH_SIZE_KB_per_launch": round(fetch / n_l, 1), "WRITE_SIZE_KB_per_launch": round(write / n_l, 1),
+                      "l2_fabric_bytes_per_launch": int((2 * fetch + write) * 1024 / n_l),
+                      "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of the fetched bytes (MI355X_MICROARCH.md, HBM); L2<->fabric traffic, not HBM",
+                      "l2_hit_rate": round(hit / max(1.0, hit + miss), 3)})
+        act, n_sq = total("SQ_ACTIVE_INST_VALU")
+        thr, _ = total("SQ_THREAD_CYCLES_VALU")
+        insts, _ = total("SQ_INSTS_VALU")
+        waves, _ = total("SQ_WAVES")
+        gui, n_g = total("GRBM_GUI_ACTIVE")
+        if n_sq and n_g and act > 0:
+            busy = 4.0 * (act / n_sq) / (N_SIMD * (gui / n_g) / 8.0)
+            lane = thr / (64.0 * act)
+            e["valu_issue"] = {"busy": round(busy, 3), "lane_util": round(lane, 3), "frac": round(busy * lane, 3),
+                               "valu_instructions_per_wave": round(insts / max(1.0, waves), 1),
+                               "source": "rocprofv3 --pmc passes of `bench.py --workload %s --depth %s --spp 1` (tools/profile_round.sh); formulae in tools/pmc_traffic.py"
+                                         % tuple(wl.split("_d"))}
+        res[wl] = e
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
+
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
