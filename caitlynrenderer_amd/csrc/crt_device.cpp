@@ -136,6 +136,7 @@ struct crt_scene {
     uint32_t oversubscribe = 0;
     bool special_materials = false;          // some material is Mirror_type / Disney_type (albedo.w, Scene.h:111-132): k_segment<MAT>
     uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 2, or 4 = 256-thread workgroups
+    uint32_t tri_share = 0;                  // triangle steps shared out to all lanes of the wave: 0 off, 1 closest hit, 2 + in-place shadow rays
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
@@ -310,6 +311,7 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
     if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
+    if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(2, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
@@ -691,6 +693,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         s->waves_per_workgroup = (uint32_t)value;
     }
     else if (!std::strcmp(name, "compact_shadow")) s->compact_shadow = value ? 1u : 0u;
+    else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(2, std::max(0, value));
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "accel")) {
         if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
@@ -763,6 +766,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         const bool small_tree = s->info.n_nodes8 < 64;
         const bool inplace = bvh2 || s->inplace_shadow != 0u;   // shadow rays walked inside k_segment: no queue, no k_shadow launch
         sa.tri_min = small_tree ? 0u : s->tri_min;
+        sa.tri_share = s->tri_share;
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
@@ -786,7 +790,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         } else if (sp) {
             crt::set_launch_events(sp->a, sp->b);
         }
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};

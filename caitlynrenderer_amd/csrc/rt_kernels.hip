@@ -199,11 +199,27 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
 // bit-identical to the oracle.
 //   load(idx, o, d, tmax)  fetches ray idx of the pool;  done(idx, best, occluded)  consumes its result.
 // The pool is [pool_begin, pool_end); refill happens when at least `refill_min` lanes are idle (or none is busy).
-template <bool ANY, bool STATS, typename Load, typename Done>
+//
+// SHARE: triangle steps hand the pending triangles of the waiting lanes to ALL lanes of the wave.  In the plain loop a
+// triangle step tests one triangle per waiting lane, so a lane with three pending triangles costs the wave three steps,
+// run with the 9-20 lanes that happen to wait (lane utilisation of the triangle blocks: 30 % / 15 % at one segment,
+// 20 % / 7 % at four, half of all wave-level steps).  Here every waiting lane publishes up to three
+// (lane, triangle) items through a wave-private LDS strip (offsets from two ballots: counts are 0..3), lane r of the wave
+// tests item r with the OWNER's ray (origin and direction live in the same strip, written when the ray was loaded), and the
+// owner folds its items' results in their original order — the same tests with the same operands, by another lane, and the
+// same acceptance rule in the same order: hits and per-ray counters stay bit-identical.
+struct TriShare {
+    float4* ray;        // [2][64]: origin, direction of each lane's current ray
+    uint32_t* items;    // [64]: triangle index | owner lane << 24
+    float4* res;        // [64]: t, u, v, original id (int bits; -1 = no hit)
+};
+#define CRT_SHARE_BYTES (2 * 64 * 16 + 64 * 4 + 64 * 16)      // per wave
+
+template <bool ANY, bool STATS, bool SHARE = false, typename Load, typename Done>
 __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* stk,
                                               int stack_entries, uint32_t* overflow, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
                                               uint32_t tri_min, Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris,
-                                              uint32_t& w_nodes, uint32_t& w_tris) {
+                                              uint32_t& w_nodes, uint32_t& w_tris, TriShare share = TriShare{nullptr, nullptr, nullptr}) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t next = pool_begin;                     // wave-uniform
     bool busy = false;
@@ -237,6 +253,10 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
                 cur = finite ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
                 tg = make_uint2(0u, 0u);
+                if (SHARE) {                        // whoever tests this ray's triangles reads its operands from here
+                    share.ray[lane] = make_float4(o.x, o.y, o.z, 0.f);
+                    share.ray[64u + lane] = make_float4(d.x, d.y, d.z, 0.f);
+                }
             }
             next = next + n_idle < pool_end ? next + n_idle : pool_end;
         }
@@ -281,6 +301,62 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 tg.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
                 tg.y = hitmask & 0x00ffffffu;
+            }
+        } else if (SHARE) {
+            // ---- shared triangle step (the whole wave takes part, waiting or not) ----
+            const unsigned long long act = __ballot(true), lt = (1ull << lane) - 1ull;
+            const uint32_t n_cons = (uint32_t)__builtin_popcountll(act), rank = (uint32_t)__builtin_popcountll(act & lt);
+            const uint32_t pend = has_tri ? (uint32_t)__builtin_popcount(tg.y) : 0u;
+            const uint32_t k = pend > 3u ? 3u : pend;
+            const unsigned long long b0 = __ballot((k & 1u) != 0u), b1 = __ballot((k & 2u) != 0u);
+            const uint32_t off = (uint32_t)__builtin_popcountll(b0 & lt) + 2u * (uint32_t)__builtin_popcountll(b1 & lt);
+            const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1);
+            if (total != 0u) {
+                const uint32_t room = off < n_cons ? n_cons - off : 0u;
+                const uint32_t lim = k < room ? k : room;        // items this lane gets tested in this step
+                uint32_t bits = tg.y;
+#pragma unroll
+                for (uint32_t j = 0; j < 3u; ++j)
+                    if (j < lim) {
+                        const int b = 31 - __builtin_clz(bits);
+                        bits &= ~(1u << b);
+                        share.items[off + j] = (tg.x + (uint32_t)b) | (lane << 24);
+                    }
+                __builtin_amdgcn_wave_barrier();
+                if (STATS) count_wave_step(w_tris);
+                const uint32_t n_items = total < n_cons ? total : n_cons;
+                if (rank < n_items) {
+                    const uint32_t item = share.items[rank];
+                    const uint32_t src = item >> 24, ti = item & 0x00ffffffu;
+                    const float4 ro = share.ray[src], rd = share.ray[64u + src];
+                    const float4* tp = tris + (size_t)ti * 3;
+                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    float u, v, t;
+                    const bool hit = mt_test(ta, tb, tc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), u, v, t);
+                    share.res[rank] = make_float4(t, u, v, hit ? ta.w : __int_as_float(-1));
+                }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t mine = tg.y;
+#pragma unroll
+                for (uint32_t j = 0; j < 3u; ++j)
+                    if (j < lim && !finished) {
+                        const int b = 31 - __builtin_clz(mine);
+                        mine &= ~(1u << b);
+                        const float4 r = share.res[off + j];
+                        if (STATS) ++n_tris;
+                        const int id = __float_as_int(r.w);
+                        if (id >= 0) {
+                            const uint32_t ti = tg.x + (uint32_t)b;
+                            if (ANY) {
+                                if (r.x < max_t) { best.tri = (int)ti; finished = true; }
+                            } else if (r.x < best.t || (r.x == best.t && best.tri >= 0 && id < best.id)) {
+                                best.t = r.x; best.u = r.y; best.v = r.z; best.tri = (int)ti; best.id = id;
+                                max_t = r.x;
+                            }
+                        }
+                    }
+                tg.y = finished ? 0u : bits;
+                __builtin_amdgcn_wave_barrier();                 // results are consumed before the next step's items overwrite the strip
             }
         } else if (has_tri) {
             const int b = 31 - __builtin_clz(tg.y);
@@ -753,7 +829,9 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // gathered through LDS (ballot + prefix over the waves) into full waves: wave w of the workgroup walks rays [64 w, 64 w + 64)
 // of the compacted list and finishes those paths itself (L + C into the sum buffer or the path state), a wave left without
 // rays retires at once.  Each ray is walked exactly as before, by another lane: sums and counters stay bit-identical.
-template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false>
+// SHARE: the closest-hit walk hands pending triangles to all lanes of the wave (traverse_pool<..., SHARE>); a.tri_share
+// == 2 also walks the in-place shadow rays that way.
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false, bool SHARE = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
     const WaveId wid = wave_id();
@@ -762,6 +840,13 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     const uint32_t wave_stride = (COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) * 64u;
     uint2* stk = s_lds + (size_t)wid.lds_wave * wave_stride + lane;
     int* stk2 = reinterpret_cast<int*>(s_lds) + (size_t)wid.lds_wave * a.stack_entries2 * 64u + lane;   // BVH2 mode
+    TriShare share{nullptr, nullptr, nullptr};
+    if (SHARE) {                                         // wave-private strip behind the stacks (and COMPACT's wave counters)
+        char* base = reinterpret_cast<char*>(s_lds + (size_t)(blockDim.x >> 6) * wave_stride) + 16 + (size_t)wid.lds_wave * CRT_SHARE_BYTES;
+        share.ray = reinterpret_cast<float4*>(base);
+        share.res = reinterpret_cast<float4*>(base + 2 * 64 * 16);
+        share.items = reinterpret_cast<uint32_t*>(base + 3 * 64 * 16);
+    }
     const float4* const recs = BVH2 ? a.tris2 : a.tris;   // intersection records the hit index refers to
     const FrameArgs& f = a.f;
     uint32_t nn = 0, nt = 0, nn_any = 0, nt_any = 0;
@@ -846,11 +931,11 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray get a non-finite origin, which finishes immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             const float qnan = __uint_as_float(0x7fc00000u);
-            traverse_pool<false, STATS>(
+            traverse_pool<false, STATS, SHARE>(
                 a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
                 [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = active ? o : V3(qnan, qnan, qnan); rd = d; tmax = CRT_INF; },
                 [&](uint32_t, const HitState& best, bool) { hit = best; },
-                nn, nt, wn, wt);
+                nn, nt, wn, wt, share);
         }
 
         bool emit_shadow = false, emit_next = false, finished = active, pending = false;
@@ -976,6 +1061,16 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
                                     if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
                                     if (COMPACT) {
                                         pending = true;                               // walked after the workgroup-wide compaction below
+                                    } else if (SHARE && a.tri_share == 2u) {
+                                        // the shadow rays of this wave's lit lanes as one lock-step batch of the voting, triangle-sharing loop
+                                        const uint32_t n_lit = (uint32_t)__builtin_popcountll(m);
+                                        bool occluded = false;
+                                        traverse_pool<true, STATS, true>(
+                                            a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, n_lit, n_lit, a.tri_min,
+                                            [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = hit_point; rd = ldir; tmax = len - CRT_EPS; },
+                                            [&](uint32_t, const HitState&, bool h) { occluded = h; },
+                                            nn_any, nt_any, wn_any, wt_any, share);
+                                        if (!occluded) L = L + c;
                                     } else {
                                         HitState sh;
                                         const bool occluded = BVH2
@@ -1269,16 +1364,19 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
 void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+    const bool share = a.tri_share != 0u && a.tri_min != 0u && inplace && !pretraced && !bvh2 && !compact;
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
     size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
     waves = fit_waves(waves, per_wave);
     compact = compact && inplace && !pretraced && !bvh2 && waves > 1u;      // shadow-ray compaction needs partner waves
     if (compact) per_wave = std::max(per_wave, (size_t)4096);                // 64 B of ray record per lane alias the stacks
     const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
-    const size_t lds = waves * per_wave + (compact ? 16 : 0);
+    const size_t lds = waves * per_wave + (compact || share ? 16 : 0) + (share ? (size_t)waves * CRT_SHARE_BYTES : 0);
     const bool tex = a.textures != nullptr;
 #define CRT_LAUNCH_SEG(F, S, T, P, Y, B) do { \
-        if (compact) { if (mat) launch(k_segment<F, S, T, false, true, false, true, true>, g, b, lds, stream, a); \
+        if (share) { if (mat) launch(k_segment<F, S, T, false, true, false, true, false, true>, g, b, lds, stream, a); \
+                     else launch(k_segment<F, S, T, false, true, false, false, false, true>, g, b, lds, stream, a); } \
+        else if (compact) { if (mat) launch(k_segment<F, S, T, false, true, false, true, true>, g, b, lds, stream, a); \
                        else launch(k_segment<F, S, T, false, true, false, false, true>, g, b, lds, stream, a); } \
         else if (mat && !(P) && !(B)) launch(k_segment<F, S, T, false, Y, false, true>, g, b, lds, stream, a); \
         else launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a); } while (0)

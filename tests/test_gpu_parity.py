@@ -266,6 +266,39 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
         assert np.array_equal(got.view(np.uint32), w.view(np.uint32)), options
 
 
+@pytest.mark.parametrize("name,depth", [("tess8", 3), ("tess40", 4)])
+def test_shared_triangle_steps_keep_sums_and_counters(cr, ob, scenes, disney_scenes, name, depth):
+    """`tri_share`: triangle steps of the voting loop hand the waiting lanes' pending triangles to all lanes of the wave
+    (1: closest-hit walk, 2: also the in-place shadow rays).  Same tests with the same operands in the same order per ray:
+    radiance, ray counts and the per-block visit totals equal the default's and the oracle's; only the number of
+    wave-level triangle steps drops."""
+    _, _, data = scenes[name]
+    W, H = 320, 184
+    for d in (data, disney_scenes[0][name]):
+        orc = ob.Oracle(d, W, H, depth, disney_scenes[1])
+        rnd = cr.Rnd()
+        rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(2)]
+        ref = np.zeros((H, W, 3), np.float32)
+        cnt = None
+        for rx, ry in rvs:
+            _, cnt = orc.render_frame(rx, ry, ref, threads=8)
+        steps = {}
+        for share in (0, 1, 2):
+            s = cr.Scene(d, W, H, depth)
+            s.set_option("tri_share", share)
+            s.set_option("count_visits", 1)
+            for rx, ry in rvs:
+                s.render_frame(rx, ry)
+            st = s.frame_stats()
+            assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["stack_overflows"] == 0, share
+            assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3], share
+            assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32)), share
+            steps[share] = (st["wave_steps_closest_tris"], st["wave_steps_any_tris"], st["tris_closest"], st["tris_any"])
+            s.close()
+        assert steps[0][2:] == steps[1][2:] == steps[2][2:]
+        assert steps[1][0] < steps[0][0] and steps[2][1] < steps[0][1]              # fewer wave-level triangle steps
+
+
 @pytest.mark.parametrize("T", [16, 24])
 def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data, T):
     """world=3 shards rendered on one GPU: the union of the ranks' pixels is bit-identical to world=1
