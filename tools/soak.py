@@ -7,25 +7,29 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import __graft_entry__ as g
 g.build()
 import caitlynrenderer_amd as cr
-from caitlynrenderer_amd.meshgen import tessellated_cornell
+from caitlynrenderer_amd.meshgen import tessellated_cornell, with_disney_materials
 from oracle import binding as ob
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 base, cam0 = g._cornell()
-meshes = {"cornell": base, "tess8": tessellated_cornell(base, 8), "tess24": tessellated_cornell(base, 24)}
+dis = with_disney_materials(base)      # mirror tall box, GGX / Disney-diffuse short box and floor (oracle-defined materials)
+meshes = {"cornell": base, "tess8": tessellated_cornell(base, 8), "tess24": tessellated_cornell(base, 24),
+          "cornell_mat": dis, "tess8_mat": tessellated_cornell(dis, 8), "tess24_mat": tessellated_cornell(dis, 24)}
 datas = {}
 bad = 0
 t_start = time.time()
 for case in range(n_cases):
     name = list(meshes)[rng.integers(0, len(meshes))]
-    builder = "lbvh" if rng.random() < 0.3 else "sbvh"
+    builder = str(rng.choice(["sbvh", "sbvh", "sbvh", "lbvh", "ploc", "ploc5"]))
     convert = "device" if rng.random() < 0.5 else "host"
     key = (name, builder, convert)
     if key not in datas:
         datas[key] = cr.SceneData.build(meshes[name], cam0, builder=builder, convert=convert)
     data = datas[key]
+    # one case in five: the scene itself is built on the device from the source-order arrays (same builder, same tree)
+    on_device = builder != "sbvh" and rng.random() < 0.4
     W, H = int(rng.integers(40, 420)), int(rng.integers(30, 260))
     depth = int(rng.integers(1, 5))
     # camera: inside or outside the box (box spans roughly 0..5.6), any direction, fov 15..100 degrees
@@ -34,16 +38,18 @@ for case in range(n_cases):
     if rng.random() < 0.15:
         tgt = pos + np.array([0, 0, -1], np.float32) * np.float32(rng.uniform(0.5, 3))      # axis-aligned view: zero components
     cam = cr.Camera(tuple(float(x) for x in pos), tuple(float(x) for x in tgt), float(rng.uniform(15, 100)))
-    scene = cr.Scene(data, W, H, depth)
+    scene = cr.Scene(cr.SceneData.for_device_build(meshes[name], cam0, builder=builder) if on_device else data, W, H, depth)
     scene.update(cam)
     jitter = 1                                   # the oracle's frame loop always jitters, like the shader
     scene.set_option("count_visits", 1)
     # pipeline variants: all must give the oracle's bits
-    accel = int(rng.choice([0, 0, 0, 1, 2]))
+    accel = 0 if name.endswith("_mat") else int(rng.choice([0, 0, 0, 1, 2]))      # the BVH2 frame mode is the Lambert-only shader
     opts = {"accel": accel}
     if accel == 0:
         opts.update(inplace_shadow=int(rng.random() < 0.7), bounce_refill=int(rng.random() < 0.3),
-                    tri_min=int(rng.choice([0, 1, 2, 2, 3])), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])))
+                    tri_min=int(rng.choice([0, 1, 2, 2, 3])), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])),
+                    tri_share=int(rng.choice([0, 1, 2, 3, 3])), waves_per_workgroup=int(rng.choice([1, 1, 2, 4])),
+                    compact_shadow=int(rng.random() < 0.5))
     for k, v in opts.items():
         scene.set_option(k, v)
     o_accel, o_tie = (ob.BVH8, ob.TIE_LOWEST_ID) if accel == 0 else (ob.BVH2, ob.TIE_FIRST_VISITED if accel == 1 else ob.TIE_LOWEST_ID)
@@ -63,7 +69,7 @@ for case in range(n_cases):
         counts = (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
         if not (same and counts):
             ok = False
-            print(f"MISMATCH case {case} frame {frame}: {key} {opts} {W}x{H} depth {depth} jitter {jitter} pos {pos} tgt {tgt} "
+            print(f"MISMATCH case {case} frame {frame}: {key} on_device={on_device} {opts} {W}x{H} depth {depth} jitter {jitter} pos {pos} tgt {tgt} "
                   f"sum_equal {same} max|d| {np.abs(out - ref).max():.3g} n_diff {(out != ref).sum()} counts {counts}", flush=True)
             break
     bad += 0 if ok else 1
