@@ -373,9 +373,9 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
         return fail(CRT_ERR_INVALID, "crt_scene_create: neither bvh nor bvh8 given (and build_flags does not ask for a build on the device)");
     if ((d->build_flags & CRT_BUILD_LBVH_ON_DEVICE) && (d->bvh || d->bvh8 || d->tri_orig_ids))
         return fail(CRT_ERR_INVALID, "crt_scene_create: CRT_BUILD_LBVH_ON_DEVICE takes the triangles in source order, without bvh / bvh8 / tri_orig_ids");
-    if (d->build_flags & ~(uint32_t)(CRT_BUILD_LBVH_ON_DEVICE | CRT_BUILD_PLOC | 0xff00u)) return fail(CRT_ERR_INVALID, "crt_scene_create: unknown build_flags");
-    if ((d->build_flags & (CRT_BUILD_PLOC | 0xff00u)) && !(d->build_flags & CRT_BUILD_LBVH_ON_DEVICE))
-        return fail(CRT_ERR_INVALID, "crt_scene_create: CRT_BUILD_PLOC only qualifies CRT_BUILD_LBVH_ON_DEVICE");
+    if (d->build_flags & ~(uint32_t)(CRT_BUILD_LBVH_ON_DEVICE | CRT_BUILD_PLOC | CRT_BUILD_SAH | 0xff00u)) return fail(CRT_ERR_INVALID, "crt_scene_create: unknown build_flags");
+    if ((d->build_flags & (CRT_BUILD_PLOC | CRT_BUILD_SAH | 0xff00u)) && !(d->build_flags & CRT_BUILD_LBVH_ON_DEVICE))
+        return fail(CRT_ERR_INVALID, "crt_scene_create: CRT_BUILD_PLOC / CRT_BUILD_SAH only qualify CRT_BUILD_LBVH_ON_DEVICE");
     if (d->width == 0 || d->height == 0 || d->width > 65535u * 8u || d->height > 65535u * 8u)
         return fail(CRT_ERR_INVALID, "crt_scene_create: bad resolution");
     if (d->max_depth == 0 || d->max_depth > 16) return fail(CRT_ERR_INVALID, "crt_scene_create: max_depth must be 1..16");
@@ -565,7 +565,8 @@ static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
 
     crt::DeviceArena arena;                       // input-order triangles + both builders' temporaries; gone when this returns
     auto P = crt::DeviceArena::padded;
-    const uint32_t gpu_build_flags = (d->build_flags & CRT_BUILD_PLOC) ? (CRT_GPU_BUILD_PLOC | (d->build_flags & 0xff00u)) : 0u;
+    const uint32_t gpu_build_flags = (d->build_flags & CRT_BUILD_SAH) ? CRT_GPU_BUILD_SAH
+                                     : (d->build_flags & CRT_BUILD_PLOC) ? (CRT_GPU_BUILD_PLOC | (d->build_flags & 0xff00u)) : 0u;
     const size_t tmp_bytes = std::max(crt::lbvh_tmp_bytes(n, gpu_build_flags), crt::cwbvh_tmp_bytes(n2, n));
     hipError_t he = arena.reserve(P((size_t)n * sizeof(crt_triangle)) + P(4) + P((size_t)n * 4) + P((size_t)n * 4) + tmp_bytes);
     if (he != hipSuccess) return fail(CRT_ERR_NOMEM, std::string("crt_scene_create: hipMalloc: ") + hipGetErrorString(he));

@@ -141,7 +141,9 @@ class SBVH:
         tris = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 12)
         verts = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         h = C.c_void_p()
-        gpu = builder in ("lbvh", "ploc") or builder.startswith("ploc")
+        gpu = builder in ("lbvh", "sah") or builder.startswith("ploc")
+        if builder == "sah":                            # crt_lbvh_build with CRT_GPU_BUILD_SAH
+            flags = 4
         if builder.startswith("ploc"):                  # "ploc" or "ploc<radius>": crt_lbvh_build with CRT_GPU_BUILD_PLOC | radius << 8
             radius = int(builder[4:]) if len(builder) > 4 else 0
             flags = 2 | (radius << 8)

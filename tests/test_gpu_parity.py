@@ -753,11 +753,11 @@ def _check_lbvh(flat, tris, verts):
     assert np.array_equal(lo[inner], np.minimum(lo[left], lo[left + 1])) and np.array_equal(hi[inner], np.maximum(hi[left], hi[left + 1]))
 
 
-@pytest.mark.parametrize("builder", ["lbvh", "ploc", "ploc4", "ploc64"])
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "ploc4", "ploc64", "sah"])
 @pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
 def test_gpu_lbvh_builder(cr, ob, cornell, tess8, tess40, scenes, name, builder):
     """crt_lbvh_build: Morton sort, then Karras' radix tree + device refit (lbvh) or parallel locally-ordered
-    clustering (ploc, search radius 16 / 4 / 64).  The tree is valid, the scene built on it (-> host CWBVH conversion)
+    clustering (ploc, search radius 16 / 4 / 64) or the top-down binned-SAH build (sah).  The tree is valid, the scene built on it (-> host CWBVH conversion)
     returns exactly the hits of the reference-builder scene."""
     mesh = {"cornell": cornell[0], "tess8": tess8[0], "tess40": tess40[0]}[name]
     sb = cr.SBVH(mesh.triangles, mesh.vertices, builder=builder)
@@ -777,7 +777,7 @@ def test_gpu_lbvh_builder(cr, ob, cornell, tess8, tess40, scenes, name, builder)
     sb2 = cr.SBVH(mesh.triangles, mesh.vertices, builder=builder)
     assert np.array_equal(sb2.flat_nodes.view(np.uint32), sb.flat_nodes.view(np.uint32)) and np.array_equal(sb2.triangle_indices, sb.triangle_indices)
     scene_l.close()
-    if builder == "ploc" and name != "cornell":
+    if builder in ("ploc", "sah") and name != "cornell":
         # the point of PLOC: a better tree than the spatial-median LBVH — fewer node visits on the same rays
         lb = cr.Scene(cr.SceneData.build(mesh, cornell[1], builder="lbvh"), 64, 64, 1)
         pl = cr.Scene(data, 64, 64, 1)
@@ -911,7 +911,7 @@ def test_hip_bvh2_walk_reproduces_the_survey_census(cr, ob, cornell_data, survey
     scene.close()
 
 
-@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
 @pytest.mark.parametrize("name", ["cornell", "tess8", "tess40"])
 def test_scene_built_entirely_on_the_device(cr, ob, cornell, tess8, tess40, name, builder):
     """crt_scene_desc.build_flags = CRT_BUILD_LBVH_ON_DEVICE: only the input arrays are uploaded; LBVH, CWBVH conversion,

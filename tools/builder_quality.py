@@ -11,7 +11,7 @@ from caitlynrenderer_amd.meshgen import tessellated_cornell
 
 base, cam = g._cornell()
 mesh = tessellated_cornell(base, 183)
-builders = sys.argv[1:] or ["sbvh", "lbvh", "ploc4", "ploc8", "ploc16", "ploc32", "ploc64"]
+builders = sys.argv[1:] or ["sbvh", "sah", "lbvh", "ploc4", "ploc16", "ploc64"]
 rnd = cr.Rnd()
 rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(60)]
 for b in builders:

@@ -22,7 +22,7 @@ bad = 0
 t_start = time.time()
 for case in range(n_cases):
     name = list(meshes)[rng.integers(0, len(meshes))]
-    builder = str(rng.choice(["sbvh", "sbvh", "sbvh", "lbvh", "ploc", "ploc5"]))
+    builder = str(rng.choice(["sbvh", "sbvh", "sbvh", "lbvh", "ploc", "ploc5", "sah", "sah"]))
     convert = "device" if rng.random() < 0.5 else "host"
     key = (name, builder, convert)
     if key not in datas:
