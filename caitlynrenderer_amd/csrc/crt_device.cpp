@@ -565,7 +565,7 @@ static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
 
     crt::DeviceArena arena;                       // input-order triangles + both builders' temporaries; gone when this returns
     auto P = crt::DeviceArena::padded;
-    const uint32_t gpu_build_flags = (d->build_flags & CRT_BUILD_SAH) ? CRT_GPU_BUILD_SAH
+    const uint32_t gpu_build_flags = (d->build_flags & CRT_BUILD_SAH) ? (CRT_GPU_BUILD_SAH | (d->build_flags & 0xff00u))
                                      : (d->build_flags & CRT_BUILD_PLOC) ? (CRT_GPU_BUILD_PLOC | (d->build_flags & 0xff00u)) : 0u;
     const size_t tmp_bytes = std::max(crt::lbvh_tmp_bytes(n, gpu_build_flags), crt::cwbvh_tmp_bytes(n2, n));
     hipError_t he = arena.reserve(P((size_t)n * sizeof(crt_triangle)) + P(4) + P((size_t)n * 4) + P((size_t)n * 4) + tmp_bytes);

@@ -434,7 +434,7 @@ __global__ void k_ploc_flatten(const uint32_t* __restrict__ order, const uint32_
 // Node numbers come from an atomic counter (any order): the final numbering is the canonical breadth-first one of
 // k_ploc_bfs_keys (depth, root-to-node path), so the output is deterministic; boxes come from the level-by-level refit.
 #define SAH_BINS 16
-#define SAH_SMALL 32
+#define SAH_SMALL 32                     // capacity of the per-thread arrays of phase B; the threshold itself is a parameter (default 16)
 #define SAH_NONE 0xffffffffu
 #define SAH_BIN_WORDS (3 * SAH_BINS * 7)
 
@@ -467,60 +467,90 @@ __global__ void k_sah_init(uint32_t n, uint32_t* __restrict__ idx, uint32_t* __r
     }
 }
 
+// A workgroup covers 256 consecutive positions.  Triangles are sorted by node and an active node owns more than `small`
+// (>= 8) of them, so a workgroup sees at most SAH_LOCAL distinct active nodes: each gets a slot in LDS (slot = number of
+// node boundaries before the position), everything is accumulated there and flushed with one global atomic per touched word.
+#define SAH_LOCAL 34
+__device__ __forceinline__ uint32_t sah_local_slot(uint32_t w, uint32_t pos, uint32_t n, const uint32_t* __restrict__ pwork, uint32_t* s_scan,
+                                                   uint32_t* s_node) {
+    // boundary = first position of the workgroup, or a different work item than the previous position
+    const uint32_t tid = threadIdx.x;
+    const bool valid = pos < n && w != SAH_NONE;
+    const bool boundary = valid && (tid == 0u || pwork[pos - 1u] != w);
+    const unsigned long long b = __ballot(boundary);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (lane == 0u) s_scan[wave] = (uint32_t)__builtin_popcountll(b);
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < wave; ++k) before += s_scan[k];
+    const uint32_t slot = before + (uint32_t)__builtin_popcountll(b & ((2ull << lane) - 1ull)) - 1u;     // inclusive count - 1
+    if (boundary && slot < SAH_LOCAL) s_node[slot] = w;
+    return valid ? slot : SAH_NONE;
+}
+
 __global__ void __launch_bounds__(256) k_sah_cbounds(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ pwork, uint32_t n,
                                                      const float* __restrict__ leaf_box, SahWork* __restrict__ work) {
-    __shared__ uint32_t s_cb[6];
+    __shared__ uint32_t s_cb[SAH_LOCAL * 6];
+    __shared__ uint32_t s_node[SAH_LOCAL];
+    __shared__ uint32_t s_scan[4];
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t w0 = pwork[blockIdx.x * 256u];                 // the node most of this workgroup's triangles belong to
-    if (threadIdx.x < 6u) s_cb[threadIdx.x] = 0u;
+    for (uint32_t t = threadIdx.x; t < SAH_LOCAL * 6; t += 256u) s_cb[t] = 0u;
+    if (threadIdx.x < SAH_LOCAL) s_node[threadIdx.x] = SAH_NONE;
     __syncthreads();
-    if (pos < n) {
-        const uint32_t w = pwork[pos];
-        if (w != SAH_NONE) {
-            float c[3];
-            sah_centroid(leaf_box, idx[pos], c);
-            uint32_t* dst = w == w0 ? s_cb : work[w].cb;
-            for (int k = 0; k < 3; ++k) { const uint32_t o = f2ord(c[k]); atomicMax(&dst[k], ~o); atomicMax(&dst[3 + k], o); }
-        }
+    const uint32_t w = pos < n ? pwork[pos] : SAH_NONE;
+    const uint32_t slot = sah_local_slot(w, pos, n, pwork, s_scan, s_node);
+    __syncthreads();
+    if (slot != SAH_NONE) {
+        float c[3];
+        sah_centroid(leaf_box, idx[pos], c);
+        uint32_t* dst = slot < SAH_LOCAL ? s_cb + 6 * slot : work[w].cb;
+        for (int k = 0; k < 3; ++k) { const uint32_t o = f2ord(c[k]); atomicMax(&dst[k], ~o); atomicMax(&dst[3 + k], o); }
     }
     __syncthreads();
-    if (threadIdx.x < 6u && w0 != SAH_NONE && s_cb[threadIdx.x] != 0u) atomicMax(&work[w0].cb[threadIdx.x], s_cb[threadIdx.x]);
+    for (uint32_t t = threadIdx.x; t < SAH_LOCAL * 6; t += 256u) {
+        const uint32_t v = s_cb[t], node = s_node[t / 6u];
+        if (v != 0u && node != SAH_NONE) atomicMax(&work[node].cb[t % 6u], v);
+    }
 }
 
 // bins[w][axis][bin] = {count, ~ord(lo.xyz), ord(hi.xyz)}: every field grows by atomicAdd / atomicMax, so all-zero = empty
 __global__ void __launch_bounds__(256) k_sah_bin(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ pwork, uint32_t n,
                                                  const float* __restrict__ leaf_box, const SahWork* __restrict__ work, uint32_t* __restrict__ bins) {
-    __shared__ uint32_t s_bins[SAH_BIN_WORDS];
+    __shared__ uint32_t s_bins[SAH_LOCAL * SAH_BIN_WORDS];        // 45.7 KB
+    __shared__ uint32_t s_node[SAH_LOCAL];
+    __shared__ uint32_t s_scan[4];
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t w0 = pwork[blockIdx.x * 256u];
-    for (uint32_t t = threadIdx.x; t < SAH_BIN_WORDS; t += 256u) s_bins[t] = 0u;
+    if (threadIdx.x < SAH_LOCAL) s_node[threadIdx.x] = SAH_NONE;
     __syncthreads();
-    if (pos < n) {
-        const uint32_t w = pwork[pos];
-        if (w != SAH_NONE) {
-            const uint32_t tri = idx[pos];
-            const float* b = leaf_box + 6 * (size_t)tri;
-            float c[3];
-            sah_centroid(leaf_box, tri, c);
-            uint32_t ob[6];
-            for (int k = 0; k < 3; ++k) { ob[k] = ~f2ord(b[k]); ob[3 + k] = f2ord(b[3 + k]); }
-            uint32_t* base = w == w0 ? s_bins : bins + (size_t)w * SAH_BIN_WORDS;
-            for (int ax = 0; ax < 3; ++ax) {
-                const int bi = sah_bin(c[ax], ord2f(~work[w].cb[ax]), ord2f(work[w].cb[3 + ax]));
-                uint32_t* d = base + (ax * SAH_BINS + bi) * 7;
-                atomicAdd(&d[0], 1u);
-                for (int k = 0; k < 6; ++k) atomicMax(&d[1 + k], ob[k]);
-            }
+    const uint32_t w = pos < n ? pwork[pos] : SAH_NONE;
+    const uint32_t slot = sah_local_slot(w, pos, n, pwork, s_scan, s_node);
+    __syncthreads();
+    uint32_t n_slots = 0;
+    for (uint32_t k = 0; k < 4u; ++k) n_slots += s_scan[k];
+    if (n_slots > SAH_LOCAL) n_slots = SAH_LOCAL;
+    for (uint32_t t = threadIdx.x; t < n_slots * SAH_BIN_WORDS; t += 256u) s_bins[t] = 0u;
+    __syncthreads();
+    if (slot != SAH_NONE) {
+        const uint32_t tri = idx[pos];
+        const float* b = leaf_box + 6 * (size_t)tri;
+        float c[3];
+        sah_centroid(leaf_box, tri, c);
+        uint32_t ob[6];
+        for (int k = 0; k < 3; ++k) { ob[k] = ~f2ord(b[k]); ob[3 + k] = f2ord(b[3 + k]); }
+        uint32_t* base = slot < SAH_LOCAL ? s_bins + (size_t)slot * SAH_BIN_WORDS : bins + (size_t)w * SAH_BIN_WORDS;
+        for (int ax = 0; ax < 3; ++ax) {
+            const int bi = sah_bin(c[ax], ord2f(~work[w].cb[ax]), ord2f(work[w].cb[3 + ax]));
+            uint32_t* d = base + (ax * SAH_BINS + bi) * 7;
+            atomicAdd(&d[0], 1u);
+            for (int k = 0; k < 6; ++k) atomicMax(&d[1 + k], ob[k]);
         }
     }
     __syncthreads();
-    if (w0 != SAH_NONE) {
-        uint32_t* g = bins + (size_t)w0 * SAH_BIN_WORDS;
-        for (uint32_t t = threadIdx.x; t < SAH_BIN_WORDS; t += 256u) {
-            const uint32_t v = s_bins[t];
-            if (v == 0u) continue;
-            if (t % 7u == 0u) atomicAdd(&g[t], v); else atomicMax(&g[t], v);
-        }
+    for (uint32_t t = threadIdx.x; t < n_slots * SAH_BIN_WORDS; t += 256u) {
+        const uint32_t v = s_bins[t];
+        if (v == 0u) continue;
+        uint32_t* g = bins + (size_t)s_node[t / SAH_BIN_WORDS] * SAH_BIN_WORDS + t % SAH_BIN_WORDS;
+        if (t % 7u == 0u) atomicAdd(g, v); else atomicMax(g, v);
     }
 }
 
@@ -532,7 +562,8 @@ __device__ __forceinline__ float sah_half_area(const float lo[3], const float hi
 }
 
 // one wave per active node: 45 candidate planes (lane = axis * 16 + plane), argmin, children
-__global__ void __launch_bounds__(64) k_sah_sweep(SahWork* __restrict__ work, uint32_t m, const uint32_t* __restrict__ bins, PlocNodes nd, SahLists out) {
+__global__ void __launch_bounds__(64) k_sah_sweep(SahWork* __restrict__ work, uint32_t m, const uint32_t* __restrict__ bins, PlocNodes nd, SahLists out,
+                                                  uint32_t small) {
     const uint32_t w = blockIdx.x, lane = threadIdx.x;
     if (w >= m) return;
     SahWork wk = work[w];
@@ -577,7 +608,7 @@ __global__ void __launch_bounds__(64) k_sah_sweep(SahWork* __restrict__ work, ui
         if (cc == 1u) {
             nd.lo[child].w = __int_as_float(-1);
             nd.hi[child].w = __int_as_float((int)cb);              // leaf slot = final position of its triangle
-        } else if (cc <= SAH_SMALL) {
+        } else if (cc <= small) {
             const uint32_t k = atomicAdd(&out.counters[2], 1u);
             out.small[3 * (size_t)k] = child; out.small[3 * (size_t)k + 1] = cb; out.small[3 * (size_t)k + 2] = ce;
         } else {
@@ -710,10 +741,10 @@ thread_local float g_last_device_ms = 0.f, g_last_total_ms = 0.f;
 
 namespace crt {
 
-static size_t sah_tmp_bytes(size_t n);
+static size_t sah_tmp_bytes(size_t n, uint32_t flags);
 size_t lbvh_tmp_bytes(size_t n_tris, uint32_t flags) {
     const size_t n_nodes = 2 * n_tris - 1;
-    if (flags & CRT_GPU_BUILD_SAH) return sah_tmp_bytes(n_tris);
+    if (flags & CRT_GPU_BUILD_SAH) return sah_tmp_bytes(n_tris, flags);
     if (flags & CRT_GPU_BUILD_PLOC) {
         size_t sort1 = 0, sort2 = 0, scan = 0;
         (void)rocprim::radix_sort_keys(nullptr, sort1, (unsigned long long*)nullptr, (unsigned long long*)nullptr, n_tris, 0, 64, (hipStream_t)0);
@@ -831,8 +862,13 @@ static int ploc_build_on_device(const int32_t* d_vidx, uint32_t stride, const fl
     return CRT_OK;
 }
 
-static size_t sah_tmp_bytes(size_t n) {
-    const size_t n_nodes = 2 * n - 1, cap = n / SAH_SMALL + 4;
+static uint32_t sah_small_of(uint32_t flags) {
+    uint32_t s = (flags >> 8) & 0xffu;
+    if (s == 0u) s = 16u;
+    return s < 8u ? 8u : s > SAH_SMALL ? SAH_SMALL : s;            // >= 8 keeps a workgroup's active nodes within SAH_LOCAL
+}
+static size_t sah_tmp_bytes(size_t n, uint32_t flags) {
+    const size_t n_nodes = 2 * n - 1, cap = n / sah_small_of(flags) + 4;
     size_t sort2 = 0, scan = 0;
     (void)rocprim::radix_sort_pairs(nullptr, sort2, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                     n_nodes, 0, 64, (hipStream_t)0);
@@ -843,9 +879,10 @@ static size_t sah_tmp_bytes(size_t n) {
            P(std::max<size_t>(scan, 16)) + 4096;
 }
 
-static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_verts, uint32_t n, DeviceArena& tmp, crt_flatnode* d_flat,
+static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_verts, uint32_t n, uint32_t flags, DeviceArena& tmp, crt_flatnode* d_flat,
                                uint32_t* d_tri_order, uint32_t* depth_out, float* device_ms, hipStream_t stream) {
-    const size_t n_nodes = 2 * (size_t)n - 1, cap = (size_t)n / SAH_SMALL + 4;
+    const uint32_t small = sah_small_of(flags);
+    const size_t n_nodes = 2 * (size_t)n - 1, cap = (size_t)n / small + 4;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&]() {
         if (ev0) (void)hipEventDestroy(ev0);
@@ -898,7 +935,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
     SahWork* work = d_w0; SahWork* next = d_w1;
     hipLaunchKernelGGL(k_sah_init, gt, dim3(256), 0, stream, n, idx, pw, work, nd.parent2);
     uint32_t m = 1, n_small = 0, levels = 0;
-    if (n <= SAH_SMALL) {                                            // the root itself is a small node
+    if (n <= small) {                                                // the root itself is a small node
         const uint32_t root_small[3] = {0u, 0u, n};
         LB_HIPCHK(hipMemcpyAsync(d_small, root_small, sizeof root_small, hipMemcpyHostToDevice, stream));
         LB_HIPCHK(hipStreamSynchronize(stream));
@@ -910,7 +947,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
         hipLaunchKernelGGL(k_sah_cbounds, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work);
         hipLaunchKernelGGL(k_sah_bin, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_bins);
         SahLists lists{d_counters, next, d_small};
-        hipLaunchKernelGGL(k_sah_sweep, dim3(m), dim3(64), 0, stream, work, m, d_bins, nd, lists);
+        hipLaunchKernelGGL(k_sah_sweep, dim3(m), dim3(64), 0, stream, work, m, d_bins, nd, lists, small);
         hipLaunchKernelGGL(k_sah_flags, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_fl);
         LB_HIPCHK(rocprim::exclusive_scan(d_tmp3, scan_bytes, d_fl, d_scan, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
         hipLaunchKernelGGL(k_sah_scatter, gt, dim3(256), 0, stream, idx, pw, n, work, d_fl, d_scan, idx2, pw2);
@@ -962,7 +999,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
 int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_verts, uint32_t n_tris_u, uint32_t flags, DeviceArena& tmp,
                          crt_flatnode* d_flat, uint32_t* d_tri_order, uint32_t* depth_out, float* device_ms, hipStream_t stream) {
     if ((flags & CRT_GPU_BUILD_SAH) && n_tris_u > 1u)
-        return sah_build_on_device(d_vidx, stride, d_verts, n_tris_u, tmp, d_flat, d_tri_order, depth_out, device_ms, stream);
+        return sah_build_on_device(d_vidx, stride, d_verts, n_tris_u, flags, tmp, d_flat, d_tri_order, depth_out, device_ms, stream);
     if ((flags & CRT_GPU_BUILD_PLOC) && n_tris_u > 1u)
         return ploc_build_on_device(d_vidx, stride, d_verts, n_tris_u, flags, tmp, d_flat, d_tri_order, depth_out, device_ms, stream);
     const size_t n_tris = n_tris_u;

@@ -141,9 +141,9 @@ class SBVH:
         tris = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 12)
         verts = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         h = C.c_void_p()
-        gpu = builder in ("lbvh", "sah") or builder.startswith("ploc")
-        if builder == "sah":                            # crt_lbvh_build with CRT_GPU_BUILD_SAH
-            flags = 4
+        gpu = builder == "lbvh" or builder.startswith(("ploc", "sah"))
+        if builder.startswith("sah"):                   # "sah" or "sah<small-node threshold>": crt_lbvh_build with CRT_GPU_BUILD_SAH
+            flags = 4 | ((int(builder[3:]) if len(builder) > 3 else 0) << 8)
         if builder.startswith("ploc"):                  # "ploc" or "ploc<radius>": crt_lbvh_build with CRT_GPU_BUILD_PLOC | radius << 8
             radius = int(builder[4:]) if len(builder) > 4 else 0
             flags = 2 | (radius << 8)

@@ -53,8 +53,8 @@ class SceneData:
         data.build_flags = CRT_BUILD_LBVH_ON_DEVICE
         if builder.startswith("ploc"):
             data.build_flags |= 2 | ((int(builder[4:]) if len(builder) > 4 else 0) << 8)
-        elif builder == "sah":
-            data.build_flags |= 4
+        elif builder.startswith("sah"):
+            data.build_flags |= 4 | ((int(builder[3:]) if len(builder) > 3 else 0) << 8)
         return data
 
     @staticmethod
