@@ -561,58 +561,91 @@ __device__ __forceinline__ float sah_half_area(const float lo[3], const float hi
     return dx * dy + dy * dz + dz * dx;
 }
 
-// one wave per active node: 45 candidate planes (lane = axis * 16 + plane), argmin, children
-__global__ void __launch_bounds__(64) k_sah_sweep(SahWork* __restrict__ work, uint32_t m, const uint32_t* __restrict__ bins, PlocNodes nd, SahLists out,
-                                                  uint32_t small) {
-    const uint32_t w = blockIdx.x, lane = threadIdx.x;
-    if (w >= m) return;
-    SahWork wk = work[w];
-    const uint32_t cnt = wk.end - wk.beg;
-    const uint32_t* B = bins + (size_t)w * SAH_BIN_WORDS;
-    const int ax = (int)(lane >> 4), p = (int)(lane & 15u);
-    float cost = 3.0e38f;
-    uint32_t nl = 0;
-    if (ax < 3 && p >= 1) {
-        float llo[3] = {3e38f, 3e38f, 3e38f}, lhi[3] = {-3e38f, -3e38f, -3e38f}, rlo[3] = {3e38f, 3e38f, 3e38f}, rhi[3] = {-3e38f, -3e38f, -3e38f};
-        uint32_t nr = 0;
-        for (int b = 0; b < SAH_BINS; ++b) {
-            const uint32_t* d = B + (ax * SAH_BINS + b) * 7;
-            const uint32_t c = d[0];
-            if (!c) continue;
-            float* lo = b < p ? llo : rlo; float* hi = b < p ? lhi : rhi;
-            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(~d[1 + k])); hi[k] = fmaxf(hi[k], ord2f(d[4 + k])); }
-            if (b < p) nl += c; else nr += c;
+// One wave per active node, four nodes per workgroup: 45 candidate planes (lane = axis * 16 + plane) evaluated from the node's
+// bins staged in LDS, argmin, children.  Child node numbers are base + 2 * (position in the level's list) — every active node
+// splits in two — and the appends to the next level's list / the small-node list are aggregated per workgroup: a returning
+// atomic per node on ONE counter was 4 of the builder's 10 ms (the same ~90 atomics per microsecond per address that capped
+// round 1's queue appends).
+__global__ void __launch_bounds__(256) k_sah_sweep(SahWork* __restrict__ work, uint32_t m, const uint32_t* __restrict__ bins, PlocNodes nd, SahLists out,
+                                                   uint32_t small, uint32_t node_base) {
+    __shared__ uint32_t s_b[4][SAH_BIN_WORDS];
+    __shared__ uint32_t s_cnt[4][2];          // per wave: entries for the next-level list, for the small list
+    __shared__ uint32_t s_base[2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t w = blockIdx.x * 4u + wave;
+    const bool live = w < m;
+    SahWork wk{};
+    uint32_t n_left = 0, cnt = 0;
+    float best = 3.0e38f; uint32_t bl = 0;
+    if (live) {
+        wk = work[w];
+        cnt = wk.end - wk.beg;
+        const uint32_t* B = bins + (size_t)w * SAH_BIN_WORDS;
+        for (uint32_t t = lane; t < SAH_BIN_WORDS; t += 64u) s_b[wave][t] = B[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+        const int ax = (int)(lane >> 4), p = (int)(lane & 15u);
+        float cost = 3.0e38f;
+        uint32_t nl = 0;
+        if (ax < 3 && p >= 1) {
+            float llo[3] = {3e38f, 3e38f, 3e38f}, lhi[3] = {-3e38f, -3e38f, -3e38f}, rlo[3] = {3e38f, 3e38f, 3e38f}, rhi[3] = {-3e38f, -3e38f, -3e38f};
+            uint32_t nr = 0;
+            for (int b = 0; b < SAH_BINS; ++b) {
+                const uint32_t* d = s_b[wave] + (ax * SAH_BINS + b) * 7;
+                const uint32_t c = d[0];
+                if (!c) continue;
+                float* lo = b < p ? llo : rlo; float* hi = b < p ? lhi : rhi;
+                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(~d[1 + k])); hi[k] = fmaxf(hi[k], ord2f(d[4 + k])); }
+                if (b < p) nl += c; else nr += c;
+            }
+            if (nl != 0u && nr != 0u) cost = sah_half_area(llo, lhi) * (float)nl + sah_half_area(rlo, rhi) * (float)nr;
         }
-        if (nl != 0u && nr != 0u) cost = sah_half_area(llo, lhi) * (float)nl + sah_half_area(rlo, rhi) * (float)nr;
+        // argmin over the wave, ties to the lower lane (axis, then plane): deterministic
+        best = cost; bl = lane;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl_down(best, off); const uint32_t ol = __shfl_down(bl, off);
+            if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
+        }
+        best = __shfl(best, 0); bl = __shfl(bl, 0);
+        n_left = best < 3.0e38f ? __shfl(nl, (int)bl) : cnt / 2u;
     }
-    // argmin over the wave, ties to the lower lane (axis, then plane): deterministic
-    float best = cost; uint32_t bl = lane;
-    for (int off = 32; off > 0; off >>= 1) {
-        const float oc = __shfl_down(best, off); const uint32_t ol = __shfl_down(bl, off);
-        if (oc < best || (oc == best && ol < bl)) { best = oc; bl = ol; }
+    // classify the two children: 0 leaf, 1 small, 2 active
+    uint32_t cls[2] = {0u, 0u};
+    if (live && lane == 0u) {
+        const uint32_t cc[2] = {n_left, cnt - n_left};
+        for (int side = 0; side < 2; ++side) cls[side] = cc[side] == 1u ? 0u : cc[side] <= small ? 1u : 2u;
+        s_cnt[wave][0] = (cls[0] == 2u) + (cls[1] == 2u);
+        s_cnt[wave][1] = (cls[0] == 1u) + (cls[1] == 1u);
+    } else if (lane == 0u) { s_cnt[wave][0] = 0u; s_cnt[wave][1] = 0u; }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        s_base[threadIdx.x] = tot ? atomicAdd(&out.counters[1u + threadIdx.x], tot) : 0u;
     }
-    best = __shfl(best, 0); bl = __shfl(bl, 0);
-    const uint32_t n_left = best < 3.0e38f ? __shfl(nl, (int)bl) : cnt / 2u;
-    if (lane != 0u) return;
+    __syncthreads();
+    if (!live || lane != 0u) return;
+    uint32_t at[2] = {s_base[0], s_base[1]};
+    for (uint32_t k = 0; k < wave; ++k) { at[0] += s_cnt[k][0]; at[1] += s_cnt[k][1]; }
     wk.axis = best < 3.0e38f ? (int)(bl >> 4) : -1;
     wk.plane = (int)(bl & 15u);
     wk.n_left = n_left;
-    const uint32_t kids = atomicAdd(&out.counters[0], 2u);
+    const uint32_t kids = node_base + 2u * w;
     nd.lo[wk.node].w = __int_as_float((int)kids);
     nd.hi[wk.node].w = __int_as_float((int)kids + 1);
     nd.parent2[kids] = 2 * (int)wk.node;
     nd.parent2[kids + 1u] = 2 * (int)wk.node + 1;
     uint32_t cw[2] = {SAH_NONE, SAH_NONE};
     for (int side = 0; side < 2; ++side) {
-        const uint32_t cb = side == 0 ? wk.beg : wk.beg + n_left, ce = side == 0 ? wk.beg + n_left : wk.end, cc = ce - cb, child = kids + (uint32_t)side;
-        if (cc == 1u) {
+        const uint32_t cb = side == 0 ? wk.beg : wk.beg + n_left, ce = side == 0 ? wk.beg + n_left : wk.end, child = kids + (uint32_t)side;
+        if (cls[side] == 0u) {
             nd.lo[child].w = __int_as_float(-1);
             nd.hi[child].w = __int_as_float((int)cb);              // leaf slot = final position of its triangle
-        } else if (cc <= small) {
-            const uint32_t k = atomicAdd(&out.counters[2], 1u);
+        } else if (cls[side] == 1u) {
+            const uint32_t k = at[1]++;
             out.small[3 * (size_t)k] = child; out.small[3 * (size_t)k + 1] = cb; out.small[3 * (size_t)k + 2] = ce;
         } else {
-            const uint32_t k = atomicAdd(&out.counters[1], 1u);
+            const uint32_t k = at[0]++;
             SahWork c{};
             c.node = child; c.beg = cb; c.end = ce;
             out.next[k] = c;
@@ -651,10 +684,16 @@ __global__ void k_sah_scatter(const uint32_t* __restrict__ idx, const uint32_t* 
 }
 
 // phase B: one thread finishes a node of <= SAH_SMALL triangles with the exact sweep (all split positions of all three axes)
+// 2 (c - 1) new nodes per small node of c triangles; their exclusive prefix gives every thread its own block of node numbers
+__global__ void k_sah_small_counts(const uint32_t* __restrict__ small, uint32_t n_small, uint32_t* __restrict__ counts) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_small) counts[t] = 2u * (small[3 * (size_t)t + 2] - small[3 * (size_t)t + 1] - 1u);
+}
 __global__ void __launch_bounds__(64) k_sah_small(const uint32_t* __restrict__ small, uint32_t n_small, uint32_t* __restrict__ idx,
-                                                  const float* __restrict__ leaf_box, PlocNodes nd, uint32_t* __restrict__ node_counter) {
+                                                  const float* __restrict__ leaf_box, PlocNodes nd, const uint32_t* __restrict__ id_offset, uint32_t node_base) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_small) return;
+    uint32_t next_id = node_base + id_offset[t];
     const uint32_t root = small[3 * (size_t)t], beg = small[3 * (size_t)t + 1], end = small[3 * (size_t)t + 2];
     const int cnt = (int)(end - beg);
     uint32_t tri[SAH_SMALL];
@@ -699,7 +738,8 @@ __global__ void __launch_bounds__(64) k_sah_small(const uint32_t* __restrict__ s
             if (ax == best_ax) for (int i = b; i < e; ++i) tmp[i] = ord[i];     // remember the winning order
         }
         for (int i = b; i < e; ++i) ord[i] = tmp[i];
-        const uint32_t kids = atomicAdd(node_counter, 2u);
+        const uint32_t kids = next_id;
+        next_id += 2u;
         nd.lo[it.node].w = __int_as_float((int)kids);
         nd.hi[it.node].w = __int_as_float((int)kids + 1);
         nd.parent2[kids] = 2 * (int)it.node;
@@ -934,7 +974,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
     uint32_t* pw = d_pw0; uint32_t* pw2 = d_pw1;
     SahWork* work = d_w0; SahWork* next = d_w1;
     hipLaunchKernelGGL(k_sah_init, gt, dim3(256), 0, stream, n, idx, pw, work, nd.parent2);
-    uint32_t m = 1, n_small = 0, levels = 0;
+    uint32_t m = 1, n_small = 0, levels = 0, nodes = 1;              // node 0 is the root
     if (n <= small) {                                                // the root itself is a small node
         const uint32_t root_small[3] = {0u, 0u, n};
         LB_HIPCHK(hipMemcpyAsync(d_small, root_small, sizeof root_small, hipMemcpyHostToDevice, stream));
@@ -947,19 +987,25 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
         hipLaunchKernelGGL(k_sah_cbounds, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work);
         hipLaunchKernelGGL(k_sah_bin, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_bins);
         SahLists lists{d_counters, next, d_small};
-        hipLaunchKernelGGL(k_sah_sweep, dim3(m), dim3(64), 0, stream, work, m, d_bins, nd, lists, small);
+        hipLaunchKernelGGL(k_sah_sweep, dim3((m + 3u) / 4u), dim3(256), 0, stream, work, m, d_bins, nd, lists, small, nodes);
+        nodes += 2u * m;
         hipLaunchKernelGGL(k_sah_flags, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_fl);
         LB_HIPCHK(rocprim::exclusive_scan(d_tmp3, scan_bytes, d_fl, d_scan, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
         hipLaunchKernelGGL(k_sah_scatter, gt, dim3(256), 0, stream, idx, pw, n, work, d_fl, d_scan, idx2, pw2);
         uint32_t c[3] = {0, 0, 0};
         LB_HIPCHK(hipMemcpyAsync(c, d_counters, 12, hipMemcpyDeviceToHost, stream));
         LB_HIPCHK(hipStreamSynchronize(stream));
-        if (c[1] > cap || c[2] > n / 2u + 1u || c[0] > n_nodes) { cleanup(); return fail(CRT_ERR_HIP, "sah: work list overflow"); }
+        if (c[1] > cap || c[2] > n / 2u + 1u || nodes > n_nodes) { cleanup(); return fail(CRT_ERR_HIP, "sah: work list overflow"); }
         m = c[1]; n_small = c[2];
         std::swap(idx, idx2); std::swap(pw, pw2); std::swap(work, next);
         if (++levels > 512u) { cleanup(); return fail(CRT_ERR_HIP, "sah: did not converge"); }
     }
-    if (n_small) hipLaunchKernelGGL(k_sah_small, dim3((n_small + 63u) / 64u), dim3(64), 0, stream, d_small, n_small, idx, d_leaf_box, nd, d_counters);
+    if (n_small) {
+        // phase B node numbers: exclusive prefix of 2 (c - 1) over the small nodes (d_fl / d_scan are free again)
+        hipLaunchKernelGGL(k_sah_small_counts, dim3((n_small + 255u) / 256u), dim3(256), 0, stream, d_small, n_small, d_fl);
+        LB_HIPCHK(rocprim::exclusive_scan(d_tmp3, scan_bytes, d_fl, d_scan, 0u, (size_t)n_small, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(k_sah_small, dim3((n_small + 63u) / 64u), dim3(64), 0, stream, d_small, n_small, idx, d_leaf_box, nd, d_scan, nodes);
+    }
     if (idx != d_tri_order) LB_HIPCHK(hipMemcpyAsync(d_tri_order, idx, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
     const dim3 gn((uint32_t)((n_nodes + 255) / 256));
     hipLaunchKernelGGL(k_ploc_bfs_keys, gn, dim3(256), 0, stream, nd.parent2, (uint32_t)n_nodes, d_bkeys, d_ids, d_bad);
@@ -967,12 +1013,10 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
     hipLaunchKernelGGL(k_bfs_pos, gn, dim3(256), 0, stream, d_order, (uint32_t)n_nodes, d_pos);
     hipLaunchKernelGGL(k_sah_flatten, gn, dim3(256), 0, stream, d_order, d_pos, nd, d_tri_order, d_leaf_box, (uint32_t)n_nodes, d_flat, d_bad);
     hipLaunchKernelGGL(k_level_starts, gn, dim3(256), 0, stream, d_bkeys2, (uint32_t)n_nodes, d_levels, (uint32_t)kMaxLevels, 56u);
-    uint32_t final_nodes = 0, bad = 0;
+    uint32_t bad = 0;
     unsigned long long deepest_key = 0;
-    LB_HIPCHK(hipMemcpyAsync(&final_nodes, d_counters, 4, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipMemcpyAsync(&deepest_key, d_bkeys2 + (n_nodes - 1), 8, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipStreamSynchronize(stream));
-    if (final_nodes != (uint32_t)n_nodes) { cleanup(); return fail(CRT_ERR_HIP, "sah: node count is not 2n - 1"); }
     const uint32_t n_levels = (uint32_t)(deepest_key >> 56) + 1u;
     std::vector<uint32_t> level_start(n_levels + 1);
     LB_HIPCHK(hipMemcpyAsync(level_start.data(), d_levels, n_levels * 4, hipMemcpyDeviceToHost, stream));
