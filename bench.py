@@ -12,6 +12,7 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
     value / roofline / cpu_baseline  = configs[1]: Cornell box, CWBVH, 1 spp primary + shadow, 1920x1080;
     "north_star"                     = configs[2]: the 1,004,672-triangle mesh, 4 spp per step, 1920x1080, primary + shadow —
                                        the workload BASELINE.json's targets are quoted on, with its own roofline and cpu_baseline;
+    "north_star_gpu_tree"            = the same over a tree built on the GPU (binned SAH, everything assembled in HBM);
     "incoherent" / "incoherent_disney" = configs[3]: same mesh, 4 path segments (incoherent bounce rays), with the reference's
                                        Lambert integrator and with the oracle-defined mirror + GGX/Disney-diffuse materials;
     "scale_base"                     = configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines
@@ -228,8 +229,10 @@ def pmc_entry(workload, depth):
         return {}
 
 
-def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials=None):
-    """Measure one workload: returns the dict of the bench line for it (rank 0) or None (other ranks)."""
+def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials=None, device_built=None):
+    """Measure one workload: returns the dict of the bench line for it (rank 0) or None (other ranks).
+    device_built = "lbvh" | "ploc<r>" | "sah": the scene is built by crt_scene_create itself from the source-order arrays
+    (BVH2, CWBVH and records produced in HBM) instead of from host-built trees."""
     import numpy as np
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd import tiles
@@ -242,7 +245,23 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
     out = None
     if takes_part:
         data, cam, label, build_s = build_workload(name, args.builder, args.convert, materials or args.materials)
-        scene = cr.Scene(data, W, H, depth)
+        build_info = None
+        if device_built:
+            from caitlynrenderer_amd.meshgen import tessellated_cornell
+            import __graft_entry__ as g
+            mesh, _ = g._cornell()
+            if name != "cornell":
+                mesh = tessellated_cornell(mesh, 183 if name == "mesh1m" else int(name[4:]))
+            t_b = time.perf_counter()
+            scene = cr.Scene(cr.SceneData.for_device_build(mesh, cam, builder=device_built), W, H, depth)
+            bi = scene.bvh_info()
+            build_info = {"builder": device_built, "scene_create_wall_ms": round((time.perf_counter() - t_b) * 1e3, 2),
+                          "upload_ms": round(bi["build_upload_ms"], 2), "bvh2_device_ms": round(bi["build_lbvh_device_ms"], 2),
+                          "cwbvh_device_ms": round(bi["build_convert_device_ms"], 2)}
+            label = label.split(",")[0] + f", CWBVH over a BVH2 built on the GPU ({device_built}), everything assembled in HBM by crt_scene_create"
+            build_s = build_info["scene_create_wall_ms"] / 1e3
+        else:
+            scene = cr.Scene(data, W, H, depth)
         scene.set_shard(rank, world, args.tile)
         for kv in args.option:
             k, v = kv.split("=")
@@ -367,6 +386,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
                        "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
             "roofline": roofline,
         }
+        if build_info:
+            out["config"]["device_build"] = build_info
         if cpu_base and not args.no_cpu_baseline and args.accel == "cwbvh":
             out["cpu_baseline"] = cpu_baseline(data, cam, W, H, depth, rvs[0], cs)
     if takes_part:
@@ -490,6 +511,7 @@ def main():
         if auto and not args.no_extra and args.accel == "cwbvh":
             if N == 1:
                 extra["north_star"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, True, "weak")
+                extra["north_star_gpu_tree"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, False, "weak", device_built="sah")
                 extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak")
                 extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak", materials="disney")
                 extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
@@ -507,6 +529,8 @@ def main():
         if head.get("dry_run"):
             out["dry_run"] = True
         descr = {"north_star": "BASELINE.json configs[2] — the workload its targets (>= 1 Gray/s, >= 50 % HBM roofline) are quoted on",
+                 "north_star_gpu_tree": "configs[2] again, over a tree built on the GPU: crt_scene_create with CRT_BUILD_LBVH_ON_DEVICE | CRT_BUILD_SAH "
+                                        "(binned-SAH BVH2, CWBVH conversion and records all in HBM; config.device_build has the times) instead of the host SBVH",
                  "incoherent": "BASELINE.json configs[3] ray mix with the reference's own (Lambert-only) integrator — 4 path segments on the same mesh",
                  "incoherent_disney": "BASELINE.json configs[3] as worded: 4 path segments with a mirror tall box and GGX / Disney-diffuse short "
                                       "box and floor (the material model has no reference code: oracle-defined, HIP == oracle bit for bit)",

@@ -1134,6 +1134,7 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     *out = nullptr;
     if (!tris || !vertices || n_tris == 0) return fail(CRT_ERR_INVALID, "crt_lbvh_build: empty input");
     if (n_tris >= (1u << 21)) return fail(CRT_ERR_LIMIT, "crt_lbvh_build: more than 2^21 triangles (FlatNode.h:24 start field)");
+    if (flags & ~(uint32_t)(CRT_GPU_BUILD_PLOC | CRT_GPU_BUILD_SAH | 0xff00u)) return fail(CRT_ERR_INVALID, "crt_lbvh_build: unknown flags");
     for (size_t i = 0; i < n_tris; ++i)
         for (int j = 0; j < 3; ++j)
             if (tris[i].v[j] < 0 || (size_t)tris[i].v[j] >= n_vertices) return fail(CRT_ERR_INVALID, "crt_lbvh_build: vertex index out of range");

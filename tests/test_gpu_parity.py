@@ -787,6 +787,28 @@ def test_gpu_lbvh_builder(cr, ob, cornell, tess8, tess40, scenes, name, builder)
         lb.close(); pl.close()
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
+def test_device_built_scenes_of_one_two_and_many_coincident_triangles(cr, builder):
+    """Degenerate inputs of the build-on-device path: a single triangle (a leaf root), two, and 300 copies of one triangle
+    (identical boxes and centroids: every SAH bin but one is empty, PLOC sees only ties)."""
+    from caitlynrenderer_amd._lib import crt_camera
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], np.float32)
+    nrm = np.array([[0, 0, 1]], np.float32)
+    mats = np.zeros((1, 16), np.float32); mats[0, 0:3] = 0.5; mats[0, 4:8] = (0, 0, 0, -1); mats[0, 12:16] = -1
+    cam = cr.Camera((0.3, 0.3, 3.0), (0.3, 0.3, 0.0), 40.0)
+    for tri_rows in ([[0, 1, 2]], [[0, 1, 2], [2, 3, 4]], [[0, 1, 2]] * 300):
+        tris = np.array([[a, b, c, 0, 0, 0, 0, 1, -1, -1, -1, 0] for a, b, c in tri_rows], np.int32)
+        mesh = cr.Mesh(v, nrm, np.zeros((0, 2), np.float32), tris, mats, np.zeros((0, 18), np.float32))
+        s = cr.Scene(cr.SceneData.for_device_build(mesh, cam, builder=builder), 32, 32, 1)
+        info = s.bvh_info()
+        assert info["n_tris8"] == len(tri_rows) and info["n_bvh2_nodes"] == 2 * len(tri_rows) - 1
+        rays = np.zeros(2, cr.RAY_DT)
+        rays["o"] = [(0.2, 0.2, 2.0), (5.0, 5.0, 2.0)]; rays["d"] = (0, 0, -1); rays["tmax"] = 1e9
+        h = s.trace(rays)
+        assert h["tri"][0] == 0 and h["t"][0] == 2.0 and h["tri"][1] == -1          # lowest id among coincident triangles
+        s.close()
+
+
 def test_gpu_lbvh_edge_cases(cr):
     for n in (1, 2, 3):
         v = (np.arange(9 * n, dtype=np.float32).reshape(-1, 3) * np.float32(0.37)) % 5
@@ -1080,6 +1102,8 @@ def test_bench_line_contract(tmp_path):
     assert ns["value"] > 1000 and ns["cpu_baseline"]["value"] > 0 and ns["config"]["stack_overflows"] == 0
     assert abs(ns["value"] - ns["config"]["rays_per_step"] / ns["ms_per_step"] / 1e3) / ns["value"] < 0.01
     check_roofline(ns["roofline"], 24)
+    gt = d["north_star_gpu_tree"]
+    assert gt["value"] > 0.9 * ns["value"] and gt["config"]["device_build"]["builder"] == "sah" and gt["config"]["device_build"]["bvh2_device_ms"] > 0
     assert d["incoherent"]["config"]["path_segments"] == 4 and d["incoherent"]["value"] > 500
     assert "Disney" in d["incoherent_disney"]["config"]["workload"] and d["incoherent_disney"]["value"] > 500
     check_roofline(d["incoherent"]["roofline"], 24)
