@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_builders -- pyt
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.log
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --workload mesh1m --resolution 3840x2160 > $O/bench_config5_world1.json 2> $O/bench_config5_world1.log
-python tools/builder_quality.py sbvh lbvh ploc16 > $O/builder_quality.txt 2>&1
+python tools/builder_quality.py sbvh sah lbvh ploc4 ploc16 ploc64 > $O/builder_quality.txt 2>&1
 for A in "mesh1m 1" "mesh1m 4" "cornell 1"; do python tools/lane_util.py $A; done > $O/lane_util.txt 2>&1
 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/valu_rate tools/ubench/valu_rate.hip && /tmp/valu_rate > $O/valu_rate.txt 2>&1
 cat $O/bench_default.json
