@@ -139,7 +139,6 @@ struct crt_scene {
     // triangle steps shared out to all lanes of the wave: 0 off, 1 closest-hit walk, 2 + in-place shadow rays, 3 (default) = 1 for
     // the first segment (coherent shadow rays: the plain loop is faster, 0.291 vs 0.298 ms) and 2 for bounce segments (0.4526 vs 0.4556 ms)
     uint32_t tri_share = 3;
-    uint32_t node_pair = 1;                  // with tri_share: two lanes per node when at most half of the lanes hold a node
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
@@ -697,7 +696,6 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         s->waves_per_workgroup = (uint32_t)value;
     }
     else if (!std::strcmp(name, "compact_shadow")) s->compact_shadow = value ? 1u : 0u;
-    else if (!std::strcmp(name, "node_pair")) s->node_pair = value ? 1u : 0u;
     else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(3, std::max(0, value));
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "accel")) {
@@ -772,7 +770,6 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         const bool inplace = bvh2 || s->inplace_shadow != 0u;   // shadow rays walked inside k_segment: no queue, no k_shadow launch
         sa.tri_min = small_tree ? 0u : s->tri_min;
         sa.tri_share = s->tri_share == 3u ? (b == 0 ? 1u : 2u) : s->tri_share;
-        sa.node_pair = s->node_pair;
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);

@@ -34,17 +34,26 @@ __device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x 
 // min3, 2 clamps, compare, shift, select); pairing the near/far fmas of an axis into v_pk_fma_f32 (24 instead of
 // 48) was measured twice: 0.224 vs 0.217 ms (200-frame averages) and 9 more VGPRs, so the scalar form stays.  Returns the hit mask: inner children in the top
 // byte at bit (24+slot)^oct, leaf triangles as unary-count bits in the low 24.
-// Four of the eight children (slots 4 half .. 4 half + 3): the unit two lanes can split a node by.  adj_inv / adj_o are the
-// per-node, per-ray constants of cwbvh.fs:385-389.
-__device__ __forceinline__ uint32_t node8_intersect_half(uint32_t meta4, uint32_t qlox, uint32_t qhix, uint32_t qloy, uint32_t qhiy, uint32_t qloz,
-                                                         uint32_t qhiz, vec3 adj_inv, vec3 adj_o, bool negx, bool negy, bool negz, uint32_t oct4,
-                                                         float max_t) {
+__device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3,
+                                                    const uint4 n4, vec3 o, vec3 inv, bool negx, bool negy, bool negz,
+                                                    uint32_t oct4, float max_t) {
+    const vec3 p = V3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
+    const uint32_t e_imask = n0.w;
+    const vec3 adj_inv = V3(__uint_as_float((e_imask & 0xffu) << 23) * inv.x,
+                            __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * inv.y,
+                            __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * inv.z);
+    const vec3 adj_o = (p - o) * inv;
     uint32_t hit_mask = 0;
-    {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t meta4 = i == 0 ? n1.z : n1.w;
         const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
         const uint32_t inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
         const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1F1F1F1Fu;
         const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+        const uint32_t qlox = i == 0 ? n2.x : n2.y, qhix = i == 0 ? n2.z : n2.w;
+        const uint32_t qloy = i == 0 ? n3.x : n3.y, qhiy = i == 0 ? n3.z : n3.w;
+        const uint32_t qloz = i == 0 ? n4.x : n4.y, qhiz = i == 0 ? n4.z : n4.w;
         const uint32_t xmin = negx ? qhix : qlox, xmax = negx ? qlox : qhix;
         const uint32_t ymin = negy ? qhiy : qloy, ymax = negy ? qloy : qhiy;
         const uint32_t zmin = negz ? qhiz : qloz, zmax = negz ? qloz : qhiz;
@@ -66,19 +75,6 @@ __device__ __forceinline__ uint32_t node8_intersect_half(uint32_t meta4, uint32_
         }
     }
     return hit_mask;
-}
-
-__device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3,
-                                                    const uint4 n4, vec3 o, vec3 inv, bool negx, bool negy, bool negz,
-                                                    uint32_t oct4, float max_t) {
-    const vec3 p = V3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
-    const uint32_t e_imask = n0.w;
-    const vec3 adj_inv = V3(__uint_as_float((e_imask & 0xffu) << 23) * inv.x,
-                            __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * inv.y,
-                            __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * inv.z);
-    const vec3 adj_o = (p - o) * inv;
-    return node8_intersect_half(n1.z, n2.x, n2.z, n3.x, n3.z, n4.x, n4.z, adj_inv, adj_o, negx, negy, negz, oct4, max_t) |
-           node8_intersect_half(n1.w, n2.y, n2.w, n3.y, n3.w, n4.y, n4.w, adj_inv, adj_o, negx, negy, negz, oct4, max_t);
 }
 
 __device__ __forceinline__ float clamp_dir(float d) {
@@ -213,18 +209,17 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
 // owner folds its items' results in their original order — the same tests with the same operands, by another lane, and the
 // same acceptance rule in the same order: hits and per-ray counters stay bit-identical.
 struct TriShare {
-    float4* ray;        // [3][64]: origin, direction, reciprocal direction (clamped, as the node test uses it) of each lane's current ray
-    uint32_t* items;    // [64]: triangle index | owner lane << 24; node steps: [32] x (node index | owner lane << 24, max_t)
-    float4* res;        // [64]: t, u, v, original id (int bits; -1 = no hit); node steps: (hit mask of 4 children, child base, triangle base, imask)
-    uint32_t pair_nodes;// 1: node steps with at most half of the lanes busy are split over two lanes per node
+    float4* ray;        // [2][64]: origin, direction of each lane's current ray
+    uint32_t* items;    // [64]: triangle index | owner lane << 24
+    float4* res;        // [64]: t, u, v, original id (int bits; -1 = no hit)
 };
-#define CRT_SHARE_BYTES (3 * 64 * 16 + 64 * 4 + 64 * 16)      // per wave
+#define CRT_SHARE_BYTES (2 * 64 * 16 + 64 * 4 + 64 * 16)      // per wave
 
 template <bool ANY, bool STATS, bool SHARE = false, typename Load, typename Done>
 __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* stk,
                                               int stack_entries, uint32_t* overflow, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
                                               uint32_t tri_min, Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris,
-                                              uint32_t& w_nodes, uint32_t& w_tris, TriShare share = TriShare{nullptr, nullptr, nullptr, 0u}) {
+                                              uint32_t& w_nodes, uint32_t& w_tris, TriShare share = TriShare{nullptr, nullptr, nullptr}) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t next = pool_begin;                     // wave-uniform
     bool busy = false;
@@ -258,10 +253,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
                 cur = finite ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
                 tg = make_uint2(0u, 0u);
-                if (SHARE) {                        // whoever tests this ray's triangles or nodes reads its operands from here
+                if (SHARE) {                        // whoever tests this ray's triangles reads its operands from here
                     share.ray[lane] = make_float4(o.x, o.y, o.z, 0.f);
                     share.ray[64u + lane] = make_float4(d.x, d.y, d.z, 0.f);
-                    share.ray[128u + lane] = make_float4(inv.x, inv.y, inv.z, 0.f);
                 }
             }
             next = next + n_idle < pool_end ? next + n_idle : pool_end;
@@ -286,67 +280,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
         // threshold of 8 waiting lanes and 0.397 ms for the un-voted loop)
         const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;
         bool finished = false;
-        // SHARE, node step with at most half of the lanes holding a node: two lanes per node, four children each (the
-        // owner's ray comes from the LDS strip, the two partial hit masks are OR-ed by the owner) — the same 8 child tests
-        // with the same operands, so the hit mask is the same bits; a bounce-segment node step runs with 30 of 64 lanes on
-        // average, i.e. mostly in this form, at ~150 instead of ~220 wave instructions.
-        bool paired = false;
-        uint32_t n_cons = 64u, rank = lane;
-        if (SHARE && node_phase) {
-            const unsigned long long act = __ballot(true);
-            n_cons = (uint32_t)__builtin_popcountll(act);
-            rank = (uint32_t)__builtin_popcountll(act & ((1ull << lane) - 1ull));
-            paired = share.pair_nodes != 0u && 2u * n_node <= n_cons;
-        }
-        if (SHARE && node_phase && paired) {
-            const unsigned long long nb = __ballot(can_node);
-            const uint32_t r = (uint32_t)__builtin_popcountll(nb & ((1ull << lane) - 1ull));
-            uint2* const items2 = reinterpret_cast<uint2*>(share.items);
-            uint4* const res2 = reinterpret_cast<uint4*>(share.res);
-            if (can_node) {
-                const uint32_t hits_imask = cur.y;
-                const int off = 31 - __builtin_clz(hits_imask);
-                const uint32_t base = cur.x;
-                cur.y &= ~(1u << off);
-                if (cur.y & 0xff000000u) {
-                    if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u);
-                }
-                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
-                const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-                items2[r] = make_uint2(nidx | (lane << 24), __float_as_uint(max_t));
-                if (STATS) ++n_nodes;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (STATS) count_wave_step(w_nodes);
-            if (rank < 2u * n_node) {
-                const uint2 it = items2[rank >> 1];
-                const uint32_t src = it.x >> 24, nidx = it.x & 0x00ffffffu, half = rank & 1u;
-                const float4 ro = share.ray[src], ri = share.ray[128u + src];
-                const bool nx = ri.x < 0.0f, ny = ri.y < 0.0f, nz = ri.z < 0.0f;
-                const uint32_t o4 = (nx ? 0u : 0x04040404u) | (ny ? 0u : 0x02020202u) | (nz ? 0u : 0x01010101u);
-                const uint4* np = nodes + (size_t)nidx * 5;
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                const vec3 pp = V3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
-                const vec3 vinv = V3(ri.x, ri.y, ri.z);
-                const vec3 adj_inv = V3(__uint_as_float((n0.w & 0xffu) << 23) * vinv.x, __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * vinv.y,
-                                        __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * vinv.z);
-                const vec3 adj_o = (pp - V3(ro.x, ro.y, ro.z)) * vinv;
-                const uint32_t part = half == 0u
-                    ? node8_intersect_half(n1.z, n2.x, n2.z, n3.x, n3.z, n4.x, n4.z, adj_inv, adj_o, nx, ny, nz, o4, __uint_as_float(it.y))
-                    : node8_intersect_half(n1.w, n2.y, n2.w, n3.y, n3.w, n4.y, n4.w, adj_inv, adj_o, nx, ny, nz, o4, __uint_as_float(it.y));
-                res2[rank] = make_uint4(part, n1.x, n1.y, n0.w >> 24);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (can_node) {
-                const uint4 ra = res2[2u * r], rb = res2[2u * r + 1u];
-                const uint32_t hitmask = ra.x | rb.x;
-                cur.x = ra.y;
-                tg.x = ra.z;
-                cur.y = (hitmask & 0xff000000u) | ra.w;
-                tg.y = hitmask & 0x00ffffffu;
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else if (node_phase) {
+        if (node_phase) {
             if (can_node) {
                 const uint32_t hits_imask = cur.y;
                 const int off = 31 - __builtin_clz(hits_imask);
@@ -906,13 +840,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
     const uint32_t wave_stride = (COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) * 64u;
     uint2* stk = s_lds + (size_t)wid.lds_wave * wave_stride + lane;
     int* stk2 = reinterpret_cast<int*>(s_lds) + (size_t)wid.lds_wave * a.stack_entries2 * 64u + lane;   // BVH2 mode
-    TriShare share{nullptr, nullptr, nullptr, 0u};
-    if (SHARE) {
-        share.pair_nodes = a.node_pair;                                         // wave-private strip behind the stacks (and COMPACT's wave counters)
+    TriShare share{nullptr, nullptr, nullptr};
+    if (SHARE) {                                         // wave-private strip behind the stacks (and COMPACT's wave counters)
         char* base = reinterpret_cast<char*>(s_lds + (size_t)(blockDim.x >> 6) * wave_stride) + 16 + (size_t)wid.lds_wave * CRT_SHARE_BYTES;
         share.ray = reinterpret_cast<float4*>(base);
-        share.res = reinterpret_cast<float4*>(base + 3 * 64 * 16);
-        share.items = reinterpret_cast<uint32_t*>(base + 4 * 64 * 16);
+        share.res = reinterpret_cast<float4*>(base + 2 * 64 * 16);
+        share.items = reinterpret_cast<uint32_t*>(base + 3 * 64 * 16);
     }
     const float4* const recs = BVH2 ? a.tris2 : a.tris;   // intersection records the hit index refers to
     const FrameArgs& f = a.f;

@@ -70,7 +70,6 @@ struct SegmentArgs {
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
     uint32_t tri_min;          // vote ratio of traverse_pool; 0 = plain per-lane loop (tiny trees)
     uint32_t tri_share;        // 0: one triangle per waiting lane and step; 1: pending triangles shared out to all lanes (closest hit); 2: + in-place shadow rays
-    uint32_t node_pair;        // with tri_share: node steps with <= half of the lanes busy use two lanes per node (four children each)
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart
     const float4* hits_in;     // k_segment<PRETRACED>: (t, u, v, CWBVH triangle) per queue entry
