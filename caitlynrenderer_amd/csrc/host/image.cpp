@@ -1,5 +1,6 @@
 // See image.hpp.  Decoders written from the formats' specifications; output contract = stbi_load(..., 3):
 // 8-bit RGB, top row first, alpha dropped, grey replicated, 16-bit samples reduced to their high byte.
+// (JPEG: jpeg.cpp.)  Pinned byte for byte against the reference's own stb_image: tests/golden/stb_decodes.npz.
 #include "image.hpp"
 
 #include <zlib.h>
@@ -46,15 +47,16 @@ bool decode_pnm(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
     const int comp = b[1] == '5' ? 1 : 3;
     int maxv = 0;
     if (!pnm_token(r, w) || !pnm_token(r, h) || !pnm_token(r, maxv)) return fail(error, "pnm: bad header");
-    if (!sane(w, h) || maxv < 1 || maxv > 65535) return fail(error, "pnm: bad size or maxval");
+    if (!sane(w, h) || maxv < 1) return fail(error, "pnm: bad size or maxval");
+    if (maxv > 255) return fail(error, "pnm: more than 8 bits per sample (the reference's stb_image refuses these too)");
     if (r.at >= n) return fail(error, "pnm: truncated");
     ++r.at;                                             // the single white-space byte after maxval
-    const size_t bps = maxv > 255 ? 2 : 1, need = (size_t)w * h * comp * bps;
+    const size_t need = (size_t)w * h * comp;
     if (r.at + need > n) return fail(error, "pnm: truncated");
     rgb.resize((size_t)w * h * 3);
     const uint8_t* s = b + r.at;
     for (size_t i = 0; i < (size_t)w * h; ++i)
-        for (int c = 0; c < 3; ++c) rgb[3 * i + c] = s[(i * comp + (comp == 1 ? 0 : c)) * bps];   // 16-bit: big-endian high byte
+        for (int c = 0; c < 3; ++c) rgb[3 * i + c] = s[i * comp + (comp == 1 ? 0 : c)];
     return true;
 }
 
@@ -65,7 +67,7 @@ bool decode_bmp(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
     const uint32_t data_off = r.le32(), hdr = r.le32();
     if (hdr != 40 && hdr != 52 && hdr != 56 && hdr != 108 && hdr != 124) return fail(error, "bmp: unsupported header");
     const int32_t bw = (int32_t)r.le32(), bh = (int32_t)r.le32();
-    r.le16();
+    const uint32_t planes = r.le16();
     const uint32_t bpp = r.le16(), comp = r.le32();
     r.skip(12);
     uint32_t n_colors = r.le32();
@@ -73,14 +75,19 @@ bool decode_bmp(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
     uint32_t mr = 0x00ff0000u, mg = 0x0000ff00u, mb = 0x000000ffu;
     if (comp == 3) { mr = r.le32(); mg = r.le32(); mb = r.le32(); }      // BI_BITFIELDS: the masks follow the 40 info bytes
     if (!r.ok) return fail(error, "bmp: truncated header");
+    if (planes != 1) return fail(error, "bmp: bad plane count");             // as stb_image
     if (comp != 0 && !(comp == 3 && bpp == 32)) return fail(error, "bmp: compressed files are not supported");
     if (comp == 3 && !(mr == 0x00ff0000u && mg == 0x0000ff00u && mb == 0x000000ffu)) return fail(error, "bmp: non-standard bit masks");
     if (bpp != 8 && bpp != 24 && bpp != 32) return fail(error, "bmp: only 8, 24 and 32 bits per pixel");
     w = bw; h = bh < 0 ? -bh : bh;
     if (!sane(w, h)) return fail(error, "bmp: bad size");
     std::vector<uint8_t> pal;
+    if (data_off < 14 + (size_t)hdr + (comp == 3 && hdr == 40 ? 12 : 0)) return fail(error, "bmp: pixel data inside the header");
     if (bpp == 8) {
-        if (n_colors == 0 || n_colors > 256) n_colors = 256;
+        // stb_image sizes the palette by the room before the pixel data, and refuses a file that leaves none
+        const size_t room = ((size_t)data_off - 14 - hdr) / 4;
+        if (room == 0 || room > 256) return fail(error, "bmp: bad palette size");
+        if (n_colors == 0 || n_colors > room) n_colors = (uint32_t)room;
         const size_t pal_at = 14 + (size_t)hdr;
         if (pal_at + 4 * (size_t)n_colors > n) return fail(error, "bmp: truncated palette");
         pal.assign(b + pal_at, b + pal_at + 4 * (size_t)n_colors);
@@ -117,6 +124,7 @@ bool decode_tga(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
     const bool rle = type >= 8;
     const uint32_t base = type & 7u;
     if (base < 1 || base > 3) return fail(error, "tga: unsupported image type");
+    if (cmap_type > 1 || (cmap_type == 1) != (base == 1)) return fail(error, "tga: colour map does not fit the image type");   // as stb_image
     if (base == 1) { if (cmap_type != 1 || bpp != 8 || (cmap_bits != 24 && cmap_bits != 32)) return fail(error, "tga: unsupported colour map"); }
     else if (base == 2) { if (bpp != 24 && bpp != 32) return fail(error, "tga: only 24 and 32 bits per pixel"); }
     else if (bpp != 8) return fail(error, "tga: only 8-bit grey");
@@ -174,7 +182,7 @@ bool decode_tga(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
     return true;
 }
 
-// ---------------------------------------------------------------- PNG (non-interlaced)
+// ---------------------------------------------------------------- PNG (plain and Adam7-interlaced; tRNS is dropped with the alpha)
 int paeth(int a, int b, int c) {
     const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
@@ -193,7 +201,9 @@ bool decode_png(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
             if (len != 13) return fail(error, "png: bad IHDR");
             Reader q{d, len};
             w = (int)q.be32(); h = (int)q.be32();
-            depth = q.u8(); ctype = q.u8(); q.u8(); q.u8(); interlace = q.u8();
+            depth = q.u8(); ctype = q.u8();
+            if (q.u8() != 0 || q.u8() != 0) return fail(error, "png: bad compression or filter method");
+            interlace = q.u8();
             have_ihdr = true;
         } else if (tag == 0x504c5445u) pal.assign(d, d + len);            // PLTE
         else if (tag == 0x49444154u) idat.insert(idat.end(), d, d + len);  // IDAT
@@ -201,48 +211,64 @@ bool decode_png(const uint8_t* b, size_t n, int& w, int& h, std::vector<uint8_t>
         r.skip((size_t)len + 4);                                           // data + CRC (not verified, as in stb_image)
     }
     if (!have_ihdr || !sane(w, h)) return fail(error, "png: bad header");
-    if (interlace != 0) return fail(error, "png: interlaced files are not supported");
+    if (interlace > 1) return fail(error, "png: bad interlace method");
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels) return fail(error, "png: bad colour type");
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))) || (ctype == 3 && depth == 16))
         return fail(error, "png: bad bit depth");
-    const size_t bits_pp = (size_t)channels * depth, stride = ((size_t)w * bits_pp + 7) / 8, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+    const size_t bits_pp = (size_t)channels * depth, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+    // the passes of the image: one, or Adam7's seven sub-images {x0, y0, dx, dy}, stored one after the other
+    static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const int whole[1][4] = {{0, 0, 1, 1}};
+    const int (*pass)[4] = interlace ? adam7 : whole;
+    const int n_pass = interlace ? 7 : 1;
+    size_t raw_need = 0;
+    for (int k = 0; k < n_pass; ++k) {
+        const size_t pw = ((size_t)w - pass[k][0] + pass[k][2] - 1) / pass[k][2], ph = ((size_t)h - pass[k][1] + pass[k][3] - 1) / pass[k][3];
+        if (w > pass[k][0] && h > pass[k][1]) raw_need += ((pw * bits_pp + 7) / 8 + 1) * ph;
+    }
     // deflate expands by at most ~1032 : 1, so a header of a few bytes cannot ask for gigabytes
-    if ((stride + 1) * (size_t)h / 1032 > idat.size() + 1) return fail(error, "png: bad compressed data");
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    if (raw_need / 1032 > idat.size() + 1) return fail(error, "png: bad compressed data");
+    std::vector<uint8_t> raw(raw_need);
     uLongf raw_len = (uLongf)raw.size();
     const int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
     if ((zrc != Z_OK && zrc != Z_BUF_ERROR) || raw_len < raw.size()) return fail(error, "png: bad compressed data");
-    std::vector<uint8_t> prev(stride, 0), cur(stride);
     rgb.resize((size_t)w * h * 3);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t* line = raw.data() + (stride + 1) * (size_t)y;
-        const uint8_t ft = line[0];
-        if (ft > 4) return fail(error, "png: bad filter type");
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, up = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            const int x = line[1 + i];
-            cur[i] = (uint8_t)(ft == 0 ? x : ft == 1 ? x + a : ft == 2 ? x + up : ft == 3 ? x + ((a + up) >> 1) : x + paeth(a, up, c));
-        }
-        uint8_t* d = rgb.data() + (size_t)y * w * 3;
-        for (int x = 0; x < w; ++x) {
-            uint8_t s[4] = {0, 0, 0, 0};
-            for (int c = 0; c < channels; ++c) {
-                if (depth == 8) s[c] = cur[(size_t)x * channels + c];
-                else if (depth == 16) s[c] = cur[((size_t)x * channels + c) * 2];                      // high byte
-                else {
-                    const size_t bit = (size_t)x * depth;
-                    const uint32_t v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
-                    s[c] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * (depth == 1 ? 255u : depth == 2 ? 85u : 17u));   // grey scaled to 0..255
-                }
+    const uint8_t* line = raw.data();
+    for (int k = 0; k < n_pass; ++k) {
+        if (w <= pass[k][0] || h <= pass[k][1]) continue;
+        const int pw = (w - pass[k][0] + pass[k][2] - 1) / pass[k][2], ph = (h - pass[k][1] + pass[k][3] - 1) / pass[k][3];
+        const size_t stride = ((size_t)pw * bits_pp + 7) / 8;
+        std::vector<uint8_t> prev(stride, 0), cur(stride);
+        for (int y = 0; y < ph; ++y, line += stride + 1) {
+            const uint8_t ft = line[0];
+            if (ft > 4) return fail(error, "png: bad filter type");
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, up = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                const int x = line[1 + i];
+                cur[i] = (uint8_t)(ft == 0 ? x : ft == 1 ? x + a : ft == 2 ? x + up : ft == 3 ? x + ((a + up) >> 1) : x + paeth(a, up, c));
             }
-            if (ctype == 3) {
-                if ((size_t)s[0] * 3 + 2 >= pal.size()) return fail(error, "png: palette index out of range");
-                d[3 * x] = pal[3 * s[0]]; d[3 * x + 1] = pal[3 * s[0] + 1]; d[3 * x + 2] = pal[3 * s[0] + 2];
-            } else if (channels <= 2) d[3 * x] = d[3 * x + 1] = d[3 * x + 2] = s[0];
-            else { d[3 * x] = s[0]; d[3 * x + 1] = s[1]; d[3 * x + 2] = s[2]; }
+            uint8_t* row = rgb.data() + (size_t)(pass[k][1] + y * pass[k][3]) * w * 3;
+            for (int x = 0; x < pw; ++x) {
+                uint8_t* d = row + 3 * (size_t)(pass[k][0] + x * pass[k][2]);
+                uint8_t s[4] = {0, 0, 0, 0};
+                for (int c = 0; c < channels; ++c) {
+                    if (depth == 8) s[c] = cur[(size_t)x * channels + c];
+                    else if (depth == 16) s[c] = cur[((size_t)x * channels + c) * 2];                      // high byte
+                    else {
+                        const size_t bit = (size_t)x * depth;
+                        const uint32_t v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                        s[c] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * (depth == 1 ? 255u : depth == 2 ? 85u : 17u));   // grey scaled to 0..255
+                    }
+                }
+                if (ctype == 3) {
+                    if ((size_t)s[0] * 3 + 2 >= pal.size()) return fail(error, "png: palette index out of range");
+                    d[0] = pal[3 * s[0]]; d[1] = pal[3 * s[0] + 1]; d[2] = pal[3 * s[0] + 2];
+                } else if (channels <= 2) d[0] = d[1] = d[2] = s[0];
+                else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+            }
+            prev.swap(cur);
         }
-        prev.swap(cur);
     }
     return true;
 }
@@ -256,7 +282,7 @@ bool decode_image_rgb8(const uint8_t* b, size_t n, int& w, int& h, std::vector<u
     if (n >= 8 && std::memcmp(b, png_sig, 8) == 0) return decode_png(b, n, w, h, rgb, error);
     if (n >= 3 && b[0] == 'P' && (b[1] == '5' || b[1] == '6')) return decode_pnm(b, n, w, h, rgb, error);
     if (n >= 26 && b[0] == 'B' && b[1] == 'M') return decode_bmp(b, n, w, h, rgb, error);
-    if (n >= 3 && b[0] == 0xff && b[1] == 0xd8) return fail(error, "jpeg textures are not supported: their decoded bytes depend on the decoder");
+    if (n >= 3 && b[0] == 0xff && b[1] == 0xd8) return decode_jpeg_rgb8(b, n, w, h, rgb, error);
     if (n >= 18) return decode_tga(b, n, w, h, rgb, error);             // TGA has no signature: tried last, like stb_image
     return fail(error, "unknown image format");
 }

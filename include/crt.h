@@ -313,8 +313,9 @@ const uint8_t*      crt_mesh_albedo_textures(const crt_mesh*, int32_t* width, in
 void crt_mesh_free(crt_mesh*);
 
 /* Texture files [host].  crt_image_decode: what `stbi_load(name, &w, &h, 0, 3)` hands the reference (Scene.h:619)
- * for the lossless formats (PNG non-interlaced, BMP, TGA, binary PNM): 8-bit RGB, top row first.  Call with
- * rgb = NULL to get the size; JPEG and other lossy formats are refused (CRT_ERR_INVALID).
+ * for PNG, BMP, TGA, binary PNM and JPEG (baseline and progressive): 8-bit RGB, top row first, byte for byte what
+ * the reference's vendored stb_image returns (tests/golden/stb_decodes.npz).  Call with rgb = NULL to get the size;
+ * GIF/PSD/PIC/HDR and damaged files are refused (CRT_ERR_INVALID).
  * crt_texture_to_array_bytes: the reference's bilinear resize to the texture-array size and its float -> byte
  * truncation (Scene.h:321-371, :648-662, :688-710); out holds out_w * out_h * 3 bytes. */
 int crt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int32_t* width, int32_t* height, uint8_t* rgb, size_t rgb_capacity);

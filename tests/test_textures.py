@@ -1,6 +1,9 @@
-"""Texture path of the loader (Scene.h:597-710): decoders for the lossless formats stb_image reads,
-the reference's bilinear resize + byte truncation, and map_Kd handling.  The checker is oracle/textures.py (numpy
-restatement of Scene.h:321-371) and the known pixels the test files were written from.  No GPU needed."""
+"""Texture path of the loader (Scene.h:597-710): the image decoders (PNG, BMP, TGA, PNM, JPEG), the
+reference's bilinear resize + byte truncation, and map_Kd handling.  Checkers: the known pixels the test files were
+written from; oracle/textures.py (numpy restatement of Scene.h:321-371); and — for every decoder — the bytes the
+reference's OWN decoder returns for the same files: tests/golden/stb_decodes.npz, made by
+tests/golden/make_stb_fixtures.py from oracle/_ref/libstbref.so (the stb_image.h the reference vendors, compiled
+where it lies).  No GPU needed."""
 import os
 
 import numpy as np
@@ -59,8 +62,95 @@ def test_bmp_tga_pnm_decoders(host):
             assert np.array_equal(host.decode_image(T.write_tga(idx, 1, rle, td, palette=pal)), pal[idx])
     assert np.array_equal(host.decode_image(T.write_pnm(rgb)), rgb)
     assert np.array_equal(host.decode_image(T.write_pnm(grey)), grey[..., None].repeat(3, 2))
-    deep = rng.integers(0, 65536, (7, 5, 3), dtype=np.uint16)
-    assert np.array_equal(host.decode_image(T.write_pnm(deep, 65535)), (deep >> 8).astype(np.uint8))
+
+
+GOLDEN_STB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stb_decodes.npz")
+
+
+def _stb_cases():
+    z = np.load(GOLDEN_STB)
+    return z, sorted(k[:-6] for k in z.files if k.endswith("__file"))
+
+
+def test_every_decoder_returns_the_bytes_of_the_references_stb_image(host):
+    """The fixture holds, per file, what the reference's stbi_load_from_memory(..., 3) returned (an empty array where it
+    refused).  JPEG included: lossy, so only the reference's decoder defines the bytes; the product must equal them."""
+    import caitlynrenderer_amd as cr
+    z, names = _stb_cases()
+    kinds = set()
+    for name in names:
+        data, want = z[name + "__file"].tobytes(), z[name + "__rgb"]
+        if want.size == 0:
+            with pytest.raises(cr.CrtError):
+                host.decode_image(data)
+        else:
+            got = host.decode_image(data)
+            assert got.shape == want.shape and np.array_equal(got, want), name
+        kinds.add(name[:3])
+    assert kinds == {"png", "bmp", "tga", "pnm", "jpe"} and len(names) >= 90
+
+
+def test_stb_fixture_is_what_the_reference_decoder_returns_today():
+    """Where the reference is present (build container) the fixture is re-derived from the live library."""
+    from oracle import stbref
+    if not stbref.available():
+        pytest.skip("oracle/_ref/libstbref.so not built (no /root/reference on this machine)")
+    z, names = _stb_cases()
+    for name in names:
+        if name == "jpeg_own_frac_non_interleaved":      # the reference decoder's output depends on uninitialised memory
+            continue
+        got = stbref.decode_rgb(z[name + "__file"].tobytes())
+        want = z[name + "__rgb"]
+        assert (got is None and want.size == 0) or (got is not None and np.array_equal(got, want)), name
+
+
+def test_png_adam7_and_transparency_chunk(host):
+    rng = np.random.default_rng(11)
+    for h, w in ((23, 31), (1, 1), (2, 3), (5, 1), (8, 8), (9, 17)):             # sizes where some of the 7 passes are empty
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(host.decode_image(T.write_png(rgb, 2, 8, interlace=True)), rgb), (h, w)
+        g = rng.integers(0, 4, (h, w, 1), dtype=np.uint8)
+        assert np.array_equal(host.decode_image(T.write_png(g, 0, 2, interlace=True)), (g * 85).astype(np.uint8).repeat(3, 2))
+        deep = rng.integers(0, 65536, (h, w, 4), dtype=np.uint16)
+        assert np.array_equal(host.decode_image(T.write_png(deep, 6, 16, interlace=True)), (deep[..., :3] >> 8).astype(np.uint8))
+    rgb = rng.integers(0, 256, (6, 7, 3), dtype=np.uint8)
+    key = bytes([0, rgb[0, 0, 0], 0, rgb[0, 0, 1], 0, rgb[0, 0, 2]])
+    assert np.array_equal(host.decode_image(T.write_png(rgb, 2, 8, trns=key)), rgb)         # colour key: dropped with the alpha
+
+
+def _jpeg_planes(rng, h, w, n):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return [np.clip(128 + 110 * np.sin(xx / (2.0 + c)) * np.cos(yy / (3.0 + c)) + rng.normal(0, 5, (h, w)), 0, 255).astype(np.uint8)
+            for c in range(n)]
+
+
+def test_jpeg_decoder_properties(host):
+    """Properties that hold whatever the decoder's rounding: a grey file decodes to the encoded plane within the
+    quantisation error; the result does not depend on how the scans are laid out (interleaved, one scan per component,
+    restart intervals, fill bytes): the same coefficients must give the same bytes."""
+    import caitlynrenderer_amd as cr
+    rng = np.random.default_rng(12)
+    (y,) = _jpeg_planes(rng, 40, 52, 1)
+    out = host.decode_image(T.write_jpeg([y], [(1, 1)], quant=1))
+    assert out.shape == (40, 52, 3) and np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])
+    assert np.abs(out[..., 0].astype(int) - y.astype(int)).max() <= 4
+    planes = _jpeg_planes(rng, 29, 43, 3)
+    for samp in ([(1, 1)] * 3, [(2, 2), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(4, 1), (1, 1), (1, 1)]):
+        base = host.decode_image(T.write_jpeg(planes, samp, quant=6))
+        for kw in (dict(interleaved=False), dict(restart=1), dict(restart=3, fill_bytes=True), dict(interleaved=False, restart=2), dict(dnl=True)):
+            assert np.array_equal(host.decode_image(T.write_jpeg(planes, samp, quant=6, **kw)), base), (samp, kw)
+    # RGB component ids: no colour conversion, the planes come back (within quantisation error)
+    rgb = host.decode_image(T.write_jpeg(planes, [(1, 1)] * 3, quant=1, ids=[ord("R"), ord("G"), ord("B")]))
+    assert np.abs(rgb.astype(int) - np.stack(planes, 2).astype(int)).max() <= 4
+    # damaged: truncated, no end marker, 12-bit samples, arithmetic coding, a scan before any table
+    good = T.write_jpeg(planes, [(2, 2), (1, 1), (1, 1)], quant=6)
+    sof = good.find(b"\xff\xc0")
+    twelve = bytearray(good); twelve[sof + 4] = 12
+    arith = bytearray(good); arith[sof + 1] = 0xC9
+    for data in (good[:len(good) // 2], good[:-2], bytes(twelve), bytes(arith), b"\xff\xd8\xff\xda\x00\x08\x01\x01\x00\x00\x3f\x00\xff\xd9",
+                 b"\xff\xd8\xff\xe0" + b"\0" * 64):
+        with pytest.raises(cr.CrtError):
+            host.decode_image(data)
 
 
 def test_refused_and_damaged_files(host):
@@ -68,9 +158,9 @@ def test_refused_and_damaged_files(host):
     from caitlynrenderer_amd import _lib
     rgb = np.zeros((4, 4, 3), np.uint8)
     png = T.write_png(rgb)
-    interlaced = bytearray(png); interlaced[28] = 1                          # IHDR interlace byte (CRC is not checked)
-    for data in (b"\xff\xd8\xff\xe0" + b"\0" * 64,                           # JPEG: refused by design
-                 bytes(interlaced), png[:40], T.write_bmp(rgb)[:60], T.write_tga(rgb)[:20], b"P6\n4 4\n255\n" + b"\0" * 10,
+    interlaced = bytearray(png); interlaced[28] = 2                          # IHDR interlace byte: 0 or 1 (CRC is not checked)
+    for data in (bytes(interlaced), png[:40], T.write_pnm(np.zeros((4, 4, 3), np.uint16), 65535),   # 16-bit PNM: stb_image refuses
+                 T.write_bmp(rgb)[:60], T.write_tga(rgb)[:20], b"P6\n4 4\n255\n" + b"\0" * 10,
                  b"not an image at all, just some text that is long enough"):
         with pytest.raises(cr.CrtError) as e:
             host.decode_image(data)
@@ -126,6 +216,12 @@ def test_loader_map_kd(host, cornell, tmp_path):
     assert np.array_equal(got.albedo_textures[1], T.texture_to_array_bytes(wood))
     assert got.materials[:, 12].tolist() == [-1.0, 0.0, 1.0, -1.0, -1.0, -1.0]                 # 3 and 4 reuse a name: no layer
     assert np.array_equal(got.texcoords, np.stack([uv[:, 0], np.float32(1) - (np.float32(1) - uv[:, 1])], axis=1))
+    # a JPEG texture: the layer is the reference decoder's pixels (fixture) through the reference's resize
+    z = np.load(GOLDEN_STB)
+    open(tmp_path / "photo.jpg", "wb").write(z["jpeg_progressive_420_q80__file"].tobytes())
+    write_obj(m, str(tmp_path / "jpg.obj"), mtl_name="jpg.mtl", map_kd={2: "photo.jpg"})
+    got = cr.Mesh.read_object(str(tmp_path / "jpg.obj"))
+    assert np.array_equal(got.albedo_textures[0], T.texture_to_array_bytes(z["jpeg_progressive_420_q80__rgb"]))
     # a missing or undecodable texture is an error, not a crash
     write_obj(m, str(tmp_path / "bad.obj"), mtl_name="bad.mtl", map_kd={1: "nowhere.png"})
     with pytest.raises(cr.CrtError):
