@@ -120,6 +120,7 @@ SYMBOLS = {
     "crt_mesh_albedo_textures": (_P, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "crt_mesh_free": (None, [_P]),
     "crt_image_decode": (_I, [_P, _SZ, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _SZ]),
+    "crt_image_encode_png": (_I, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _SZ, C.POINTER(C.c_size_t)]),
     "crt_texture_to_array_bytes": (_I, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "crt_last_error": (C.c_char_p, []),
     "crt_abi_version": (_U32, []),

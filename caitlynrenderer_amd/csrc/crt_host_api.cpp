@@ -162,6 +162,23 @@ int crt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int32_t* width, 
     }
     return CRT_OK;
 }
+int crt_image_encode_png(const uint8_t* pixels, int32_t width, int32_t height, int32_t channels, int32_t bottom_up,
+                         uint8_t* file, size_t file_capacity, size_t* file_size) {
+    if (!pixels || !file_size || width <= 0 || height <= 0 || (channels != 3 && channels != 4))
+        return fail(CRT_ERR_INVALID, "crt_image_encode_png: bad argument");
+    try {
+        std::vector<uint8_t> out;
+        crt::encode_png(pixels, width, height, channels, bottom_up != 0, out);
+        *file_size = out.size();
+        if (file) {
+            if (file_capacity < out.size()) return fail(CRT_ERR_INVALID, "crt_image_encode_png: output buffer too small");
+            std::memcpy(file, out.data(), out.size());
+        }
+    } catch (const std::exception& e) {
+        return fail(CRT_ERR_NOMEM, std::string("crt_image_encode_png: ") + e.what());
+    }
+    return CRT_OK;
+}
 int crt_texture_to_array_bytes(const uint8_t* rgb, int32_t width, int32_t height, int32_t out_w, int32_t out_h, uint8_t* out) {
     if (!rgb || !out || width <= 0 || height <= 0 || out_w <= 0 || out_h <= 0) return fail(CRT_ERR_INVALID, "crt_texture_to_array_bytes: bad argument");
     try {

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <stdexcept>
 
 namespace crt {
 namespace {
@@ -296,6 +297,49 @@ bool decode_image_rgb8(const std::string& path, int& w, int& h, std::vector<uint
     std::fclose(f);
     if (!decode_image_rgb8(bytes.data(), bytes.size(), w, h, rgb, error)) { error = path + ": " + error; return false; }
     return true;
+}
+
+void encode_png(const uint8_t* pixels, int width, int height, int channels, bool bottom_up, std::vector<uint8_t>& file) {
+    const size_t stride = (size_t)width * channels;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)height), cand(stride);
+    const std::vector<uint8_t> zero(stride, 0);
+    for (int y = 0; y < height; ++y) {
+        const uint8_t* cur = pixels + stride * (size_t)(bottom_up ? height - 1 - y : y);
+        const uint8_t* prev = y == 0 ? zero.data() : pixels + stride * (size_t)(bottom_up ? height - y : y - 1);
+        uint8_t* dst = raw.data() + (stride + 1) * (size_t)y;
+        // the filter whose output has the smallest sum of absolute values (the heuristic of the PNG specification, 12.8)
+        uint64_t best = ~0ull;
+        for (int ft = 0; ft < 5; ++ft) {
+            uint64_t sum = 0;
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= (size_t)channels ? cur[i - channels] : 0, up = prev[i], c = i >= (size_t)channels ? prev[i - channels] : 0;
+                const int pred = ft == 0 ? 0 : ft == 1 ? a : ft == 2 ? up : ft == 3 ? (a + up) >> 1 : paeth(a, up, c);
+                cand[i] = (uint8_t)(cur[i] - pred);
+                sum += cand[i] < 128 ? cand[i] : 256 - cand[i];
+            }
+            if (sum < best) { best = sum; dst[0] = (uint8_t)ft; std::memcpy(dst + 1, cand.data(), stride); }
+        }
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) throw std::runtime_error("png: deflate failed");
+    auto be32 = [&](std::vector<uint8_t>& v, uint32_t x) { for (int k = 3; k >= 0; --k) v.push_back((uint8_t)(x >> (8 * k))); };
+    auto chunk = [&](const char* tag, const uint8_t* d, size_t n) {
+        be32(file, (uint32_t)n);
+        const size_t at = file.size();
+        file.insert(file.end(), tag, tag + 4);
+        file.insert(file.end(), d, d + n);
+        be32(file, (uint32_t)crc32(0, file.data() + at, (uInt)(n + 4)));
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    file.assign(sig, sig + 8);
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)width); be32(ihdr, (uint32_t)height);
+    const uint8_t tail[5] = {8, (uint8_t)(channels == 4 ? 6 : 2), 0, 0, 0};
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    chunk("IHDR", ihdr.data(), ihdr.size());
+    chunk("IDAT", z.data(), zlen);
+    chunk("IEND", nullptr, 0);
 }
 
 void texture_to_array_bytes(const uint8_t* rgb, int img_w, int img_h, int width, int height, uint8_t* out) {

@@ -25,6 +25,11 @@ bool decode_image_rgb8(const uint8_t* bytes, size_t n, int& w, int& h, std::vect
 // 256 values in fp32, as the tests check; `texture_to_array_bytes` follows both paths.
 bool decode_jpeg_rgb8(const uint8_t* bytes, size_t n, int& w, int& h, std::vector<uint8_t>& rgb, std::string& error);   // jpeg.cpp
 
+// PNG file (8-bit RGB or RGBA, rows filtered adaptively, zlib deflate) of `height` rows of `width` pixels with `channels`
+// (3 or 4) bytes each; `bottom_up`: the first row in memory is the bottom row of the picture (the GL orientation of
+// crt_resolve's output) and the file is written top row first.
+void encode_png(const uint8_t* pixels, int width, int height, int channels, bool bottom_up, std::vector<uint8_t>& file);
+
 void texture_to_array_bytes(const uint8_t* rgb, int w, int h, int out_w, int out_h, uint8_t* out);
 
 }  // namespace crt

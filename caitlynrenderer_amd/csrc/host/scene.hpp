@@ -137,6 +137,22 @@ struct Scene {
         return true;
     }
 
+    // PNG (RGB), top row first
+    bool write_png(const std::string& path) {
+        const std::vector<uint8_t> rgba = resolve();
+        std::vector<uint8_t> rgb((size_t)width * height * 3);
+        for (size_t i = 0; i < (size_t)width * height; ++i) { rgb[3 * i] = rgba[4 * i]; rgb[3 * i + 1] = rgba[4 * i + 1]; rgb[3 * i + 2] = rgba[4 * i + 2]; }
+        size_t size = 0;
+        if (crt_image_encode_png(rgb.data(), (int32_t)width, (int32_t)height, 3, 1, nullptr, 0, &size) != CRT_OK) return false;
+        std::vector<uint8_t> file(size);
+        if (crt_image_encode_png(rgb.data(), (int32_t)width, (int32_t)height, 3, 1, file.data(), file.size(), &size) != CRT_OK) return false;
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f) return false;
+        const bool ok = std::fwrite(file.data(), 1, size, f) == size;
+        std::fclose(f);
+        return ok;
+    }
+
     void delete_cpu_data() {                         // Scene.h:961-976
         std::vector<float3>().swap(vertices); std::vector<float3>().swap(normals); std::vector<float>().swap(texcoords);
         std::vector<crt_triangle>().swap(triangles); std::vector<crt_material>().swap(mats);

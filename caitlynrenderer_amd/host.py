@@ -121,6 +121,18 @@ def decode_image(file_bytes):
     return out
 
 
+def encode_png(pixels, bottom_up=False):
+    """crt_image_encode_png: PNG file bytes of an (H, W, 3|4) uint8 image."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint8)
+    assert px.ndim == 3 and px.shape[2] in (3, 4)
+    L = lib()
+    size = C.c_size_t()
+    check(L.crt_image_encode_png(_ptr(px), px.shape[1], px.shape[0], px.shape[2], int(bottom_up), None, 0, C.byref(size)))
+    out = np.empty(size.value, np.uint8)
+    check(L.crt_image_encode_png(_ptr(px), px.shape[1], px.shape[0], px.shape[2], int(bottom_up), _ptr(out), out.size, C.byref(size)))
+    return out[:size.value].tobytes()
+
+
 def texture_to_array_bytes(rgb, out_w=256, out_h=256):
     """crt_texture_to_array_bytes: the reference's resize + byte truncation (Scene.h:321-371, :648-662, :688-710)."""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

@@ -14,6 +14,13 @@ def write_ppm(path, rgba):
         f.write(np.ascontiguousarray(img).tobytes())
 
 
+def write_png(path, rgba):
+    """PNG of an (H, W, 4|3) uint8 bottom-up image (alpha kept when present), top row first in the file."""
+    from .host import encode_png
+    with open(path, "wb") as f:
+        f.write(encode_png(np.asarray(rgba, dtype=np.uint8), bottom_up=True))
+
+
 def read_ppm(path):
     """Inverse of write_ppm: returns the bottom-up (H, W, 3) uint8 image."""
     with open(path, "rb") as f:

@@ -1,7 +1,7 @@
 // Minimal host program with the reference's frame-loop shape (Caitlyn/main.cpp:244 init, :262-300 loop)
 // on top of crt::Scene: load an OBJ, render N progressive frames on the GPU, write the tone-mapped image.
 //
-//   render_obj scene.obj out.ppm [width height frames max_depth [sum.f32]]
+//   render_obj scene.obj out.ppm|out.png [width height frames max_depth [sum.f32]]
 //
 // Build: make -C caitlynrenderer_amd/csrc example   (g++, links libcrt.so)
 #include <cstdio>
@@ -12,7 +12,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s scene.obj out.ppm [width height frames max_depth [sum.f32]]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s scene.obj out.ppm|out.png [width height frames max_depth [sum.f32]]\n", argv[0]);
         return 2;
     }
     const uint32_t w = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 700, h = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 700;
@@ -25,7 +25,9 @@ int main(int argc, char** argv) {
         scn.Render();
         if (!scn.error.empty()) { std::fprintf(stderr, "render failed: %s\n", scn.error.c_str()); return 1; }
     }
-    if (!scn.write_ppm(argv[2])) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
+    const std::string out = argv[2];
+    const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+    if (!(png ? scn.write_png(out) : scn.write_ppm(out))) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
     if (argc > 7) {
         const std::vector<float> sum = scn.read_sum();
         FILE* f = std::fopen(argv[7], "wb");

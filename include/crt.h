@@ -319,6 +319,12 @@ void crt_mesh_free(crt_mesh*);
  * crt_texture_to_array_bytes: the reference's bilinear resize to the texture-array size and its float -> byte
  * truncation (Scene.h:321-371, :648-662, :688-710); out holds out_w * out_h * 3 bytes. */
 int crt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int32_t* width, int32_t* height, uint8_t* rgb, size_t rgb_capacity);
+/* Image file of a resolved frame [host] (the step after the path; the reference only shows the texture on
+ * screen, Scene.h:1224-1230).  crt_image_encode_png: PNG (8-bit, colour type 2 or 6) of `height` rows of `width` pixels,
+ * `channels` = 3 or 4 bytes each; bottom_up != 0: the first row in memory is the bottom row (crt_resolve's orientation).
+ * Call with file = NULL to get the size an upper bound needs; *file_size returns the bytes written. */
+int crt_image_encode_png(const uint8_t* pixels, int32_t width, int32_t height, int32_t channels, int32_t bottom_up,
+                         uint8_t* file, size_t file_capacity, size_t* file_size);
 int crt_texture_to_array_bytes(const uint8_t* rgb, int32_t width, int32_t height, int32_t out_w, int32_t out_h, uint8_t* out);
 
 const char* crt_last_error(void);

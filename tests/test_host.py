@@ -352,6 +352,23 @@ def test_obj_round_trip_and_ppm(cr, cornell, tmp_path):
     img = (np.arange(5 * 7 * 4) % 251).astype(np.uint8).reshape(5, 7, 4)
     write_ppm(str(tmp_path / "a.ppm"), img)
     assert np.array_equal(read_ppm(str(tmp_path / "a.ppm")), img[:, :, :3])
+    # PNG writer of the boundary (crt_image_encode_png): the file decodes to the picture, top row first
+    from caitlynrenderer_amd import host
+    from caitlynrenderer_amd.image import write_png
+    write_png(str(tmp_path / "a.png"), img)
+    assert np.array_equal(host.decode_image(open(tmp_path / "a.png", "rb").read()), img[::-1, :, :3])
+    rng = np.random.default_rng(3)
+    for shape in ((1, 1, 3), (9, 4, 4), (120, 77, 3)):
+        px = rng.integers(0, 256, shape, dtype=np.uint8)
+        px[: shape[0] // 2] = px[0, 0]                                    # flat rows and noisy rows: different filters win
+        data = host.encode_png(px)
+        assert data[:8] == b"\x89PNG\r\n\x1a\n" and np.array_equal(host.decode_image(data), px[..., :3])
+        import zlib, struct
+        at = 8
+        while at < len(data):                                             # every chunk carries a valid CRC
+            n, tag = struct.unpack(">I4s", data[at:at + 8])
+            assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(data[at + 4:at + 8 + n])
+            at += 12 + n
 
 
 def test_cpp_example_builds_and_reports_usage(cr):
