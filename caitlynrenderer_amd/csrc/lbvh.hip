@@ -13,7 +13,6 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
-#include <chrono>
 #include <string>
 #include <vector>
 
@@ -478,12 +477,11 @@ __global__ void k_sah_init(uint32_t n, uint32_t* __restrict__ idx, uint32_t* __r
 // (>= 8) of them, so a workgroup sees at most SAH_LOCAL distinct active nodes: each gets a slot in LDS (slot = number of
 // node boundaries before the position), everything is accumulated there and flushed with one global atomic per touched word.
 #define SAH_LOCAL 34
-__device__ __forceinline__ uint32_t sah_local_slot(uint32_t w, uint32_t pos, uint32_t n, const uint32_t* __restrict__ pwork, uint32_t* s_scan,
-                                                   uint32_t* s_node) {
-    // boundary = first position of the workgroup, or a different work item than the previous position
+__device__ __forceinline__ uint32_t sah_local_slot(uint32_t w, uint32_t w_prev, bool in_range, uint32_t* s_scan, uint32_t* s_node) {
+    // boundary = first position of the chunk, or a different work item than the previous position
     const uint32_t tid = threadIdx.x;
-    const bool valid = pos < n && w != SAH_NONE;
-    const bool boundary = valid && (tid == 0u || pwork[pos - 1u] != w);
+    const bool valid = in_range && w != SAH_NONE;
+    const bool boundary = valid && (tid == 0u || w_prev != w);
     const unsigned long long b = __ballot(boundary);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     if (lane == 0u) s_scan[wave] = (uint32_t)__builtin_popcountll(b);
@@ -495,29 +493,77 @@ __device__ __forceinline__ uint32_t sah_local_slot(uint32_t w, uint32_t pos, uin
     return valid ? slot : SAH_NONE;
 }
 
+// A workgroup walks SAH_CHUNKS consecutive chunks of 256 positions.  While the chunks lie inside ONE node (the upper
+// levels: node ranges of thousands of positions) its LDS accumulators are carried from chunk to chunk and flushed once:
+// at level 0 every workgroup flushes into the same words, and ~90 atomics per microsecond per address made the flush —
+// not the binning — the cost of the upper levels (cbounds 51 us, bins 102 us at 4096 workgroups).
+#define SAH_CHUNKS 4
 __global__ void __launch_bounds__(256) k_sah_cbounds(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ pwork, uint32_t n,
                                                      const float* __restrict__ leaf_box, SahWork* __restrict__ work) {
     __shared__ uint32_t s_cb[SAH_LOCAL * 6];
     __shared__ uint32_t s_node[SAH_LOCAL];
     __shared__ uint32_t s_scan[4];
-    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    for (uint32_t t = threadIdx.x; t < SAH_LOCAL * 6; t += 256u) s_cb[t] = 0u;
-    if (threadIdx.x < SAH_LOCAL) s_node[threadIdx.x] = SAH_NONE;
-    __syncthreads();
-    const uint32_t w = pos < n ? pwork[pos] : SAH_NONE;
-    const uint32_t slot = sah_local_slot(w, pos, n, pwork, s_scan, s_node);
-    __syncthreads();
-    if (slot != SAH_NONE) {
-        float c[3];
-        sah_centroid(leaf_box, idx[pos], c);
-        uint32_t* dst = slot < SAH_LOCAL ? s_cb + 6 * slot : work[w].cb;
-        for (int k = 0; k < 3; ++k) { const uint32_t o = f2ord(c[k]); atomicMax(&dst[k], ~o); atomicMax(&dst[3 + k], o); }
+    // all four chunks' loads are issued before the first barrier: the kernel is a chain of dependent loads (work item ->
+    // triangle -> box) at three workgroups per CU, and was bound by that latency, not by the atomics
+    uint32_t wv[SAH_CHUNKS], wp[SAH_CHUNKS], tri[SAH_CHUNKS];
+    float cen[SAH_CHUNKS][3];
+#pragma unroll
+    for (int c = 0; c < SAH_CHUNKS; ++c) {
+        const uint32_t pos = (blockIdx.x * SAH_CHUNKS + c) * 256u + threadIdx.x;
+        wv[c] = pos < n ? pwork[pos] : SAH_NONE;
+        wp[c] = (pos < n && threadIdx.x != 0u) ? pwork[pos - 1u] : SAH_NONE;
     }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < SAH_LOCAL * 6; t += 256u) {
-        const uint32_t v = s_cb[t], node = s_node[t / 6u];
-        if (v != 0u && node != SAH_NONE) atomicMax(&work[node].cb[t % 6u], v);
+#pragma unroll
+    for (int c = 0; c < SAH_CHUNKS; ++c) {
+        const uint32_t pos = (blockIdx.x * SAH_CHUNKS + c) * 256u + threadIdx.x;
+        tri[c] = wv[c] != SAH_NONE ? idx[pos] : 0u;
     }
+#pragma unroll
+    for (int c = 0; c < SAH_CHUNKS; ++c) {
+        cen[c][0] = cen[c][1] = cen[c][2] = 0.f;
+        if (wv[c] != SAH_NONE) sah_centroid(leaf_box, tri[c], cen[c]);
+    }
+    uint32_t carried = SAH_NONE;                                     // node whose bounds are live in slot 0 (uniform)
+#pragma unroll
+    for (int chunk = 0; chunk < SAH_CHUNKS; ++chunk) {
+        const uint32_t pos = (blockIdx.x * SAH_CHUNKS + chunk) * 256u + threadIdx.x;
+        __syncthreads();
+        if (threadIdx.x < SAH_LOCAL) s_node[threadIdx.x] = SAH_NONE;
+        __syncthreads();
+        const uint32_t w = wv[chunk];
+        const uint32_t slot = sah_local_slot(w, wp[chunk], pos < n, s_scan, s_node);
+        __syncthreads();
+        uint32_t n_slots = 0;
+        for (uint32_t k = 0; k < 4u; ++k) n_slots += s_scan[k];
+        if (n_slots > SAH_LOCAL) n_slots = SAH_LOCAL;
+        const bool single = n_slots == 1u;
+        const uint32_t node0 = s_node[0];
+        if (carried != SAH_NONE && !(single && node0 == carried)) {
+            if (threadIdx.x < 6u) { const uint32_t v = s_cb[threadIdx.x]; if (v != 0u) atomicMax(&work[carried].cb[threadIdx.x], v); }
+            carried = SAH_NONE;
+            __syncthreads();
+        }
+        if (carried == SAH_NONE) {
+            for (uint32_t t = threadIdx.x; t < n_slots * 6u; t += 256u) s_cb[t] = 0u;
+            __syncthreads();
+        }
+        if (slot != SAH_NONE) {
+            uint32_t* dst = slot < SAH_LOCAL ? s_cb + 6 * slot : work[w].cb;
+            // a bound only grows: most triangles leave it unchanged, and a plain read (same-address reads broadcast) spares the atomic
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t o = f2ord(cen[chunk][k]);
+                if (~o > *(volatile uint32_t*)&dst[k]) atomicMax(&dst[k], ~o);
+                if (o > *(volatile uint32_t*)&dst[3 + k]) atomicMax(&dst[3 + k], o);
+            }
+        }
+        __syncthreads();
+        if (single) { carried = node0; continue; }
+        for (uint32_t t = threadIdx.x; t < n_slots * 6u; t += 256u) {
+            const uint32_t v = s_cb[t], node = s_node[t / 6u];
+            if (v != 0u && node != SAH_NONE) atomicMax(&work[node].cb[t % 6u], v);
+        }
+    }
+    if (carried != SAH_NONE && threadIdx.x < 6u) { const uint32_t v = s_cb[threadIdx.x]; if (v != 0u) atomicMax(&work[carried].cb[threadIdx.x], v); }
 }
 
 // bins[w][axis][bin] = {count, ~ord(lo.xyz), ord(hi.xyz)}: every field grows by atomicAdd / atomicMax, so all-zero = empty
@@ -526,42 +572,89 @@ __global__ void __launch_bounds__(256) k_sah_bin(const uint32_t* __restrict__ id
     __shared__ uint32_t s_bins[SAH_LOCAL * SAH_BIN_WORDS];        // 45.7 KB
     __shared__ uint32_t s_node[SAH_LOCAL];
     __shared__ uint32_t s_scan[4];
-    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    if (threadIdx.x < SAH_LOCAL) s_node[threadIdx.x] = SAH_NONE;
-    __syncthreads();
-    const uint32_t w = pos < n ? pwork[pos] : SAH_NONE;
-    const uint32_t slot = sah_local_slot(w, pos, n, pwork, s_scan, s_node);
-    __syncthreads();
-    uint32_t n_slots = 0;
-    for (uint32_t k = 0; k < 4u; ++k) n_slots += s_scan[k];
-    if (n_slots > SAH_LOCAL) n_slots = SAH_LOCAL;
-    for (uint32_t t = threadIdx.x; t < n_slots * SAH_BIN_WORDS; t += 256u) s_bins[t] = 0u;
-    __syncthreads();
-    if (slot != SAH_NONE) {
-        const uint32_t tri = idx[pos];
-        const float* b = leaf_box + 6 * (size_t)tri;
-        float c[3];
-        sah_centroid(leaf_box, tri, c);
-        uint32_t ob[6];
-        for (int k = 0; k < 3; ++k) { ob[k] = ~f2ord(b[k]); ob[3 + k] = f2ord(b[3 + k]); }
-        uint32_t* base = slot < SAH_LOCAL ? s_bins + (size_t)slot * SAH_BIN_WORDS : bins + (size_t)w * SAH_BIN_WORDS;
-        for (int ax = 0; ax < 3; ++ax) {
-            const int bi = sah_bin(c[ax], ord2f(~work[w].cb[ax]), ord2f(work[w].cb[3 + ax]));
-            uint32_t* d = base + (ax * SAH_BINS + bi) * 7;
-            atomicAdd(&d[0], 1u);
-            for (int k = 0; k < 6; ++k) atomicMax(&d[1 + k], ob[k]);
+    auto flush = [&](uint32_t slots) {
+        for (uint32_t t = threadIdx.x; t < slots * SAH_BIN_WORDS; t += 256u) {
+            const uint32_t v = s_bins[t];
+            if (v == 0u) continue;
+            uint32_t* g = bins + (size_t)s_node[t / SAH_BIN_WORDS] * SAH_BIN_WORDS + t % SAH_BIN_WORDS;
+            if (t % 7u == 0u) atomicAdd(g, v); else atomicMax(g, v);
+        }
+    };
+    // everything a position needs — work item, triangle box as ordered integers, its three bin numbers — for all four
+    // chunks before the first barrier (see k_sah_cbounds)
+    uint32_t wv[SAH_CHUNKS], wp[SAH_CHUNKS], tri[SAH_CHUNKS], ob[SAH_CHUNKS][6];
+    int bi[SAH_CHUNKS][3];
+#pragma unroll
+    for (int c = 0; c < SAH_CHUNKS; ++c) {
+        const uint32_t pos = (blockIdx.x * SAH_CHUNKS + c) * 256u + threadIdx.x;
+        wv[c] = pos < n ? pwork[pos] : SAH_NONE;
+        wp[c] = (pos < n && threadIdx.x != 0u) ? pwork[pos - 1u] : SAH_NONE;
+    }
+#pragma unroll
+    for (int c = 0; c < SAH_CHUNKS; ++c) {
+        const uint32_t pos = (blockIdx.x * SAH_CHUNKS + c) * 256u + threadIdx.x;
+        tri[c] = wv[c] != SAH_NONE ? idx[pos] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < SAH_CHUNKS; ++c) {
+        for (int k = 0; k < 6; ++k) ob[c][k] = 0u;
+        bi[c][0] = bi[c][1] = bi[c][2] = 0;
+        if (wv[c] == SAH_NONE) continue;
+        const float* b = leaf_box + 6 * (size_t)tri[c];
+        const float bx[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};
+        const uint32_t* cbw = work[wv[c]].cb;
+        for (int k = 0; k < 3; ++k) {
+            ob[c][k] = ~f2ord(bx[k]); ob[c][3 + k] = f2ord(bx[3 + k]);
+            bi[c][k] = sah_bin(0.5f * (bx[k] + bx[3 + k]), ord2f(~cbw[k]), ord2f(cbw[3 + k]));
         }
     }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < n_slots * SAH_BIN_WORDS; t += 256u) {
-        const uint32_t v = s_bins[t];
-        if (v == 0u) continue;
-        uint32_t* g = bins + (size_t)s_node[t / SAH_BIN_WORDS] * SAH_BIN_WORDS + t % SAH_BIN_WORDS;
-        if (t % 7u == 0u) atomicAdd(g, v); else atomicMax(g, v);
+    auto accumulate = [&](uint32_t* base, int c) {
+        for (int ax = 0; ax < 3; ++ax) {
+            uint32_t* d = base + (ax * SAH_BINS + bi[c][ax]) * 7;
+            atomicAdd(&d[0], 1u);
+            for (int k = 0; k < 6; ++k) if (ob[c][k] > *(volatile uint32_t*)&d[1 + k]) atomicMax(&d[1 + k], ob[c][k]);   // bounds only grow
+        }
+    };
+    uint32_t carried = SAH_NONE;                                     // node whose bins are live in slot 0 (uniform)
+#pragma unroll
+    for (int chunk = 0; chunk < SAH_CHUNKS; ++chunk) {
+        const uint32_t first = (blockIdx.x * SAH_CHUNKS + chunk) * 256u, last = first + 255u, pos = first + threadIdx.x;
+        const uint32_t w = wv[chunk];
+        // the chunk lies wholly inside node x  <=>  its first and last position belong to x (positions are sorted by node)
+        const uint32_t w_last = last < n ? pwork[last] : SAH_NONE;
+        __syncthreads();
+        if (carried != SAH_NONE) {
+            if (w_last == carried && pwork[first] == carried) { accumulate(s_bins, chunk); continue; }
+            flush(1u);                                               // s_node[0] is still the carried node
+            carried = SAH_NONE;
+            __syncthreads();
+        }
+        if (threadIdx.x < SAH_LOCAL) s_node[threadIdx.x] = SAH_NONE;
+        __syncthreads();
+        const uint32_t slot = sah_local_slot(w, wp[chunk], pos < n, s_scan, s_node);
+        __syncthreads();
+        uint32_t n_slots = 0;
+        for (uint32_t k = 0; k < 4u; ++k) n_slots += s_scan[k];
+        if (n_slots > SAH_LOCAL) n_slots = SAH_LOCAL;
+        for (uint32_t t = threadIdx.x; t < n_slots * SAH_BIN_WORDS; t += 256u) s_bins[t] = 0u;
+        __syncthreads();
+        if (slot != SAH_NONE) accumulate(slot < SAH_LOCAL ? s_bins + (size_t)slot * SAH_BIN_WORDS : bins + (size_t)w * SAH_BIN_WORDS, chunk);
+        __syncthreads();
+        // a chunk that lies wholly inside one node keeps its bins for the next chunk
+        if (n_slots == 1u && w_last != SAH_NONE && w_last == s_node[0] && pwork[first] == w_last && chunk + 1 < SAH_CHUNKS) { carried = w_last; continue; }
+        flush(n_slots);
     }
+    if (carried != SAH_NONE) { __syncthreads(); flush(1u); }
 }
 
-struct SahLists { uint32_t* counters; SahWork* next; uint32_t* small; };   // counters: [0] nodes, [1] next-level work items, [2] small nodes (node, beg, end triples)
+struct SahLists { uint32_t* counters; SahWork* next; uint32_t* small; };   // counters: [0] nodes so far, [1] next-level work items, [2] small nodes (node, beg, end triples), [3] this level's work items
+
+// between two levels: the children of this level's m nodes are numbered, the next list becomes the current one
+__global__ void k_sah_advance(uint32_t* __restrict__ counters) {
+    counters[0] += 2u * counters[3];
+    counters[3] = counters[1];
+    counters[1] = 0u;
+}
 
 __device__ __forceinline__ float sah_half_area(const float lo[3], const float hi[3]) {
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -573,12 +666,16 @@ __device__ __forceinline__ float sah_half_area(const float lo[3], const float hi
 // splits in two — and the appends to the next level's list / the small-node list are aggregated per workgroup: a returning
 // atomic per node on ONE counter was 4 of the builder's 10 ms (the same ~90 atomics per microsecond per address that capped
 // round 1's queue appends).
-__global__ void __launch_bounds__(256) k_sah_sweep(SahWork* __restrict__ work, uint32_t m, const uint32_t* __restrict__ bins, PlocNodes nd, SahLists out,
-                                                   uint32_t small, uint32_t node_base) {
+// The number of active nodes m and the first free node number live on the device (counters[3], counters[0]): the host
+// launches an upper bound of workgroups and does not wait for a level to finish.  The bins are zeroed again as they are
+// staged, so the array is cleared once per build, not once per level.
+__global__ void __launch_bounds__(256) k_sah_sweep(SahWork* __restrict__ work, uint32_t* __restrict__ bins, PlocNodes nd, SahLists out, uint32_t small) {
     __shared__ uint32_t s_b[4][SAH_BIN_WORDS];
     __shared__ uint32_t s_cnt[4][2];          // per wave: entries for the next-level list, for the small list
     __shared__ uint32_t s_base[2];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t m = out.counters[3], node_base = out.counters[0];
+    if (blockIdx.x * 4u >= m) return;                               // whole workgroup beyond the list (uniform)
     const uint32_t w = blockIdx.x * 4u + wave;
     const bool live = w < m;
     SahWork wk{};
@@ -587,26 +684,44 @@ __global__ void __launch_bounds__(256) k_sah_sweep(SahWork* __restrict__ work, u
     if (live) {
         wk = work[w];
         cnt = wk.end - wk.beg;
-        const uint32_t* B = bins + (size_t)w * SAH_BIN_WORDS;
-        for (uint32_t t = lane; t < SAH_BIN_WORDS; t += 64u) s_b[wave][t] = B[t];
+        uint32_t* B = bins + (size_t)w * SAH_BIN_WORDS;
+        for (uint32_t t = lane; t < SAH_BIN_WORDS; t += 64u) { const uint32_t v = B[t]; s_b[wave][t] = v; if (v) B[t] = 0u; }
     }
     __builtin_amdgcn_wave_barrier();
     if (live) {
+        // lane = axis * 16 + bin: the box and count left of plane p are an inclusive prefix over the 16 lanes of an axis
+        // taken from lane p - 1, those right of it an inclusive suffix — min / max / integer sums, so the order of the
+        // combination does not change a bit of the result (same tree as the O(16) loop per lane it replaces; at the deep levels
+        // the kernel is bound by the 1.3 KB of bins per node it reads, not by this arithmetic)
         const int ax = (int)(lane >> 4), p = (int)(lane & 15u);
         float cost = 3.0e38f;
         uint32_t nl = 0;
-        if (ax < 3 && p >= 1) {
-            float llo[3] = {3e38f, 3e38f, 3e38f}, lhi[3] = {-3e38f, -3e38f, -3e38f}, rlo[3] = {3e38f, 3e38f, 3e38f}, rhi[3] = {-3e38f, -3e38f, -3e38f};
-            uint32_t nr = 0;
-            for (int b = 0; b < SAH_BINS; ++b) {
-                const uint32_t* d = s_b[wave] + (ax * SAH_BINS + b) * 7;
-                const uint32_t c = d[0];
-                if (!c) continue;
-                float* lo = b < p ? llo : rlo; float* hi = b < p ? lhi : rhi;
-                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ord2f(~d[1 + k])); hi[k] = fmaxf(hi[k], ord2f(d[4 + k])); }
-                if (b < p) nl += c; else nr += c;
+        {
+            const uint32_t* d = s_b[wave] + ((ax < 3 ? ax : 0) * SAH_BINS + p) * 7;
+            const uint32_t c0 = ax < 3 ? d[0] : 0u;
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) { lo[k] = c0 ? ord2f(~d[1 + k]) : 3e38f; hi[k] = c0 ? ord2f(d[4 + k]) : -3e38f; }
+            uint32_t cl = c0, cr = c0;
+            float llo[3] = {lo[0], lo[1], lo[2]}, lhi[3] = {hi[0], hi[1], hi[2]}, rlo[3] = {lo[0], lo[1], lo[2]}, rhi[3] = {hi[0], hi[1], hi[2]};
+            for (int dlt = 1; dlt < SAH_BINS; dlt <<= 1) {
+                const uint32_t ucl = __shfl_up(cl, dlt, SAH_BINS), ucr = __shfl_down(cr, dlt, SAH_BINS);
+                float ul[3], uh[3], dl[3], dh[3];
+                for (int k = 0; k < 3; ++k) {
+                    ul[k] = __shfl_up(llo[k], dlt, SAH_BINS); uh[k] = __shfl_up(lhi[k], dlt, SAH_BINS);
+                    dl[k] = __shfl_down(rlo[k], dlt, SAH_BINS); dh[k] = __shfl_down(rhi[k], dlt, SAH_BINS);
+                }
+                if (p >= dlt) { cl += ucl; for (int k = 0; k < 3; ++k) { llo[k] = fminf(llo[k], ul[k]); lhi[k] = fmaxf(lhi[k], uh[k]); } }
+                if (p + dlt < SAH_BINS) { cr += ucr; for (int k = 0; k < 3; ++k) { rlo[k] = fminf(rlo[k], dl[k]); rhi[k] = fmaxf(rhi[k], dh[k]); } }
             }
-            if (nl != 0u && nr != 0u) cost = sah_half_area(llo, lhi) * (float)nl + sah_half_area(rlo, rhi) * (float)nr;
+            // left of plane p = bins [0, p): the inclusive prefix of lane p - 1
+            const uint32_t pl = __shfl_up(cl, 1, SAH_BINS);
+            float pll[3], plh[3];
+            for (int k = 0; k < 3; ++k) { pll[k] = __shfl_up(llo[k], 1, SAH_BINS); plh[k] = __shfl_up(lhi[k], 1, SAH_BINS); }
+            if (ax < 3 && p >= 1) {
+                nl = pl;
+                const uint32_t nr = cr;
+                if (nl != 0u && nr != 0u) cost = sah_half_area(pll, plh) * (float)nl + sah_half_area(rlo, rhi) * (float)nr;
+            }
         }
         // argmin over the wave, ties to the lower lane (axis, then plane): deterministic
         best = cost; bl = lane;
@@ -696,65 +811,92 @@ __global__ void k_sah_small_counts(const uint32_t* __restrict__ small, uint32_t 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_small) counts[t] = 2u * (small[3 * (size_t)t + 2] - small[3 * (size_t)t + 1] - 1u);
 }
+// The per-thread work arrays (triangles, boxes, centroids, sort order, suffix areas, stack) are columns of LDS arrays
+// [entry][lane] — dynamic indexing into private arrays lives in scratch memory (0.92 ms of the 5.3 ms build at 1 M triangles
+// with arrays of 32 entries); CAP = 8 / 16 / 32 is the smallest capacity that holds the threshold.
+template <int CAP>
 __global__ void __launch_bounds__(64) k_sah_small(const uint32_t* __restrict__ small, uint32_t n_small, uint32_t* __restrict__ idx,
                                                   const float* __restrict__ leaf_box, PlocNodes nd, const uint32_t* __restrict__ id_offset, uint32_t node_base) {
+    constexpr bool kBoxes = CAP <= 16;                              // the boxes fit as well (24 KB at CAP = 16)
+    __shared__ uint32_t s_tri[CAP][64];
+    __shared__ float s_cen[3][CAP][64];
+    __shared__ float s_box[kBoxes ? 6 : 1][kBoxes ? CAP : 1][64];
+    __shared__ float s_rarea[CAP][64];
+    __shared__ uint8_t s_ord[CAP][64], s_tmp[CAP][64];
+    __shared__ uint32_t s_stack_node[CAP][64];
+    __shared__ uint16_t s_stack_be[CAP][64];
+    const uint32_t lane = threadIdx.x;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_small) return;
     uint32_t next_id = node_base + id_offset[t];
     const uint32_t root = small[3 * (size_t)t], beg = small[3 * (size_t)t + 1], end = small[3 * (size_t)t + 2];
     const int cnt = (int)(end - beg);
-    uint32_t tri[SAH_SMALL];
-    float cen[SAH_SMALL][3];
-    for (int i = 0; i < cnt; ++i) { tri[i] = idx[beg + i]; sah_centroid(leaf_box, tri[i], cen[i]); }
-    uint8_t ord[SAH_SMALL], tmp[SAH_SMALL];
-    for (int i = 0; i < cnt; ++i) ord[i] = (uint8_t)i;
-    float rarea[SAH_SMALL];
-    struct Item { uint32_t node; uint8_t b, e; } stack[SAH_SMALL];
+    for (int i = 0; i < cnt; ++i) {
+        const uint32_t tr = idx[beg + i];
+        const float* bx = leaf_box + 6 * (size_t)tr;
+        s_tri[i][lane] = tr;
+        for (int k = 0; k < 3; ++k) s_cen[k][i][lane] = 0.5f * (bx[k] + bx[3 + k]);
+        if constexpr (kBoxes) for (int k = 0; k < 6; ++k) s_box[k][i][lane] = bx[k];
+        s_ord[i][lane] = (uint8_t)i;
+    }
+    auto grow = [&](int item, float lo[3], float hi[3]) {
+        if constexpr (kBoxes) {
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], s_box[k][item][lane]); hi[k] = fmaxf(hi[k], s_box[3 + k][item][lane]); }
+        } else {
+            const float* bx = leaf_box + 6 * (size_t)s_tri[item][lane];
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], bx[k]); hi[k] = fmaxf(hi[k], bx[3 + k]); }
+        }
+    };
     int sp = 0;
-    stack[sp++] = Item{root, 0, (uint8_t)cnt};
+    s_stack_node[0][lane] = root; s_stack_be[0][lane] = (uint16_t)(cnt << 8); sp = 1;
     while (sp > 0) {
-        const Item it = stack[--sp];
-        const int b = it.b, e = it.e, c = e - b;
+        --sp;
+        const uint32_t node = s_stack_node[sp][lane];
+        const int b = s_stack_be[sp][lane] & 255, e = s_stack_be[sp][lane] >> 8, c = e - b;
         if (c == 1) {
-            nd.lo[it.node].w = __int_as_float(-1);
-            nd.hi[it.node].w = __int_as_float((int)(beg + (uint32_t)b));
+            nd.lo[node].w = __int_as_float(-1);
+            nd.hi[node].w = __int_as_float((int)(beg + (uint32_t)b));
             continue;
         }
         float best = 3.0e38f; int best_ax = 0, best_i = c / 2;
         for (int ax = 0; ax < 3; ++ax) {
             // insertion sort of ord[b..e) by (centroid[ax], triangle index): a strict total order
             for (int i = b + 1; i < e; ++i) {
-                const uint8_t v = ord[i];
+                const uint8_t v = s_ord[i][lane];
+                const float cv = s_cen[ax][v][lane]; const uint32_t tv = s_tri[v][lane];
                 int j = i - 1;
-                while (j >= b && (cen[ord[j]][ax] > cen[v][ax] || (cen[ord[j]][ax] == cen[v][ax] && tri[ord[j]] > tri[v]))) { ord[j + 1] = ord[j]; --j; }
-                ord[j + 1] = v;
+                while (j >= b) {
+                    const uint8_t o = s_ord[j][lane];
+                    const float co = s_cen[ax][o][lane];
+                    if (!(co > cv || (co == cv && s_tri[o][lane] > tv))) break;
+                    s_ord[j + 1][lane] = o; --j;
+                }
+                s_ord[j + 1][lane] = v;
             }
             float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
             for (int i = e - 1; i > b; --i) {
-                const float* bx = leaf_box + 6 * (size_t)tri[ord[i]];
-                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], bx[k]); hi[k] = fmaxf(hi[k], bx[3 + k]); }
-                rarea[i] = sah_half_area(lo, hi);
+                grow(s_ord[i][lane], lo, hi);
+                s_rarea[i][lane] = sah_half_area(lo, hi);
             }
             for (int k = 0; k < 3; ++k) { lo[k] = 3e38f; hi[k] = -3e38f; }
             for (int i = b + 1; i < e; ++i) {
-                const float* bx = leaf_box + 6 * (size_t)tri[ord[i - 1]];
-                for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], bx[k]); hi[k] = fmaxf(hi[k], bx[3 + k]); }
-                const float cost = sah_half_area(lo, hi) * (float)(i - b) + rarea[i] * (float)(e - i);
+                grow(s_ord[i - 1][lane], lo, hi);
+                const float cost = sah_half_area(lo, hi) * (float)(i - b) + s_rarea[i][lane] * (float)(e - i);
                 if (cost < best) { best = cost; best_ax = ax; best_i = i - b; }
             }
-            if (ax == best_ax) for (int i = b; i < e; ++i) tmp[i] = ord[i];     // remember the winning order
+            if (ax == best_ax) for (int i = b; i < e; ++i) s_tmp[i][lane] = s_ord[i][lane];     // remember the winning order
         }
-        for (int i = b; i < e; ++i) ord[i] = tmp[i];
+        for (int i = b; i < e; ++i) s_ord[i][lane] = s_tmp[i][lane];
         const uint32_t kids = next_id;
         next_id += 2u;
-        nd.lo[it.node].w = __int_as_float((int)kids);
-        nd.hi[it.node].w = __int_as_float((int)kids + 1);
-        nd.parent2[kids] = 2 * (int)it.node;
-        nd.parent2[kids + 1u] = 2 * (int)it.node + 1;
-        stack[sp++] = Item{kids + 1u, (uint8_t)(b + best_i), (uint8_t)e};
-        stack[sp++] = Item{kids, (uint8_t)b, (uint8_t)(b + best_i)};
+        nd.lo[node].w = __int_as_float((int)kids);
+        nd.hi[node].w = __int_as_float((int)kids + 1);
+        nd.parent2[kids] = 2 * (int)node;
+        nd.parent2[kids + 1u] = 2 * (int)node + 1;
+        s_stack_node[sp][lane] = kids + 1u; s_stack_be[sp][lane] = (uint16_t)((b + best_i) | (e << 8)); ++sp;
+        s_stack_node[sp][lane] = kids;      s_stack_be[sp][lane] = (uint16_t)(b | ((b + best_i) << 8)); ++sp;
     }
-    for (int i = 0; i < cnt; ++i) idx[beg + i] = tri[ord[i]];
+    for (int i = 0; i < cnt; ++i) idx[beg + i] = s_tri[s_ord[i][lane]][lane];
 }
 
 // FlatNode array in the canonical BFS order: links for every node, boxes for the leaves (slot j holds triangle order[j])
@@ -911,7 +1053,7 @@ static int ploc_build_on_device(const int32_t* d_vidx, uint32_t stride, const fl
 
 static uint32_t sah_small_of(uint32_t flags) {
     uint32_t s = (flags >> 8) & 0xffu;
-    if (s == 0u) s = 8u;                                             // measured at 1 M triangles: 5.2 / 5.8 / 6.8 / 18 ms for 8 / 12 / 16 / 32, same tree quality
+    if (s == 0u) s = 8u;                                             // measured at 1 M triangles: 3.8 / 4.0 / 6.2 ms for 8 / 16 / 32, same tree quality
     return s < 8u ? 8u : s > SAH_SMALL ? SAH_SMALL : s;            // >= 8 keeps a workgroup's active nodes within SAH_LOCAL
 }
 static size_t sah_tmp_bytes(size_t n, uint32_t flags) {
@@ -968,7 +1110,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
         !d_small || !d_counters || !d_bkeys || !d_bkeys2 || !d_ids || !d_order || !d_pos || !d_bad || !d_levels || !d_tmp2 || !d_tmp3)
         return fail(CRT_ERR_NOMEM, "sah: temporary arena too small");
     const uint32_t scene_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    const uint32_t counters_init[4] = {1u, 0u, 0u, 0u};          // node 0 is the root
+    const uint32_t counters_init[4] = {1u, 0u, 0u, 1u};          // node 0 is the root, and the first level's only work item
     LB_HIPCHK(hipEventCreate(&ev0));
     LB_HIPCHK(hipEventCreate(&ev1));
     LB_HIPCHK(hipMemcpyAsync(d_scene, scene_init, sizeof scene_init, hipMemcpyHostToDevice, stream));
@@ -988,30 +1130,41 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
         LB_HIPCHK(hipStreamSynchronize(stream));
         m = 0; n_small = 1;
     }
+    if (m > 0) LB_HIPCHK(hipMemsetAsync(d_bins, 0, cap * SAH_BIN_WORDS * 4, stream));
+    // a level's list is at most twice the previous one and never longer than n / small (an active node owns more than
+    // `small` triangles): that bound sizes the sweep's grid, and the host looks at the real count only from the level on at
+    // which a balanced tree runs out of active nodes
+    const dim3 gc((n + 256u * SAH_CHUNKS - 1u) / (256u * SAH_CHUNKS));
+    uint32_t bound = 1, sync_from = 0;
+    while (((size_t)small << sync_from) < (size_t)n) ++sync_from;
     while (m > 0) {
-        LB_HIPCHK(hipMemsetAsync(d_bins, 0, (size_t)m * SAH_BIN_WORDS * 4, stream));
-        LB_HIPCHK(hipMemsetAsync(d_counters + 1, 0, 4, stream));
-        hipLaunchKernelGGL(k_sah_cbounds, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work);
-        hipLaunchKernelGGL(k_sah_bin, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_bins);
+        hipLaunchKernelGGL(k_sah_cbounds, gc, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work);
+        hipLaunchKernelGGL(k_sah_bin, gc, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_bins);
         SahLists lists{d_counters, next, d_small};
-        hipLaunchKernelGGL(k_sah_sweep, dim3((m + 3u) / 4u), dim3(256), 0, stream, work, m, d_bins, nd, lists, small, nodes);
-        nodes += 2u * m;
+        hipLaunchKernelGGL(k_sah_sweep, dim3((bound + 3u) / 4u), dim3(256), 0, stream, work, d_bins, nd, lists, small);
+        hipLaunchKernelGGL(k_sah_advance, dim3(1), dim3(1), 0, stream, d_counters);
         hipLaunchKernelGGL(k_sah_flags, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_fl);
         LB_HIPCHK(rocprim::exclusive_scan(d_tmp3, scan_bytes, d_fl, d_scan, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
         hipLaunchKernelGGL(k_sah_scatter, gt, dim3(256), 0, stream, idx, pw, n, work, d_fl, d_scan, idx2, pw2);
-        uint32_t c[3] = {0, 0, 0};
-        LB_HIPCHK(hipMemcpyAsync(c, d_counters, 12, hipMemcpyDeviceToHost, stream));
-        LB_HIPCHK(hipStreamSynchronize(stream));
-        if (c[1] > cap || c[2] > n / 2u + 1u || nodes > n_nodes) { cleanup(); return fail(CRT_ERR_HIP, "sah: work list overflow"); }
-        m = c[1]; n_small = c[2];
         std::swap(idx, idx2); std::swap(pw, pw2); std::swap(work, next);
+        bound = (uint32_t)std::min<size_t>(2 * (size_t)bound, cap);
         if (++levels > 512u) { cleanup(); return fail(CRT_ERR_HIP, "sah: did not converge"); }
+        if (levels >= sync_from) {
+            uint32_t c[4] = {0, 0, 0, 0};
+            LB_HIPCHK(hipMemcpyAsync(c, d_counters, 16, hipMemcpyDeviceToHost, stream));
+            LB_HIPCHK(hipStreamSynchronize(stream));
+            if (c[3] > cap || c[2] > n / 2u + 1u || c[0] > n_nodes) { cleanup(); return fail(CRT_ERR_HIP, "sah: work list overflow"); }
+            nodes = c[0]; n_small = c[2]; m = c[3];
+        }
     }
     if (n_small) {
         // phase B node numbers: exclusive prefix of 2 (c - 1) over the small nodes (d_fl / d_scan are free again)
         hipLaunchKernelGGL(k_sah_small_counts, dim3((n_small + 255u) / 256u), dim3(256), 0, stream, d_small, n_small, d_fl);
         LB_HIPCHK(rocprim::exclusive_scan(d_tmp3, scan_bytes, d_fl, d_scan, 0u, (size_t)n_small, rocprim::plus<uint32_t>(), stream));
-        hipLaunchKernelGGL(k_sah_small, dim3((n_small + 63u) / 64u), dim3(64), 0, stream, d_small, n_small, idx, d_leaf_box, nd, d_scan, nodes);
+        const dim3 gs((n_small + 63u) / 64u);
+        if (small <= 8u) hipLaunchKernelGGL(k_sah_small<8>, gs, dim3(64), 0, stream, d_small, n_small, idx, d_leaf_box, nd, d_scan, nodes);
+        else if (small <= 16u) hipLaunchKernelGGL(k_sah_small<16>, gs, dim3(64), 0, stream, d_small, n_small, idx, d_leaf_box, nd, d_scan, nodes);
+        else hipLaunchKernelGGL(k_sah_small<SAH_SMALL>, gs, dim3(64), 0, stream, d_small, n_small, idx, d_leaf_box, nd, d_scan, nodes);
     }
     if (idx != d_tri_order) LB_HIPCHK(hipMemcpyAsync(d_tri_order, idx, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
     const dim3 gn((uint32_t)((n_nodes + 255) / 256));
