@@ -29,9 +29,11 @@ forwards rank 0's JSON line and exits with the children's status; launched under
 simply is one of the ranks.
 
 Prints ONE JSON line on rank 0 with the driver's keys plus "roofline" (dominant kernel = the fused segment kernel:
-algorithmic bytes of SURVEY §8d / HIP-event launch time on the kernel's own stream; the committed --pmc pass supplies the
-L2<->fabric traffic and the VALU-issue fraction, which is the real ceiling of this kernel) and "cpu_baseline" (the CPU oracle on
-the same workload, bounded sample, rank 0, N = 1).
+algorithmic bytes of SURVEY §8d / HIP-event launch time on the kernel's own stream; `traffic` (L2<->fabric bytes per launch) and
+`valu_issue` (issue slots busy x lanes enabled — the real ceiling of this kernel) come from rocprofv3 --pmc passes: at N = 1 in
+auto mode this invocation runs them itself, as child processes before its own first GPU call (`traffic_source: "live"`, ~1.5 min;
+--no-live-pmc or a missing rocprofv3 falls back to the committed passes of profiles/pmc_traffic.json, `"committed"`)) and
+"cpu_baseline" (the CPU oracle on the same workload, bounded sample, rank 0, N = 1).
 """
 import argparse
 import json
@@ -79,6 +81,9 @@ def parse_args(argv=None):
                          "material of configs[3] (oracle-defined, no reference code)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="crt_set_option passthrough (tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="auto workload at N = 1: do not run the rocprofv3 --pmc passes (roofline.traffic / valu_issue then come from the "
+                         "committed profiles/pmc_traffic.json and say so)")
     ap.add_argument("--no-extra", action="store_true", help="auto workload: only the headline block")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
@@ -220,13 +225,69 @@ class Ctx:
             self.dist.destroy_process_group()
 
 
+_LIVE_PMC = {}          # "<workload>_d<depth>" -> entry measured by live_pmc() in this run
+
+
 def pmc_entry(workload, depth):
-    """What the committed rocprofv3 --pmc passes say about this workload's dominant kernel (tools/pmc_traffic.py)."""
+    """Counter figures of this workload's dominant kernel: measured in this run when live_pmc() ran (source "live"), otherwise what
+    the committed rocprofv3 --pmc passes say (profiles/pmc_traffic.json, source "committed")."""
+    key = f"{workload}_d{depth}"
+    if key in _LIVE_PMC:
+        return dict(_LIVE_PMC[key], source="live")
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(tpath)).get(f"{workload}_d{depth}", {})
+        e = json.load(open(tpath)).get(key, {})
+        return dict(e, source="committed") if e else {}
     except Exception:
         return {}
+
+
+def live_pmc(workloads, budget_s=240.0):
+    """The hardware-counter passes of THIS run: for each (workload, depth) four `rocprofv3 --pmc <group> -- python3 bench.py
+    --workload ... --no-live-pmc` children (separate passes per counter group, as MI355X_MICROARCH.md prescribes), started
+    before this process has touched the GPU.  Counters perturb timing, so the children's own throughput is discarded; what is
+    kept is bytes and instruction counts per launch.  Any failure leaves the committed figures in place."""
+    import importlib.util
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        log("[bench] live pmc: rocprofv3 not found, using the committed passes")
+        return
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+    pt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pt)
+    t_start = time.time()
+    top = tempfile.mkdtemp(prefix="crt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for name, depth in workloads:
+            key, dirs, ok = f"{name}_d{depth}", {}, True
+            for kind, counters in pt.PASSES.items():
+                if time.time() - t_start > budget_s:
+                    ok = False
+                    log(f"[bench] live pmc: time budget used up before {key}/{kind}")
+                    break
+                d = os.path.join(top, f"pmc_{kind}_{key}")
+                cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
+                       "--workload", name, "--depth", str(depth), "--spp", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc"]
+                try:
+                    run = subprocess.run(cmd, cwd=top, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=120)
+                except subprocess.TimeoutExpired:
+                    run = None
+                if run is None or run.returncode != 0:
+                    ok = False
+                    log(f"[bench] live pmc: pass {kind} of {key} failed ({'timeout' if run is None else 'rc %d' % run.returncode}): "
+                        + ("" if run is None else run.stderr[-300:]))
+                    break
+                dirs[kind] = d
+            if ok:
+                e = pt.entry_from_dirs(dirs, key)
+                if e and "l2_fabric_bytes_per_launch" in e:
+                    _LIVE_PMC[key] = e
+                    log(f"[bench] live pmc {key}: {e['l2_fabric_bytes_per_launch']} B/launch L2<->fabric, valu_issue {e.get('valu_issue')}")
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
 
 
 def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials=None, device_built=None):
@@ -359,8 +420,11 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         roofline = {
             "bound": "hbm", "kernel": kernel_label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "traffic_is": "L2<->fabric bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the committed --pmc passes of this "
-                          "workload (profiles/pmc_traffic.json); the scene sits in the 256 MiB Infinity Cache, so true HBM bytes are lower still",
+            "traffic_source": pmc.get("source"),
+            "traffic_is": "L2<->fabric bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes of this workload ("
+                          + ("run by this bench.py invocation as child processes before its own measurements" if pmc.get("source") == "live"
+                             else "the committed ones, profiles/pmc_traffic.json")
+                          + "); the scene sits in the 256 MiB Infinity Cache, so true HBM bytes are lower still",
             "limiter": "valu_issue",
             "valu_issue": pmc.get("valu_issue"),
             "algorithmic_bytes_per_launch": int(alg),
@@ -475,6 +539,11 @@ def main():
     # communicator creation, for one) is sent to stderr instead
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    if (args.gpus == 1 and "RANK" not in os.environ and args.workload == "auto" and args.accel == "cwbvh"
+            and not (args.dry_run or args.no_live_pmc or args.option)):
+        # hardware counters of this very run, from child processes, before this process makes its first GPU call
+        live_pmc([("cornell", args.depth)] + ([] if args.no_extra else [("mesh1m", 1), ("mesh1m", 4)]))
 
     ctx = Ctx(args)
     if ctx.world != args.gpus:

@@ -24,42 +24,56 @@ def per_kernel(dirname):
     return agg
 
 
+def entry_from_dirs(dirs, wl):
+    """dirs: {"fetch" | "write" | "sq" | "grbm": directory of that --pmc pass}; wl = "<workload>_d<depth>".  None if no pass
+    saw the segment kernels."""
+    agg = {}
+    for d in dirs.values():
+        agg.update(per_kernel(d))
+    names = sorted({k for k, _ in agg if k.startswith("void crt::k_segment<") and k.split(",")[1].strip() == "false"})
+    if not names:
+        return None
+
+    def total(c):       # summed over the segment kernels (first + bounce), per launch
+        vals = [v for k in names for v in agg.get((k, c), [])]
+        return sum(vals), len(vals)
+    fetch, n_l = total("FETCH_SIZE")
+    write, n_w = total("WRITE_SIZE")
+    hit, _ = total("TCC_HIT_sum")
+    miss, _ = total("TCC_MISS_sum")
+    e = {"kernels": names, "dispatches": n_l}
+    if n_l and n_w:
+        e.update({"FETCH_SIZE_KB_per_launch": round(fetch / n_l, 1), "WRITE_SIZE_KB_per_launch": round(write / n_w, 1),
+                  "l2_fabric_bytes_per_launch": int((2 * fetch / n_l + write / n_w) * 1024),
+                  "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of the fetched bytes (MI355X_MICROARCH.md, HBM); L2<->fabric traffic, not HBM",
+                  "l2_hit_rate": round(hit / max(1.0, hit + miss), 3)})
+    act, n_sq = total("SQ_ACTIVE_INST_VALU")
+    thr, _ = total("SQ_THREAD_CYCLES_VALU")
+    insts, _ = total("SQ_INSTS_VALU")
+    waves, _ = total("SQ_WAVES")
+    gui, n_g = total("GRBM_GUI_ACTIVE")
+    if n_sq and n_g and act > 0:
+        busy = 4.0 * (act / n_sq) / (N_SIMD * (gui / n_g) / 8.0)
+        lane = thr / (64.0 * act)
+        e["valu_issue"] = {"busy": round(busy, 3), "lane_util": round(lane, 3), "frac": round(busy * lane, 3),
+                           "valu_instructions_per_wave": round(insts / max(1.0, waves), 1),
+                           "source": "rocprofv3 --pmc passes of `bench.py --workload %s --depth %s --spp 1`; formulae in tools/pmc_traffic.py"
+                                     % tuple(wl.split("_d"))}
+    return e
+
+
+# the four counter groups, one rocprofv3 pass each (MI355X_MICROARCH.md: separate --pmc passes)
+PASSES = {"fetch": ["FETCH_SIZE", "TCC_HIT_sum"], "write": ["WRITE_SIZE", "TCC_MISS_sum"],
+          "sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"],
+          "grbm": ["GRBM_GUI_ACTIVE", "GRBM_TA_BUSY"]}
+
+
 def main(round_dir, out):
     res = {}
     for wl in ("cornell_d1", "mesh1m_d1", "mesh1m_d4"):
-        agg = {}
-        for kind in ("fetch", "write", "sq", "grbm"):
-            agg.update(per_kernel(os.path.join(round_dir, f"pmc_{kind}_{wl}")))
-        names = sorted({k for k, _ in agg if k.startswith("void crt::k_segment<") and k.split(",")[1].strip() == "false"})
-        if not names:
-            continue
-
-        def total(c):       # summed over the segment kernels (first + bounce), per launch
-            vals = [v for k in names for v in agg.get((k, c), [])]
-            return sum(vals), len(vals)
-        fetch, n_l = total("FETCH_SIZE")
-        write, _ = total("WRITE_SIZE")
-        hit, _ = total("TCC_HIT_sum")
-        miss, _ = total("TCC_MISS_sum")
-        e = {"kernels": names, "dispatches": n_l}
-        if n_l:
-            e.update({"FETCH_SIZE_KB_per_launch": round(fetch / n_l, 1), "WRITE_SIZE_KB_per_launch": round(write / n_l, 1),
-                      "l2_fabric_bytes_per_launch": int((2 * fetch + write) * 1024 / n_l),
-                      "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of the fetched bytes (MI355X_MICROARCH.md, HBM); L2<->fabric traffic, not HBM",
-                      "l2_hit_rate": round(hit / max(1.0, hit + miss), 3)})
-        act, n_sq = total("SQ_ACTIVE_INST_VALU")
-        thr, _ = total("SQ_THREAD_CYCLES_VALU")
-        insts, _ = total("SQ_INSTS_VALU")
-        waves, _ = total("SQ_WAVES")
-        gui, n_g = total("GRBM_GUI_ACTIVE")
-        if n_sq and n_g and act > 0:
-            busy = 4.0 * (act / n_sq) / (N_SIMD * (gui / n_g) / 8.0)
-            lane = thr / (64.0 * act)
-            e["valu_issue"] = {"busy": round(busy, 3), "lane_util": round(lane, 3), "frac": round(busy * lane, 3),
-                               "valu_instructions_per_wave": round(insts / max(1.0, waves), 1),
-                               "source": "rocprofv3 --pmc passes of `bench.py --workload %s --depth %s --spp 1` (tools/profile_round.sh); formulae in tools/pmc_traffic.py"
-                                         % tuple(wl.split("_d"))}
-        res[wl] = e
+        e = entry_from_dirs({kind: os.path.join(round_dir, f"pmc_{kind}_{wl}") for kind in PASSES}, wl)
+        if e:
+            res[wl] = e
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
