@@ -272,14 +272,14 @@ def live_pmc(workloads, budget_s=240.0):
                 cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
                        "--workload", name, "--depth", str(depth), "--spp", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc"]
                 try:
-                    run = subprocess.run(cmd, cwd=top, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=120)
+                    run = subprocess.run(cmd, cwd=top, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=90)
                 except subprocess.TimeoutExpired:
                     run = None
                 if run is None or run.returncode != 0:
                     ok = False
-                    log(f"[bench] live pmc: pass {kind} of {key} failed ({'timeout' if run is None else 'rc %d' % run.returncode}): "
-                        + ("" if run is None else run.stderr[-300:]))
-                    break
+                    log(f"[bench] live pmc: pass {kind} of {key} failed ({'timeout' if run is None else 'rc %d' % run.returncode}), "
+                        "no further passes: " + ("" if run is None else run.stderr[-300:]))
+                    return                                           # counters do not work here: do not spend minutes finding out twice
                 dirs[kind] = d
             if ok:
                 e = pt.entry_from_dirs(dirs, key)
