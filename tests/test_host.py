@@ -23,6 +23,37 @@ def test_host_rng_known_answers(cr, ob, survey):
         assert cr.pcg_hash(x) == ob.lib().orc_pcg_hash(x)
 
 
+def test_host_rng_equals_the_references_own_rnd_h(cr, ob):
+    """tests/golden/ref_rnd.json was produced by the reference's Caitlyn/Rnd.h itself, compiled where it lies
+    (oracle/_ref/librndref.so, tests/golden/make_ref_rnd_fixture.py): the product's crt_randf2 / crt_pcg_hash and the oracle's
+    restatement must give the same bits and states; where the library exists (build container) the fixture is re-derived live."""
+    import ctypes as C
+    import struct
+    ref = json.load(open(os.path.join(GOLDEN, "ref_rnd.json")))
+    assert len(ref["sequences"]["1"]) == 256
+    for start, seq in ref["sequences"].items():
+        r = cr.Rnd(int(start))
+        o_state = C.c_uint32(int(start))
+        for want_bits, want_state in seq:
+            got = r.randf2()
+            assert struct.unpack("<I", struct.pack("<f", got))[0] == want_bits and r.state.value == want_state, (start, want_state)
+            og = ob.lib().orc_randf2(C.byref(o_state))
+            assert struct.unpack("<I", struct.pack("<f", og))[0] == want_bits and o_state.value == want_state
+    for x, h in ref["pcg_hash"].items():
+        assert cr.pcg_hash(int(x)) == h and ob.lib().orc_pcg_hash(int(x)) == h
+    from oracle import rndref
+    if rndref.available():
+        L = rndref.lib()
+        for start, seq in ref["sequences"].items():
+            L.ref_rnd_set_state(int(start))
+            for want_bits, want_state in seq:
+                v = L.ref_randf2()
+                assert struct.unpack("<I", struct.pack("<f", v))[0] == want_bits and L.ref_rnd_state() == want_state
+        rng = np.random.default_rng(4)
+        for x in rng.integers(0, 2 ** 32, 2000, dtype=np.uint64):
+            assert cr.pcg_hash(int(x)) == L.ref_pcg_hash(int(x))
+
+
 def test_camera_matches_reference_construction(cr, survey):
     cam = cr.Camera((-2.755610, 2.745992, 7.58545), (-2.755610, 2.745992, 6.58545), 40.0)   # Scene.h:468
     ka = survey["cornell_load"]
