@@ -108,6 +108,44 @@ def seeded_rays(mesh, n, seed, dt):
     return rays
 
 
+def numpy_brute_force(mesh, rays):
+    """A third, independent implementation of the hit definition (no BVH, no C): Moeller-Trumbore over ALL triangles per ray in
+    float32 numpy, same operation order as path_trace.fs:322-374 ((x*x + y*y) + z*z dots, no fused multiply-adds), nearest t,
+    ties to the lowest triangle id.  Returns (tri, t, u, v); tri = -1 for a miss."""
+    f = np.float32
+    V = mesh.vertices.astype(np.float32)
+    T = mesh.triangles[:, :3].astype(np.int64)
+    v0 = V[T[:, 0]]
+    e1 = (V[T[:, 1]] - v0).astype(f)
+    e2 = (V[T[:, 2]] - v0).astype(f)
+
+    def dot(a, b):
+        return ((a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]).astype(f) + a[..., 2] * b[..., 2]).astype(f)
+
+    def cross(a, b):
+        return np.stack([(a[..., 1] * b[..., 2]).astype(f) - (a[..., 2] * b[..., 1]).astype(f),
+                         (a[..., 2] * b[..., 0]).astype(f) - (a[..., 0] * b[..., 2]).astype(f),
+                         (a[..., 0] * b[..., 1]).astype(f) - (a[..., 1] * b[..., 0]).astype(f)], -1).astype(f)
+    n = rays.shape[0]
+    tri = np.full(n, -1, np.int32)
+    tt, uu, vv = np.zeros(n, f), np.zeros(n, f), np.zeros(n, f)
+    with np.errstate(all="ignore"):
+        for i in range(n):
+            o, d = rays["o"][i].astype(f), rays["d"][i].astype(f)
+            pv = cross(np.broadcast_to(d, e2.shape), e2)
+            tv = (o - v0).astype(f)
+            qv = cross(tv, e1)
+            u, v, t = dot(tv, pv), dot(np.broadcast_to(d, qv.shape), qv), dot(e2, qv)
+            inv = (f(1.0) / dot(e1, pv)).astype(f)
+            u, v, t = (u * inv).astype(f), (v * inv).astype(f), (t * inv).astype(f)
+            w = ((f(1.0) - u).astype(f) - v).astype(f)
+            ok = (u >= 0) & (v >= 0) & (t >= 0) & (w >= 0) & (t < rays["tmax"][i])
+            if ok.any():
+                k = int(np.argmin(np.where(ok, t, np.inf)))              # first index of the minimum = lowest id among equal t
+                tri[i], tt[i], uu[i], vv[i] = k, t[k], u[k], v[k]
+    return tri, tt, uu, vv
+
+
 def have_reference():
     return os.path.isdir(os.path.join(REFERENCE, "Models"))
 

@@ -63,6 +63,25 @@ def test_any_hit_bit_exact(cr, ob, cornell, tess8, tess40, scenes, name):
     assert np.array_equal(got["tri"] >= 0, (c["tri"] >= 0) & (c["t"] < rays["tmax"]))
 
 
+@pytest.mark.parametrize("name,n", [("tess8", 3000), ("tess40", 400)])
+def test_hip_walk_equals_a_numpy_brute_force_that_shares_no_code_with_the_oracle(cr, tess8, tess40, scenes, name, n):
+    """The HIP CWBVH walk against a third implementation (vectorised numpy over all triangles, tests/conftest.py): (id, t, u, v)
+    bit for bit, and occlusion consistent with it.  The oracle is not involved."""
+    from conftest import numpy_brute_force
+    scene, _, _ = scenes[name]
+    mesh = {"tess8": tess8[0], "tess40": tess40[0]}[name]
+    rays = seeded_rays(mesh, n, 29, cr.RAY_DT)
+    rays["tmax"][::5] = np.float32(2.5)
+    tri, t, u, v = numpy_brute_force(mesh, rays)
+    got = scene.trace(rays, cr.CRT_TRACE_CLOSEST)
+    hit = tri >= 0
+    assert hit.sum() > n // 2 and np.array_equal(got["tri"], tri)
+    for a, b in ((got["t"], t), (got["u"], u), (got["v"], v)):
+        assert np.array_equal(a[hit].view(np.uint32), b[hit].view(np.uint32))
+    occ = scene.trace(rays, cr.CRT_TRACE_ANY)["tri"] >= 0
+    assert np.array_equal(occ, hit)
+
+
 def test_edge_cases(cr, ob, scenes, cornell):
     scene, orc, _ = scenes["cornell"]
     assert len(scene.trace(np.zeros(0, cr.RAY_DT))) == 0                      # empty input

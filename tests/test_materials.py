@@ -158,3 +158,53 @@ def test_furnace_nee_plus_bsdf_sampling_sum_to_the_directional_albedo(cr, ob, tm
     want = (fs * Wd[:, 2:3]).mean(0) * 2 * np.pi
     np.testing.assert_allclose(got, want, rtol=0.04)
     assert (got < 1.0).all()
+
+
+def test_lambert_estimator_converges_to_the_quadrature_of_its_own_formula(cr, ob, tmp_path):
+    """An independent check of the radiance the reference's integrator (path_trace.fs:857-1024, restated in oracle.c and in
+    k_segment) produces — a different method, not a second copy of the walker: a Lambert patch (albedo rho) in the middle of
+    a cube whose six walls emit 1, two path segments.  The expectation of what the shader adds up is, per unit solid angle of
+    the patch's hemisphere,
+        rho * [ 2 w_l + (cos/pi) w_b ],   w_l = p_l^2 / (p_l^2 + p_b^2),  w_b = 1 - w_l,  p_b = cos/pi,
+        p_l = r^2 / (cos_wall * sum|u x v|)       (the shader's light pdf, Scene.h:865-913: |u x v| is twice a triangle's area)
+    — the NEE sample is uniform on the light (true density r^2 / (cos_wall * A_total)) but divided by p_l, hence the 2, and
+    its contribution carries no cos/pi (path_trace.fs:950-960) — integrated here by quadrature over the cube seen from the
+    patch.  The Monte-Carlo average of the oracle's frames (RNG, light choice, triangle sampling, visibility, both MIS
+    weights, cosine sampling) must converge to it."""
+    rho = (0.75, 0.5, 0.25)
+    c = [(-4, -4, -4), (4, -4, -4), (4, 4, -4), (-4, 4, -4), (-4, -4, 4), (4, -4, 4), (4, 4, 4), (-4, 4, 4)]
+    walls = [[c[0], c[1], c[2], c[3]], [c[5], c[4], c[7], c[6]], [c[4], c[0], c[3], c[7]],
+             [c[1], c[5], c[6], c[2]], [c[4], c[5], c[1], c[0]], [c[3], c[2], c[6], c[7]]]      # all normals point inwards
+    quads = [("W", wq) for wq in walls] + [("D", [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)])]     # patch, normal +z
+    mtl = f"newmtl W\nKd 0 0 0\nKe 1 1 1\nnewmtl D\nKd {rho[0]} {rho[1]} {rho[2]}\nKe 0 0 0\n"
+    path = _write_scene(tmp_path, mtl, quads)
+    cam_pos = np.array([1.0, 0.5, 2.5])
+    cam = cr.Camera(tuple(cam_pos), (0.0, 0.0, 0.0), 6.0)
+    data = cr.SceneData.from_obj(path, cam)
+    W = H = 16
+    orc = ob.Oracle(data, W, H, 2, cam)
+    rnd = cr.Rnd()
+    acc = np.zeros((H, W, 3), np.float32)
+    frames = 1500
+    for _ in range(frames):
+        orc.render_frame(rnd.randf2(), rnd.randf2(), acc, threads=8)
+    got = acc[4:12, 4:12].reshape(-1, 3).astype(np.float64).mean(0) / frames
+    # quadrature over the hemisphere above the patch centre: distance and wall cosine of the cube [-4, 4]^3 per direction
+    n_dir = 1_000_000
+    g = np.random.default_rng(1)
+    z = (np.arange(n_dir) + g.random(n_dir)) / n_dir                       # stratified in cos(theta): uniform solid angle
+    phi = 2 * np.pi * g.random(n_dir)
+    s = np.sqrt(1 - z * z)
+    w = np.stack([s * np.cos(phi), s * np.sin(phi), z], 1)
+    t = 4.0 / np.maximum(np.abs(w), 1e-12)                                  # distance to the three facing planes
+    k = np.argmin(t, axis=1)
+    r = t[np.arange(n_dir), k]
+    cos_wall = np.abs(w[np.arange(n_dir), k])
+    p_l = r * r / (cos_wall * 12 * 64.0)
+    p_b = z / np.pi
+    w_l = p_l ** 2 / (p_l ** 2 + p_b ** 2)
+    integrand = 2.0 * w_l + p_b * (1.0 - w_l)
+    want = np.array(rho) * integrand.mean() * 2 * np.pi
+    np.testing.assert_allclose(got, want, rtol=0.02)
+    # per unit albedo about 3, not 1: the NEE term has no cos/pi and counts double — the reference's image, reproduced as it is
+    assert 2.5 < got[0] / rho[0] < 3.5 and np.allclose(got / np.array(rho), got[0] / rho[0], rtol=0.02)

@@ -86,6 +86,25 @@ def test_brute_force_bvh2_cwbvh_agree(ob, cornell, cornell_data, tess8, scene):
     assert np.array_equal(ab, (hb["tri"] >= 0) & (hb["t"] < 1.5))
 
 
+@pytest.mark.parametrize("scene,n", [("tess8", 1500), ("tess40", 250)])
+def test_numpy_brute_force_agrees_with_all_three_walks(ob, cornell, tess8, tess40, scene, n):
+    """Breaks the symmetry between oracle.c and the HIP kernel with a third implementation that shares no code with either:
+    vectorised numpy over all triangles (tests/conftest.py numpy_brute_force).  Bit-equal (id, t, u, v)."""
+    from conftest import numpy_brute_force
+    mesh, data = tess8 if scene == "tess8" else tess40
+    o = ob.Oracle(data, 64, 64, 3, cornell[1])
+    rays = seeded_rays(mesh, n, 23, ob.RAY_DT)
+    rays["tmax"][::7] = np.float32(2.0)                                    # some rays with a finite reach
+    tri, t, u, v = numpy_brute_force(mesh, rays)
+    assert (tri >= 0).sum() > n // 2 and (tri < 0).sum() > 0
+    for accel in (ob.BRUTE, ob.BVH2, ob.BVH8):
+        h = o.trace(rays, accel, ob.CLOSEST, ob.TIE_LOWEST_ID, threads=4)
+        assert np.array_equal(h["tri"], tri), accel
+        hit = tri >= 0
+        for a, b in ((h["t"], t), (h["u"], u), (h["v"], v)):
+            assert np.array_equal(a[hit].view(np.uint32), b[hit].view(np.uint32)), accel
+
+
 def test_duplicate_references_report_original_ids(ob, tess8, cornell):
     mesh, data = tess8
     o = ob.Oracle(data, 64, 64, 3, cornell[1])
