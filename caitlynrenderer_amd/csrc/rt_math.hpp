@@ -33,42 +33,54 @@ __device__ __forceinline__ vec3 normalize(vec3 a) {
 __device__ __forceinline__ float rcp_ieee(float x) { return __fdiv_rn(1.0f, x); }
 
 // ---- pinned sin/cos: Cody-Waite by pi in double, Taylor polynomial, one rounding to float.
-// Same constants and the same sequence of +,-,* as oracle/oracle.c orc_sin / orc_cos.  (Written as fused multiply-adds —
-// 18 instead of 32 half-rate double-precision instructions per call, same float results on every fixture — it was 8 % SLOWER
-// on the 1 M-triangle frame: hipcc turns the chain into v_fmac_f64 with the coefficients parked in VGPR pairs, and the
-// kernel, already at its 96-register budget, spills 144 bytes per lane; the mul + add form takes them as SGPR operands.)
+// Same constants and the same sequence of operations as oracle/oracle.c orc_sin / orc_cos: three fused multiply-adds for the
+// reduction, the two highest coefficients by a plain multiply and add, the rest of the Horner chain fused — 19 half-rate
+// double-precision instructions per call instead of the 32 of the all mul + add form this replaced (+1.7 % on the Cornell
+// frame, +0.5 .. 0.8 % on the 1 M-triangle frames, same floats on every fixture).  The fused form only pays with the
+// coefficients as SGPR operands: left to itself hipcc emits v_fmac_f64 with every coefficient parked in a VGPR pair, and the
+// kernel, at its 96-register budget, spilled 144 bytes per lane and ran 8 % SLOWER (profiles/r02_experiments.md §3).
+// a * b + c as ONE v_fma_f64 whose constant operand sits in an SGPR pair (a VOP3 instruction may read one): written as inline
+// assembly because hipcc, left to itself, picks v_fmac_f64 and parks every coefficient in a VGPR pair
+__device__ __forceinline__ double fma_add_const(double a, double b, double c) {      // c: compile-time constant
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double fma_mul_const(double a, double m, double c) {      // m: compile-time constant
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(c));
+    return r;
+}
 __device__ __forceinline__ double reduce_pi(double x, double& k) {
     k = __builtin_rint(x * 0x1.45f306dc9c883p-2);
-    return ((x - k * 0x1.921fb544p+1) - k * 0x1.0b4611a6p-33) - k * 0x1.3198a2ep-68;
+    return fma_mul_const(k, -0x1.3198a2ep-68, fma_mul_const(k, -0x1.0b4611a6p-33, fma_mul_const(k, -0x1.921fb544p+1, x)));
 }
 __device__ __forceinline__ double sin_poly(double r) {
     double z = r * r;
-    double p = 1.0 / 51090942171709440000.0;
-    p = p * z + (-1.0 / 121645100408832000.0);
-    p = p * z + (1.0 / 355687428096000.0);
-    p = p * z + (-1.0 / 1307674368000.0);
-    p = p * z + (1.0 / 6227020800.0);
-    p = p * z + (-1.0 / 39916800.0);
-    p = p * z + (1.0 / 362880.0);
-    p = p * z + (-1.0 / 5040.0);
-    p = p * z + (1.0 / 120.0);
-    p = p * z + (-1.0 / 6.0);
-    return r + (r * z) * p;
+    double p = z * (1.0 / 51090942171709440000.0) + (-1.0 / 121645100408832000.0);   // mul, add: no coefficient ever sits in a VGPR
+    p = fma_add_const(p, z, 1.0 / 355687428096000.0);
+    p = fma_add_const(p, z, -1.0 / 1307674368000.0);
+    p = fma_add_const(p, z, 1.0 / 6227020800.0);
+    p = fma_add_const(p, z, -1.0 / 39916800.0);
+    p = fma_add_const(p, z, 1.0 / 362880.0);
+    p = fma_add_const(p, z, -1.0 / 5040.0);
+    p = fma_add_const(p, z, 1.0 / 120.0);
+    p = fma_add_const(p, z, -1.0 / 6.0);
+    return __builtin_fma(r * z, p, r);
 }
 __device__ __forceinline__ double cos_poly(double r) {
     double z = r * r;
-    double p = 1.0 / 1124000727777607680000.0;
-    p = p * z + (-1.0 / 2432902008176640000.0);
-    p = p * z + (1.0 / 6402373705728000.0);
-    p = p * z + (-1.0 / 20922789888000.0);
-    p = p * z + (1.0 / 87178291200.0);
-    p = p * z + (-1.0 / 479001600.0);
-    p = p * z + (1.0 / 3628800.0);
-    p = p * z + (-1.0 / 40320.0);
-    p = p * z + (1.0 / 720.0);
-    p = p * z + (-1.0 / 24.0);
-    p = p * z + 0.5;
-    return 1.0 - z * p;
+    double p = z * (1.0 / 1124000727777607680000.0) + (-1.0 / 2432902008176640000.0);
+    p = fma_add_const(p, z, 1.0 / 6402373705728000.0);
+    p = fma_add_const(p, z, -1.0 / 20922789888000.0);
+    p = fma_add_const(p, z, 1.0 / 87178291200.0);
+    p = fma_add_const(p, z, -1.0 / 479001600.0);
+    p = fma_add_const(p, z, 1.0 / 3628800.0);
+    p = fma_add_const(p, z, -1.0 / 40320.0);
+    p = fma_add_const(p, z, 1.0 / 720.0);
+    p = fma_add_const(p, z, -1.0 / 24.0);
+    p = fma_add_const(p, z, 0.5);
+    return __builtin_fma(-z, p, 1.0);
 }
 __device__ __forceinline__ float pinned_sin(float xf) {
     double x = (double)xf;

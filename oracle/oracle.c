@@ -35,7 +35,7 @@
  *     IEEE correctly rounded operations;
  *   - min/max = fminf/fmaxf (IEEE minNum/maxNum: a NaN operand is ignored), which is also
  *     what v_min_f32/v_max_f32 do on gfx950;
- *   - sin/cos are evaluated in double by a fixed sequence of +,-,* (orc_sin/orc_cos) and
+ *   - sin/cos are evaluated in double by a fixed sequence of *, + and fused multiply-adds (orc_sin/orc_cos) and
  *     rounded once to float; tan(fov/2) is computed once per frame on the host with tanf.
  */
 #include "oracle.h"
@@ -74,42 +74,51 @@ static inline v3 norm3(v3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return scl(
 static const double PI_1 = 0x1.921fb544p+1, PI_2 = 0x1.0b4611a6p-33, PI_3 = 0x1.3198a2ep-68;
 static const double INV_PI = 0x1.45f306dc9c883p-2;
 
-static inline double reduce_pi(double x, double* k_out) {
+/* The sequence below is the definition shared with csrc/rt_math.hpp: Cody-Waite reduction by pi with three fused
+ * multiply-adds, the two highest Taylor coefficients combined by a plain multiply and add, the rest of the Horner chain and the
+ * final r + (r z) p / 1 - z p as fused multiply-adds (on the GPU: v_fma_f64 with the coefficient in an SGPR pair, 19 instead of
+ * 32 half-rate instructions per call).  fma() is exactly defined by IEEE 754, so the clone that uses the FMA unit and the one
+ * that calls libm's software fma give the same bits; target_clones picks at load time. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define ORC_FMA_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define ORC_FMA_CLONES
+#endif
+#define ORC_INLINE static inline __attribute__((always_inline))
+ORC_INLINE double reduce_pi(double x, double* k_out) {
     double k = rint(x * INV_PI);
-    double r = ((x - k * PI_1) - k * PI_2) - k * PI_3;
+    double r = __builtin_fma(k, -PI_3, __builtin_fma(k, -PI_2, __builtin_fma(k, -PI_1, x)));
     *k_out = k;
     return r;
 }
-static inline double sin_poly(double r) {
+ORC_INLINE double sin_poly(double r) {
     double z = r * r;
-    double p = 1.0 / 51090942171709440000.0;          /*  1/21! */
-    p = p * z + (-1.0 / 121645100408832000.0);        /* -1/19! */
-    p = p * z + (1.0 / 355687428096000.0);            /*  1/17! */
-    p = p * z + (-1.0 / 1307674368000.0);             /* -1/15! */
-    p = p * z + (1.0 / 6227020800.0);                 /*  1/13! */
-    p = p * z + (-1.0 / 39916800.0);                  /* -1/11! */
-    p = p * z + (1.0 / 362880.0);                     /*  1/9!  */
-    p = p * z + (-1.0 / 5040.0);                      /* -1/7!  */
-    p = p * z + (1.0 / 120.0);                        /*  1/5!  */
-    p = p * z + (-1.0 / 6.0);                         /* -1/3!  */
-    return r + (r * z) * p;
+    double p = z * (1.0 / 51090942171709440000.0) + (-1.0 / 121645100408832000.0);   /*  1/21!, -1/19! */
+    p = __builtin_fma(p, z, 1.0 / 355687428096000.0);            /*  1/17! */
+    p = __builtin_fma(p, z, -1.0 / 1307674368000.0);             /* -1/15! */
+    p = __builtin_fma(p, z, 1.0 / 6227020800.0);                 /*  1/13! */
+    p = __builtin_fma(p, z, -1.0 / 39916800.0);                  /* -1/11! */
+    p = __builtin_fma(p, z, 1.0 / 362880.0);                     /*  1/9!  */
+    p = __builtin_fma(p, z, -1.0 / 5040.0);                      /* -1/7!  */
+    p = __builtin_fma(p, z, 1.0 / 120.0);                        /*  1/5!  */
+    p = __builtin_fma(p, z, -1.0 / 6.0);                         /* -1/3!  */
+    return __builtin_fma(r * z, p, r);
 }
-static inline double cos_poly(double r) {
+ORC_INLINE double cos_poly(double r) {
     double z = r * r;
-    double p = 1.0 / 1124000727777607680000.0;        /*  1/22! */
-    p = p * z + (-1.0 / 2432902008176640000.0);       /* -1/20! */
-    p = p * z + (1.0 / 6402373705728000.0);           /*  1/18! */
-    p = p * z + (-1.0 / 20922789888000.0);            /* -1/16! */
-    p = p * z + (1.0 / 87178291200.0);                /*  1/14! */
-    p = p * z + (-1.0 / 479001600.0);                 /* -1/12! */
-    p = p * z + (1.0 / 3628800.0);                    /*  1/10! */
-    p = p * z + (-1.0 / 40320.0);                     /* -1/8!  */
-    p = p * z + (1.0 / 720.0);                        /*  1/6!  */
-    p = p * z + (-1.0 / 24.0);                        /* -1/4!  */
-    p = p * z + 0.5;                                  /*  1/2!  */
-    return 1.0 - z * p;
+    double p = z * (1.0 / 1124000727777607680000.0) + (-1.0 / 2432902008176640000.0);   /*  1/22!, -1/20! */
+    p = __builtin_fma(p, z, 1.0 / 6402373705728000.0);           /*  1/18! */
+    p = __builtin_fma(p, z, -1.0 / 20922789888000.0);            /* -1/16! */
+    p = __builtin_fma(p, z, 1.0 / 87178291200.0);                /*  1/14! */
+    p = __builtin_fma(p, z, -1.0 / 479001600.0);                 /* -1/12! */
+    p = __builtin_fma(p, z, 1.0 / 3628800.0);                    /*  1/10! */
+    p = __builtin_fma(p, z, -1.0 / 40320.0);                     /* -1/8!  */
+    p = __builtin_fma(p, z, 1.0 / 720.0);                        /*  1/6!  */
+    p = __builtin_fma(p, z, -1.0 / 24.0);                        /* -1/4!  */
+    p = __builtin_fma(p, z, 0.5);                                /*  1/2!  */
+    return __builtin_fma(-z, p, 1.0);
 }
-float orc_sin(float xf) {
+ORC_FMA_CLONES float orc_sin(float xf) {
     double x = (double)xf;
     if (!(fabs(x) < 1e9)) return 0.0f;                /* outside the domain the shaders reach */
     double k, r = reduce_pi(x, &k);
@@ -117,7 +126,7 @@ float orc_sin(float xf) {
     if (((long long)k) & 1) s = -s;
     return (float)s;
 }
-float orc_cos(float xf) {
+ORC_FMA_CLONES float orc_cos(float xf) {
     double x = (double)xf;
     if (!(fabs(x) < 1e9)) return 1.0f;
     double k, r = reduce_pi(x, &k);
