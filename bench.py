@@ -415,7 +415,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             kernel_label = "k_segment (raygen / queue fetch + CWBVH closest hit + shading + in-place NEE any-hit walk), mean per path segment"
         else:
             kernel_label = "k_segment (raygen / queue fetch + CWBVH closest hit + shading + queue emission), mean per path segment"
-        pmc = pmc_entry(name, depth)
+        # the counter passes run the host-built tree, Lambert, 1920x1080: other blocks carry no counter figures of their own
+        pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and not device_built and materials in (None, "lambert")) else {}
         traffic = pmc.get("l2_fabric_bytes_per_launch", pmc.get("hbm_bytes_per_launch"))
         roofline = {
             "bound": "hbm", "kernel": kernel_label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
