@@ -28,10 +28,11 @@ int parse_corners(const char* t, std::vector<Corner>& out, bool& double_slash) {
         int vals[3] = {0, 0, 0};
         int n = 0;
         for (;;) {
-            int sign = 1, acc = 0;
+            int sign = 1;
+            long long acc = 0;
             if (*t == '-') { sign = -1; ++t; }
-            while (*t >= '0' && *t <= '9') acc = 10 * acc + (*t++ - '0');
-            if (n < 3) vals[n] = sign * acc;
+            while (*t >= '0' && *t <= '9') { acc = 10 * acc + (*t++ - '0'); if (acc > 0x7fffffffLL) acc = 0x7fffffffLL; }   // saturates: out of range either way
+            if (n < 3) vals[n] = sign * (int)acc;
             ++n;
             if (*t != '/') break;
             ++t;
