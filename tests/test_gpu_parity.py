@@ -894,8 +894,8 @@ def test_device_cwbvh_conversion_edge_cases_and_errors(cr, cornell):
 
 
 def test_textured_scene_from_obj_mtl_and_image_files(cr, ob, textured, tmp_path):
-    """SURVEY 8f-4 end to end: OBJ + MTL with map_Kd textures (PNG and RLE TGA files) -> loader (decode, the reference's
-    256x256 resize) -> the Python path, the C++ crt::Scene path and the oracle agree on the running sum."""
+    """SURVEY 8f-4 end to end: OBJ + MTL with map_Kd textures (PNG, RLE TGA and progressive JPEG files) -> loader (decode, the
+    reference's 256x256 resize) -> the Python path, the C++ crt::Scene path and the oracle agree on the running sum."""
     import os
     import subprocess
     from conftest import ROOT, write_obj
@@ -907,12 +907,15 @@ def test_textured_scene_from_obj_mtl_and_image_files(cr, ob, textured, tmp_path)
     noise = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
     open(tmp_path / "checker.png", "wb").write(T.write_png(checker))
     open(tmp_path / "noise.tga", "wb").write(T.write_tga(noise, rle=True, top_down=True))
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "stb_decodes.npz"))     # a JPEG and what the reference's stb_image makes of it
+    open(tmp_path / "photo.jpg", "wb").write(golden["jpeg_progressive_420_q80__file"].tobytes())
     obj = str(tmp_path / "textured.obj")
-    write_obj(mesh, obj, map_kd={2: "noise.tga", 3: "checker.png"})
+    write_obj(mesh, obj, map_kd={2: "noise.tga", 3: "checker.png", 4: "photo.jpg"})
     cam = cr.Camera((-2.755610, 2.745992, 7.58545), (-2.755610, 2.745992, 6.58545), 40.0)   # Scene.h:468
     data = cr.SceneData.from_obj(obj, cam)
-    assert data.albedo_textures.shape == (2, 256, 256, 3) and np.array_equal(data.albedo_textures[0], noise)
+    assert data.albedo_textures.shape == (3, 256, 256, 3) and np.array_equal(data.albedo_textures[0], noise)
     assert np.array_equal(data.albedo_textures[1], T.texture_to_array_bytes(checker))
+    assert np.array_equal(data.albedo_textures[2], T.texture_to_array_bytes(golden["jpeg_progressive_420_q80__rgb"]))
     W, H, frames, depth = 200, 120, 3, 3
     orc = ob.Oracle(data, W, H, depth, cam)
     scene = cr.Scene(data, W, H, depth)
