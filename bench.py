@@ -261,7 +261,7 @@ def live_pmc(workloads, budget_s=240.0):
     top = tempfile.mkdtemp(prefix="crt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for name, depth in workloads:
+        for name, depth, spp in workloads:
             key, dirs, ok = f"{name}_d{depth}", {}, True
             for kind, counters in pt.PASSES.items():
                 if time.time() - t_start > budget_s:
@@ -270,7 +270,7 @@ def live_pmc(workloads, budget_s=240.0):
                     break
                 d = os.path.join(top, f"pmc_{kind}_{key}")
                 cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
-                       "--workload", name, "--depth", str(depth), "--spp", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc"]
+                       "--workload", name, "--depth", str(depth), "--spp", str(spp), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc"]
                 try:
                     run = subprocess.run(cmd, cwd=top, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=90)
                 except subprocess.TimeoutExpired:
@@ -284,6 +284,7 @@ def live_pmc(workloads, budget_s=240.0):
             if ok:
                 e = pt.entry_from_dirs(dirs, key)
                 if e and "l2_fabric_bytes_per_launch" in e:
+                    e["samples_per_launch"] = spp if depth == 1 else 1        # what one launch of the pass rendered (crt_render_frames)
                     _LIVE_PMC[key] = e
                     log(f"[bench] live pmc {key}: {e['l2_fabric_bytes_per_launch']} B/launch L2<->fabric, valu_issue {e.get('valu_issue')}")
     finally:
@@ -355,8 +356,17 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             scene.copy_packed_device(gather_buf.data_ptr(), n_floats)
             tiles.gather_packed_to_root(gather_buf, recv, world)
 
-        for i in range(Wu * spp):
-            scene.render_frame(*rvs[1 + i], sync=False)
+        def step(k):
+            """one step = spp samples per pixel; crt_render_frames shares launches among them where the path allows
+            (one segment, shadow rays in place: up to 8 samples per launch), with the same sums bit for bit"""
+            part = rvs[1 + k * spp:1 + (k + 1) * spp]
+            if spp > 1:
+                scene.render_frames(part, sync=False)
+            else:
+                scene.render_frame(*part[0], sync=False)
+
+        for k in range(Wu):
+            step(k)
         scene.sync()
         if use_dist:    # warm the collective too
             read_back()
@@ -370,8 +380,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         torch.cuda.synchronize(); scene.sync()
     if takes_part:
         t0 = time.perf_counter()
-        for i in range(K * spp):
-            scene.render_frame(*rvs[1 + Wu * spp + i], sync=False)
+        for k in range(K):
+            step(Wu + k)
         scene.sync()
         if use_dist:
             read_back()
@@ -389,6 +399,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         st = scene.frame_stats()
         launch_ms_timed = st["ms_trace_closest"] / max(1, st["n_trace_launches"])
         n_timed_launches = st["n_trace_launches"]
+        # samples per pixel one launch rendered: 1, or the step's spp where crt_render_frames batched them
+        samples_per_launch = max(1, round(K * spp * max(1, depth) / max(1, n_timed_launches)))
         scene.set_option("timing_accumulate", 0)
         scene.set_option("timing", 2)
         any_ms, total_ms = [], []
@@ -397,18 +409,18 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             s = scene.frame_stats()
             any_ms.append(s["ms_trace_any"] / max(1, depth))
             total_ms.append(s["ms_total"])
-        rays_frame = st["closest_rays"] + st["any_rays"]
+        rays_frame = (st["closest_rays"] + st["any_rays"]) / samples_per_launch      # the stats describe the last launch
         rays_all = ctx.sum_over_ranks(rays_frame) if sharded else float(rays_frame)
         value = rays_all * K * spp / dt / 1e6
 
     if takes_part and ctx.rank == 0:
         launches = max(1, depth)
         node_bytes = 96 if args.accel == "bvh2" else NODE_BYTES      # own 2 texels + 4 child texels per BVH2 visit
-        alg = (node_bytes * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches
+        alg = (node_bytes * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches * samples_per_launch
         # the segment kernel also walks the NEE shadow rays in place (no k_shadow launch): their visits are this launch's bytes too
         fused_shadow = st["any_rays"] > 0 and float(np.median(any_ms)) == 0.0
         if fused_shadow:
-            alg += (node_bytes * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches
+            alg += (node_bytes * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches * samples_per_launch
         t_launch = launch_ms_timed * 1e-3
         achieved = alg / t_launch / 1e9 if t_launch > 0 else 0.0
         if fused_shadow:
@@ -418,6 +430,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         # the counter passes run the host-built tree, Lambert, 1920x1080: other blocks carry no counter figures of their own
         pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and not device_built and materials in (None, "lambert")) else {}
         traffic = pmc.get("l2_fabric_bytes_per_launch", pmc.get("hbm_bytes_per_launch"))
+        if traffic is not None:      # a pass that rendered fewer samples per launch than this block's launches: scaled to the same unit
+            traffic = int(traffic * samples_per_launch / max(1, pmc.get("samples_per_launch", 1)))
         roofline = {
             "bound": "hbm", "kernel": kernel_label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -429,12 +443,12 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             "limiter": "valu_issue",
             "valu_issue": pmc.get("valu_issue"),
             "algorithmic_bytes_per_launch": int(alg),
-            "bytes_per_ray": round(alg / max(1, (cs["closest_rays"] + (cs["any_rays"] if fused_shadow else 0)) / launches), 2),
+            "bytes_per_ray": round(alg / samples_per_launch / max(1, (cs["closest_rays"] + (cs["any_rays"] if fused_shadow else 0)) / launches), 2),
             "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3),
             "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
             "any_hit_nodes_per_ray": round(cs["nodes_any"] / max(1, cs["any_rays"]), 3),
             "any_hit_tris_per_ray": round(cs["tris_any"] / max(1, cs["any_rays"]), 3),
-            "launch_ms": round(t_launch * 1e3, 4), "launches_timed": int(n_timed_launches),
+            "launch_ms": round(t_launch * 1e3, 4), "launches_timed": int(n_timed_launches), "samples_per_launch": int(samples_per_launch),
             "any_hit_launch_ms": round(float(np.median(any_ms)), 4),
             "frame_device_ms": round(float(np.median(total_ms)), 4),
             "note": ("frac = SURVEY §8d algorithmic bytes / launch time / HBM peak; the kernel itself is bound by VALU issue (valu_issue.frac = "
@@ -445,8 +459,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         out = {
             "value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling,
             "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": spp, "path_segments": depth,
-                       "rays_per_step": int(rays_all) * spp, "closest_rays_rank0": int(st["closest_rays"]),
-                       "any_rays_rank0": int(st["any_rays"]), "tile": tile, "parallelism": f"tiles/{world}",
+                       "rays_per_step": int(rays_all) * spp, "closest_rays_rank0": int(st["closest_rays"] // samples_per_launch),
+                       "any_rays_rank0": int(st["any_rays"] // samples_per_launch), "tile": tile, "parallelism": f"tiles/{world}",
                        "stack_overflows": int(st["stack_overflows"]),
                        "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
             "roofline": roofline,
@@ -544,7 +558,7 @@ def main():
     if (args.gpus == 1 and "RANK" not in os.environ and args.workload == "auto" and args.accel == "cwbvh"
             and not (args.dry_run or args.no_live_pmc or args.option)):
         # hardware counters of this very run, from child processes, before this process makes its first GPU call
-        live_pmc([("cornell", args.depth)] + ([] if args.no_extra else [("mesh1m", 1), ("mesh1m", 4)]))
+        live_pmc([("cornell", args.depth, args.spp or 1)] + ([] if args.no_extra else [("mesh1m", 1, 4), ("mesh1m", 4, 1)]))
 
     ctx = Ctx(args)
     if ctx.world != args.gpus:

@@ -70,6 +70,8 @@ SYMBOLS = {
     "crt_set_camera": (_I, [_P, C.POINTER(crt_camera)]),
     "crt_render_frame": (_I, [_P, _F, _F]),
     "crt_render_frame_async": (_I, [_P, _F, _F]),
+    "crt_render_frames": (_I, [_P, C.c_uint32, _P, _P]),
+    "crt_render_frames_async": (_I, [_P, C.c_uint32, _P, _P]),
     "crt_sync": (_I, [_P]),
     "crt_set_option": (_I, [_P, C.c_char_p, _I]),
     "crt_reset": (_I, [_P]),

@@ -141,6 +141,7 @@ struct crt_scene {
     uint32_t tri_share = 3;
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
+    uint32_t samples_in_stats = 1;           // samples per pixel of the launch the pending stats describe (crt_render_frames batches)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
     bool timing_accumulate = false;          // spans pile up over frames (crt_frame_stats then holds sums) instead of per frame
 
@@ -725,8 +726,10 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     return CRT_OK;
 }
 
-// One sample per pixel: raygen -> [closest, shade, any, resolve] x max_depth -> accumulate.
-int crt_render_frame_async(crt_scene* s, float rx, float ry) {
+// One sample per pixel: raygen -> [closest, shade, any, resolve] x max_depth -> accumulate.  n_samples > 1 (a one-segment path
+// whose shadow rays are walked in place: nothing is queued between launches): the same launch renders that many samples of
+// every pixel one after the other — what n_samples calls would do, bit for bit, without their launch gaps and kernel tails.
+static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs, const float* rys) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_render_frame: null scene");
     if (!s->have_camera) return fail(CRT_ERR_INVALID, "crt_render_frame: crt_set_camera was never called");
     HIPCHK(hipSetDevice(s->device));
@@ -734,6 +737,7 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
     if (rc) return rc;
     if (s->n_local_pixels == 0) return CRT_OK;
     const uint32_t P = s->n_local_pixels;
+    const float rx = rxs[0], ry = rys[0];
     const crt::FrameArgs f = frame_args(s, rx, ry);
     if (!s->timing_accumulate) s->n_spans = 0;
     if (s->count_visits) {
@@ -779,6 +783,8 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
         sa.visit_totals = s->d_visit_totals;
         sa.overflow = s->d_overflow;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
+        sa.n_samples = b == 0 ? n_samples : 1u;
+        for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
         const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u && !s->special_materials;
         if (pretraced) {
@@ -812,7 +818,37 @@ int crt_render_frame_async(crt_scene* s, float rx, float ry) {
     s->counts_clean = true;
     s->stats_pending = true;
     s->stats_from_frame = true;   // ray counts come from h_counts at the next sync
+    s->samples_in_stats = n_samples;
     return CRT_OK;
+}
+
+// how many samples one launch may render: more than one only when nothing travels between launches (one path segment, shadow
+// rays walked in place) — bounce queues and the shadow queue hold one entry per pixel
+static uint32_t batch_limit(const crt_scene* s) {
+    const bool inplace = s->accel != 0u || s->inplace_shadow != 0u;
+    const bool compact = s->compact_shadow != 0u && s->tri_share == 0u && s->waves_per_workgroup > 1u;   // as launch_segment decides
+    return (s->max_depth == 1u && inplace && !compact && !s->count_visits) ? 8u : 1u;   // counting frames run one by one
+}
+
+int crt_render_frame_async(crt_scene* s, float rx, float ry) { return render_batch_async(s, 1u, &rx, &ry); }
+
+int crt_render_frames_async(crt_scene* s, uint32_t n, const float* rx, const float* ry) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_render_frames: null scene");
+    if (n && (!rx || !ry)) return fail(CRT_ERR_INVALID, "crt_render_frames: null argument");
+    const uint32_t lim = batch_limit(s);
+    for (uint32_t i = 0; i < n;) {
+        const uint32_t k = std::min(lim, n - i);
+        const int rc = render_batch_async(s, k, rx + i, ry + i);
+        if (rc) return rc;
+        i += k;
+    }
+    return CRT_OK;
+}
+
+int crt_render_frames(crt_scene* s, uint32_t n, const float* rx, const float* ry) {
+    const int rc = crt_render_frames_async(s, n, rx, ry);
+    if (rc) return rc;
+    return crt_sync(s);
 }
 
 int crt_sync(crt_scene* s) {
@@ -838,7 +874,7 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
             // the queue counters stay valid until the next frame's memset: fetch them only when asked
             HIPCHK(hipMemcpy(s->h_counts, s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
             uint64_t closest = 0, any = 0;
-            closest = s->n_local_in_frame;             // segment 0: one primary ray per in-frame pixel
+            closest = (uint64_t)s->n_local_in_frame * s->samples_in_stats;   // segment 0: one primary ray per in-frame pixel and sample
             for (uint32_t b = 0; b < s->max_depth; ++b)
                 for (uint32_t g = 0; g < 8; ++g) {
                     if (b) closest += s->h_counts[counter_index(b, 0, g)];

@@ -86,6 +86,8 @@ struct SegmentArgs {
     uint32_t* zero_counts;     // FIRST: the other frame's counter bank, cleared here for the next frame (no memset launch)
     uint32_t n_zero;
     uint32_t* overflow;        // += 1 per dropped stack push
+    uint32_t n_samples;        // FIRST: samples per pixel rendered by this launch (>= 1); > 1 only for one-segment paths walked in place
+    float rv_s[8];             // randomVector.x * randomVector.y of each of them (f.rv = rv_s[0])
 };
 
 struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-written path-ray queue

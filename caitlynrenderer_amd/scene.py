@@ -126,6 +126,14 @@ class Scene:
         fn = lib().crt_render_frame if sync else lib().crt_render_frame_async
         check(fn(self._h, float(np.float32(rx)), float(np.float32(ry))))
 
+    def render_frames(self, rvs, sync=True):
+        """crt_render_frames: rvs = sequence of (rx, ry); the same sums as render_frame per pair, fewer launches where
+        the path allows (one segment, shadow rays in place: up to 8 samples per launch)."""
+        rx = np.ascontiguousarray([r[0] for r in rvs], dtype=np.float32)
+        ry = np.ascontiguousarray([r[1] for r in rvs], dtype=np.float32)
+        fn = lib().crt_render_frames if sync else lib().crt_render_frames_async
+        check(fn(self._h, int(rx.size), _ptr(rx), _ptr(ry)))
+
     def sync(self):
         check(lib().crt_sync(self._h))
 

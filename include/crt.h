@@ -143,6 +143,13 @@ int crt_render_frame(crt_scene* s, float rx, float ry);
 /* same, without the final stream synchronise: frames queue back to back on the scene's
  * stream; crt_sync (or any read-back call) waits for them. */
 int crt_render_frame_async(crt_scene* s, float rx, float ry);
+/* n consecutive frames: exactly what n calls of crt_render_frame with (rx[i], ry[i]) add to the sum buffer, bit for bit.
+ * When nothing travels between launches — a one-segment path (max_depth 1) whose shadow rays are walked in place — up to
+ * 8 of them share one launch (each lane renders its pixel's samples one after the other), which saves their launch gaps and
+ * kernel tails; otherwise the frames are simply queued one by one.  crt_get_frame_stats then describes the last launch
+ * (ray and visit counts summed over the samples it rendered). */
+int crt_render_frames(crt_scene* s, uint32_t n, const float* rx, const float* ry);
+int crt_render_frames_async(crt_scene* s, uint32_t n, const float* rx, const float* ry);
 int crt_sync(crt_scene* s);
 /* Options (name, value).  Results never depend on the tuning options: every combination is bit-identical.
  *   behaviour
