@@ -106,6 +106,18 @@ struct Scene {
         ++frame_count;                               // Scene.h:1223
     }
 
+    // n frames of the loop above in one call: the same random vectors in the same order, the same sums bit for bit
+    // (crt_render_frames shares launches among them on a one-segment path); for offline rendering, where nothing
+    // happens between frames
+    void RenderFrames(int n) {
+        if (!gpu || n <= 0) return;
+        if (camera.isMoving) { crt_reset(gpu); frame_count = 0; camera.isMoving = false; }
+        std::vector<float> rx((size_t)n), ry((size_t)n);
+        for (int i = 0; i < n; ++i) { rx[(size_t)i] = rnd.randf2(); ry[(size_t)i] = rnd.randf2(); }
+        if (crt_render_frames(gpu, (uint32_t)n, rx.data(), ry.data()) != CRT_OK) { error = crt_last_error(); return; }
+        frame_count += n;
+    }
+
     void update(float /*second*/) {                  // Scene.h:1233-1246
         if (!gpu) return;
         const crt_camera c = camera.abi();

@@ -20,11 +20,15 @@ int main(int argc, char** argv) {
     const uint32_t depth = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 3;
     crt::Scene scn(argv[1], w, h, depth);                 // init_scene, main.cpp:28-67
     if (!scn.ok()) { std::fprintf(stderr, "scene failed: %s\n", scn.error.c_str()); return 1; }
-    for (int i = 0; i < frames; ++i) {                    // main.cpp:262-300: update(dt); render();
+    const bool batched = std::getenv("RENDER_OBJ_BATCHED") != nullptr;   // all frames through one crt_render_frames call
+    scn.update(0.0f);
+    if (batched) scn.RenderFrames(frames);
+    else for (int i = 0; i < frames; ++i) {               // main.cpp:262-300: update(dt); render();
         scn.update(0.0f);
         scn.Render();
         if (!scn.error.empty()) { std::fprintf(stderr, "render failed: %s\n", scn.error.c_str()); return 1; }
     }
+    if (!scn.error.empty()) { std::fprintf(stderr, "render failed: %s\n", scn.error.c_str()); return 1; }
     const std::string out = argv[2];
     const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
     if (!(png ? scn.write_png(out) : scn.write_ppm(out))) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }

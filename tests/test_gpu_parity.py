@@ -485,6 +485,18 @@ def test_cpp_host_scene_matches_python_path(cr, ob, cornell, tmp_path):
     for _ in range(frames):
         orc.render_frame(rnd.randf2(), rnd.randf2(), ref, threads=8)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # crt::Scene::RenderFrames (all frames in one crt_render_frames call; depth 1 so that they share launches): same sums, and a PNG
+    out = subprocess.run([os.path.join(ROOT, "examples", "render_obj"), obj, str(tmp_path / "o.png"), str(W), str(H), "11", "1",
+                          str(tmp_path / "sum1.f32")], capture_output=True, text=True, env=dict(os.environ, RENDER_OBJ_BATCHED="1"))
+    assert out.returncode == 0, out.stderr
+    orc1 = ob.Oracle(data, W, H, 1, cam)
+    rnd1, ref1 = cr.Rnd(), np.zeros((H, W, 3), np.float32)
+    for _ in range(11):
+        orc1.render_frame(rnd1.randf2(), rnd1.randf2(), ref1, threads=8)
+    assert np.array_equal(np.fromfile(tmp_path / "sum1.f32", np.float32).reshape(H, W, 3).view(np.uint32), ref1.view(np.uint32))
+    from caitlynrenderer_amd import host
+    png = host.decode_image(open(tmp_path / "o.png", "rb").read())
+    assert png.shape == (H, W, 3) and png.std() > 5
     scene = cr.Scene(data, W, H, depth)
     for _ in range(frames):
         scene.Render()

@@ -59,6 +59,34 @@ for case in range(n_cases):
         rnd.randf2()
     ref = np.zeros((H, W, 3), np.float32)
     ok = True
+    if rng.random() < 0.25:
+        # crt_render_frames: the frames of the case in one call (one launch where the path allows: one segment walked in place, no
+        # counting kernels) — the sum and the ray counts of the call must be those of the frames one by one
+        scene.set_option("count_visits", 0)
+        n_fr = int(rng.integers(1, 12))
+        rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(n_fr)]
+        scene.render_frames(rvs)
+        tot = np.zeros(2, np.int64)
+        last = np.zeros(2, np.int64)
+        per_launch = 8 if (depth == 1 and (accel != 0 or opts.get("inplace_shadow", 1) == 1)
+                           and not (opts.get("compact_shadow", 1) and opts.get("tri_share", 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
+        in_last = n_fr - ((n_fr - 1) // per_launch) * per_launch
+        for k, (rx, ry) in enumerate(rvs):
+            _, cnt = orc.render_frame(rx, ry, ref, accel=o_accel, tie=o_tie, threads=16)
+            if k >= n_fr - in_last:
+                last += (cnt[0], cnt[1])
+        st = scene.frame_stats()
+        out = scene.read_sum()
+        same = np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+        counts = (st["closest_rays"], st["any_rays"]) == (last[0], last[1])
+        if not (same and counts):
+            bad += 1
+            print(f"MISMATCH case {case} (render_frames x{n_fr}): {key} on_device={on_device} {opts} {W}x{H} depth {depth} sum_equal {same} counts {counts} "
+                  f"{(st['closest_rays'], st['any_rays'])} vs {tuple(last)}", flush=True)
+        scene.close()
+        if case % 10 == 9:
+            print(f"case {case + 1}/{n_cases}: {bad} mismatching, {time.time() - t_start:.0f}s", flush=True)
+        continue
     for frame in range(3):
         rx, ry = rnd.randf2(), rnd.randf2()
         scene.render_frame(rx, ry)
