@@ -86,6 +86,18 @@ struct crt_scene {
     // shard + frame buffers
     uint32_t rank = 0, world = 1, tile = 64;
     std::vector<uint2> tiles;            // local tiles
+    // Processing order of the local tiles (FrameArgs::tile_order): centre-out to begin with, then by measured cost, most
+    // expensive first (longest-processing-time-first scheduling of the launch).  One frame after every change of camera,
+    // shard or frame size has each wave add the clock ticks it spent to its tile's counter; the counters come back
+    // through a pinned buffer without a stream synchronise, and the re-sorted order is uploaded in stream order.
+    uint32_t* d_tile_order = nullptr; uint32_t* d_tile_cost = nullptr;
+    uint32_t* h_tile_cost = nullptr; uint32_t* h_tile_order = nullptr;      // pinned
+    hipEvent_t ev_tile_cost = nullptr, ev_tile_order = nullptr;
+    enum { TILES_WANT = 0, TILES_PENDING = 1, TILES_DONE = 2 };
+    int tile_state = TILES_WANT;
+    uint32_t adaptive_tiles = 1;             // option: 0 keeps the centre-out order
+    bool tile_order_uploading = false;
+    bool capturing = false;                  // crt_debug_time_graph: no host-side decisions inside a stream capture
     uint2* d_tile_xy = nullptr;
     uint32_t n_local_tiles = 0, n_local_pixels = 0;
     uint64_t n_local_in_frame = 0;
@@ -150,8 +162,12 @@ struct crt_scene {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
-                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow};
+                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost};
         for (void* p : ptrs) if (p) hipFree(p);
+        if (h_tile_cost) hipHostFree(h_tile_cost);
+        if (h_tile_order) hipHostFree(h_tile_order);
+        if (ev_tile_cost) hipEventDestroy(ev_tile_cost);
+        if (ev_tile_order) hipEventDestroy(ev_tile_order);
         if (h_counts) hipHostFree(h_counts);
         if (h_visit_totals) hipHostFree(h_visit_totals);
         for (EventSpan& s : spans) { if (s.a) hipEventDestroy(s.a); if (s.b) hipEventDestroy(s.b); }
@@ -221,9 +237,11 @@ int build_shard(crt_scene* s) {
 }
 
 void free_frame_buffers(crt_scene* s) {
-    void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
+    void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_tile_order, (void**)&s->d_tile_cost, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
                      (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
+    if (s->h_tile_cost) { (void)hipHostFree(s->h_tile_cost); s->h_tile_cost = nullptr; }
+    if (s->h_tile_order) { (void)hipHostFree(s->h_tile_order); s->h_tile_order = nullptr; }
     s->frame_buffers_ready = false;
 }
 
@@ -234,6 +252,23 @@ int alloc_frame_buffers(crt_scene* s) {
     const size_t P = s->n_local_pixels;
     if ((rc = dev_alloc(&s->d_tile_xy, s->n_local_tiles))) return rc;
     HIPCHK(hipMemcpy(s->d_tile_xy, s->tiles.data(), s->tiles.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    {   // processing order: centre-out until a frame has been measured
+        const uint32_t nt = s->n_local_tiles, T = s->tile;
+        const float cx = 0.5f * (float)((s->width + T - 1) / T) - 0.5f, cy = 0.5f * (float)((s->height + T - 1) / T) - 0.5f;
+        std::vector<uint32_t> order(nt);
+        for (uint32_t i = 0; i < nt; ++i) order[i] = i;
+        auto d2 = [&](uint32_t i) { const float dx = (float)s->tiles[i].x - cx, dy = (float)s->tiles[i].y - cy; return dx * dx + dy * dy; };
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return d2(a) < d2(b); });
+        if ((rc = dev_alloc(&s->d_tile_order, std::max<uint32_t>(nt, 1)))) return rc;
+        if ((rc = dev_alloc(&s->d_tile_cost, std::max<uint32_t>(nt, 1)))) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_tile_cost), std::max<uint32_t>(nt, 1) * sizeof(uint32_t)));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_tile_order), std::max<uint32_t>(nt, 1) * sizeof(uint32_t)));
+        if (nt) HIPCHK(hipMemcpy(s->d_tile_order, order.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!s->ev_tile_cost) HIPCHK(hipEventCreateWithFlags(&s->ev_tile_cost, hipEventDisableTiming));
+        if (!s->ev_tile_order) HIPCHK(hipEventCreateWithFlags(&s->ev_tile_order, hipEventDisableTiming));
+        s->tile_state = crt_scene::TILES_WANT;
+        s->tile_order_uploading = false;
+    }
     if ((rc = dev_alloc(&s->d_sum, 3 * P))) return rc;
     HIPCHK(hipMemset(s->d_sum, 0, 3 * std::max<size_t>(P, 1) * sizeof(float)));
     // a workgroup group handles every 8th unit of 4096 pixels/rays, so it can emit at most this many rays per segment
@@ -255,6 +290,7 @@ int alloc_frame_buffers(crt_scene* s) {
 crt::FrameArgs frame_args(const crt_scene* s, float rx, float ry) {
     crt::FrameArgs f{};
     f.tile_xy = s->d_tile_xy;
+    f.tile_order = s->d_tile_order;
     f.n_local_pixels = s->n_local_pixels;
     f.tile = s->tile; f.width = s->width; f.height = s->height;
     f.tile_log2 = (s->tile & (s->tile - 1u)) == 0u ? (uint32_t)__builtin_ctz(s->tile) : 0u;
@@ -655,6 +691,7 @@ int crt_scene_destroy(crt_scene* s) {
 
 int crt_set_camera(crt_scene* s, const crt_camera* cam) {
     if (!s || !cam) return fail(CRT_ERR_INVALID, "crt_set_camera: null argument");
+    if (!s->have_camera || std::memcmp(&s->cam, cam, sizeof *cam) != 0) s->tile_state = crt_scene::TILES_WANT;   // a new view: new tile costs
     s->cam = *cam;
     s->have_camera = true;
     return CRT_OK;
@@ -699,6 +736,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "compact_shadow")) s->compact_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(3, std::max(0, value));
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
+    else if (!std::strcmp(name, "adaptive_tiles")) { s->adaptive_tiles = value ? 1u : 0u; if (value) s->tile_state = crt_scene::TILES_WANT; }
     else if (!std::strcmp(name, "accel")) {
         if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
         if (value != 0 && !s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_set_option: the scene was created without a BVH2 (desc.bvh)");
@@ -754,6 +792,35 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         if (!s->inplace_shadow && s->accel == 0u && !s->d_shadow && (rc = dev_alloc(&s->d_shadow, 3 * Q))) return rc;
         if (s->bounce_refill && s->max_depth > 1 && !s->d_qhits && (rc = dev_alloc(&s->d_qhits, Q))) return rc;
     }
+    // tile order: adopt a finished measurement, start one if the view is new
+    bool measure_tiles = false;
+    if (s->adaptive_tiles && s->n_local_tiles > 1 && !s->capturing) {
+        const bool arrived = s->tile_state == crt_scene::TILES_PENDING && hipEventQuery(s->ev_tile_cost) == hipSuccess;
+        (void)hipGetLastError();                                    // "not ready" is an answer, not an error to report later
+        if (arrived) {
+            if (s->tile_order_uploading) HIPCHK(hipEventSynchronize(s->ev_tile_order));     // the pinned order buffer is free again
+            const uint32_t nt = s->n_local_tiles;
+            // most expensive first; processing slot u belongs to workgroup group u & 7 (one group per XCD, no rebalancing between
+            // them), so the sorted list is dealt to the eight groups in snake order — 0..7, 7..0, ... — which keeps their sums level
+            std::vector<uint32_t> sorted(nt);
+            for (uint32_t i = 0; i < nt; ++i) sorted[i] = i;
+            const uint32_t* cost = s->h_tile_cost;
+            std::stable_sort(sorted.begin(), sorted.end(), [cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+            for (uint32_t u = 0; u < nt; ++u) {
+                const uint32_t round = u >> 3, g = u & 7u, first = round * 8u, in_round = std::min(8u, nt - first);
+                const uint32_t k = (round & 1u) ? (in_round - 1u - std::min(g, in_round - 1u)) : g;
+                s->h_tile_order[u] = sorted[first + std::min(k, in_round - 1u)];
+            }
+            HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order, nt * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipEventRecord(s->ev_tile_order, s->stream));
+            s->tile_order_uploading = true;
+            s->tile_state = crt_scene::TILES_DONE;
+        }
+        if (s->tile_state == crt_scene::TILES_WANT) {
+            HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, s->n_local_tiles * sizeof(uint32_t), s->stream));
+            measure_tiles = true;
+        }
+    }
     s->bank ^= 1u;
     if (!s->counts_clean) HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * kCounters * sizeof(uint32_t), s->stream));
     s->counts_clean = false;
@@ -783,6 +850,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.visit_totals = s->d_visit_totals;
         sa.overflow = s->d_overflow;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
+        sa.tile_cost = (b == 0 && measure_tiles) ? s->d_tile_cost : nullptr;
         sa.n_samples = b == 0 ? n_samples : 1u;
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
@@ -813,6 +881,11 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
     }
     if (s->count_visits)
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    if (measure_tiles) {
+        HIPCHK(hipMemcpyAsync(s->h_tile_cost, s->d_tile_cost, s->n_local_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipEventRecord(s->ev_tile_cost, s->stream));
+        s->tile_state = crt_scene::TILES_PENDING;
+    }
     s->stats_counted = s->count_visits;
     HIPCHK(hipGetLastError());
     s->counts_clean = true;
@@ -1001,8 +1074,10 @@ int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint
     G_CHK(hipEventElapsedTime(&ms, e0, e1));
     *ms_stream = ms / (float)(reps * n_frames);
     G_CHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    s->capturing = true;
     for (uint32_t f = 0; f < n_frames; ++f)
-        if ((rc = crt_render_frame_async(s, rxy[2 * f], rxy[2 * f + 1]))) { (void)hipStreamEndCapture(s->stream, &graph); return done(rc); }
+        if ((rc = crt_render_frame_async(s, rxy[2 * f], rxy[2 * f + 1]))) { s->capturing = false; (void)hipStreamEndCapture(s->stream, &graph); return done(rc); }
+    s->capturing = false;
     G_CHK(hipStreamEndCapture(s->stream, &graph));
     G_CHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     G_CHK(hipGraphLaunch(exec, s->stream));                // warm

@@ -866,9 +866,21 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         float4* const shadow_q = a.shadow + 3 * (size_t)g * a.sub_capacity;
         float4* const next_q = a.rays_next + 2 * (size_t)g * a.sub_capacity;
         uint32_t e, n;
+        uint32_t cost_tile = 0;
+        unsigned long long cost_t0 = 0;
         if (FIRST) {
             e = dense_item(v, wave, lane);
             n = f.n_local_pixels;
+            // the unit of work says WHEN a tile is rendered, tile_order says WHICH tile that is: expensive tiles first, so that the
+            // launch does not end on a few long waves (the same pixels, the same sums; 1 M triangles 0.356 -> 0.331 ms,
+            // Cornell 0.082 -> 0.076 ms with nothing but a centre-out order).  A batch of 64 items never straddles two tiles.
+            if (f.tile_order && e < n) {
+                const uint32_t tile_px = f.tile * f.tile;
+                const uint32_t slot = f.tile_log2 ? e >> (2u * f.tile_log2) : e / tile_px;
+                cost_tile = f.tile_order[slot];
+                e = cost_tile * tile_px + (e - slot * tile_px);
+            }
+            if (a.tile_cost) cost_t0 = __builtin_readcyclecounter();
         } else {
             e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
             n = a.count_in[g * CRT_COUNTER_STRIDE];
@@ -1197,6 +1209,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
         const uint32_t ni = wave_append(emit_next, count_next);
         if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
         }   // samples
+        if (FIRST && a.tile_cost && lane == 0u && e < n)
+            atomicAdd(a.tile_cost + cost_tile, (uint32_t)(__builtin_readcyclecounter() - cost_t0));
     }
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
     if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any, wn_any, wt_any);

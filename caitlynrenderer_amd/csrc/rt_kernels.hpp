@@ -45,6 +45,8 @@ struct PathBuffers {           // indexed by local pixel; touched only by paths 
 
 struct FrameArgs {
     const uint2* tile_xy;      // local tile -> (tile x, tile y)
+    const uint32_t* tile_order; // processing slot -> local tile (which tile's pixels the k-th unit of work renders); null = identity.
+                               // Storage (sum buffer, path state, the gather between ranks) is always by local tile.
     uint32_t n_local_pixels;   // n_local_tiles * tile * tile
     uint32_t tile, width, height;
     uint32_t tile_log2;        // log2(tile) when the tile is a power of two (shifts instead of integer divisions), else 0
@@ -86,6 +88,7 @@ struct SegmentArgs {
     uint32_t* zero_counts;     // FIRST: the other frame's counter bank, cleared here for the next frame (no memset launch)
     uint32_t n_zero;
     uint32_t* overflow;        // += 1 per dropped stack push
+    uint32_t* tile_cost;       // FIRST, optional: += the clock ticks every wave spent on a tile's pixels, per local tile (feeds tile_order)
     uint32_t n_samples;        // FIRST: samples per pixel rendered by this launch (>= 1); > 1 only for one-segment paths walked in place
     float rv_s[8];             // randomVector.x * randomVector.y of each of them (f.rv = rv_s[0])
 };

@@ -82,6 +82,48 @@ def test_hip_walk_equals_a_numpy_brute_force_that_shares_no_code_with_the_oracle
     assert np.array_equal(occ, hit)
 
 
+def test_tile_processing_order_changes_nothing_but_the_time(cr, ob, cornell, tess8):
+    """The order in which the tiles of the frame are handed to the GPU (centre-out, then by measured cost, dealt to the eight
+    XCD groups in snake order) is a scheduling decision: sums, ray counts and visit counters are the oracle's for every
+    frame before, during and after the measurement, at every tile size and for a shard; a camera change measures again."""
+    mesh, data = tess8
+    cam0 = cornell[1]
+    cam1 = cr.Camera((1.0, 4.5, 9.0), (2.5, 2.0, 2.0), 55.0)
+    for W, H, tile, shard in ((333, 217, 64, None), (333, 217, 16, None), (640, 360, 64, (2, 3)), (200, 150, 40, None)):
+        results = {}
+        for adaptive in (1, 0):
+            scene = cr.Scene(data, W, H, 2)
+            scene.set_option("adaptive_tiles", adaptive)
+            scene.set_shard(shard[0] if shard else 0, shard[1] if shard else 1, tile)
+            scene.set_option("count_visits", 1)
+            rnd = cr.Rnd()
+            sums, stats = [], []
+            for cam in (cam0, cam1):
+                scene.update(cam)
+                for _ in range(4):                                  # frame 1 measures, a later one adopts the order
+                    scene.render_frame(rnd.randf2(), rnd.randf2())
+                    st = scene.frame_stats()
+                    stats.append((st["closest_rays"], st["any_rays"], st["nodes_closest"] + st["nodes_any"], st["tris_closest"] + st["tris_any"]))
+                    scene.sync()
+                sums.append(scene.read_sum().copy())
+            results[adaptive] = (sums, stats)
+            scene.close()
+        for a, b in zip(results[1][0], results[0][0]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (W, H, tile, shard)
+        assert results[1][1] == results[0][1]
+        if shard is None:                                           # and both are the oracle's
+            rnd = cr.Rnd()
+            ref = np.zeros((H, W, 3), np.float32)
+            k = 0
+            for cam in (cam0, cam1):
+                orc = ob.Oracle(data, W, H, 2, cam)
+                for _ in range(4):
+                    _, cnt = orc.render_frame(rnd.randf2(), rnd.randf2(), ref, threads=8)
+                    assert results[1][1][k] == (cnt[0], cnt[1], cnt[2], cnt[3]), (W, H, tile, k)
+                    k += 1
+            assert np.array_equal(results[1][0][1].view(np.uint32), ref.view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["cornell", "tess8", "tess8_mat", "textured"])
 def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8, textured, name):
     """crt_render_frames: n frames in ceil(n / 8) launches on a one-segment path walked in place (each lane renders its pixel's
