@@ -80,6 +80,9 @@ def parse_args(argv=None):
                     help="mesh workloads: lambert = the reference's only BSDF (default); disney = the boxes get the GGX / Disney-diffuse "
                          "material of configs[3] (oracle-defined, no reference code)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="crt_set_option passthrough (tuning experiments)")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="untimed rendering before the warm-up steps, in ms of wall time (default 100): clocks and caches reach the steady "
+                         "state the metric is about; 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="auto workload at N = 1: do not run the rocprofv3 --pmc passes (roofline.traffic / valu_issue then come from the "
@@ -365,6 +368,14 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             else:
                 scene.render_frame(*part[0], sync=False)
 
+        # settle: the GPU comes out of the idle period in which this workload was built with its clocks down, and frame times keep
+        # falling for the first ~150 frames (Cornell: 0.090 -> 0.075 ms); the metric is the steady state of a progressive renderer, so
+        # untimed frames are rendered for --settle-ms of wall time before the W warm-up steps (which then also run at speed)
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for k in range(max(1, Wu)):
+                step(k % max(1, Wu))
+            scene.sync()
         for k in range(Wu):
             step(k)
         scene.sync()
@@ -460,7 +471,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             "value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling,
             "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": spp, "path_segments": depth,
                        "rays_per_step": int(rays_all) * spp, "closest_rays_rank0": int(st["closest_rays"] // samples_per_launch),
-                       "any_rays_rank0": int(st["any_rays"] // samples_per_launch), "tile": tile, "parallelism": f"tiles/{world}",
+                       "any_rays_rank0": int(st["any_rays"] // samples_per_launch), "tile": tile, "parallelism": f"tiles/{world}", "settle_ms": args.settle_ms,
                        "stack_overflows": int(st["stack_overflows"]),
                        "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
             "roofline": roofline,

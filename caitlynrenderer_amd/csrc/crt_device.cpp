@@ -816,7 +816,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             s->tile_order_uploading = true;
             s->tile_state = crt_scene::TILES_DONE;
         }
-        if (s->tile_state == crt_scene::TILES_WANT) {
+        if (s->tile_state == crt_scene::TILES_WANT && !s->count_visits) {   // the counting kernels have another cost profile (measured: a worse order)
             HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, s->n_local_tiles * sizeof(uint32_t), s->stream));
             measure_tiles = true;
         }
