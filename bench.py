@@ -17,7 +17,7 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
                                        Lambert integrator and with the oracle-defined mirror + GGX/Disney-diffuse materials;
     "scale_base"                     = configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines
                                        divide by).
-  N > 1, --workload auto: configs[4]: ONE fixed 3840x2160 frame of the 1 M-triangle mesh, 4 spp per step, its 64x64 tiles dealt
+  N > 1, --workload auto: configs[4]: ONE fixed 3840x2160 frame of the 1 M-triangle mesh, 4 spp per step, its 16x16 tiles dealt
     to the N ranks (strong scaling, no data-path collective), one RCCL gather of the per-tile radiance to rank 0 inside the timed
     region; "n1_same_workload" is the same frame rendered by rank 0 alone in the same job.  `--scaling weak` keeps the round-1
     behaviour (the frame grows with N, ~1920x1080 pixels per rank).
@@ -67,7 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (default: 1 for cornell, 4 for the mesh workloads)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = one fixed frame split over the ranks (configs[4], default); weak = the frame grows with N")
-    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--tile", type=int, default=16, help="tile edge in pixels (multiple of 8): unit of the ranks' shards and of the cost-sorted launch order")
     ap.add_argument("--builder", default="sbvh",
                     help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build); "
                          "ploc / ploc<radius> = GPU parallel locally-ordered clustering")

@@ -84,7 +84,7 @@ struct crt_scene {
     uint32_t bvh2_stack = 0;             // BVH2 depth + 2
 
     // shard + frame buffers
-    uint32_t rank = 0, world = 1, tile = 64;
+    uint32_t rank = 0, world = 1, tile = 16;   // 16x16: four waves per tile — fine enough for the cost-sorted schedule (1 M triangles: 0.273 ms at 64, 0.257 at 16)
     std::vector<uint2> tiles;            // local tiles
     // Processing order of the local tiles (FrameArgs::tile_order): centre-out to begin with, then by measured cost, most
     // expensive first (longest-processing-time-first scheduling of the launch).  One frame after every change of camera,
@@ -800,16 +800,26 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         if (arrived) {
             if (s->tile_order_uploading) HIPCHK(hipEventSynchronize(s->ev_tile_order));     // the pinned order buffer is free again
             const uint32_t nt = s->n_local_tiles;
-            // most expensive first; processing slot u belongs to workgroup group u & 7 (one group per XCD, no rebalancing between
-            // them), so the sorted list is dealt to the eight groups in snake order — 0..7, 7..0, ... — which keeps their sums level
+            // Most expensive first.  A unit of work is 4096 pixels = spu tiles (1 for the default 64x64 tile); unit U belongs to
+            // workgroup group U & 7 (one group per XCD, no rebalancing between them) and a group renders its units in order.
+            // So group g's k-th tile sits in slot ((k / spu) * 8 + g) * spu + k % spu, and the sorted list is dealt to the
+            // groups' k-th places in snake order — 0..7, 7..0, ... — which keeps the groups' sums level and every group's
+            // own sequence descending.
             std::vector<uint32_t> sorted(nt);
             for (uint32_t i = 0; i < nt; ++i) sorted[i] = i;
             const uint32_t* cost = s->h_tile_cost;
             std::stable_sort(sorted.begin(), sorted.end(), [cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-            for (uint32_t u = 0; u < nt; ++u) {
-                const uint32_t round = u >> 3, g = u & 7u, first = round * 8u, in_round = std::min(8u, nt - first);
-                const uint32_t k = (round & 1u) ? (in_round - 1u - std::min(g, in_round - 1u)) : g;
-                s->h_tile_order[u] = sorted[first + std::min(k, in_round - 1u)];
+            const uint32_t tile_px = s->tile * s->tile, spu = tile_px < 4096u && 4096u % tile_px == 0u ? 4096u / tile_px : 1u;
+            uint32_t next = 0;
+            std::vector<uint32_t> row;
+            for (uint32_t k = 0; next < nt; ++k) {
+                row.clear();
+                for (uint32_t g = 0; g < 8u; ++g) {
+                    const uint64_t slot = ((uint64_t)(k / spu) * 8u + g) * spu + k % spu;
+                    if (slot < nt) row.push_back((uint32_t)slot);
+                }
+                if (k & 1u) std::reverse(row.begin(), row.end());
+                for (uint32_t slot : row) s->h_tile_order[slot] = sorted[next++];
             }
             HIPCHK(hipMemcpyAsync(s->d_tile_order, s->h_tile_order, nt * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
             HIPCHK(hipEventRecord(s->ev_tile_order, s->stream));

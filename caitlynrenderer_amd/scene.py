@@ -171,7 +171,7 @@ class Scene:
         check(lib().crt_debug_read_queue(self._h, int(which), int(segment), _ptr(out), n.value, C.byref(n)))
         return out
 
-    def set_shard(self, rank, world, tile=64):
+    def set_shard(self, rank, world, tile=16):
         check(lib().crt_set_shard(self._h, int(rank), int(world), int(tile)))
 
     def packed_info(self):

@@ -159,7 +159,7 @@ int crt_sync(crt_scene* s);
  *                         the lowest-id tie rule; 1 and 2 need desc.bvh
  *   telemetry
  *     "count_visits"      0/1: traversal launches also count node fetches / triangle tests (crt_frame_stats)
- *     "adaptive_tiles"    1 (default): the order in which the 64x64 tiles of the frame are handed to the GPU follows their
+ *     "adaptive_tiles"    1 (default): the order in which the tiles of the frame (16x16 pixels unless crt_set_shard says otherwise) are handed to the GPU follows their
  *                         measured cost, most expensive first (one frame per new view is timed, tile by tile); 0: centre-out
  *                         order only.  Which pixel lands where — in the image and in the sum buffer — does not depend on it.
  *     "timing"            HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit

@@ -31,10 +31,10 @@ def test_plain_command_launches_its_own_ranks(n, tmp_path):
     assert d["dry_run"] is True and d["n_gpus"] == n and d["steps"] == 3 and d["warmup"] == 1
     cfg = d["config"]
     if n == 1:
-        assert d["scaling"] == "weak" and cfg["resolution"] == "1920x1080" and cfg["tiles"] == 30 * 17
+        assert d["scaling"] == "weak" and cfg["resolution"] == "1920x1080" and cfg["tiles"] == 120 * 68
     else:
         # BASELINE.json configs[4]: ONE fixed 3840x2160 frame split over the ranks
-        assert d["scaling"] == "strong" and cfg["resolution"] == "3840x2160" and cfg["tiles"] == 60 * 34
+        assert d["scaling"] == "strong" and cfg["resolution"] == "3840x2160" and cfg["tiles"] == 240 * 135
         assert cfg["parallelism"] == f"tiles/{n}" and cfg["gather_floats_per_rank"] == -(-2040 // n) * 64 * 64 * 3
 
 
