@@ -35,7 +35,7 @@ def test_plain_command_launches_its_own_ranks(n, tmp_path):
     else:
         # BASELINE.json configs[4]: ONE fixed 3840x2160 frame split over the ranks
         assert d["scaling"] == "strong" and cfg["resolution"] == "3840x2160" and cfg["tiles"] == 240 * 135
-        assert cfg["parallelism"] == f"tiles/{n}" and cfg["gather_floats_per_rank"] == -(-2040 // n) * 64 * 64 * 3
+        assert cfg["parallelism"] == f"tiles/{n}" and cfg["gather_floats_per_rank"] == -(-32400 // n) * 16 * 16 * 3
 
 
 def test_weak_scaling_option_keeps_per_rank_pixels(tmp_path):
