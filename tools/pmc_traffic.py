@@ -53,9 +53,12 @@ def entry_from_dirs(dirs, wl):
     waves, _ = total("SQ_WAVES")
     gui, n_g = total("GRBM_GUI_ACTIVE")
     if n_sq and n_g and act > 0:
-        busy = 4.0 * (act / n_sq) / (N_SIMD * (gui / n_g) / 8.0)
+        busy_raw = 4.0 * (act / n_sq) / (N_SIMD * (gui / n_g) / 8.0)
+        # 4 cycles per wave64 VALU instruction is the nominal figure; the microbenchmark measures 3.6 - 4.3 (profiles/r02_valu_rate_ubench.txt),
+        # so a launch that keeps every SIMD issuing can come out a little above 1: reported as 1, with the raw value next to it
+        busy = min(1.0, busy_raw)
         lane = thr / (64.0 * act)
-        e["valu_issue"] = {"busy": round(busy, 3), "lane_util": round(lane, 3), "frac": round(busy * lane, 3),
+        e["valu_issue"] = {"busy": round(busy, 3), "busy_raw": round(busy_raw, 3), "lane_util": round(lane, 3), "frac": round(busy * lane, 3),
                            "valu_instructions_per_wave": round(insts / max(1.0, waves), 1),
                            "source": "rocprofv3 --pmc passes of `bench.py --workload %s --depth %s --spp 1`; formulae in tools/pmc_traffic.py"
                                      % tuple(wl.split("_d"))}
