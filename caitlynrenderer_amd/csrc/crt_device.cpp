@@ -97,6 +97,8 @@ struct crt_scene {
     int tile_state = TILES_WANT;
     uint32_t adaptive_tiles = 1;             // option: 0 keeps the centre-out order
     bool tile_order_uploading = false;
+    bool tiles_measured_once = false;
+    uint32_t frames_since_tile_measure = 0;
     bool capturing = false;                  // crt_debug_time_graph: no host-side decisions inside a stream capture
     uint2* d_tile_xy = nullptr;
     uint32_t n_local_tiles = 0, n_local_pixels = 0;
@@ -268,6 +270,7 @@ int alloc_frame_buffers(crt_scene* s) {
         if (!s->ev_tile_order) HIPCHK(hipEventCreateWithFlags(&s->ev_tile_order, hipEventDisableTiming));
         s->tile_state = crt_scene::TILES_WANT;
         s->tile_order_uploading = false;
+        s->tiles_measured_once = false;
     }
     if ((rc = dev_alloc(&s->d_sum, 3 * P))) return rc;
     HIPCHK(hipMemset(s->d_sum, 0, 3 * std::max<size_t>(P, 1) * sizeof(float)));
@@ -826,7 +829,12 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             s->tile_order_uploading = true;
             s->tile_state = crt_scene::TILES_DONE;
         }
-        if (s->tile_state == crt_scene::TILES_WANT && !s->count_visits) {   // the counting kernels have another cost profile (measured: a worse order)
+        ++s->frames_since_tile_measure;
+        // a camera that moves every frame would otherwise sort the tiles on the host every frame: at most one measurement per 16
+        // frames (the first one at once); the counting kernels have another cost profile (measured: a worse order) and do not measure
+        if (s->tile_state == crt_scene::TILES_WANT && !s->count_visits && (!s->tiles_measured_once || s->frames_since_tile_measure >= 16u)) {
+            s->tiles_measured_once = true;
+            s->frames_since_tile_measure = 0;
             HIPCHK(hipMemsetAsync(s->d_tile_cost, 0, s->n_local_tiles * sizeof(uint32_t), s->stream));
             measure_tiles = true;
         }
