@@ -180,7 +180,7 @@ int crt_sync(crt_scene* s);
  *                         levels at 4 waves) runs with 1
  *     "tri_share"         triangle steps of the voting loop hand the waiting lanes' pending triangles (up to 3 each) to ALL lanes
  *                         of the wave through a wave-private LDS strip: 0 off, 1 closest-hit walk, 2 also the in-place shadow
- *                         rays, 3 (default) = 1 for the first segment, 2 for bounce segments
+ *                         rays, 3 (default) = off for the first segment, 2 for bounce segments
  *     "compact_shadow"    1 (default): with 2 or 4 waves per workgroup and in-place shadows, the workgroup's NEE shadow rays
  *                         are gathered through LDS into full waves before they are walked; 0: every wave walks its own */
 int crt_set_option(crt_scene* s, const char* name, int value);
