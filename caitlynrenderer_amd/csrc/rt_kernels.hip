@@ -802,6 +802,9 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 }
 
 // ------------------------------------------------------------------ path segment -----
+#ifndef CRT_SEG_OCC
+#define CRT_SEG_OCC 5        // waves per SIMD the segment kernel is compiled for (96 VGPRs); see the note above k_segment
+#endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
 // shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
@@ -834,7 +837,7 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // BATCH (FIRST + INPLACE, a one-segment path): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.
 template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false, bool SHARE = false,
           bool BATCH = false>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, 5) k_segment(SegmentArgs a) {
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
