@@ -257,6 +257,7 @@ def live_pmc(workloads, budget_s=240.0):
     if rocprof is None:
         log("[bench] live pmc: rocprofv3 not found, using the committed passes")
         return
+    import torch  # noqa: F401  (no GPU call: only pages the library in, so that the children's own imports fit their time limit on a fresh box)
     spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
     pt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(pt)
