@@ -16,7 +16,8 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
     "incoherent" / "incoherent_disney" = configs[3]: same mesh, 4 path segments (incoherent bounce rays), with the reference's
                                        Lambert integrator and with the oracle-defined mirror + GGX/Disney-diffuse materials;
     "scale_base"                     = configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines
-                                       divide by).
+                                       divide by);
+    "cornell_8_frames_per_launch"    = for information: configs[1]'s scene with 8 frames per crt_render_frames call (one launch).
   N > 1, --workload auto: configs[4]: ONE fixed 3840x2160 frame of the 1 M-triangle mesh, 4 spp per step, its 16x16 tiles dealt
     to the N ranks (strong scaling, no data-path collective), one RCCL gather of the per-tile radiance to rank 0 inside the timed
     region; "n1_same_workload" is the same frame rendered by rank 0 alone in the same job.  `--scaling weak` keeps the round-1
@@ -611,6 +612,7 @@ def main():
                 extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak")
                 extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak", materials="disney")
                 extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
+                extra["cornell_8_frames_per_launch"] = run_block(ctx, "cornell", 1920, 1080, 1, 8, True, False, "weak")
             elif args.scaling == "strong":
                 ctx.barrier()
                 extra["n1_same_workload"] = run_block(ctx, name, W, H, args.depth, spp, False, False, "strong")
@@ -631,6 +633,9 @@ def main():
                  "incoherent_disney": "BASELINE.json configs[3] as worded: 4 path segments with a mirror tall box and GGX / Disney-diffuse short "
                                       "box and floor (the material model has no reference code: oracle-defined, HIP == oracle bit for bit)",
                  "scale_base": "BASELINE.json configs[4] at N = 1: what the N > 1 lines of `bench.py --gpus N` divide by",
+                 "cornell_8_frames_per_launch": "NOT the headline: configs[1]'s scene with 8 frames handed to crt_render_frames per step, i.e. one launch per 8 "
+                                                "samples — what the top-level line (one launch per frame, as the reference's frame loop issues them) leaves "
+                                                "in launch gaps and kernel tails",
                  "n1_same_workload": "the same frame rendered by rank 0 alone in this job (strong-scaling base)"}
         for k, v in extra.items():
             if v is not None:

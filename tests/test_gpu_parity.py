@@ -1246,6 +1246,7 @@ def test_bench_line_contract(tmp_path):
     assert d["incoherent"]["config"]["path_segments"] == 4 and d["incoherent"]["value"] > 500
     assert "Disney" in d["incoherent_disney"]["config"]["workload"] and d["incoherent_disney"]["value"] > 500
     check_roofline(d["incoherent"]["roofline"], 24, live=True)
+    assert d["cornell_8_frames_per_launch"]["roofline"]["samples_per_launch"] == 8 and d["cornell_8_frames_per_launch"]["value"] > d["value"]
     sb = d["scale_base"]
     assert sb["config"]["resolution"] == "3840x2160" and sb["scaling"] == "strong" and sb["value"] > 1000
 
