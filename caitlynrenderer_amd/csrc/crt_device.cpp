@@ -808,13 +808,13 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             // So group g's k-th tile sits in slot ((k / spu) * 8 + g) * spu + k % spu, and the sorted list is dealt to the
             // groups' k-th places in snake order — 0..7, 7..0, ... — which keeps the groups' sums level and every group's
             // own sequence descending.
-            std::vector<uint32_t> sorted(nt);
+            std::vector<uint32_t> sorted, row;
+            try { sorted.resize(nt); row.reserve(8); } catch (const std::exception&) { return fail(CRT_ERR_NOMEM, "crt_render_frame: out of host memory (tile order)"); }
             for (uint32_t i = 0; i < nt; ++i) sorted[i] = i;
             const uint32_t* cost = s->h_tile_cost;
-            std::stable_sort(sorted.begin(), sorted.end(), [cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+            std::sort(sorted.begin(), sorted.end(), [cost](uint32_t a, uint32_t b) { return cost[a] > cost[b] || (cost[a] == cost[b] && a < b); });
             const uint32_t tile_px = s->tile * s->tile, spu = tile_px < 4096u && 4096u % tile_px == 0u ? 4096u / tile_px : 1u;
             uint32_t next = 0;
-            std::vector<uint32_t> row;
             for (uint32_t k = 0; next < nt; ++k) {
                 row.clear();
                 for (uint32_t g = 0; g < 8u; ++g) {
