@@ -155,6 +155,8 @@ struct crt_scene {
     uint32_t tri_share = 3;
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
+    float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
+    uint32_t batch_cap = 1;                  // samples the path state, the ray queues and d_lfinal are sized for (1 until crt_render_frames needs more)
     uint32_t samples_in_stats = 1;           // samples per pixel of the launch the pending stats describe (crt_render_frames batches)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
     bool timing_accumulate = false;          // spans pile up over frames (crt_frame_stats then holds sums) instead of per frame
@@ -164,7 +166,7 @@ struct crt_scene {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
-                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost};
+                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_tile_cost) hipHostFree(h_tile_cost);
         if (h_tile_order) hipHostFree(h_tile_order);
@@ -240,8 +242,10 @@ int build_shard(crt_scene* s) {
 
 void free_frame_buffers(crt_scene* s) {
     void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_tile_order, (void**)&s->d_tile_cost, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
-                     (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed};
+                     (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed,
+                     (void**)&s->d_lfinal};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
+    s->batch_cap = 1;
     if (s->h_tile_cost) { (void)hipHostFree(s->h_tile_cost); s->h_tile_cost = nullptr; }
     if (s->h_tile_order) { (void)hipHostFree(s->h_tile_order); s->h_tile_order = nullptr; }
     s->frame_buffers_ready = false;
@@ -770,6 +774,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
 // One sample per pixel: raygen -> [closest, shade, any, resolve] x max_depth -> accumulate.  n_samples > 1 (a one-segment path
 // whose shadow rays are walked in place: nothing is queued between launches): the same launch renders that many samples of
 // every pixel one after the other — what n_samples calls would do, bit for bit, without their launch gaps and kernel tails.
+static int ensure_batch_buffers(crt_scene* s, uint32_t cap);
 static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs, const float* rys) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_render_frame: null scene");
     if (!s->have_camera) return fail(CRT_ERR_INVALID, "crt_render_frame: crt_set_camera was never called");
@@ -778,6 +783,8 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
     if (rc) return rc;
     if (s->n_local_pixels == 0) return CRT_OK;
     const uint32_t P = s->n_local_pixels;
+    const bool deferred = n_samples > 1u && s->max_depth > 1u;       // finished paths leave their radiance in d_lfinal
+    if (deferred && (rc = ensure_batch_buffers(s, 4u))) return rc;
     const float rx = rxs[0], ry = rys[0];
     const crt::FrameArgs f = frame_args(s, rx, ry);
     if (!s->timing_accumulate) s->n_spans = 0;
@@ -871,6 +878,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.visit_totals = s->d_visit_totals;
         sa.overflow = s->d_overflow;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
+        sa.l_final = deferred ? s->d_lfinal : nullptr;
         sa.tile_cost = (b == 0 && measure_tiles) ? s->d_tile_cost : nullptr;
         sa.n_samples = b == 0 ? n_samples : 1u;
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
@@ -888,7 +896,9 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         } else if (sp) {
             crt::set_launch_events(sp->a, sp->b);
         }
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, s->trace_grid(P, 5), s->waves_per_workgroup, s->stream);
+        // bounce launches of a batched frame may find up to n_samples rays per pixel in their queue
+        const uint32_t items = (b > 0 && deferred) ? P * n_samples : P;
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, s->trace_grid(items, 5), s->waves_per_workgroup, s->stream);
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};
@@ -900,6 +910,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         if (sp) crt::set_launch_events(sp->a, sp->b);
         crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->waves_per_workgroup, s->stream);
     }
+    if (deferred) crt::launch_accumulate_samples(s->d_sum, s->d_lfinal, P, n_samples, s->stream);
     if (s->count_visits)
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     if (measure_tiles) {
@@ -916,12 +927,39 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
     return CRT_OK;
 }
 
+// Path state, ray queues and the final-radiance buffer for `cap` samples per launch (multi-segment paths).  The per-group queue
+// capacity grows with it, so the lazily allocated shadow queue / hit buffer are dropped and come back at the new size.
+static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
+    if (s->batch_cap >= cap) return CRT_OK;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    void** drop[] = {(void**)&s->d_rays[0], (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T,
+                     (void**)&s->pb.seed, (void**)&s->d_lfinal};
+    for (void** p : drop) { if (*p) hipFree(*p); *p = nullptr; }
+    const size_t P = s->n_local_pixels;
+    s->sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096) * cap;
+    const size_t Q = 8 * (size_t)s->sub_capacity;
+    int rc;
+    if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
+    if ((rc = dev_alloc(&s->d_rays[1], 2 * Q))) return rc;
+    if ((rc = dev_alloc(&s->pb.L, P * cap))) return rc;
+    if ((rc = dev_alloc(&s->pb.T, P * cap))) return rc;
+    if ((rc = dev_alloc(&s->pb.seed, P * cap))) return rc;
+    if ((rc = dev_alloc(&s->d_lfinal, P * cap))) return rc;
+    HIPCHK(hipMemset(s->d_lfinal, 0, P * cap * sizeof(float4)));        // pixels outside the frame are never written: they stay zero
+    s->batch_cap = cap;
+    return CRT_OK;
+}
+
 // how many samples one launch may render: more than one only when nothing travels between launches (one path segment, shadow
 // rays walked in place) — bounce queues and the shadow queue hold one entry per pixel
 static uint32_t batch_limit(const crt_scene* s) {
     const bool inplace = s->accel != 0u || s->inplace_shadow != 0u;
     const bool compact = s->compact_shadow != 0u && s->tri_share == 0u && s->waves_per_workgroup > 1u;   // as launch_segment decides
-    return (s->max_depth == 1u && inplace && !compact && !s->count_visits) ? 8u : 1u;   // counting frames run one by one
+    if (!inplace || compact || s->count_visits) return 1u;            // counting frames run one by one
+    if (s->max_depth == 1u) return 8u;
+    // several segments: every sample keeps its own path state and queue entries (ensure_batch_buffers) and the samples' radiance is
+    // added in frame order by k_accumulate_samples; the bounce pools' hit buffer is not part of that
+    return s->bounce_refill ? 1u : 4u;
 }
 
 int crt_render_frame_async(crt_scene* s, float rx, float ry) { return render_batch_async(s, 1u, &rx, &ry); }

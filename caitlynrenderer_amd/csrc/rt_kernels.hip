@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(Segmen
         // the loop-carried state costs the single-sample kernel 50 bytes of scratch per lane otherwise.
         const uint32_t n_smp = BATCH ? a.n_samples : 1u;
         for (uint32_t smp = 0; smp < n_smp; ++smp) {
-        const float rv = BATCH ? a.rv_s[smp] : f.rv;
+        float rv = BATCH ? a.rv_s[smp] : f.rv;
         bool active = e < n;
         uint32_t pix = 0;
         vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(Segmen
         bool is_specular = true, true_area = false;
         if (FIRST) {                                        // path_trace.fs:1026-1047
             uint32_t px = 0, py = 0;
-            pix = e;
+            pix = BATCH ? smp * f.n_local_pixels + e : e;     // the path's id: its pixel, or (sample, pixel) when a launch renders several samples
             active = active && pixel_of(f, e, px, py);
             sx = (float)px + 0.5f; sy = (float)py + 0.5f;
             const float W = (float)f.width, H = (float)f.height;
@@ -931,6 +931,11 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(Segmen
             const float4 r0 = rq[0], r1 = rq[1];
             o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z);
             pix = __float_as_uint(r1.w);
+            if (a.l_final) {                               // a batched frame: the path belongs to sample pix / n_local_pixels, with that frame's randomVector
+                const uint32_t smp_of = pix / f.n_local_pixels;
+                rv = a.rv_s[0];
+                for (uint32_t k = 1; k < 4u; ++k) rv = smp_of == k ? a.rv_s[k] : rv;
+            }
             const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
             const float2 sd = a.pb.seed[pix];
             L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w;
@@ -1156,7 +1161,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(Segmen
             }
         }
         // a path that ends here with nothing pending adds its radiance to the running sum now
-        if (finished && !pending && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, pix, L);
+        if (finished && !pending) {
+            // several samples per launch on a path of several segments: the samples of a pixel finish in different launches, so each
+            // leaves its radiance at its own place and k_accumulate_samples adds them in the order the frames would have come
+            if (a.l_final) a.l_final[pix] = make_float4(L.x, L.y, L.z, 0.f);
+            else if (L.x != 0.f || L.y != 0.f || L.z != 0.f) add_to_sum(a.sum, (FIRST && BATCH) ? e : pix, L);
+        }
         if (COMPACT) {
             // ---- gather the workgroup's shadow rays into full waves (LDS), walk them, finish their paths ----
             const uint32_t W = blockDim.x >> 6;
@@ -1299,6 +1309,17 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
 }
 
 // packed tile-major -> linear frame (bottom row first); pixels of other ranks stay untouched.
+// sum[p] = (((sum[p] + L_0[p]) + L_1[p]) + ...): what n consecutive frames would have added, in their order, zero radiance skipped
+// as add_to_sum's callers skip it
+__global__ void __launch_bounds__(256) k_accumulate_samples(float* __restrict__ sum, const float4* __restrict__ l_final, uint32_t n_pixels, uint32_t n_samples) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    for (uint32_t smp = 0; smp < n_samples; ++smp) {
+        const float4 l = l_final[(size_t)smp * n_pixels + p];
+        if (l.x != 0.f || l.y != 0.f || l.z != 0.f) add_to_sum(sum, p, V3(l.x, l.y, l.z));
+    }
+}
+
 __global__ void __launch_bounds__(256) k_untile(FrameArgs f, const float* __restrict__ packed, float* __restrict__ linear) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < f.n_local_pixels; i += gridDim.x * blockDim.x) {
         uint32_t px, py;
@@ -1445,6 +1466,9 @@ void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t wave
     const size_t lds = waves * stack_bytes(a.stack_entries);
     if (stats) launch(k_shadow<true>, g, b, lds, stream, a);
     else       launch(k_shadow<false>, g, b, lds, stream, a);
+}
+void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pixels, uint32_t n_samples, hipStream_t stream) {
+    hipLaunchKernelGGL(k_accumulate_samples, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, sum, l_final, n_pixels, n_samples);
 }
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_untile, dim3(grid), dim3(256), 0, stream, f, packed, linear);

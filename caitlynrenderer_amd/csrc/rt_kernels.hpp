@@ -37,7 +37,7 @@ struct Bvh2Args {               // the reference's live BVH2 walk (path_trace.fs
     uint32_t* overflow;
 };
 
-struct PathBuffers {           // indexed by local pixel; touched only by paths longer than one segment
+struct PathBuffers {           // indexed by path = local pixel (+ sample * n_local_pixels in a batched launch); touched only by paths longer than one segment
     float4* L;                 // radiance so far, prev_pdf
     float4* T;                 // throughput, is_specular
     float2* seed;              // shader RNG state (path_trace.fs:27)
@@ -88,6 +88,8 @@ struct SegmentArgs {
     uint32_t* zero_counts;     // FIRST: the other frame's counter bank, cleared here for the next frame (no memset launch)
     uint32_t n_zero;
     uint32_t* overflow;        // += 1 per dropped stack push
+    float4* l_final;           // crt_render_frames on paths of several segments: where a finished path leaves its radiance, indexed like
+                               // the path state by sample * n_local_pixels + pixel; k_accumulate_samples adds them to `sum` in sample order
     uint32_t* tile_cost;       // FIRST, optional: += the clock ticks every wave spent on a tile's pixels, per local tile (feeds tile_order)
     uint32_t n_samples;        // FIRST: samples per pixel rendered by this launch (>= 1); > 1 only for one-segment paths walked in place
     float rv_s[8];             // randomVector.x * randomVector.y of each of them (f.rv = rv_s[0])
@@ -132,6 +134,7 @@ void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, ui
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
+void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pixels, uint32_t n_samples, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 
