@@ -289,7 +289,7 @@ def live_pmc(workloads, budget_s=240.0):
             if ok:
                 e = pt.entry_from_dirs(dirs, key)
                 if e and "l2_fabric_bytes_per_launch" in e:
-                    e["samples_per_launch"] = spp if depth == 1 else 1        # what one launch of the pass rendered (crt_render_frames)
+                    e["samples_per_launch"] = spp                              # what one launch of the pass rendered (crt_render_frames)
                     _LIVE_PMC[key] = e
                     log(f"[bench] live pmc {key}: {e['l2_fabric_bytes_per_launch']} B/launch L2<->fabric, valu_issue {e.get('valu_issue')}")
     finally:
@@ -571,7 +571,7 @@ def main():
     if (args.gpus == 1 and "RANK" not in os.environ and args.workload == "auto" and args.accel == "cwbvh"
             and not (args.dry_run or args.no_live_pmc or args.option)):
         # hardware counters of this very run, from child processes, before this process makes its first GPU call
-        live_pmc([("cornell", args.depth, args.spp or 1)] + ([] if args.no_extra else [("mesh1m", 1, 4), ("mesh1m", 4, 1)]))
+        live_pmc([("cornell", args.depth, args.spp or 1)] + ([] if args.no_extra else [("mesh1m", 1, 4), ("mesh1m", 4, 4)]))
 
     ctx = Ctx(args)
     if ctx.world != args.gpus:
@@ -609,8 +609,8 @@ def main():
             if N == 1:
                 extra["north_star"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, True, "weak")
                 extra["north_star_gpu_tree"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, False, "weak", device_built="sah")
-                extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak")
-                extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 1, True, False, "weak", materials="disney")
+                extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak")
+                extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak", materials="disney")
                 extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
                 extra["cornell_8_frames_per_launch"] = run_block(ctx, "cornell", 1920, 1080, 1, 8, True, False, "weak")
             elif args.scaling == "strong":

@@ -784,7 +784,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
     if (s->n_local_pixels == 0) return CRT_OK;
     const uint32_t P = s->n_local_pixels;
     const bool deferred = n_samples > 1u && s->max_depth > 1u;       // finished paths leave their radiance in d_lfinal
-    if (deferred && (rc = ensure_batch_buffers(s, 4u))) return rc;
+    if (deferred && (rc = ensure_batch_buffers(s, n_samples))) return rc;   // grows to the largest batch ever asked for
     const float rx = rxs[0], ry = rys[0];
     const crt::FrameArgs f = frame_args(s, rx, ry);
     if (!s->timing_accumulate) s->n_spans = 0;
@@ -959,7 +959,7 @@ static uint32_t batch_limit(const crt_scene* s) {
     if (s->max_depth == 1u) return 8u;
     // several segments: every sample keeps its own path state and queue entries (ensure_batch_buffers) and the samples' radiance is
     // added in frame order by k_accumulate_samples; the bounce pools' hit buffer is not part of that
-    return s->bounce_refill ? 1u : 4u;
+    return s->bounce_refill ? 1u : 8u;         // 1 M triangles, 4 segments: 1.78 / 1.61 / 1.50 / 1.45 ms per frame at 1 / 2 / 4 / 8 frames per launch
 }
 
 int crt_render_frame_async(crt_scene* s, float rx, float ry) { return render_batch_async(s, 1u, &rx, &ry); }

@@ -934,7 +934,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(Segmen
             if (a.l_final) {                               // a batched frame: the path belongs to sample pix / n_local_pixels, with that frame's randomVector
                 const uint32_t smp_of = pix / f.n_local_pixels;
                 rv = a.rv_s[0];
-                for (uint32_t k = 1; k < 4u; ++k) rv = smp_of == k ? a.rv_s[k] : rv;
+                for (uint32_t k = 1; k < 8u; ++k) rv = smp_of == k ? a.rv_s[k] : rv;
             }
             const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
             const float2 sd = a.pb.seed[pix];

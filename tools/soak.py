@@ -69,7 +69,7 @@ for case in range(n_cases):
         scene.render_frames(rvs)
         tot = np.zeros(2, np.int64)
         last = np.zeros(2, np.int64)
-        per_launch = 8 if (depth == 1 and (accel != 0 or opts.get("inplace_shadow", 1) == 1)
+        per_launch = 8 if ((accel != 0 or opts.get("inplace_shadow", 1) == 1) and (depth == 1 or not opts.get("bounce_refill", 0))
                            and not (opts.get("compact_shadow", 1) and opts.get("tri_share", 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
         in_last = n_fr - ((n_fr - 1) // per_launch) * per_launch
         for k, (rx, ry) in enumerate(rvs):
