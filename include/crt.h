@@ -144,10 +144,14 @@ int crt_render_frame(crt_scene* s, float rx, float ry);
  * stream; crt_sync (or any read-back call) waits for them. */
 int crt_render_frame_async(crt_scene* s, float rx, float ry);
 /* n consecutive frames: exactly what n calls of crt_render_frame with (rx[i], ry[i]) add to the sum buffer, bit for bit.
- * When nothing travels between launches — a one-segment path (max_depth 1) whose shadow rays are walked in place — up to
- * 8 of them share one launch (each lane renders its pixel's samples one after the other), which saves their launch gaps and
- * kernel tails; otherwise the frames are simply queued one by one.  crt_get_frame_stats then describes the last launch
- * (ray and visit counts summed over the samples it rendered). */
+ * With the shadow rays walked in place (the default) up to 8 of them share a launch: on a one-segment path (max_depth 1)
+ * each lane renders its pixel's samples one after the other; on longer paths every sample keeps its own path state and
+ * queue entries, all samples' rays go through each segment's launch together, and a last kernel adds the samples'
+ * radiance to the sum in frame order (the extra buffers, ~250 B per pixel and frame of the batch, are allocated by the
+ * first such call).  That saves the launch gaps and kernel tails between frames (1 M triangles: 0.246 -> 0.235 ms per
+ * frame at max_depth 1, 1.78 -> 1.45 ms at max_depth 4).  Otherwise (shadow queue, bounce pools, counting frames) the
+ * frames are simply queued one by one.  crt_get_frame_stats then describes the last launch (ray and visit counts summed
+ * over the samples it rendered). */
 int crt_render_frames(crt_scene* s, uint32_t n, const float* rx, const float* ry);
 int crt_render_frames_async(crt_scene* s, uint32_t n, const float* rx, const float* ry);
 int crt_sync(crt_scene* s);
