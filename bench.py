@@ -13,7 +13,7 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
     "north_star"                     = configs[2]: the 1,004,672-triangle mesh, 4 spp per step, 1920x1080, primary + shadow —
                                        the workload BASELINE.json's targets are quoted on, with its own roofline and cpu_baseline;
     "north_star_gpu_tree"            = the same over a tree built on the GPU (binned SAH, everything assembled in HBM);
-    "incoherent" / "incoherent_disney" = configs[3]: same mesh, 4 path segments (incoherent bounce rays), with the reference's
+    "incoherent" / "incoherent_disney" = configs[3]: same mesh and 4 spp per step, 4 path segments (incoherent bounce rays), with the reference's
                                        Lambert integrator and with the oracle-defined mirror + GGX/Disney-diffuse materials;
     "scale_base"                     = configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines
                                        divide by);
@@ -629,7 +629,8 @@ def main():
         descr = {"north_star": "BASELINE.json configs[2] — the workload its targets (>= 1 Gray/s, >= 50 % HBM roofline) are quoted on",
                  "north_star_gpu_tree": "configs[2] again, over a tree built on the GPU: crt_scene_create with CRT_BUILD_LBVH_ON_DEVICE | CRT_BUILD_SAH "
                                         "(binned-SAH BVH2, CWBVH conversion and records all in HBM; config.device_build has the times) instead of the host SBVH",
-                 "incoherent": "BASELINE.json configs[3] ray mix with the reference's own (Lambert-only) integrator — 4 path segments on the same mesh",
+                 "incoherent": "BASELINE.json configs[3] ray mix with the reference's own (Lambert-only) integrator — 4 path segments on the same mesh, "
+                               "4 spp per step as in configs[2] (the step's four frames share each segment's launch: crt_render_frames)",
                  "incoherent_disney": "BASELINE.json configs[3] as worded: 4 path segments with a mirror tall box and GGX / Disney-diffuse short "
                                       "box and floor (the material model has no reference code: oracle-defined, HIP == oracle bit for bit)",
                  "scale_base": "BASELINE.json configs[4] at N = 1: what the N > 1 lines of `bench.py --gpus N` divide by",
