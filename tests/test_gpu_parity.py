@@ -549,6 +549,11 @@ def test_cpp_host_scene_matches_python_path(cr, ob, cornell, tmp_path):
     from caitlynrenderer_amd import host
     png = host.decode_image(open(tmp_path / "o.png", "rb").read())
     assert png.shape == (H, W, 3) and png.std() > 5
+    # the same with three path segments: the frames share each segment's launch, the sums are those of `frames` single frames above
+    out = subprocess.run([os.path.join(ROOT, "examples", "render_obj"), obj, str(tmp_path / "o3.ppm"), str(W), str(H), str(frames),
+                          str(depth), str(tmp_path / "sum3.f32")], capture_output=True, text=True, env=dict(os.environ, RENDER_OBJ_BATCHED="1"))
+    assert out.returncode == 0, out.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "sum3.f32", np.float32).reshape(H, W, 3).view(np.uint32), ref.view(np.uint32))
     scene = cr.Scene(data, W, H, depth)
     for _ in range(frames):
         scene.Render()
