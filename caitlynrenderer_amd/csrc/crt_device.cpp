@@ -959,7 +959,10 @@ static uint32_t batch_limit(const crt_scene* s) {
     if (s->max_depth == 1u) return 8u;
     // several segments: every sample keeps its own path state and queue entries (ensure_batch_buffers) and the samples' radiance is
     // added in frame order by k_accumulate_samples; the bounce pools' hit buffer is not part of that
-    return s->bounce_refill ? 1u : 8u;         // 1 M triangles, 4 segments: 1.78 / 1.61 / 1.50 / 1.45 ms per frame at 1 / 2 / 4 / 8 frames per launch
+    if (s->bounce_refill) return 1u;
+    // path ids are sample * n_local_pixels + pixel and must stay below 2^31 (bit 31 tags queue entries)
+    const uint64_t fit = s->n_local_pixels ? 0x7fffffffull / s->n_local_pixels : 8ull;
+    return (uint32_t)std::min<uint64_t>(8ull, std::max<uint64_t>(1ull, fit));         // 1 M triangles, 4 segments: 1.78 / 1.61 / 1.50 / 1.45 ms per frame at 1 / 2 / 4 / 8 frames per launch
 }
 
 int crt_render_frame_async(crt_scene* s, float rx, float ry) { return render_batch_async(s, 1u, &rx, &ry); }
