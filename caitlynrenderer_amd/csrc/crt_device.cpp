@@ -112,6 +112,21 @@ struct crt_scene {
     // segments >= 1: 0 = fused lock-step k_segment (default: with the shadow rays walked in place it beats the pools,
     // 1.87 vs 2.09 ms for 4 segments at 1 M triangles); 1 = closest hits through lane-refill pools (k_closest_queue) + shade-only pass
     uint32_t bounce_refill = 0;
+    // crt_render_frames: the samples of a launch on the waves of a workgroup (0 never, 1 always, 2 when the launch is bound by its
+    // longest waves rather than by throughput)
+    uint32_t wave_samples = 2;
+    float tile_cost_spread = 0.f;       // 99th percentile of the measured tile costs over their mean; 0 = nothing measured yet
+    bool use_wave_samples() const {
+        if (wave_samples != 2u) return wave_samples != 0u;
+        // One wave renders the n samples of its 64 pixels one after the other: the launch cannot end before the most expensive
+        // waves have done n samples, c99 * n, while the chip needs about mean * n * waves / slots for all of them.  When the first
+        // is the larger, the samples go on 4 waves side by side (1 M triangles at 1080p, 8 frames per launch: 1/4 of the frame
+        // 0.133 -> 0.062 ms per frame, 1/8 0.114 -> 0.039; the whole frame is throughput-bound and stays as it is, and so does a
+        // Cornell box down to 1/4 of the frame — its waves are short and four times as many of them cost more than they save).
+        const double waves = (double)(n_local_pixels + 63u) / 64.0, slots = (double)n_cu * 4.0 * 5.0;
+        if (tile_cost_spread == 0.f) return waves <= 2.0 * slots;
+        return (double)tile_cost_spread * slots >= 0.9 * waves;
+    }
     crt::PathBuffers pb{};
     uint32_t stack_entries = CRT_STACK_ENTRIES;
     uint32_t sub_capacity = 0;                // entries per sub-queue (8 per queue)
@@ -275,6 +290,7 @@ int alloc_frame_buffers(crt_scene* s) {
         s->tile_state = crt_scene::TILES_WANT;
         s->tile_order_uploading = false;
         s->tiles_measured_once = false;
+        s->tile_cost_spread = 0.f;
     }
     if ((rc = dev_alloc(&s->d_sum, 3 * P))) return rc;
     HIPCHK(hipMemset(s->d_sum, 0, 3 * std::max<size_t>(P, 1) * sizeof(float)));
@@ -735,6 +751,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
+    else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "waves_per_workgroup")) {
         if (value != 1 && value != 2 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: waves_per_workgroup is 1, 2 or 4");
@@ -821,6 +838,10 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             const uint32_t* cost = s->h_tile_cost;
             std::sort(sorted.begin(), sorted.end(), [cost](uint32_t a, uint32_t b) { return cost[a] > cost[b] || (cost[a] == cost[b] && a < b); });
             const uint32_t tile_px = s->tile * s->tile, spu = tile_px < 4096u && 4096u % tile_px == 0u ? 4096u / tile_px : 1u;
+            // how far the expensive tiles stand above the rest (99th percentile over mean): what wave_samples = 2 decides on
+            uint64_t cost_sum = 0;
+            for (uint32_t i = 0; i < nt; ++i) cost_sum += cost[i];
+            s->tile_cost_spread = cost_sum ? (float)((double)cost[sorted[nt / 100u]] * nt / (double)cost_sum) : 0.f;
             uint32_t next = 0;
             for (uint32_t k = 0; next < nt; ++k) {
                 row.clear();
@@ -881,6 +902,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.l_final = deferred ? s->d_lfinal : nullptr;
         sa.tile_cost = (b == 0 && measure_tiles) ? s->d_tile_cost : nullptr;
         sa.n_samples = b == 0 ? n_samples : 1u;
+        sa.wave_samples = (b == 0 && n_samples > 1u && s->use_wave_samples()) ? 1u : 0u;
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
         const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u && !s->special_materials;

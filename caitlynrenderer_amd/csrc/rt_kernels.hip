@@ -424,14 +424,15 @@ __device__ __forceinline__ uint32_t queue_chunks(uint32_t n) { return (((n + 63u
 // A workgroup is 4 waves (256 threads), 2 waves or a single wave: with fewer than 4 waves per workgroup, 4 / W
 // consecutive workgroups of the same XCD stand for one chunk, so the dispatcher refills CUs (half-)wave-pair by wave.
 struct WaveId { uint32_t lane, wave, lds_wave, vblock, vgrid; };
-__device__ __forceinline__ WaveId wave_id() {
+__device__ __forceinline__ WaveId wave_id(bool one_batch_per_workgroup = false) {
     WaveId w;
     w.lane = threadIdx.x & 63u;
     w.lds_wave = threadIdx.x >> 6;
-    // W = 1, 2 or 4 waves per workgroup: 4 / W consecutive workgroups of the same XCD slice stand for one 4-batch chunk
-    const uint32_t W = blockDim.x >> 6, per_log2 = W == 1u ? 2u : W == 2u ? 1u : 0u;
+    // W = 1, 2 or 4 waves per workgroup: 4 / W consecutive workgroups of the same XCD slice stand for one 4-batch chunk.
+    // one_batch_per_workgroup (wave_samples): the workgroup's waves all work on ONE batch, so it maps like a single wave.
+    const uint32_t W = one_batch_per_workgroup ? 1u : blockDim.x >> 6, per_log2 = W == 1u ? 2u : W == 2u ? 1u : 0u;
     const uint32_t q = blockIdx.x >> 3;
-    w.wave = (q & ((1u << per_log2) - 1u)) * W + w.lds_wave;
+    w.wave = (q & ((1u << per_log2) - 1u)) * W + (one_batch_per_workgroup ? 0u : w.lds_wave);
     w.vblock = ((q >> per_log2) << 3) | (blockIdx.x & 7u);
     w.vgrid = gridDim.x >> per_log2;
     return w;
@@ -839,7 +840,8 @@ template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool B
           bool BATCH = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
-    const WaveId wid = wave_id();
+    const bool wave_samples = BATCH && a.wave_samples != 0u;      // uniform: the workgroup's waves are the samples of one 64-pixel batch
+    const WaveId wid = wave_id(wave_samples);
     const uint32_t lane = wid.lane, wave = wid.wave;
     // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
     const uint32_t wave_stride = (COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) * 64u;
@@ -892,10 +894,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(Segmen
         // other — exactly what the same number of launches would do to this pixel, without their launch gaps and kernel
         // tails (1 M triangles, 4 samples: 0.299 -> 0.276 ms per frame; Cornell 0.080 -> 0.064).  A separate instantiation:
         // the loop-carried state costs the single-sample kernel 50 bytes of scratch per lane otherwise.
-        const uint32_t n_smp = BATCH ? a.n_samples : 1u;
-        for (uint32_t smp = 0; smp < n_smp; ++smp) {
-        float rv = BATCH ? a.rv_s[smp] : f.rv;
-        bool active = e < n;
+        const uint32_t ws_waves = blockDim.x >> 6;           // wave_samples: wave w renders samples w, w + W, w + 2 W, ...
+        const uint32_t n_smp = BATCH ? (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : a.n_samples) : 1u;
+        for (uint32_t smp_it = 0; smp_it < n_smp; ++smp_it) {
+        const uint32_t smp = wave_samples ? smp_it * ws_waves + wid.lds_wave : smp_it;
+        float rv = BATCH ? a.rv_s[smp & 7u] : f.rv;
+        bool active = e < n && (!wave_samples || smp < a.n_samples);
         uint32_t pix = 0;
         vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
         vec3 L = V3(0.f, 0.f, 0.f), T = V3(1.f, 1.f, 1.f);
@@ -1165,7 +1169,23 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(Segmen
             // several samples per launch on a path of several segments: the samples of a pixel finish in different launches, so each
             // leaves its radiance at its own place and k_accumulate_samples adds them in the order the frames would have come
             if (a.l_final) a.l_final[pix] = make_float4(L.x, L.y, L.z, 0.f);
-            else if (L.x != 0.f || L.y != 0.f || L.z != 0.f) add_to_sum(a.sum, (FIRST && BATCH) ? e : pix, L);
+            else if (!wave_samples && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, (FIRST && BATCH) ? e : pix, L);
+        }
+        if (wave_samples && !a.l_final) {
+            // the waves' samples of this batch, added in sample order by wave 0 (what the frames one after the other would add)
+            // behind the workgroup's stacks, whose size per wave is the larger of the two kinds of stack as in launch_segment
+            const uint32_t stack_words = BVH2 && a.stack_entries2 * 64u > 2u * wave_stride ? a.stack_entries2 * 64u : 2u * wave_stride;
+            float4* const s_res = reinterpret_cast<float4*>(reinterpret_cast<uint32_t*>(s_lds) + (size_t)ws_waves * stack_words);
+            const bool mine = finished && !pending;
+            s_res[wid.lds_wave * 64u + lane] = mine ? make_float4(L.x, L.y, L.z, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+            if (wid.lds_wave == 0u && e < n) {
+                for (uint32_t k = 0; k < ws_waves && smp_it * ws_waves + k < a.n_samples; ++k) {
+                    const float4 r = s_res[k * 64u + lane];
+                    if (r.w != 0.f && (r.x != 0.f || r.y != 0.f || r.z != 0.f)) add_to_sum(a.sum, e, V3(r.x, r.y, r.z));
+                }
+            }
+            __syncthreads();                                       // persistent grids: the next pass reuses the strip
         }
         if (COMPACT) {
             // ---- gather the workgroup's shadow rays into full waves (LDS), walk them, finish their paths ----
@@ -1424,6 +1444,21 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
     if (a.n_samples > 1u) {
         // several samples per launch: first segment of a one-segment path, shadow rays in place, no counting, no shadow-ray compaction
         // (crt_device.cpp batch_limit)
+        const uint32_t ws = a.n_samples <= 2u ? 2u : 4u;
+        const size_t lds4 = ws * per_wave + ws * 64 * sizeof(float4);
+        SegmentArgs seq = a;                         // the sequential form, should the stacks and the result strip not fit
+        seq.wave_samples = 0u;
+        if (a.wave_samples && lds4 > 64u * 1024u) return launch_segment(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
+        if (a.wave_samples) {
+            // the samples on the 2 or 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups
+            const dim3 g4(grid * 4u), b4(ws * 64u);
+#define CRT_LAUNCH_WS(T, B2, M) launch(k_segment<true, false, T, false, true, B2, M, false, false, true>, g4, b4, lds4, stream, a)
+            if (bvh2) { if (tex) CRT_LAUNCH_WS(true, true, false); else CRT_LAUNCH_WS(false, true, false); }
+            else if (mat) { if (tex) CRT_LAUNCH_WS(true, false, true); else CRT_LAUNCH_WS(false, false, true); }
+            else { if (tex) CRT_LAUNCH_WS(true, false, false); else CRT_LAUNCH_WS(false, false, false); }
+#undef CRT_LAUNCH_WS
+            return;
+        }
 #define CRT_LAUNCH_BATCH(T, B2, M, SH) launch(k_segment<true, false, T, false, true, B2, M, false, SH, true>, g, b, lds, stream, a)
         if (bvh2) { if (tex) CRT_LAUNCH_BATCH(true, true, false, false); else CRT_LAUNCH_BATCH(false, true, false, false); }
         else if (share) {

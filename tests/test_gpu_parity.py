@@ -126,11 +126,12 @@ def test_tile_processing_order_changes_nothing_but_the_time(cr, ob, cornell, tes
 
 @pytest.mark.parametrize("name", ["cornell", "tess8", "tess8_mat", "textured"])
 def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8, textured, name):
-    """crt_render_frames: n frames in ceil(n / 8) launches on a one-segment path walked in place (each lane renders its pixel's
-    samples one after the other); on paths of several segments up to 4 frames share each segment's launch (per-sample path state, the
-    samples' radiance added in frame order by a last kernel); frame by frame otherwise.  The sum buffer is the same bit for bit either
-    way, and equal to the oracle's.  Sharded frames, the BVH2 walks, the new materials, textures, the shadow queue, the bounce pools
-    and 2 - 4 segments are all in the loop."""
+    """crt_render_frames: n frames in ceil(n / 8) launches on a one-segment path walked in place; on paths of several segments up to
+    8 frames share each segment's launch (per-sample path state, the samples' radiance added in frame order by a last kernel); frame
+    by frame otherwise.  The samples of a launch's first segment sit on the waves of a workgroup (wave_samples: what a frame this
+    small picks by itself, added in sample order through LDS) or follow one another in one wave (wave_samples = 0).  The sum buffer
+    is the same bit for bit every way, and equal to the oracle's.  Sharded frames, the BVH2 walks, the new materials, textures, the
+    shadow queue, the bounce pools and 2 - 4 segments are all in the loop."""
     from caitlynrenderer_amd.meshgen import tessellated_cornell, with_disney_materials
     mesh_c, cam = cornell
     if name == "cornell":
@@ -146,7 +147,9 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(19)]                  # 19 = 8 + 8 + 3
     for depth, opts, shard in ((1, {}, None), (1, {"tri_share": 0}, None), (1, {"accel": 1}, None), (1, {"inplace_shadow": 0}, None),
                                (2, {}, None), (1, {"waves_per_workgroup": 4}, (1, 3)), (4, {}, None), (3, {"tri_share": 1}, (0, 2)),
-                               (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None)):
+                               (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None),
+                               (1, {"wave_samples": 0}, None), (3, {"wave_samples": 0}, (1, 2)), (1, {"wave_samples": 1, "accel": 1}, (2, 3)),
+                               (4, {"wave_samples": 1, "tri_share": 2}, None)):
         if name in ("tess8_mat",) and opts.get("accel"):
             continue                                                          # the BVH2 frame mode is the Lambert-only shader
         a, b = cr.Scene(data, W, H, depth), cr.Scene(data, W, H, depth)
