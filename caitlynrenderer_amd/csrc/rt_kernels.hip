@@ -1444,13 +1444,14 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
     if (a.n_samples > 1u) {
         // several samples per launch: first segment of a one-segment path, shadow rays in place, no counting, no shadow-ray compaction
         // (crt_device.cpp batch_limit)
-        const uint32_t ws = a.n_samples <= 2u ? 2u : 4u;
+        // as few passes as 4 waves allow, and no more waves than those passes need (5 samples: 2 passes of 3 waves)
+        const uint32_t ws_passes = (a.n_samples + 3u) / 4u, ws = (a.n_samples + ws_passes - 1u) / ws_passes;
         const size_t lds4 = ws * per_wave + ws * 64 * sizeof(float4);
         SegmentArgs seq = a;                         // the sequential form, should the stacks and the result strip not fit
         seq.wave_samples = 0u;
         if (a.wave_samples && lds4 > 64u * 1024u) return launch_segment(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
         if (a.wave_samples) {
-            // the samples on the 2 or 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups
+            // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups
             const dim3 g4(grid * 4u), b4(ws * 64u);
 #define CRT_LAUNCH_WS(T, B2, M) launch(k_segment<true, false, T, false, true, B2, M, false, false, true>, g4, b4, lds4, stream, a)
             if (bvh2) { if (tex) CRT_LAUNCH_WS(true, true, false); else CRT_LAUNCH_WS(false, true, false); }

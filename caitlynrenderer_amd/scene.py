@@ -128,7 +128,8 @@ class Scene:
 
     def render_frames(self, rvs, sync=True):
         """crt_render_frames: rvs = sequence of (rx, ry); the same sums as render_frame per pair, fewer launches where
-        the path allows (one segment, shadow rays in place: up to 8 samples per launch)."""
+        the path allows (shadow rays in place: up to 8 samples per launch; on a shard or a small frame the samples of a
+        launch run side by side on the waves of a workgroup, option "wave_samples")."""
         rx = np.ascontiguousarray([r[0] for r in rvs], dtype=np.float32)
         ry = np.ascontiguousarray([r[1] for r in rvs], dtype=np.float32)
         fn = lib().crt_render_frames if sync else lib().crt_render_frames_async

@@ -188,7 +188,7 @@ int crt_sync(crt_scene* s);
  *     "compact_shadow"    1 (default): with 2 or 4 waves per workgroup and in-place shadows, the workgroup's NEE shadow rays
  *                         are gathered through LDS into full waves before they are walked; 0: every wave walks its own
  *     "wave_samples"      crt_render_frames, first segment: where the samples of a 64-pixel batch run.  0 = one after the other
- *                         in one wave; 1 = side by side on the 2 or 4 waves of one workgroup, added to the sum in sample order
+ *                         in one wave; 1 = side by side on the 2 to 4 waves of one workgroup, added to the sum in sample order
  *                         through LDS (the same bits); 2 (default) = 1 when the launch would otherwise be bound by its longest
  *                         waves — a shard of a frame, a small frame — as judged from the measured tile costs, else 0 */
 int crt_set_option(crt_scene* s, const char* name, int value);
