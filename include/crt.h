@@ -145,7 +145,9 @@ int crt_render_frame(crt_scene* s, float rx, float ry);
 int crt_render_frame_async(crt_scene* s, float rx, float ry);
 /* n consecutive frames: exactly what n calls of crt_render_frame with (rx[i], ry[i]) add to the sum buffer, bit for bit.
  * With the shadow rays walked in place (the default) up to 8 of them share a launch: on a one-segment path (max_depth 1)
- * each lane renders its pixel's samples one after the other; on longer paths every sample keeps its own path state and
+ * each lane renders its pixel's samples one after the other — or, where the launch has too few waves to fill the GPU (a shard
+ * from crt_set_shard, a small frame), the samples run side by side on the waves of a workgroup and are added in frame order
+ * (option "wave_samples"); on longer paths every sample keeps its own path state and
  * queue entries, all samples' rays go through each segment's launch together, and a last kernel adds the samples'
  * radiance to the sum in frame order (the extra buffers, ~250 B per pixel and frame of the batch, are allocated by the
  * first such call).  That saves the launch gaps and kernel tails between frames (1 M triangles: 0.246 -> 0.235 ms per
