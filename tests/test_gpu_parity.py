@@ -649,7 +649,8 @@ def test_config4_million_triangles_four_segments(cr, ob, mesh1m):
 def test_config5_4k_frame_of_the_million_triangle_mesh(cr, ob, mesh1m):
     """BASELINE configs[4]'s workload: the 3840x2160 frame (2,040 tiles of 64x64) of the 1,004,672-triangle mesh.  The whole
     frame on one rank and ranks 0, 3 and 7 of 8 are each bit-identical to the oracle on their pixels (ray counts included for the
-    full frame); the eight shards are disjoint and cover the frame, so composing them is the single-GPU frame."""
+    full frame); the eight shards are disjoint and cover the frame, so composing them is the single-GPU frame.  Rank 5 of 8 then
+    renders five frames in one crt_render_frames launch over 16x16 tiles, as the bench's ranks do, in both launch forms."""
     from caitlynrenderer_amd import tiles
     _, data, cam = mesh1m
     W, H = 3840, 2160
@@ -676,6 +677,24 @@ def test_config5_4k_frame_of_the_million_triangle_mesh(cr, ob, mesh1m):
             mine[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = True
         assert np.array_equal(part[mine].view(np.uint32), ref[mine].view(np.uint32)) and not part[~mine].any(), r
         assert shard.packed_info()[0] == len(tiles.local_tiles(W, H, 64, r, 8)) == 255
+        shard.close()
+    # what a rank of the N = 8 bench does: its 16x16 tiles, a step's frames through crt_render_frames — 5 frames in one launch, the
+    # samples one after the other in each wave and side by side on the waves of a workgroup (3 waves, two passes)
+    rnd = cr.Rnd()
+    rvs = [(RX1, RY1)] + [(rnd.randf2(), rnd.randf2()) for _ in range(4)]
+    for rv in rvs[1:]:
+        orc.render_frame(rv[0], rv[1], ref, threads=16)
+    mine = np.zeros((H, W), bool)
+    for tx, ty in tiles.local_tiles(W, H, 16, 5, 8):
+        mine[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    for ws in (0, 1):
+        shard = cr.Scene(data, W, H, 1)
+        shard.set_option("wave_samples", ws)
+        shard.set_shard(5, 8, 16)
+        shard.render_frames(rvs)
+        part = shard.read_sum()
+        assert np.array_equal(part[mine].view(np.uint32), ref[mine].view(np.uint32)) and not part[~mine].any(), ws
+        assert shard.frame_stats()["closest_rays"] == 5 * int(mine.sum()) and shard.frame_stats()["stack_overflows"] == 0
         shard.close()
 
 
