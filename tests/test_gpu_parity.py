@@ -622,7 +622,8 @@ def test_config4_million_triangles_four_segments(cr, ob, mesh1m):
     """BASELINE configs[3] at full size: the 1,004,672-triangle CWBVH, 4 path segments (incoherent bounce rays), 1920x1080.
     Two frames; after each the accumulated radiance is bit-identical to the oracle's, the closest / any-hit ray counts and the
     node / triangle visit totals are equal, and no stack push was dropped.  (The reference has no BSDF but Lambert —
-    path_trace.fs:274-310 — so this is its integrator run one segment longer than the shader's hard-coded 3, :867.)"""
+    path_trace.fs:274-310 — so this is its integrator run one segment longer than the shader's hard-coded 3, :867.)  Then three
+    frames through one crt_render_frames call, as the bench's step renders them."""
     _, data, cam = mesh1m
     W, H, depth = 1920, 1080, 4
     scene = cr.Scene(data, W, H, depth)
@@ -630,8 +631,10 @@ def test_config4_million_triangles_four_segments(cr, ob, mesh1m):
     scene.set_option("count_visits", 1)
     rnd = cr.Rnd()
     ref = np.zeros((H, W, 3), np.float32)
+    rvs = []
     for frame in range(2):
         rx, ry = rnd.randf2(), rnd.randf2()
+        rvs.append((rx, ry))
         scene.render_frame(rx, ry)
         _, cnt = orc.render_frame(rx, ry, ref, threads=16)
         st = scene.frame_stats()
@@ -644,6 +647,17 @@ def test_config4_million_triangles_four_segments(cr, ob, mesh1m):
         out = scene.read_sum()
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
     scene.close()
+    # the bench's form of this workload: the frames of a step share each segment's launch (crt_render_frames, per-sample path
+    # state, radiance added in frame order at the end) — three frames at once, first segment in either launch form
+    rvs.append((rnd.randf2(), rnd.randf2()))
+    orc.render_frame(rvs[2][0], rvs[2][1], ref, threads=16)
+    for ws in (0, 1):
+        batched = cr.Scene(data, W, H, depth)
+        batched.set_option("wave_samples", ws)
+        batched.render_frames(rvs)
+        assert np.array_equal(batched.read_sum().view(np.uint32), ref.view(np.uint32)), ws
+        assert batched.frame_stats()["stack_overflows"] == 0
+        batched.close()
 
 
 def test_config5_4k_frame_of_the_million_triangle_mesh(cr, ob, mesh1m):
