@@ -81,6 +81,7 @@ SYMBOLS = {
     "crt_trace_device": (_I, [_P, _P, _SZ, _P, _I, _P, _I]),
     "crt_debug_read_queue": (_I, [_P, _I, _U32, _P, _SZ, C.POINTER(_SZ)]),
     "crt_debug_time_graph": (_I, [_P, _U32, _P, _U32, C.POINTER(_F), C.POINTER(_F)]),
+    "crt_debug_launch_form": (_I, [_P, C.POINTER(C.c_int32)]),
     "crt_set_shard": (_I, [_P, _U32, _U32, _U32]),
     "crt_packed_info": (_I, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_SZ)]),
     "crt_read_packed": (_I, [_P, _P, _SZ]),

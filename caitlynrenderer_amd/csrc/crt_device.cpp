@@ -116,6 +116,7 @@ struct crt_scene {
     // longest waves rather than by throughput)
     uint32_t wave_samples = 2;
     float tile_cost_spread = 0.f;       // 99th percentile of the measured tile costs over their mean; 0 = nothing measured yet
+    int last_launch_form = 0;           // crt_debug_launch_form
     bool use_wave_samples() const {
         if (wave_samples != 2u) return wave_samples != 0u;
         // One wave renders the n samples of its 64 pixels one after the other: the launch cannot end before the most expensive
@@ -903,6 +904,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.tile_cost = (b == 0 && measure_tiles) ? s->d_tile_cost : nullptr;
         sa.n_samples = b == 0 ? n_samples : 1u;
         sa.wave_samples = (b == 0 && n_samples > 1u && s->use_wave_samples()) ? 1u : 0u;
+        if (b == 0) s->last_launch_form = (int)sa.wave_samples;
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
         const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u && !s->special_materials;
@@ -1126,6 +1128,12 @@ int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
 
 // Debug/test hook: copy out one of the frame's ray queues as left by the last crt_render_frame.
 // which: 0/1 = path-ray queue written for an even/odd segment, 2 = shadow-ray queue of the last segment.
+int crt_debug_launch_form(crt_scene* s, int32_t* form) {
+    if (!s || !form) return fail(CRT_ERR_INVALID, "crt_debug_launch_form: null argument");
+    *form = s->last_launch_form;
+    return CRT_OK;
+}
+
 int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint32_t reps, float* ms_stream, float* ms_graph) {
     if (!s || !rxy || !ms_stream || !ms_graph || n_frames == 0 || (n_frames & 1u) || reps == 0)
         return fail(CRT_ERR_INVALID, "crt_debug_time_graph: bad argument (n_frames must be even: the counter banks alternate)");

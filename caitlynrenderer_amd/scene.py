@@ -172,6 +172,13 @@ class Scene:
         check(lib().crt_debug_read_queue(self._h, int(which), int(segment), _ptr(out), n.value, C.byref(n)))
         return out
 
+    def debug_launch_form(self):
+        """0: the last launch ran its samples one after the other in each wave (or had one); 1: side by side on the waves
+        of a workgroup (option "wave_samples")."""
+        form = C.c_int32()
+        check(lib().crt_debug_launch_form(self._h, C.byref(form)))
+        return form.value
+
     def set_shard(self, rank, world, tile=16):
         check(lib().crt_set_shard(self._h, int(rank), int(world), int(tile)))
 

@@ -215,6 +215,9 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
 /* measurement aid: the same n_frames (rxy = n_frames pairs) queued `reps` times on the stream and replayed `reps`
  * times as one captured hipGraph; device milliseconds per frame of either way ("hipGraph") */
 int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint32_t reps, float* ms_stream, float* ms_graph);
+/* test hook: how the last launch of crt_render_frame(s) ran the samples of its first segment: *form = 0 one sample, or several
+ * one after the other in each wave; 1 = side by side on the waves of a workgroup (option "wave_samples") */
+int crt_debug_launch_form(crt_scene* s, int32_t* form);
 
 /* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is
  * cut into tile x tile squares dealt round-robin in Morton order to `world` ranks;

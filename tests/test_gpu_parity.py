@@ -193,6 +193,37 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
     c.close()
 
 
+def test_launch_form_follows_the_size_of_the_launch(cr, cornell, tess8):
+    """wave_samples = 2 (default): a launch of crt_render_frames runs its samples side by side on the waves of a workgroup when it
+    has too few 64-pixel batches to fill the GPU's wave slots with their samples one after the other — a shard, a small frame —
+    and keeps them in one wave when it is bound by throughput (the whole 1080p frame: 32,400 batches on 5,120 slots).  The choice is
+    made from the measured tile costs once there are any; 0 and 1 force either form; a single frame has nothing to choose."""
+    _, data = tess8
+    _, cam = cornell
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(8)]
+    def forms(W, H, shard=None, option=None):
+        s = cr.Scene(data, W, H, 1)
+        s.update(cam)
+        if option is not None:
+            s.set_option("wave_samples", option)
+        if shard:
+            s.set_shard(shard[0], shard[1], 16)
+        out = []
+        for _ in range(4):                      # the first launch measures the tiles; a later one has adopted the costs
+            s.render_frames(rvs)
+            out.append(s.debug_launch_form())
+        s.render_frame(*rvs[0])
+        out.append(s.debug_launch_form())
+        s.close()
+        return out
+    assert forms(1920, 1080) == [0, 0, 0, 0, 0]
+    assert forms(1920, 1080, (3, 8)) == [1, 1, 1, 1, 0]
+    assert forms(320, 200) == [1, 1, 1, 1, 0]
+    assert forms(1920, 1080, (3, 8), option=0) == [0, 0, 0, 0, 0]
+    assert forms(1920, 1080, option=1) == [1, 1, 1, 1, 0]
+
+
 def test_edge_cases(cr, ob, scenes, cornell):
     scene, orc, _ = scenes["cornell"]
     assert len(scene.trace(np.zeros(0, cr.RAY_DT))) == 0                      # empty input
