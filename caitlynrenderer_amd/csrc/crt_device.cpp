@@ -115,10 +115,11 @@ struct crt_scene {
     // crt_render_frames: the samples of a launch on the waves of a workgroup (0 never, 1 always, 2 when the launch is bound by its
     // longest waves rather than by throughput)
     uint32_t wave_samples = 2;
+    uint32_t wide_first = 2;            // first-segment kernels built for 6 waves per SIMD: 0 never, 1 always, 2 by the same measure
     float tile_cost_spread = 0.f;       // 99th percentile of the measured tile costs over their mean; 0 = nothing measured yet
     int last_launch_form = 0;           // crt_debug_launch_form
-    bool use_wave_samples() const {
-        if (wave_samples != 2u) return wave_samples != 0u;
+    bool use_wave_samples() const { return wave_samples == 2u ? bound_by_longest_waves() : wave_samples != 0u; }
+    bool bound_by_longest_waves() const {
         // One wave renders the n samples of its 64 pixels one after the other: the launch cannot end before the most expensive
         // waves have done n samples, c99 * n, while the chip needs about mean * n * waves / slots for all of them.  When the first
         // is the larger, the samples go on 4 waves side by side (1 M triangles at 1080p, 8 frames per launch: 1/4 of the frame
@@ -753,6 +754,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
+    else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "waves_per_workgroup")) {
         if (value != 1 && value != 2 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: waves_per_workgroup is 1, 2 or 4");
@@ -904,6 +906,8 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.tile_cost = (b == 0 && measure_tiles) ? s->d_tile_cost : nullptr;
         sa.n_samples = b == 0 ? n_samples : 1u;
         sa.wave_samples = (b == 0 && n_samples > 1u && s->use_wave_samples()) ? 1u : 0u;
+        // the first segment's 6-wave build where the launch is bound by throughput, the 5-wave build where its longest waves set its length
+        sa.wide_first = (b == 0 && (s->wide_first == 2u ? !s->bound_by_longest_waves() : s->wide_first != 0u)) ? 1u : 0u;
         if (b == 0) s->last_launch_form = (int)sa.wave_samples;
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
@@ -922,7 +926,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         }
         // bounce launches of a batched frame may find up to n_samples rays per pixel in their queue
         const uint32_t items = (b > 0 && deferred) ? P * n_samples : P;
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, s->trace_grid(items, 5), s->waves_per_workgroup, s->stream);
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, s->trace_grid(items, sa.wide_first ? 6 : 5), s->waves_per_workgroup, s->stream);
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};

@@ -804,7 +804,13 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 
 // ------------------------------------------------------------------ path segment -----
 #ifndef CRT_SEG_OCC
-#define CRT_SEG_OCC 5        // waves per SIMD the segment kernel is compiled for (96 VGPRs); see the note above k_segment
+#define CRT_SEG_OCC 5        // waves per SIMD the bounce-segment kernels are compiled for (96 VGPRs); see the note above k_segment
+#endif
+#ifndef CRT_SEG_OCC_FIRST
+// The first-segment kernels (ray generation instead of a queue fetch and path state) can take 6 waves per SIMD at 80 VGPRs: same box,
+// three runs each, 5 / 6 / 7 / 8 waves: 1 M triangles 1080p 12,205 / 12,384 / 12,032 / 10,875 Mray/s, 4K 13,980 / 14,267 / 13,979 /
+// 12,759, Cornell 40,349 / 40,556 / 37,648 / 32,226.  The bounce kernels lose at 6 (spills: 1.77 -> 2.15 ms for 4 segments).
+#define CRT_SEG_OCC_FIRST 6
 #endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
@@ -812,8 +818,9 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // wave-ballot compaction.  Nothing but the two output queues (and, for paths that go on, 40 B of path
 // state) touches HBM; a path that ends here adds its radiance to the sum buffer directly.
 // TEX compiles the textured-albedo branch in (its double-precision pow costs registers the untextured path
-// should not pay for).  96-VGPR budget = 5 waves per SIMD; 80 and 64 were measured slower, and 80 again
-// under wave-granular dispatch: no change (0.225 vs 0.226 ms) with 56 bytes of scratch per lane.
+// should not pay for).  96-VGPR budget = 5 waves per SIMD for the bounce segments; the first segment runs at 80 VGPRs = 6 waves
+// (CRT_SEG_OCC_FIRST above: since the launch is scheduled by tile cost and every SIMD issues all the time, the sixth wave pays
+// for its scratch traffic; under round 1's schedule 80 was no faster, 0.225 vs 0.226 ms) and 64 is slower everywhere.
 // PRETRACED: the closest hit of each queue entry was found by k_closest_queue (incoherent bounce rays are
 // traced with lane refill, which cannot be fused with lock-step shading); the kernel then only shades.
 // INPLACE: the NEE shadow ray is walked right here (path_trace.fs:968, where the shader has it) instead of going
@@ -837,8 +844,8 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // == 2 also walks the in-place shadow rays that way.
 // BATCH (FIRST + INPLACE, a one-segment path): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.
 template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false, bool SHARE = false,
-          bool BATCH = false>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, CRT_SEG_OCC) k_segment(SegmentArgs a) {
+          bool BATCH = false, bool WIDE = false>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
     const bool wave_samples = BATCH && a.wave_samples != 0u;      // uniform: the workgroup's waves are the samples of one 64-pixel batch
     const WaveId wid = wave_id(wave_samples);
@@ -1429,6 +1436,13 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
         else       launch(k_trace_bvh2<false, false>, g, b, lds, stream, a);
     }
 }
+// The first-segment kernels exist twice: compiled for 5 waves per SIMD (96 VGPRs) and for 6 (80 VGPRs, a few more scratch accesses
+// per wave).  A launch that fills the chip several times over runs faster with the sixth wave (CRT_SEG_OCC_FIRST); one that is
+// only as long as its longest waves — a shard, a small frame, the side-by-side sample form — runs those waves faster without the
+// extra scratch traffic (1/8 of a 1080p frame, 4 samples side by side: 0.0453 ms per frame at 5 waves, 0.0503 at 6).  The host
+// says which (SegmentArgs::wide_first); counting kernels keep the one form.
+#define CRT_KSEG(F, S, T, P, Y, B, M, C, SH, BA) \
+    (a.wide_first ? k_segment<F, S, T, P, Y, B, M, C, SH, BA, (F) && !(S)> : k_segment<F, S, T, P, Y, B, M, C, SH, BA, false>)
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
 void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
@@ -1460,7 +1474,7 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
 #undef CRT_LAUNCH_WS
             return;
         }
-#define CRT_LAUNCH_BATCH(T, B2, M, SH) launch(k_segment<true, false, T, false, true, B2, M, false, SH, true>, g, b, lds, stream, a)
+#define CRT_LAUNCH_BATCH(T, B2, M, SH) launch(CRT_KSEG(true, false, T, false, true, B2, M, false, SH, true), g, b, lds, stream, a)
         if (bvh2) { if (tex) CRT_LAUNCH_BATCH(true, true, false, false); else CRT_LAUNCH_BATCH(false, true, false, false); }
         else if (share) {
             if (mat) { if (tex) CRT_LAUNCH_BATCH(true, false, true, true); else CRT_LAUNCH_BATCH(false, false, true, true); }
@@ -1473,12 +1487,12 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
         return;
     }
 #define CRT_LAUNCH_SEG(F, S, T, P, Y, B) do { \
-        if (share) { if (mat) launch(k_segment<F, S, T, false, true, false, true, false, true>, g, b, lds, stream, a); \
-                     else launch(k_segment<F, S, T, false, true, false, false, false, true>, g, b, lds, stream, a); } \
-        else if (compact) { if (mat) launch(k_segment<F, S, T, false, true, false, true, true>, g, b, lds, stream, a); \
-                       else launch(k_segment<F, S, T, false, true, false, false, true>, g, b, lds, stream, a); } \
-        else if (mat && !(P) && !(B)) launch(k_segment<F, S, T, false, Y, false, true>, g, b, lds, stream, a); \
-        else launch(k_segment<F, S, T, P, Y, B>, g, b, lds, stream, a); } while (0)
+        if (share) { if (mat) launch(CRT_KSEG(F, S, T, false, true, false, true, false, true, false), g, b, lds, stream, a); \
+                     else launch(CRT_KSEG(F, S, T, false, true, false, false, false, true, false), g, b, lds, stream, a); } \
+        else if (compact) { if (mat) launch(CRT_KSEG(F, S, T, false, true, false, true, true, false, false), g, b, lds, stream, a); \
+                       else launch(CRT_KSEG(F, S, T, false, true, false, false, true, false, false), g, b, lds, stream, a); } \
+        else if (mat && !(P) && !(B)) launch(CRT_KSEG(F, S, T, false, Y, false, true, false, false, false), g, b, lds, stream, a); \
+        else launch(CRT_KSEG(F, S, T, P, Y, B, false, false, false, false), g, b, lds, stream, a); } while (0)
 #define CRT_LAUNCH_SEG_T(F, S, P, Y, B) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y, B); else CRT_LAUNCH_SEG(F, S, false, P, Y, B); } while (0)
 #define CRT_LAUNCH_SEG_S(F, P, Y, B) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y, B); else CRT_LAUNCH_SEG_T(F, false, P, Y, B); } while (0)
     if (pretraced) { if (inplace) CRT_LAUNCH_SEG_S(false, true, true, false); else CRT_LAUNCH_SEG_S(false, true, false, false); }   // shade (+ shadow walk)

@@ -91,6 +91,7 @@ struct SegmentArgs {
     float4* l_final;           // crt_render_frames on paths of several segments: where a finished path leaves its radiance, indexed like
                                // the path state by sample * n_local_pixels + pixel; k_accumulate_samples adds them to `sum` in sample order
     uint32_t* tile_cost;       // FIRST, optional: += the clock ticks every wave spent on a tile's pixels, per local tile (feeds tile_order)
+    uint32_t wide_first;       // FIRST: 1 = the 6-waves-per-SIMD build of the kernel (launches bound by throughput), 0 = the 5-wave one
     uint32_t wave_samples;     // BATCH, one-segment paths: 1 = the launch's samples (2..4) sit on the waves of a 4-wave workgroup, one sample of
                                // the workgroup's 64 pixels each, and are added to the sum in sample order through LDS; 0 = one wave
                                // renders its pixels' samples one after the other

@@ -149,7 +149,7 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
                                (2, {}, None), (1, {"waves_per_workgroup": 4}, (1, 3)), (4, {}, None), (3, {"tri_share": 1}, (0, 2)),
                                (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None),
                                (1, {"wave_samples": 0}, None), (3, {"wave_samples": 0}, (1, 2)), (1, {"wave_samples": 1, "accel": 1}, (2, 3)),
-                               (4, {"wave_samples": 1, "tri_share": 2}, None)):
+                               (4, {"wave_samples": 1, "tri_share": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2))):
         if name in ("tess8_mat",) and opts.get("accel"):
             continue                                                          # the BVH2 frame mode is the Lambert-only shader
         a, b = cr.Scene(data, W, H, depth), cr.Scene(data, W, H, depth)

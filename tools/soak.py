@@ -52,6 +52,7 @@ for case in range(n_cases):
                     compact_shadow=int(rng.random() < 0.5))
     opts["adaptive_tiles"] = int(rng.random() < 0.7)          # cost-sorted or centre-out tile order: the same pixels either way
     opts["wave_samples"] = int(rng.choice([0, 1, 2]))         # the samples of a launch in one wave or on the waves of a workgroup
+    opts["wide_first"] = int(rng.choice([0, 1, 2]))           # the 5- or the 6-waves-per-SIMD build of the first-segment kernel
     for k, v in opts.items():
         scene.set_option(k, v)
     o_accel, o_tie = (ob.BVH8, ob.TIE_LOWEST_ID) if accel == 0 else (ob.BVH2, ob.TIE_FIRST_VISITED if accel == 1 else ob.TIE_LOWEST_ID)
