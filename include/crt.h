@@ -192,7 +192,10 @@ int crt_sync(crt_scene* s);
  *     "wave_samples"      crt_render_frames, first segment: where the samples of a 64-pixel batch run.  0 = one after the other
  *                         in one wave; 1 = side by side on the 2 to 4 waves of one workgroup, added to the sum in sample order
  *                         through LDS (the same bits); 2 (default) = 1 when the launch would otherwise be bound by its longest
- *                         waves — a shard of a frame, a small frame — as judged from the measured tile costs, else 0 */
+ *                         waves — a shard of a frame, a small frame — as judged from the measured tile costs, else 0
+ *     "wide_first"        which build of the first-segment kernel a launch runs: 0 = compiled for 5 waves per SIMD (96 VGPRs),
+ *                         1 = for 6 (80 VGPRs), 2 (default) = 6 where the launch is bound by throughput, 5 where its longest
+ *                         waves set its length (the same measure as "wave_samples") */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);
