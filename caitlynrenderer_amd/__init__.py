@@ -11,5 +11,11 @@ from .scene import HIT_DT, RAY_DT, STATS_DT, Scene, SceneData
 
 _lib.lib()   # fail loudly at import time if the HIP extension is missing
 
-__all__ = ["Scene", "SceneData", "Camera", "Mesh", "SBVH", "CWBVH", "Rnd", "pcg_hash", "CrtError",
+
+def has_experiments():
+    """True when libcrt.so was built with the experimental kernel variants (make EXPERIMENTS=1, include/crt.h crt_set_option)."""
+    return bool(_lib.lib().crt_has_experiments())
+
+
+__all__ = ["has_experiments", "Scene", "SceneData", "Camera", "Mesh", "SBVH", "CWBVH", "Rnd", "pcg_hash", "CrtError",
            "RAY_DT", "HIT_DT", "STATS_DT", "CRT_TRACE_CLOSEST", "CRT_TRACE_ANY", "CRT_TRACE_BVH2", "CRT_TRACE_TIE_LOWEST_ID"]

@@ -89,6 +89,7 @@ SYMBOLS = {
     "crt_get_frame_stats": (_I, [_P, C.POINTER(crt_frame_stats)]),
     "crt_get_bvh_info": (_I, [_P, C.POINTER(crt_bvh_info)]),
     "crt_device_count": (_I, []),
+    "crt_has_experiments": (_I, []),
     "crt_camera_look_at": (_I, [C.POINTER(_F), C.POINTER(_F), _F, C.POINTER(crt_camera)]),
     "crt_pcg_hash": (_U32, [_U32]),
     "crt_randf2": (_F, [C.POINTER(_U32)]),

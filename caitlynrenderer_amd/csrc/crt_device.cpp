@@ -370,11 +370,13 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (hipGetDevice(&s->device) != hipSuccess) return (fail(CRT_ERR_HIP, "hipGetDevice failed"));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+#ifdef CRT_EXPERIMENTS
     if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
     if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
     if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
+#endif
     if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(3, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
@@ -407,6 +409,14 @@ int crt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int crt_has_experiments(void) {
+#ifdef CRT_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 static int scene_create_impl(const crt_scene_desc* d, crt_scene** out);
@@ -750,17 +760,20 @@ int crt_reset(crt_scene* s) {
 int crt_set_option(crt_scene* s, const char* name, int value) {
     if (!s || !name) return fail(CRT_ERR_INVALID, "crt_set_option: null argument");
     if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
-    else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
+#ifdef CRT_EXPERIMENTS
+    else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
+#else
+    // variants that lost every measurement live in the CRT_EXPERIMENTS build only (make EXPERIMENTS=1); their default values are accepted
+    else if (!std::strcmp(name, "trace_occupancy") || !std::strcmp(name, "bounce_refill") || !std::strcmp(name, "oversubscribe") ||
+             !std::strcmp(name, "waves_per_workgroup") || !std::strcmp(name, "compact_shadow")) {
+        const bool is_default = !std::strcmp(name, "waves_per_workgroup") ? value == 1 : !std::strcmp(name, "bounce_refill") || !std::strcmp(name, "oversubscribe") ? value == 0 : true;
+        if (!is_default) return fail(CRT_ERR_INVALID, std::string("crt_set_option: ") + name + " is an experimental variant: this library was built without CRT_EXPERIMENTS");
+    }
+#endif
     else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
-    else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
-    else if (!std::strcmp(name, "waves_per_workgroup")) {
-        if (value != 1 && value != 2 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: waves_per_workgroup is 1, 2 or 4");
-        s->waves_per_workgroup = (uint32_t)value;
-    }
-    else if (!std::strcmp(name, "compact_shadow")) s->compact_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(3, std::max(0, value));
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "adaptive_tiles")) { s->adaptive_tiles = value ? 1u : 0u; if (value) s->tile_state = crt_scene::TILES_WANT; }
@@ -911,7 +924,12 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         if (b == 0) s->last_launch_form = (int)sa.wave_samples;
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
+#ifdef CRT_EXPERIMENTS
         const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u && !s->special_materials;
+#else
+        const bool pretraced = false;
+#endif
+#ifdef CRT_EXPERIMENTS
         if (pretraced) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
@@ -921,9 +939,9 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8, 1024), s->waves_per_workgroup, s->stream);
             sa.hits_in = s->d_qhits;
             if (sp) crt::set_launch_events(nullptr, sp->b);
-        } else if (sp) {
-            crt::set_launch_events(sp->a, sp->b);
-        }
+        } else
+#endif
+        if (sp) crt::set_launch_events(sp->a, sp->b);
         // bounce launches of a batched frame may find up to n_samples rays per pixel in their queue
         const uint32_t items = (b > 0 && deferred) ? P * n_samples : P;
         crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, s->trace_grid(items, sa.wide_first ? 6 : 5), s->waves_per_workgroup, s->stream);
@@ -984,6 +1002,9 @@ static uint32_t batch_limit(const crt_scene* s) {
     const bool inplace = s->accel != 0u || s->inplace_shadow != 0u;
     const bool compact = s->compact_shadow != 0u && s->tri_share == 0u && s->waves_per_workgroup > 1u;   // as launch_segment decides
     if (!inplace || compact || s->count_visits) return 1u;            // counting frames run one by one
+#ifndef CRT_EXPERIMENTS
+    if (s->accel != 0u) return 1u;                                     // the BVH2 frame mode (a comparison aid) has no batched build
+#endif
     if (s->max_depth == 1u) return 8u;
     // several segments: every sample keeps its own path state and queue entries (ensure_batch_buffers) and the samples' radiance is
     // added in frame order by k_accumulate_samples; the bounce pools' hit buffer is not part of that

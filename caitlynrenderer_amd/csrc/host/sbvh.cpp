@@ -1,8 +1,8 @@
 // Split-BVH construction.  Behavioural contract: Caitlyn/sbvh.h (cited per function).
 // The output (node boxes, BFS numbering, leaf order, duplicate references) has to be
 // the tree the reference would have built, because everything downstream — CWBVH
-// conversion, triangle slots, hit IDs — is keyed on it.  tests/test_sbvh.py pins it
-// against the known-answer values of SURVEY.md §8c.
+// conversion, triangle slots, hit IDs — is keyed on it.  tests/test_host.py pins it against
+// the known-answer values of SURVEY.md §8c (Cornell tree entry for entry; the n = 8 and n = 183 spatial-split probes).
 #include "sbvh.hpp"
 
 #include <sched.h>
@@ -176,60 +176,73 @@ struct Builder {
         return best;
     }
 
-    // sbvh.h:497-569: partition the tail; straddlers are unsplit to one side or duplicated.
-    void do_spatial_split(Spec& left, Spec& right, const Spec& spec, const SpatialSplit& sp) {
-        const size_t left_start = refs.size() - spec.n;
-        size_t left_end = left_start;
-        size_t right_start = refs.size();
+    // Carry out a spatial split (behaviour of sbvh.h:497-569).  The node's references are the tail of `refs`; afterwards that tail
+    // reads [left child's refs ..., right child's refs ...].  References that lie wholly on one side of the plane go there.  Each
+    // straddler then meets one of three fates, whichever the SAH prices lowest against the children's boxes as they stand when
+    // its turn comes: stay whole in the left child, stay whole in the right child, or be clipped at the plane into a reference for
+    // each (the "split" of a split BVH: the triangle then sits in two leaves).  Ties go in that order.  The straddlers are taken in
+    // the order the first sweep leaves them, which the outcome depends on, so both sweeps move elements exactly as the reference's do.
+    void do_spatial_split(Spec& left, Spec& right, const Spec& spec, const SpatialSplit& plane) {
+        const int axis = plane.dim;
+        const float at = plane.pos;
+        const size_t begin = refs.size() - spec.n;
+        size_t lo = begin;              // refs[begin, lo): decided for the left child
+        size_t hi = refs.size();        // refs[hi, end):   decided for the right child; refs[lo, hi) undecided
         left.box = right.box = Aabb();
-        const int dim = sp.dim;
-        const float pos = sp.pos;
 
-        for (size_t i = left_end; i < right_start; ++i) {
-            if (refs[i].box.hi[dim] <= pos) {
-                left.box.grow(refs[i].box);
-                std::swap(refs[i], refs[left_end++]);
-            } else if (refs[i].box.lo[dim] >= pos) {
-                right.box.grow(refs[i].box);
-                std::swap(refs[i], refs[--right_start]);
-                --i;   // re-examine the element swapped in
-            }
-        }
-
-        while (left_end < right_start) {
-            Ref lref, rref;
-            split_ref(lref, rref, refs[left_end], dim, pos);
-
-            Aabb lub = left.box, rub = right.box, ldb = left.box, rdb = right.box;
-            lub.grow(refs[left_end].box);
-            rub.grow(refs[left_end].box);
-            ldb.grow(lref.box);
-            rdb.grow(rref.box);
-
-            const float lac = (float)(left_end - left_start);
-            const float rac = (float)(refs.size() - right_start);
-            const float lbc = lac + 1, rbc = rac + 1;
-
-            const float unsplit_left = lub.half_area() * lbc + right.box.half_area() * rac;
-            const float unsplit_right = left.box.half_area() * lac + rub.half_area() * rbc;
-            const float duplicate = ldb.half_area() * lbc + rdb.half_area() * rbc;
-            const float m = fmin_(unsplit_left, fmin_(unsplit_right, duplicate));   // sbvh.h:58-61
-
-            if (m == unsplit_left) {
-                left.box = lub;
-                left_end++;
-            } else if (m == unsplit_right) {
-                right.box = rub;
-                std::swap(refs[left_end], refs[--right_start]);
+        // sweep 1: everything that does not straddle the plane
+        for (size_t i = lo; i < hi;) {
+            const Aabb box = refs[i].box;
+            if (box.hi[axis] <= at) {
+                left.box.grow(box);
+                std::swap(refs[i], refs[lo]);
+                ++lo;
+                ++i;
+            } else if (box.lo[axis] >= at) {
+                right.box.grow(box);
+                --hi;
+                std::swap(refs[i], refs[hi]);      // position i now holds an unexamined reference: look at it next
             } else {
-                left.box = ldb;
-                right.box = rdb;
-                refs[left_end++] = lref;
-                refs.push_back(rref);
+                ++i;
             }
         }
-        left.n = (int)(left_end - left_start);
-        right.n = (int)(refs.size() - right_start);
+
+        // sweep 2: the straddlers, refs[lo, hi), front to back
+        auto priced = [](const Aabb& box, float count) { return box.half_area() * count; };
+        while (lo < hi) {
+            const Ref whole = refs[lo];
+            Ref left_part, right_part;
+            split_ref(left_part, right_part, whole, axis, at);
+            const float n_left = (float)(lo - begin), n_right = (float)(refs.size() - hi);
+
+            Aabb left_if_whole = left.box, right_if_whole = right.box, left_if_clipped = left.box, right_if_clipped = right.box;
+            left_if_whole.grow(whole.box);
+            right_if_whole.grow(whole.box);
+            left_if_clipped.grow(left_part.box);
+            right_if_clipped.grow(right_part.box);
+
+            const float cost_whole_left = priced(left_if_whole, n_left + 1) + priced(right.box, n_right);
+            const float cost_whole_right = priced(left.box, n_left) + priced(right_if_whole, n_right + 1);
+            const float cost_clipped = priced(left_if_clipped, n_left + 1) + priced(right_if_clipped, n_right + 1);
+            const float cheapest = fmin_(cost_whole_left, fmin_(cost_whole_right, cost_clipped));   // sbvh.h:58-61
+
+            if (cheapest == cost_whole_left) {
+                left.box = left_if_whole;
+                ++lo;
+            } else if (cheapest == cost_whole_right) {
+                right.box = right_if_whole;
+                --hi;
+                std::swap(refs[lo], refs[hi]);
+            } else {
+                left.box = left_if_clipped;
+                right.box = right_if_clipped;
+                refs[lo] = left_part;
+                ++lo;
+                refs.push_back(right_part);         // the duplicate joins the right child's end of the tail
+            }
+        }
+        left.n = (int)(lo - begin);
+        right.n = (int)(refs.size() - hi);
     }
 
     void make_leaf(int node, const Spec& spec) {   // sbvh.h:190-205

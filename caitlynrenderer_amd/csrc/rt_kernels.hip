@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
                 vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
                 if (TEX) {                                                        // path_trace.fs:471-483
                     const float tex = a.materials[4 * (size_t)mtl + 3].x;
-                    if (tex != -1.0f) {
+                    if (tex != -1.0f && a.textures != nullptr) {
                         const int4 vt = a.triangles[3 * (size_t)slot + 2];
                         const float2 ta = a.texcoords[vt.x], tb2 = a.texcoords[vt.y], tc2 = a.texcoords[vt.z];
                         const float w = 1.0f - bu - bv;
@@ -1257,6 +1257,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
     (void)stk; (void)stk2;
 }
 
+#ifdef CRT_EXPERIMENTS
 // Closest hit for a device-written path-ray queue (segments >= 1): per-wave 256-ray pools with lane refill
 // (traverse_pool); hits go to a buffer parallel to the queue and k_segment<PRETRACED> shades them.
 template <bool STATS>
@@ -1290,6 +1291,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
     (void)lane;
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
 }
+#endif  // CRT_EXPERIMENTS
 
 // NEE occlusion test (path_trace.fs:968) fused with its resolve: an unoccluded ray adds its pending
 // contribution C to the path's radiance; if the path ended with this segment the total goes straight
@@ -1441,6 +1443,80 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 // only as long as its longest waves — a shard, a small frame, the side-by-side sample form — runs those waves faster without the
 // extra scratch traffic (1/8 of a 1080p frame, 4 samples side by side: 0.0453 ms per frame at 5 waves, 0.0503 at 6).  The host
 // says which (SegmentArgs::wide_first); counting kernels keep the one form.
+#ifndef CRT_EXPERIMENTS
+// ---- default build: the variants that won their measurements, 24 instantiations of k_segment ----
+// Feature level of the shading code: PLAIN (Lambert, untextured: the reference's shipped scene), MAT (+ mirror / Disney), FULL (+ textured
+// albedo).  Counting kernels, the BVH2 frame mode and the shadow-queue form are not timed against anything and exist at the
+// highest level only (the extra branches are decided per material at run time: same arithmetic, same sums).  What lost every
+// measurement of rounds 1-2 — shadow-ray compaction across waves (COMPACT), bounce pools (PRETRACED + k_closest_queue), persistent
+// grids, 2- and 4-wave workgroups, triangle sharing in the first segment, batched BVH2 frames — is compiled only with
+// -DCRT_EXPERIMENTS (make EXPERIMENTS=1), where the GPU suite still checks it bit for bit.
+//               k_segment<FIRST, STATS, TEX, PRETRACED, INPLACE, BVH2, MAT, COMPACT, SHARE, BATCH, WIDE>
+#define CRT_K(F, S, T, Y, B2, M, SH, BA, WI) k_segment<F, S, T, false, Y, B2, M, false, SH, BA, WI>
+void launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool inplace, bool bvh2, bool mat, bool /*compact*/, bool stats, uint32_t grid, uint32_t /*waves*/,
+                    hipStream_t stream) {
+    const bool tex = a.textures != nullptr;
+    const bool share = !first && a.tri_share != 0u && a.tri_min != 0u && inplace && !bvh2;
+    // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
+    const size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
+    const dim3 g = grid_dim(grid, 1u), b = block_dim(1u);
+    const size_t lds = per_wave + (share ? 16 + (size_t)CRT_SHARE_BYTES : 0);
+    const int feat = tex ? 2 : mat ? 1 : 0;
+    if (first && a.n_samples > 1u) {
+        // several samples per launch (crt_render_frames): CWBVH, shadow rays in place, no counting (crt_device.cpp batch_limit)
+        // wave_samples: as few passes as 4 waves allow, and no more waves than those passes need (5 samples: 2 passes of 3 waves)
+        const uint32_t ws_passes = (a.n_samples + 3u) / 4u, ws = (a.n_samples + ws_passes - 1u) / ws_passes;
+        const size_t lds4 = ws * per_wave + ws * 64 * sizeof(float4);
+        SegmentArgs v = a;
+        if (a.wave_samples && lds4 > 64u * 1024u) v.wave_samples = 0u;     // the sequential form, should the stacks and the result strip not fit
+        const bool side_by_side = v.wave_samples != 0u;
+        // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups
+        const dim3 gg = side_by_side ? dim3(grid * 4u) : g, bb = side_by_side ? dim3(ws * 64u) : b;
+        const size_t ll = side_by_side ? lds4 : lds;
+        if (feat == 2)      launch(CRT_K(true, false, true, true, false, true, false, true, false), gg, bb, ll, stream, v);
+        else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, true, false), gg, bb, ll, stream, v);
+        else if (v.wide_first && !side_by_side) launch(CRT_K(true, false, false, true, false, false, false, true, true), gg, bb, ll, stream, v);
+        else                launch(CRT_K(true, false, false, true, false, false, false, true, false), gg, bb, ll, stream, v);
+        return;
+    }
+    if (bvh2) {                                          // the shipped shader's own walks as a frame renderer: Lambert (+ textures) only
+        if (first) { if (stats) launch(CRT_K(true, true, true, true, true, false, false, false, false), g, b, lds, stream, a);
+                     else       launch(CRT_K(true, false, true, true, true, false, false, false, false), g, b, lds, stream, a); }
+        else       { if (stats) launch(CRT_K(false, true, true, true, true, false, false, false, false), g, b, lds, stream, a);
+                     else       launch(CRT_K(false, false, true, true, true, false, false, false, false), g, b, lds, stream, a); }
+        return;
+    }
+    if (!inplace) {                                      // shadow queue + k_shadow (option "inplace_shadow" 0)
+        if (first) { if (stats) launch(CRT_K(true, true, true, false, false, true, false, false, false), g, b, lds, stream, a);
+                     else       launch(CRT_K(true, false, true, false, false, true, false, false, false), g, b, lds, stream, a); }
+        else       { if (stats) launch(CRT_K(false, true, true, false, false, true, false, false, false), g, b, lds, stream, a);
+                     else       launch(CRT_K(false, false, true, false, false, true, false, false, false), g, b, lds, stream, a); }
+        return;
+    }
+    if (stats) {
+        if (first)      launch(CRT_K(true, true, true, true, false, true, false, false, false), g, b, lds, stream, a);
+        else if (share) launch(CRT_K(false, true, true, true, false, true, true, false, false), g, b, lds, stream, a);
+        else            launch(CRT_K(false, true, true, true, false, true, false, false, false), g, b, lds, stream, a);
+        return;
+    }
+    if (first) {
+        if (feat == 2)      launch(CRT_K(true, false, true, true, false, true, false, false, false), g, b, lds, stream, a);
+        else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, false, false), g, b, lds, stream, a);
+        else                launch(CRT_K(true, false, false, true, false, false, false, false, false), g, b, lds, stream, a);
+        return;
+    }
+    if (share) {
+        if (feat == 2)      launch(CRT_K(false, false, true, true, false, true, true, false, false), g, b, lds, stream, a);
+        else if (feat == 1) launch(CRT_K(false, false, false, true, false, true, true, false, false), g, b, lds, stream, a);
+        else                launch(CRT_K(false, false, false, true, false, false, true, false, false), g, b, lds, stream, a);
+    } else {
+        if (feat == 2)      launch(CRT_K(false, false, true, true, false, true, false, false, false), g, b, lds, stream, a);
+        else if (feat == 1) launch(CRT_K(false, false, false, true, false, true, false, false, false), g, b, lds, stream, a);
+        else                launch(CRT_K(false, false, false, true, false, false, false, false, false), g, b, lds, stream, a);
+    }
+}
+#undef CRT_K
+#else   // CRT_EXPERIMENTS: every variant the kernel's template parameters describe
 #define CRT_KSEG(F, S, T, P, Y, B, M, C, SH, BA) \
     (a.wide_first ? k_segment<F, S, T, P, Y, B, M, C, SH, BA, (F) && !(S)> : k_segment<F, S, T, P, Y, B, M, C, SH, BA, false>)
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
@@ -1503,6 +1579,8 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
 #undef CRT_LAUNCH_SEG_T
 #undef CRT_LAUNCH_SEG
 }
+#endif  // CRT_EXPERIMENTS
+#ifdef CRT_EXPERIMENTS
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
     waves = fit_waves(waves, stack_bytes(a.stack_entries));
     const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
@@ -1510,6 +1588,7 @@ void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, ui
     if (stats) launch(k_closest_queue<true>, g, b, lds, stream, a);
     else       launch(k_closest_queue<false>, g, b, lds, stream, a);
 }
+#endif
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
     waves = fit_waves(waves, stack_bytes(a.stack_entries));
     const dim3 g = grid_dim(grid, waves), b = block_dim(waves);

@@ -177,25 +177,28 @@ int crt_sync(crt_scene* s);
  *     "inplace_shadow"    1 = NEE shadow rays walked inside the segment kernel (default), 0 = shadow queue + k_shadow
  *     "tri_min"           vote ratio of the closest-hit traversal loop (default 2); 0 = plain per-lane loop, which
  *                         trees under 64 nodes get anyway
- *     "bounce_refill"     segments >= 1: 0 = lock-step segment kernel (default), 1 = closest hits through lane-refill
- *                         pools (k_closest_queue) + shade-only pass; "refill_min" = idle lanes that trigger a refill
- *     "oversubscribe"     0 = one 64-ray batch per workgroup, the hardware dispatcher balances (default); k >= 1 =
- *                         persistent grid of k x the resident workgroups with a static schedule, then
- *                         "trace_occupancy" = workgroups per CU
- *     "waves_per_workgroup" 1, 2 or 4, per scene; a launch whose LDS stacks would exceed 64 KB (a BVH2 deeper than ~60
- *                         levels at 4 waves) runs with 1
  *     "tri_share"         triangle steps of the voting loop hand the waiting lanes' pending triangles (up to 3 each) to ALL lanes
- *                         of the wave through a wave-private LDS strip: 0 off, 1 closest-hit walk, 2 also the in-place shadow
- *                         rays, 3 (default) = off for the first segment, 2 for bounce segments
- *     "compact_shadow"    1 (default): with 2 or 4 waves per workgroup and in-place shadows, the workgroup's NEE shadow rays
- *                         are gathered through LDS into full waves before they are walked; 0: every wave walks its own
+ *                         of the wave through a wave-private LDS strip, in bounce segments (the coherent first segment is faster
+ *                         without): 0 off, 1 closest-hit walk, 2 or 3 (default) also the in-place shadow rays
  *     "wave_samples"      crt_render_frames, first segment: where the samples of a 64-pixel batch run.  0 = one after the other
  *                         in one wave; 1 = side by side on the 2 to 4 waves of one workgroup, added to the sum in sample order
  *                         through LDS (the same bits); 2 (default) = 1 when the launch would otherwise be bound by its longest
  *                         waves — a shard of a frame, a small frame — as judged from the measured tile costs, else 0
  *     "wide_first"        which build of the first-segment kernel a launch runs: 0 = compiled for 5 waves per SIMD (96 VGPRs),
  *                         1 = for 6 (80 VGPRs), 2 (default) = 6 where the launch is bound by throughput, 5 where its longest
- *                         waves set its length (the same measure as "wave_samples") */
+ *                         waves set its length (the same measure as "wave_samples"); the 6-wave build exists for the batched
+ *                         launches of crt_render_frames on Lambert scenes
+ *   experimental (a library built with `make EXPERIMENTS=1`, crt_has_experiments() != 0; otherwise only the default value is
+ *   accepted) — variants that lost every measurement and are kept for re-measurement, bit-identical like the rest:
+ *     "bounce_refill"     segments >= 1: 0 = lock-step segment kernel (default), 1 = closest hits through lane-refill
+ *                         pools (k_closest_queue) + shade-only pass
+ *     "oversubscribe"     0 = one 64-ray batch per workgroup, the hardware dispatcher balances (default); k >= 1 =
+ *                         persistent grid of k x the resident workgroups with a static schedule, then
+ *                         "trace_occupancy" = workgroups per CU
+ *     "waves_per_workgroup" 1 (default), 2 or 4, per scene
+ *     "compact_shadow"    with 2 or 4 waves per workgroup and in-place shadows, the workgroup's NEE shadow rays are gathered
+ *                         through LDS into full waves before they are walked
+ *     also: "tri_share" 1 / 2 then share triangle steps in the first segment too, and BVH2 frames are batched */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);
@@ -264,6 +267,8 @@ typedef struct crt_bvh_info {
 } crt_bvh_info;
 int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out);
 int crt_device_count(void);
+/* 1 when the library carries the experimental kernel variants (built with -DCRT_EXPERIMENTS), else 0 */
+int crt_has_experiments(void);
 
 /* --------------------------------------------------- host side ([host]) ----- */
 

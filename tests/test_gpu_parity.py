@@ -10,6 +10,17 @@ pytestmark = pytest.mark.gpu
 
 RX1, RY1 = 0.6591631174087524, 0.9108020067214966      # frame-1 randomVector
 
+# kernel variants that lost every measurement are compiled only with `make EXPERIMENTS=1` (include/crt.h, crt_set_option); the
+# default library refuses their options, and the cases below that use them run only against an experiments build
+class _Experiments:
+    def __bool__(self):                                 # asked inside the tests, i.e. after conftest's `built` fixture
+        import caitlynrenderer_amd
+        return caitlynrenderer_amd.has_experiments()
+
+
+EXPERIMENTS = _Experiments()
+EXPERIMENTAL_OPTIONS = {"bounce_refill", "oversubscribe", "waves_per_workgroup", "compact_shadow", "trace_occupancy"}
+
 
 def _assert_hits_equal(got, want):
     assert np.array_equal(got["tri"], want["tri"])
@@ -152,6 +163,8 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
                                (4, {"wave_samples": 1, "tri_share": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2))):
         if name in ("tess8_mat",) and opts.get("accel"):
             continue                                                          # the BVH2 frame mode is the Lambert-only shader
+        if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(opts):
+            continue                                                          # variants of the CRT_EXPERIMENTS build only
         a, b = cr.Scene(data, W, H, depth), cr.Scene(data, W, H, depth)
         for s in (a, b):
             s.update(cam)
@@ -167,6 +180,8 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
         # the stats of a batched launch are its totals: 3 samples in the last launch of 19 = 8 + 8 + 3 where batching applies
         st_a, st_b = a.frame_stats(), b.frame_stats()
         inplace = opts.get("inplace_shadow", 1) == 1 or opts.get("accel", 0) != 0
+        if opts.get("accel", 0) != 0 and not EXPERIMENTS:
+            inplace = False                                                   # the default build renders BVH2 frames one by one
         if depth == 1:
             assert st_b["closest_rays"] == (3 if inplace else 1) * st_a["closest_rays"]
         elif inplace and not opts.get("bounce_refill"):
@@ -408,12 +423,22 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
 
     want, want_counts = run({})
     assert want.max() > 0.1
-    # waves_per_workgroup is a per-scene setting: a 4-wave scene next to a 1-wave scene leaves the latter alone
-    other = cr.Scene(data, 64, 64, 1)
-    other.set_option("waves_per_workgroup", 4)
-    got, counts = run({})
-    other.close()
-    assert counts == want_counts and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if EXPERIMENTS:
+        # waves_per_workgroup is a per-scene setting: a 4-wave scene next to a 1-wave scene leaves the latter alone
+        other = cr.Scene(data, 64, 64, 1)
+        other.set_option("waves_per_workgroup", 4)
+        got, counts = run({})
+        other.close()
+        assert counts == want_counts and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    else:
+        # the default build carries none of the variants that lost their measurements: asking for one is an error, their defaults are accepted
+        other = cr.Scene(data, 64, 64, 1)
+        for k, v in (("waves_per_workgroup", 4), ("oversubscribe", 1), ("bounce_refill", 1)):
+            with pytest.raises(cr.CrtError, match="CRT_EXPERIMENTS"):
+                other.set_option(k, v)
+        for k, v in (("waves_per_workgroup", 1), ("oversubscribe", 0), ("bounce_refill", 0), ("compact_shadow", 1)):
+            other.set_option(k, v)
+        other.close()
     for options in ({"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
                     {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
                     {"tri_share": 0, "waves_per_workgroup": 2}, {"tri_share": 2, "tri_min": 1}, {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
@@ -421,6 +446,8 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
                     {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5},
                     {"bounce_refill": 1}, {"bounce_refill": 1, "refill_min": 1}, {"bounce_refill": 1, "refill_min": 40}, {"inplace_shadow": 0},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
+        if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):
+            continue
         ref_opts = options.pop("_ref", None)             # a variant compared with another baseline (the BVH2 frame mode)
         w, wc = (want, want_counts) if ref_opts is None else run(ref_opts)
         got, counts = run(options)
@@ -807,6 +834,8 @@ def test_special_materials_restrictions_and_options(cr, ob, disney_scenes):
     want = run({})
     for options in ({"bounce_refill": 1}, {"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
                     {"oversubscribe": 2}, {"tri_min": 0}, {"inplace_shadow": 0, "tri_min": 3}):
+        if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):
+            continue
         assert np.array_equal(run(options).view(np.uint32), want.view(np.uint32)), options
     s = cr.Scene(data, W, H, depth)
     with pytest.raises(cr.CrtError) as e:

@@ -10,6 +10,8 @@ import caitlynrenderer_amd as cr
 from caitlynrenderer_amd.meshgen import tessellated_cornell, with_disney_materials
 from oracle import binding as ob
 
+EXPERIMENTS = cr.has_experiments()
+
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
@@ -46,10 +48,10 @@ for case in range(n_cases):
     accel = 0 if name.endswith("_mat") else int(rng.choice([0, 0, 0, 1, 2]))      # the BVH2 frame mode is the Lambert-only shader
     opts = {"accel": accel}
     if accel == 0:
-        opts.update(inplace_shadow=int(rng.random() < 0.7), bounce_refill=int(rng.random() < 0.3),
-                    tri_min=int(rng.choice([0, 1, 2, 2, 3])), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])),
-                    tri_share=int(rng.choice([0, 1, 2, 3, 3])), waves_per_workgroup=int(rng.choice([1, 1, 2, 4])),
-                    compact_shadow=int(rng.random() < 0.5))
+        opts.update(inplace_shadow=int(rng.random() < 0.7), tri_min=int(rng.choice([0, 1, 2, 2, 3])), tri_share=int(rng.choice([0, 1, 2, 3, 3])))
+        if EXPERIMENTS:          # variants of a `make EXPERIMENTS=1` library only
+            opts.update(bounce_refill=int(rng.random() < 0.3), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])),
+                        waves_per_workgroup=int(rng.choice([1, 1, 2, 4])), compact_shadow=int(rng.random() < 0.5))
     opts["adaptive_tiles"] = int(rng.random() < 0.7)          # cost-sorted or centre-out tile order: the same pixels either way
     opts["wave_samples"] = int(rng.choice([0, 1, 2]))         # the samples of a launch in one wave or on the waves of a workgroup
     opts["wide_first"] = int(rng.choice([0, 1, 2]))           # the 5- or the 6-waves-per-SIMD build of the first-segment kernel
@@ -71,7 +73,7 @@ for case in range(n_cases):
         scene.render_frames(rvs)
         tot = np.zeros(2, np.int64)
         last = np.zeros(2, np.int64)
-        per_launch = 8 if ((accel != 0 or opts.get("inplace_shadow", 1) == 1) and (depth == 1 or not opts.get("bounce_refill", 0))
+        per_launch = 8 if (((accel != 0 and EXPERIMENTS) or (accel == 0 and opts.get("inplace_shadow", 1) == 1)) and (depth == 1 or not opts.get("bounce_refill", 0))
                            and not (opts.get("compact_shadow", 1) and opts.get("tri_share", 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
         in_last = n_fr - ((n_fr - 1) // per_launch) * per_launch
         for k, (rx, ry) in enumerate(rvs):
