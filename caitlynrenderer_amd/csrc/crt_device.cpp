@@ -173,6 +173,7 @@ struct crt_scene {
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
+    uint32_t debug_fail_batch_alloc = 0;     // test hook (option of the same name): the next growth of the batch buffers fails before it allocates
     uint32_t batch_cap = 1;                  // samples the path state, the ray queues and d_lfinal are sized for (1 until crt_render_frames needs more)
     uint32_t samples_in_stats = 1;           // samples per pixel of the launch the pending stats describe (crt_render_frames batches)
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
@@ -466,6 +467,9 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
                 if (t.vn[j] < 0 || (size_t)t.vn[j] >= d->n_normals || !d->normals)
                     return fail(CRT_ERR_INVALID, "crt_scene_create: normal index out of range");
     }
+    // a non-finite vertex turns boxes and areas into NaN (the GPU builders check the same on the device)
+    for (size_t i = 0; i < 3 * d->n_vertices; ++i)
+        if (!(std::fabs(d->vertices[i]) <= 1.0e18f)) return fail(CRT_ERR_INVALID, "crt_scene_create: a vertex coordinate is not finite or exceeds 1e18");
     const bool have_tex = d->albedo_textures && d->n_textures > 0;
     if (have_tex && (d->tex_width == 0 || d->tex_height == 0 || d->tex_width > 16384 || d->tex_height > 16384))
         return fail(CRT_ERR_INVALID, "crt_scene_create: bad texture size");
@@ -798,6 +802,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
             s->spans.push_back(sp);
         }
     }
+    else if (!std::strcmp(name, "debug_fail_batch_alloc")) s->debug_fail_batch_alloc = value ? 1u : 0u;
     else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: plain per-lane closest-hit loop (what trees of a few nodes get)
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
@@ -906,6 +911,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         // scheduled by tile cost, sharing also paid in the first segment — it shortened the long waves a launch ended on; with
         // every SIMD busy only the instruction count matters: 1 M triangles 0.2566 -> 0.2486 ms, 4K 3.45 -> 3.26 ms without it.)
         sa.tri_share = s->tri_share == 3u ? (b == 0 ? 0u : 2u) : s->tri_share;
+        if (s->info.n_tris8 > (1ull << 24)) sa.tri_share = 0u;     // a shared item is (triangle index | owner lane << 24)
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
@@ -978,20 +984,30 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
 static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
     if (s->batch_cap >= cap) return CRT_OK;
     HIPCHK(hipStreamSynchronize(s->stream));
-    void** drop[] = {(void**)&s->d_rays[0], (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T,
-                     (void**)&s->pb.seed, (void**)&s->d_lfinal};
-    for (void** p : drop) { if (*p) hipFree(*p); *p = nullptr; }
+    // The lazily allocated shadow queue and hit buffer follow the per-group capacity: dropped now (null pointers the next frame
+    // re-allocates at the size then in force), whatever happens below.
+    for (void** p : {(void**)&s->d_shadow, (void**)&s->d_qhits}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    // Everything else is allocated at the new size FIRST and swapped in only when all of it exists: a failed growth (~250 B per
+    // pixel and sample: 16 GB for a 4K frame at 8 samples) leaves the scene exactly as it was, able to render frame by frame.
     const size_t P = s->n_local_pixels;
-    s->sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096) * cap;
-    const size_t Q = 8 * (size_t)s->sub_capacity;
+    const uint32_t sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096) * cap;
+    const size_t Q = 8 * (size_t)sub_capacity;
+    float4 *rays0 = nullptr, *rays1 = nullptr, *L = nullptr, *T = nullptr, *lfinal = nullptr;
+    float2* seed = nullptr;
+    auto undo = [&](int code) {
+        for (void* p : {(void*)rays0, (void*)rays1, (void*)L, (void*)T, (void*)seed, (void*)lfinal}) if (p) (void)hipFree(p);
+        return code;
+    };
     int rc;
-    if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
-    if ((rc = dev_alloc(&s->d_rays[1], 2 * Q))) return rc;
-    if ((rc = dev_alloc(&s->pb.L, P * cap))) return rc;
-    if ((rc = dev_alloc(&s->pb.T, P * cap))) return rc;
-    if ((rc = dev_alloc(&s->pb.seed, P * cap))) return rc;
-    if ((rc = dev_alloc(&s->d_lfinal, P * cap))) return rc;
-    HIPCHK(hipMemset(s->d_lfinal, 0, P * cap * sizeof(float4)));        // pixels outside the frame are never written: they stay zero
+    if (s->debug_fail_batch_alloc) { s->debug_fail_batch_alloc = 0; return fail(CRT_ERR_NOMEM, "hipMalloc: injected failure (debug_fail_batch_alloc)"); }
+    if ((rc = dev_alloc(&rays0, 2 * Q)) || (rc = dev_alloc(&rays1, 2 * Q)) || (rc = dev_alloc(&L, P * cap)) || (rc = dev_alloc(&T, P * cap)) ||
+        (rc = dev_alloc(&seed, P * cap)) || (rc = dev_alloc(&lfinal, P * cap)))
+        return undo(rc);
+    if (hipMemset(lfinal, 0, P * cap * sizeof(float4)) != hipSuccess)      // pixels outside the frame are never written: they stay zero
+        return undo(fail(CRT_ERR_HIP, "hipMemset failed"));
+    for (void* p : {(void*)s->d_rays[0], (void*)s->d_rays[1], (void*)s->pb.L, (void*)s->pb.T, (void*)s->pb.seed, (void*)s->d_lfinal}) if (p) (void)hipFree(p);
+    s->d_rays[0] = rays0; s->d_rays[1] = rays1; s->pb.L = L; s->pb.T = T; s->pb.seed = seed; s->d_lfinal = lfinal;
+    s->sub_capacity = sub_capacity;
     s->batch_cap = cap;
     return CRT_OK;
 }

@@ -115,12 +115,16 @@ struct Decoder {
     }
     int get_bits(int k) {                                 // k in 1..16
         if (bits < k) fill();
+        // fill() adds nothing once it has met a marker: entropy data that ends in mid-coefficient is refused here (stb_image
+        // goes on with a negative bit count and returns partly decoded garbage); `bits` therefore never drops below zero
+        if (bits < k) throw Fail{"jpeg: entropy-coded data ends inside a coefficient"};
         const int v = (int)(buf >> (32 - k));
         buf <<= k; bits -= k;
         return v;
     }
     int get_bit() {
         if (bits < 1) fill();
+        if (bits < 1) throw Fail{"jpeg: entropy-coded data ends inside a coefficient"};
         const int v = (int)(buf >> 31);
         buf <<= 1; --bits;
         return v;

@@ -41,7 +41,12 @@ __global__ void k_tri_order(const unsigned long long* __restrict__ sorted, uint3
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-// Triangle boxes + the bounds of their centroids.  Grid-stride over the triangles with at most 1024 workgroups, the
+// Largest |coordinate| a builder accepts: box extents stay below 2e18, so half-areas (sums of products of two extents) stay
+// below 1.2e37 and finite in fp32.
+#define CRT_MAX_COORD 1.0e18f
+
+// Triangle boxes + the bounds of their centroids.  scene_box[0..5] = centroid bounds (ordered-uint form), [6] = 1 once a triangle
+// with a non-finite or over-range vertex was seen.  Grid-stride over the triangles with at most 1024 workgroups, the
 // centroid bounds reduced per lane, per wave and per workgroup before they touch the six global words: one atomic
 // per wave and component (94 k atomics on one cache line) made this kernel 1.07 ms of a 5 ms build.
 __global__ void __launch_bounds__(256) k_tri_bounds(const int32_t* __restrict__ vidx, uint32_t stride, const float* __restrict__ verts, uint32_t n,
@@ -50,9 +55,19 @@ __global__ void __launch_bounds__(256) k_tri_bounds(const int32_t* __restrict__ 
     float cmn[3] = {1e30f, 1e30f, 1e30f}, cmx[3] = {-1e30f, -1e30f, -1e30f};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        bool ok = true;
         for (int k = 0; k < 3; ++k) {
             const float* p = verts + 3 * (size_t)vidx[(size_t)stride * i + k];
-            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]);
+                ok = ok && fabsf(p[a]) <= CRT_MAX_COORD;             // false for NaN and +-inf as well
+            }
+        }
+        if (!ok) {
+            // The build is refused on the host once this flag comes back (CRT_ERR_INVALID); until then every later kernel sees a
+            // finite box, so no surface area overflows to inf / NaN (which is what let a PLOC cluster go without a neighbour)
+            for (int a = 0; a < 3; ++a) lo[a] = hi[a] = 0.f;
+            atomicOr(&scene_box[6], 1u);
         }
         for (int a = 0; a < 3; ++a) {
             leaf_box[6 * (size_t)i + a] = lo[a]; leaf_box[6 * (size_t)i + 3 + a] = hi[a];
@@ -258,7 +273,7 @@ __global__ void __launch_bounds__(256) k_ploc_nn(const int* __restrict__ C, uint
             if (j < 0 || j >= (int)m) continue;
             const float* o = s_box + 6 * ((int)threadIdx.x + radius + dj);
             const float a = half_area_union(me, me + 3, o, o + 3);
-            if (a < best) { best = a; bj = j; }          // ties keep the earlier candidate
+            if (a < best || bj < 0) { best = a < 3.0e38f ? a : 3.0e38f; bj = j; }   // ties keep the earlier candidate; every cluster gets a neighbour
         }
     nn[i] = bj;
 }
@@ -332,28 +347,37 @@ __global__ void __launch_bounds__(1024) k_ploc_tail(const int* __restrict__ C, u
                     if (j < 0 || j >= (int)m) continue;
                     const float* o = s_box[cur] + 6 * j;
                     const float a = half_area_union(me, me + 3, o, o + 3);
-                    if (a < best) { best = a; bj = j; }
+                    if (a < best || bj < 0) { best = a < 3.0e38f ? a : 3.0e38f; bj = j; }
                 }
             s_nn[tid] = bj;
         }
         __syncthreads();
+        // Progress guard: an iteration in which no two clusters chose each other (possible only when areas tie in a cycle)
+        // merges positions 0 and 1 instead, so the loop always ends after at most m - 1 iterations.
         bool keep = false, merge = false;
-        if (tid < (int)m) {
-            const bool mutual = bj >= 0 && s_nn[bj] == tid;
-            keep = !(mutual && tid > bj);
-            merge = mutual && tid < bj;
-        }
-        // exclusive prefix sums of keep and merge over the workgroup: wave ballots + per-wave totals
-        const unsigned long long bk = __ballot(keep), bm = __ballot(merge);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        uint32_t pk = (uint32_t)__builtin_popcountll(bk & lt), pm = (uint32_t)__builtin_popcountll(bm & lt);
-        if (lane == 0) { s_wave[0][wave] = (uint32_t)__builtin_popcountll(bk); s_wave[1][wave] = (uint32_t)__builtin_popcountll(bm); }
-        __syncthreads();
-        uint32_t tk = 0, tm = 0;
-        for (int w = 0; w < 16; ++w) {
-            const uint32_t a = s_wave[0][w], b = s_wave[1][w];
-            if (w < wave) { pk += a; pm += b; }
-            tk += a; tm += b;
+        uint32_t pk = 0, pm = 0, tk = 0, tm = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            keep = false; merge = false;
+            if (tid < (int)m) {
+                if (attempt == 1) { if (tid == 0) bj = 1; else if (tid == 1) bj = 0; else bj = -1; }
+                const bool mutual = attempt == 1 ? tid < 2 : (bj >= 0 && s_nn[bj] == tid);
+                keep = !(mutual && tid > bj);
+                merge = mutual && tid < bj;
+            }
+            // exclusive prefix sums of keep and merge over the workgroup: wave ballots + per-wave totals
+            const unsigned long long bk = __ballot(keep), bm = __ballot(merge);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            pk = (uint32_t)__builtin_popcountll(bk & lt); pm = (uint32_t)__builtin_popcountll(bm & lt);
+            if (lane == 0) { s_wave[0][wave] = (uint32_t)__builtin_popcountll(bk); s_wave[1][wave] = (uint32_t)__builtin_popcountll(bm); }
+            __syncthreads();
+            tk = 0; tm = 0;
+            for (int w = 0; w < 16; ++w) {
+                const uint32_t a = s_wave[0][w], b = s_wave[1][w];
+                if (w < wave) { pk += a; pm += b; }
+                tk += a; tm += b;
+            }
+            if (tm != 0u) break;                 // uniform: every thread sums the same LDS words
+            __syncthreads();                     // s_wave is rewritten by the forced attempt
         }
         if (keep) {
             int c = s_c[cur][tid];
@@ -399,9 +423,13 @@ __global__ void k_ploc_bfs_keys(const int* __restrict__ parent2, uint32_t total,
     if (id >= total) return;
     unsigned long long path = 0;
     uint32_t depth = 0;
-    for (int p = parent2[id]; p >= 0; p = parent2[p >> 1]) {
+    for (int p = parent2[id]; p >= 0;) {
         if (depth < 56u) path |= (unsigned long long)(p & 1) << depth;
         ++depth;
+        // stop where the key ends (such a tree is refused on the host) and never follow a link that points outside the array
+        if (depth > 56u) break;
+        if ((uint32_t)(p >> 1) >= total) { atomicOr(bad, 1u); break; }
+        p = parent2[p >> 1];
     }
     if (depth > 56u) { atomicOr(bad, 2u); depth = 56u; }
     keys[id] = ((unsigned long long)depth << 56) | path;
@@ -647,7 +675,7 @@ __global__ void __launch_bounds__(256) k_sah_bin(const uint32_t* __restrict__ id
     if (carried != SAH_NONE) { __syncthreads(); flush(1u); }
 }
 
-struct SahLists { uint32_t* counters; SahWork* next; uint32_t* small; };   // counters: [0] nodes so far, [1] next-level work items, [2] small nodes (node, beg, end triples), [3] this level's work items
+struct SahLists { uint32_t* counters; SahWork* next; uint32_t* small; uint32_t cap_next, cap_small; uint32_t* bad; };   // counters: [0] nodes so far, [1] next-level work items, [2] small nodes (node, beg, end triples), [3] this level's work items
 
 // between two levels: the children of this level's m nodes are numbered, the next list becomes the current one
 __global__ void k_sah_advance(uint32_t* __restrict__ counters) {
@@ -764,14 +792,18 @@ __global__ void __launch_bounds__(256) k_sah_sweep(SahWork* __restrict__ work, u
             nd.lo[child].w = __int_as_float(-1);
             nd.hi[child].w = __int_as_float((int)cb);              // leaf slot = final position of its triangle
         } else if (cls[side] == 1u) {
+            // small nodes own disjoint ranges of >= 2 triangles (at most n / 2 of them over the whole build), active ones disjoint
+            // ranges of more than `small` (at most n / small per level): the lists are sized for that, and an append that would
+            // fall outside anyway is dropped and flagged instead of written
             const uint32_t k = at[1]++;
-            out.small[3 * (size_t)k] = child; out.small[3 * (size_t)k + 1] = cb; out.small[3 * (size_t)k + 2] = ce;
+            if (k < out.cap_small) { out.small[3 * (size_t)k] = child; out.small[3 * (size_t)k + 1] = cb; out.small[3 * (size_t)k + 2] = ce; }
+            else atomicOr(out.bad, 4u);
         } else {
             const uint32_t k = at[0]++;
             SahWork c{};
             c.node = child; c.beg = cb; c.end = ce;
-            out.next[k] = c;
-            cw[side] = k;
+            if (k < out.cap_next) { out.next[k] = c; cw[side] = k; }
+            else atomicOr(out.bad, 4u);
         }
     }
     wk.left_work = cw[0]; wk.right_work = cw[1];
@@ -941,7 +973,7 @@ size_t lbvh_tmp_bytes(size_t n_tris, uint32_t flags) {
                                         (uint32_t*)nullptr, n_nodes, 0, 64, (hipStream_t)0);
         (void)rocprim::exclusive_scan(nullptr, scan, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, n_tris, rocprim::plus<unsigned long long>(), (hipStream_t)0);
         auto P = DeviceArena::padded;
-        return P(n_tris * 24) + P(24) + 2 * P(n_tris * 8) + 2 * P(n_nodes * 16) + P(n_nodes * 4) + 3 * P(n_tris * 4) + 2 * P(n_tris * 8) + P(16) +
+        return P(n_tris * 24) + P(32) + 2 * P(n_tris * 8) + 2 * P(n_nodes * 16) + P(n_nodes * 4) + 3 * P(n_tris * 4) + 2 * P(n_tris * 8) + P(16) +
                2 * P(n_nodes * 8) + 3 * P(n_nodes * 4) + P(4) + P(std::max<size_t>(sort1, 16)) + P(std::max<size_t>(sort2, 16)) + P(std::max<size_t>(scan, 16)) + 4096;
     }
     size_t sort1 = 0, sort2 = 0;
@@ -949,7 +981,7 @@ size_t lbvh_tmp_bytes(size_t n_tris, uint32_t flags) {
     (void)rocprim::radix_sort_pairs(nullptr, sort2, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
                                     (uint32_t*)nullptr, n_nodes, 0, 64, (hipStream_t)0);
     auto P = DeviceArena::padded;
-    return P(n_tris * 24) + P(24) + 2 * P(n_tris * 8) + P(std::max<size_t>(n_tris - 1, 1) * sizeof(int2)) + P(n_nodes * 4) + P(kMaxLevels * 4) +
+    return P(n_tris * 24) + P(32) + 2 * P(n_tris * 8) + P(std::max<size_t>(n_tris - 1, 1) * sizeof(int2)) + P(n_nodes * 4) + P(kMaxLevels * 4) +
            P(std::max<size_t>(n_tris - 1, 1) * 4) + 2 * P(n_nodes * 8) + 3 * P(n_nodes * 4) + P(4) + P(std::max<size_t>(sort1, 16)) +
            P(std::max<size_t>(sort2, 16)) + 4096;
 }
@@ -973,7 +1005,7 @@ static int ploc_build_on_device(const int32_t* d_vidx, uint32_t stride, const fl
     LB_HIPCHK(rocprim::exclusive_scan(nullptr, scan_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull, n_tris,
                                       rocprim::plus<unsigned long long>(), stream));
     float* d_leaf_box = tmp.take<float>(n_tris * 6);
-    uint32_t* d_scene = tmp.take<uint32_t>(6);
+    uint32_t* d_scene = tmp.take<uint32_t>(8);
     unsigned long long* d_keys = tmp.take<unsigned long long>(n_tris);
     unsigned long long* d_sorted = tmp.take<unsigned long long>(n_tris);
     PlocNodes nd;
@@ -998,7 +1030,7 @@ static int ploc_build_on_device(const int32_t* d_vidx, uint32_t stride, const fl
     if (!d_leaf_box || !d_scene || !d_keys || !d_sorted || !nd.lo || !nd.hi || !nd.parent2 || !d_c0 || !d_c1 || !d_nn || !d_f || !d_scan || !d_counts ||
         !d_bkeys || !d_bkeys2 || !d_ids || !d_order || !d_pos || !d_bad || !d_tmp || !d_tmp2 || !d_tmp3)
         return fail(CRT_ERR_NOMEM, "ploc: temporary arena too small");
-    const uint32_t scene_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    const uint32_t scene_init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     LB_HIPCHK(hipEventCreate(&ev0));
     LB_HIPCHK(hipEventCreate(&ev1));
     LB_HIPCHK(hipMemcpyAsync(d_scene, scene_init, sizeof scene_init, hipMemcpyHostToDevice, stream));
@@ -1021,7 +1053,7 @@ static int ploc_build_on_device(const int32_t* d_vidx, uint32_t stride, const fl
         uint32_t counts[2] = {0, 0};
         LB_HIPCHK(hipMemcpyAsync(counts, d_counts, 8, hipMemcpyDeviceToHost, stream));
         LB_HIPCHK(hipStreamSynchronize(stream));
-        if (counts[0] >= m || counts[0] == 0u) { cleanup(); return fail(CRT_ERR_HIP, "ploc: an iteration merged nothing"); }
+        if (counts[0] >= m || counts[0] == 0u) { cleanup(); return fail(CRT_ERR_INVALID, "ploc: an iteration merged nothing (cyclic ties between cluster areas)"); }
         m = counts[0]; nodes = counts[1];
         std::swap(C, Cn);
         if (++iterations > 4096u) { cleanup(); return fail(CRT_ERR_HIP, "ploc: did not converge"); }
@@ -1035,6 +1067,8 @@ static int ploc_build_on_device(const int32_t* d_vidx, uint32_t stride, const fl
     LB_HIPCHK(hipEventRecord(ev1, stream));
     uint32_t bad = 0, tail[3] = {0, 0, 0};
     unsigned long long deepest_key = 0;
+    uint32_t bad_vertex = 0;
+    LB_HIPCHK(hipMemcpyAsync(&bad_vertex, d_scene + 6, 4, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipMemcpyAsync(tail, d_counts, 12, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipMemcpyAsync(&deepest_key, d_bkeys2 + (n_nodes - 1), 8, hipMemcpyDeviceToHost, stream));
@@ -1043,6 +1077,7 @@ static int ploc_build_on_device(const int32_t* d_vidx, uint32_t stride, const fl
     float ms = 0.f;
     LB_HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
     cleanup();
+    if (bad_vertex) return fail(CRT_ERR_INVALID, "ploc: a vertex coordinate is not finite or exceeds 1e18");
     if (tail[1] != (uint32_t)n_nodes) return fail(CRT_ERR_HIP, "ploc: node count is not 2n - 1");
     if (bad & 2u) return fail(CRT_ERR_LIMIT, "ploc: tree deeper than 56 levels");
     if (bad) return fail(CRT_ERR_HIP, "ploc: breadth-first renumbering is inconsistent");
@@ -1063,7 +1098,7 @@ static size_t sah_tmp_bytes(size_t n, uint32_t flags) {
                                     n_nodes, 0, 64, (hipStream_t)0);
     (void)rocprim::exclusive_scan(nullptr, scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
     auto P = DeviceArena::padded;
-    return P(n * 24) + P(24) + 2 * P(n_nodes * 16) + P(n_nodes * 4) + 5 * P(n * 4) + 2 * P(cap * sizeof(SahWork)) + P(cap * SAH_BIN_WORDS * 4) +
+    return P(n * 24) + P(32) + 2 * P(n_nodes * 16) + P(n_nodes * 4) + 5 * P(n * 4) + 2 * P(cap * sizeof(SahWork)) + P(cap * SAH_BIN_WORDS * 4) +
            P((n / 2 + 2) * 12) + P(16) + 2 * P(n_nodes * 8) + 3 * P(n_nodes * 4) + P(4) + P(kMaxLevels * 4) + P(std::max<size_t>(sort2, 16)) +
            P(std::max<size_t>(scan, 16)) + 4096;
 }
@@ -1082,7 +1117,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
                                         (uint32_t*)nullptr, n_nodes, 0, 64, stream));
     LB_HIPCHK(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     float* d_leaf_box = tmp.take<float>((size_t)n * 6);
-    uint32_t* d_scene = tmp.take<uint32_t>(6);
+    uint32_t* d_scene = tmp.take<uint32_t>(8);
     PlocNodes nd;
     nd.lo = tmp.take<float4>(n_nodes);
     nd.hi = tmp.take<float4>(n_nodes);
@@ -1109,7 +1144,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
     if (!d_leaf_box || !d_scene || !nd.lo || !nd.hi || !nd.parent2 || !d_idx2 || !d_pw0 || !d_pw1 || !d_fl || !d_scan || !d_w0 || !d_w1 || !d_bins ||
         !d_small || !d_counters || !d_bkeys || !d_bkeys2 || !d_ids || !d_order || !d_pos || !d_bad || !d_levels || !d_tmp2 || !d_tmp3)
         return fail(CRT_ERR_NOMEM, "sah: temporary arena too small");
-    const uint32_t scene_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    const uint32_t scene_init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     const uint32_t counters_init[4] = {1u, 0u, 0u, 1u};          // node 0 is the root, and the first level's only work item
     LB_HIPCHK(hipEventCreate(&ev0));
     LB_HIPCHK(hipEventCreate(&ev1));
@@ -1140,7 +1175,7 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
     while (m > 0) {
         hipLaunchKernelGGL(k_sah_cbounds, gc, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work);
         hipLaunchKernelGGL(k_sah_bin, gc, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_bins);
-        SahLists lists{d_counters, next, d_small};
+        SahLists lists{d_counters, next, d_small, (uint32_t)cap, n / 2u + 2u, d_bad};
         hipLaunchKernelGGL(k_sah_sweep, dim3((bound + 3u) / 4u), dim3(256), 0, stream, work, d_bins, nd, lists, small);
         hipLaunchKernelGGL(k_sah_advance, dim3(1), dim3(1), 0, stream, d_counters);
         hipLaunchKernelGGL(k_sah_flags, gt, dim3(256), 0, stream, idx, pw, n, d_leaf_box, work, d_fl);
@@ -1150,10 +1185,11 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
         bound = (uint32_t)std::min<size_t>(2 * (size_t)bound, cap);
         if (++levels > 512u) { cleanup(); return fail(CRT_ERR_HIP, "sah: did not converge"); }
         if (levels >= sync_from) {
-            uint32_t c[4] = {0, 0, 0, 0};
+            uint32_t c[4] = {0, 0, 0, 0}, flags_now = 0;
             LB_HIPCHK(hipMemcpyAsync(c, d_counters, 16, hipMemcpyDeviceToHost, stream));
+            LB_HIPCHK(hipMemcpyAsync(&flags_now, d_bad, 4, hipMemcpyDeviceToHost, stream));
             LB_HIPCHK(hipStreamSynchronize(stream));
-            if (c[3] > cap || c[2] > n / 2u + 1u || c[0] > n_nodes) { cleanup(); return fail(CRT_ERR_HIP, "sah: work list overflow"); }
+            if ((flags_now & 4u) || c[3] > cap || c[2] > n / 2u + 1u || c[0] > n_nodes) { cleanup(); return fail(CRT_ERR_HIP, "sah: work list overflow"); }
             nodes = c[0]; n_small = c[2]; m = c[3];
         }
     }
@@ -1187,12 +1223,16 @@ static int sah_build_on_device(const int32_t* d_vidx, uint32_t stride, const flo
         hipLaunchKernelGGL(k_refit_level, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_flat, level_start[l], level_start[l + 1]);
     }
     LB_HIPCHK(hipEventRecord(ev1, stream));
+    uint32_t bad_vertex = 0;
+    LB_HIPCHK(hipMemcpyAsync(&bad_vertex, d_scene + 6, 4, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipStreamSynchronize(stream));
     LB_HIPCHK(hipGetLastError());
     float ms = 0.f;
     LB_HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
     cleanup();
+    if (bad_vertex) return fail(CRT_ERR_INVALID, "sah: a vertex coordinate is not finite or exceeds 1e18");
+    if (bad & 4u) return fail(CRT_ERR_HIP, "sah: work list overflow");
     if (bad & 2u) return fail(CRT_ERR_LIMIT, "sah: tree deeper than 56 levels");
     if (bad) return fail(CRT_ERR_HIP, "sah: breadth-first renumbering is inconsistent");
     if (device_ms) *device_ms = ms;
@@ -1219,7 +1259,7 @@ int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_
     LB_HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp2_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
                                         (uint32_t*)nullptr, n_nodes, 0, 64, stream));
     float* d_leaf_box = tmp.take<float>(n_tris * 6);
-    uint32_t* d_scene = tmp.take<uint32_t>(6);
+    uint32_t* d_scene = tmp.take<uint32_t>(8);
     unsigned long long* d_keys = tmp.take<unsigned long long>(n_tris);
     unsigned long long* d_sorted = tmp.take<unsigned long long>(n_tris);
     int2* d_child = tmp.take<int2>(std::max<size_t>(n_tris - 1, 1));
@@ -1237,7 +1277,7 @@ int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_
     if (!d_leaf_box || !d_scene || !d_keys || !d_sorted || !d_child || !d_parent || !d_levels || !d_first || !d_bkeys || !d_bkeys2 || !d_ids ||
         !d_order || !d_pos || !d_bad || !d_tmp || !d_tmp2)
         return fail(CRT_ERR_NOMEM, "lbvh: temporary arena too small");
-    const uint32_t scene_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    const uint32_t scene_init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     LB_HIPCHK(hipEventCreate(&ev0));
     LB_HIPCHK(hipEventCreate(&ev1));
     LB_HIPCHK(hipMemcpyAsync(d_scene, scene_init, sizeof scene_init, hipMemcpyHostToDevice, stream));
@@ -1272,13 +1312,15 @@ int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_
         hipLaunchKernelGGL(k_refit_level, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_flat, level_start[l], level_start[l + 1]);
     }
     LB_HIPCHK(hipEventRecord(ev1, stream));
-    uint32_t bad = 0;
+    uint32_t bad = 0, bad_vertex = 0;
+    LB_HIPCHK(hipMemcpyAsync(&bad_vertex, d_scene + 6, 4, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
     LB_HIPCHK(hipStreamSynchronize(stream));
     LB_HIPCHK(hipGetLastError());
     float ms = 0.f;
     LB_HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
     cleanup();
+    if (bad_vertex) return fail(CRT_ERR_INVALID, "crt_lbvh_build: a vertex coordinate is not finite or exceeds 1e18");
     if (bad) return fail(CRT_ERR_HIP, "crt_lbvh_build: breadth-first renumbering is inconsistent");
     if (device_ms) *device_ms = ms;
     if (depth_out) *depth_out = n_levels - 1u;           // the deepest level holds leaves only

@@ -79,3 +79,17 @@ def test_scene_create_rejects_bad_indices(cr, cornell_data):
     with pytest.raises(cr.CrtError) as e:
         cr.Scene(d, 32, 32, 1)
     assert e.value.code == _lib.CRT_ERR_INVALID
+
+
+def test_scene_create_rejects_non_finite_vertices(cr, cornell_data):
+    """an inf / NaN / absurdly large coordinate turns boxes and surface areas into inf or NaN (one such cluster never
+    found a neighbour and the PLOC tail spun); refused up front, before any device work."""
+    import copy
+    from caitlynrenderer_amd import _lib
+    for bad in (np.inf, -np.inf, np.nan, 3.0e19):
+        d = copy.copy(cornell_data)
+        d.vertices = d.vertices.copy()
+        d.vertices[5, 1] = bad
+        with pytest.raises(cr.CrtError) as e:
+            cr.Scene(d, 32, 32, 1)
+        assert e.value.code == _lib.CRT_ERR_INVALID and "vertex coordinate" in str(e.value)

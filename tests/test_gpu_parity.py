@@ -1066,6 +1066,58 @@ def test_gpu_lbvh_edge_cases(cr):
     assert cw.depth <= 16
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "ploc4", "sah"])
+def test_gpu_builders_refuse_non_finite_vertices_and_always_end(cr, builder):
+    """one inf coordinate made every union area with that triangle inf; its PLOC cluster never found a neighbour and the
+    single-workgroup tail looped for ever.  Every builder now gives such triangles a point box (so all later kernels see finite
+    data and end), flags the vertex, and the call returns CRT_ERR_INVALID."""
+    from caitlynrenderer_amd import _lib
+    rng = np.random.default_rng(11)
+    n = 700                                                    # below 1024 clusters: PLOC goes straight to the tail kernel
+    v = rng.random((3 * n, 3)).astype(np.float32) * 4
+    t = np.zeros((n, 12), np.int32)
+    t[:, :3] = np.arange(3 * n).reshape(-1, 3)
+    for bad in (np.inf, np.nan, -3.0e19):
+        vb = v.copy()
+        vb[37, 1] = bad
+        with pytest.raises(cr.CrtError) as e:
+            cr.SBVH(t, vb, builder=builder)
+        assert e.value.code == _lib.CRT_ERR_INVALID and "vertex coordinate" in str(e.value)
+    # 5000 coincident boxes and a grid of equal boxes: areas tie everywhere; the builders still end with a valid tree
+    for verts in (np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (5000, 1)),):
+        tt = np.zeros((5000, 12), np.int32)
+        tt[:, :3] = np.arange(15000).reshape(-1, 3)
+        sb = cr.SBVH(tt, verts, builder=builder)
+        assert sb.flat_nodes.shape[0] == 2 * 5000 - 1
+
+
+def test_a_failed_growth_of_the_batch_buffers_leaves_the_scene_usable(cr, ob, cornell, tess8):
+    """crt_render_frames on a multi-segment path grows path state and queues (~250 B per pixel and sample).  A failed
+    allocation there used to leave null queues behind a scene that still claimed to be ready.  Now the new buffers are allocated
+    first and swapped in only when all of them exist: the call fails with CRT_ERR_NOMEM, and the scene renders on, frame by frame
+    and — at the next attempt — batched, with the oracle's bits."""
+    from caitlynrenderer_amd import _lib
+    _, data = tess8
+    _, cam = cornell
+    W, H, depth = 200, 120, 3
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(6)]
+    s = cr.Scene(data, W, H, depth)
+    s.render_frame(*rvs[0])
+    s.set_option("debug_fail_batch_alloc", 1)
+    with pytest.raises(cr.CrtError) as e:
+        s.render_frames(rvs[1:5])
+    assert e.value.code == _lib.CRT_ERR_NOMEM
+    s.render_frame(*rvs[1])                                     # still works one by one ...
+    s.render_frames(rvs[2:6])                                   # ... and batched, once the allocation succeeds
+    orc = ob.Oracle(data, W, H, depth, cam)
+    ref = np.zeros((H, W, 3), np.float32)
+    for r in rvs:
+        orc.render_frame(r[0], r[1], ref, threads=8)
+    assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32))
+    s.close()
+
+
 def _same_cwbvh(a, b):
     assert a.depth == b.depth and a.nodes.shape == b.nodes.shape
     assert np.array_equal(a.nodes, b.nodes), int((a.nodes != b.nodes).any(axis=1).sum())

@@ -153,6 +153,27 @@ def test_jpeg_decoder_properties(host):
             host.decode_image(data)
 
 
+def test_entropy_data_that_ends_inside_a_coefficient_is_refused(host):
+    """a marker in mid-coefficient.  The bit reader adds nothing once it has met a marker; a coefficient that needs more
+    bits than are left is refused (the bit count used to go negative, and the next refill shifted by more than 31)."""
+    import caitlynrenderer_amd as cr
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stb_decodes.npz"))
+    names = [k[:-6] for k in z.files if k.endswith("__file") and k.startswith("jpeg")]
+    assert names
+    refused = 0
+    for name in names[:12]:
+        good = bytes(z[name + "__file"])
+        sos = good.rfind(b"\xff\xda")
+        body = sos + 2 + ((good[sos + 2] << 8) | good[sos + 3])           # first byte of the last scan's entropy-coded data
+        for cut in (body + 1, body + 3, body + (len(good) - body) // 2):
+            data = good[:cut] + b"\xff\xd9"                                # EOI right inside the entropy-coded segment
+            try:
+                host.decode_image(data)
+            except cr.CrtError:
+                refused += 1
+    assert refused > 0                                                    # no crash, no hang; the truncated scans are refused
+
+
 def test_refused_and_damaged_files(host):
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd import _lib
