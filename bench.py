@@ -9,19 +9,20 @@ tiles (ray generation -> CWBVH closest hit -> shading / NEE -> CWBVH any hit -> 
 
 Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
   N = 1, --workload auto (the default):
-    value / roofline / cpu_baseline  = configs[1]: Cornell box, CWBVH, 1 spp primary + shadow, 1920x1080;
-    "north_star"                     = configs[2]: the 1,004,672-triangle mesh, 4 spp per step, 1920x1080, primary + shadow —
-                                       the workload BASELINE.json's targets are quoted on, with its own roofline and cpu_baseline;
-    "north_star_gpu_tree"            = the same over a tree built on the GPU (binned SAH, everything assembled in HBM);
-    "incoherent" / "incoherent_disney" = configs[3]: same mesh and 4 spp per step, 4 path segments (incoherent bounce rays), with the reference's
-                                       Lambert integrator and with the oracle-defined mirror + GGX/Disney-diffuse materials;
-    "scale_base"                     = configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines
-                                       divide by);
-    "cornell_8_frames_per_launch"    = for information: configs[1]'s scene with 8 frames per crt_render_frames call (one launch).
+    value / roofline / cpu_baseline  = configs[2]: the 1,004,672-triangle mesh, CWBVH, 4 spp per step, 1920x1080, primary + shadow —
+                                       the workload BASELINE.json's targets (>= 1 Gray/s, >= 50 % roofline) are quoted on;
+    "extras" (compact: value, ms_per_step, launch_ms, frac, algorithmic_gbps, traffic):
+      "cornell"            configs[1]: Cornell box, CWBVH, 1 spp primary + shadow, 1920x1080 (one launch per frame);
+      "gpu_tree"           configs[2] over a tree built on the GPU (binned SAH, everything assembled in HBM by crt_scene_create);
+      "incoherent"         configs[3]: same mesh, 4 path segments (incoherent bounce rays), the reference's Lambert integrator;
+      "incoherent_disney"  configs[3] with the oracle-defined mirror + GGX / Disney-diffuse materials;
+      "scale_base"         configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines divide by);
+      "hbm_resident"       the same scene tessellated to ~8 M triangles (n = 520): records + nodes exceed the 256 MiB Infinity
+                           Cache, so its traffic figure is HBM traffic (1 segment and 4 segments).
   N > 1, --workload auto: configs[4]: ONE fixed 3840x2160 frame of the 1 M-triangle mesh, 4 spp per step, its 16x16 tiles dealt
     to the N ranks (strong scaling, no data-path collective), one RCCL gather of the per-tile radiance to rank 0 inside the timed
-    region; "n1_same_workload" is the same frame rendered by rank 0 alone in the same job.  `--scaling weak` keeps the round-1
-    behaviour (the frame grows with N, ~1920x1080 pixels per rank).
+    region; the line carries gather_ms, per-rank device time, the same frame rendered by rank 0 alone and the efficiency against it.
+    `--scaling weak` keeps the round-1 behaviour (the frame grows with N, ~1920x1080 pixels per rank).
   An explicit --workload measures just that one (used by the profiling scripts).
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts its N ranks itself, as fresh child processes
@@ -29,12 +30,16 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
 forwards rank 0's JSON line and exits with the children's status; launched under torch.distributed.run by someone else it
 simply is one of the ranks.
 
-Prints ONE JSON line on rank 0 with the driver's keys plus "roofline" (dominant kernel = the fused segment kernel:
-algorithmic bytes of SURVEY §8d / HIP-event launch time on the kernel's own stream; `traffic` (L2<->fabric bytes per launch) and
-`valu_issue` (issue slots busy x lanes enabled — the real ceiling of this kernel) come from rocprofv3 --pmc passes: at N = 1 in
-auto mode this invocation runs them itself, as child processes before its own first GPU call (`traffic_source: "live"`, ~1.5 min;
---no-live-pmc or a missing rocprofv3 falls back to the committed passes of profiles/pmc_traffic.json, `"committed"`)) and
-"cpu_baseline" (the CPU oracle on the same workload, bounded sample, rank 0, N = 1).
+Prints ONE JSON line (< 6 KB) on rank 0 with the driver's keys plus
+  "roofline": the dominant kernel (the fused segment kernel) against the roof that binds it — VECTOR-INSTRUCTION ISSUE, not HBM (every
+      BASELINE scene is cache-resident: SURVEY §8d's algorithmic bytes / time exceeds the HBM peak and is reported as
+      `algorithmic_gbps`, never as a fraction).  achieved = algorithmic wave-instructions of a launch / its mean HIP-event duration;
+      peak = 1024 SIMDs x 2.4 GHz / 2 cycles; definitions, instruction counts and the script that recomputes every frac:
+      tools/roofline.py, profiles/isa_counts.json.  `traffic` = L2<->fabric bytes per launch, (2 FETCH_SIZE + WRITE_SIZE) x 1024 from
+      rocprofv3 --pmc passes this invocation runs itself as child processes before its own first GPU call (`traffic_source:
+      "live"`; --no-live-pmc or a missing rocprofv3: the committed passes of profiles/pmc_traffic.json, "committed"); `issue_busy`,
+      `lane_util` from the SQ pass of the same.
+  "cpu_baseline": the CPU oracle on the same workload, bounded sample, rank 0, N = 1.
 """
 import argparse
 import json
@@ -48,7 +53,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, MI355X_MICROARCH.md "Chip-level parameters" (algorithmic_gbps is quoted against it in DESIGN.md only)
+VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0   # G wave64-instructions/s: 1024 SIMD-32s, one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 NODE_BYTES, TRI_BYTES, FB_BYTES = 80, 52, 24   # SURVEY.md §8d algorithmic bytes per node fetch / triangle test / pixel-sample
 METRIC = "Mray/s (primary+1 bounce) at 1920x1080"
 
@@ -88,7 +94,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="auto workload at N = 1: do not run the rocprofv3 --pmc passes (roofline.traffic / valu_issue then come from the "
                          "committed profiles/pmc_traffic.json and say so)")
+    ap.add_argument("--device-built", default=None, metavar="BUILDER",
+                    help="explicit workload: crt_scene_create builds the tree itself on the GPU from the source-order arrays (lbvh, ploc<r>, sah)")
     ap.add_argument("--no-extra", action="store_true", help="auto workload: only the headline block")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="auto workload: skip the 8 M-triangle (> Infinity Cache) blocks")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
                          "(what the CPU tests exercise); the line says dry_run and reports no throughput")
@@ -168,6 +177,21 @@ def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
     return _SCENE_CACHE[key]
 
 
+_MESH_CACHE = {}
+
+
+def source_mesh(name):
+    """(mesh in source order, camera) of a workload name: cornell, mesh1m (n = 183) or mesh<n>"""
+    if name not in _MESH_CACHE:
+        import __graft_entry__ as g
+        from caitlynrenderer_amd.meshgen import tessellated_cornell
+        mesh, cam = g._cornell()
+        if name != "cornell":
+            mesh = tessellated_cornell(mesh, 183 if name == "mesh1m" else int(name[4:]))
+        _MESH_CACHE[name] = (mesh, cam)
+    return _MESH_CACHE[name]
+
+
 def weak_frame_size(n_gpus):
     if n_gpus == 1:
         return 1920, 1080
@@ -223,6 +247,15 @@ class Ctx:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather_floats(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank"""
+        if not self.use_dist:
+            return [float(x)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.device)
+        t[self.rank] = float(x)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
     def close(self):
         if self.use_dist:
             self.dist.barrier()
@@ -246,7 +279,7 @@ def pmc_entry(workload, depth):
         return {}
 
 
-def live_pmc(workloads, budget_s=240.0):
+def live_pmc(workloads, budget_s=330.0):
     """The hardware-counter passes of THIS run: for each (workload, depth) four `rocprofv3 --pmc <group> -- python3 bench.py
     --workload ... --no-live-pmc` children (separate passes per counter group, as MI355X_MICROARCH.md prescribes), started
     before this process has touched the GPU.  Counters perturb timing, so the children's own throughput is discarded; what is
@@ -266,7 +299,7 @@ def live_pmc(workloads, budget_s=240.0):
     top = tempfile.mkdtemp(prefix="crt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for name, depth, spp in workloads:
+        for name, depth, spp, *more in workloads:
             key, dirs, ok = f"{name}_d{depth}", {}, True
             for kind, counters in pt.PASSES.items():
                 if time.time() - t_start > budget_s:
@@ -275,9 +308,10 @@ def live_pmc(workloads, budget_s=240.0):
                     break
                 d = os.path.join(top, f"pmc_{kind}_{key}")
                 cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
-                       "--workload", name, "--depth", str(depth), "--spp", str(spp), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc"]
+                       "--workload", name, "--depth", str(depth), "--spp", str(spp), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc",
+                       "--settle-ms", "0"] + [str(x) for x in more]
                 try:
-                    run = subprocess.run(cmd, cwd=top, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=90)
+                    run = subprocess.run(cmd, cwd=top, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=150)
                 except subprocess.TimeoutExpired:
                     run = None
                 if run is None or run.returncode != 0:
@@ -311,23 +345,22 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
 
     out = None
     if takes_part:
-        data, cam, label, build_s = build_workload(name, args.builder, args.convert, materials or args.materials)
         build_info = None
         if device_built:
-            from caitlynrenderer_amd.meshgen import tessellated_cornell
-            import __graft_entry__ as g
-            mesh, _ = g._cornell()
-            if name != "cornell":
-                mesh = tessellated_cornell(mesh, 183 if name == "mesh1m" else int(name[4:]))
+            # crt_scene_create gets the source-order arrays only and builds BVH2, CWBVH and records in HBM: no host tree at all
+            mesh, cam = source_mesh(name)
+            data = None
             t_b = time.perf_counter()
             scene = cr.Scene(cr.SceneData.for_device_build(mesh, cam, builder=device_built), W, H, depth)
             bi = scene.bvh_info()
             build_info = {"builder": device_built, "scene_create_wall_ms": round((time.perf_counter() - t_b) * 1e3, 2),
                           "upload_ms": round(bi["build_upload_ms"], 2), "bvh2_device_ms": round(bi["build_lbvh_device_ms"], 2),
                           "cwbvh_device_ms": round(bi["build_convert_device_ms"], 2)}
-            label = label.split(",")[0] + f", CWBVH over a BVH2 built on the GPU ({device_built}), everything assembled in HBM by crt_scene_create"
+            label = (f"procedural tessellated Cornell n={183 if name == 'mesh1m' else name[4:]}: {mesh.triangles.shape[0]} tris" if name != "cornell" else "cornell-box 32 tris") \
+                + f", CWBVH over a BVH2 built on the GPU ({device_built}), everything assembled in HBM by crt_scene_create"
             build_s = build_info["scene_create_wall_ms"] / 1e3
         else:
+            data, cam, label, build_s = build_workload(name, args.builder, args.convert, materials or args.materials)
             scene = cr.Scene(data, W, H, depth)
         scene.set_shard(rank, world, args.tile)
         for kv in args.option:
@@ -391,13 +424,17 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         ctx.barrier(scene)
     elif takes_part:
         torch.cuda.synchronize(); scene.sync()
+    gather_ms = 0.0
     if takes_part:
         t0 = time.perf_counter()
         for k in range(K):
             step(Wu + k)
         scene.sync()
+        render_s = time.perf_counter() - t0            # this rank's rendering, without the gather
         if use_dist:
             read_back()
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - t0 - render_s) * 1e3
     if sharded:
         ctx.barrier(scene)
     if takes_part:
@@ -425,59 +462,54 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         rays_frame = (st["closest_rays"] + st["any_rays"]) / samples_per_launch      # the stats describe the last launch
         rays_all = ctx.sum_over_ranks(rays_frame) if sharded else float(rays_frame)
         value = rays_all * K * spp / dt / 1e6
+        # primary rays of one frame of this rank = its in-frame pixels
+        n_primary = sum(min(tile, W - tx * tile) * min(tile, H - ty * tile) for tx, ty in tiles.local_tiles(W, H, tile, rank, world))
+        rank_ms = ctx.gather_floats(render_s / K * 1e3) if use_dist else [render_s / K * 1e3]
 
     if takes_part and ctx.rank == 0:
         launches = max(1, depth)
         node_bytes = 96 if args.accel == "bvh2" else NODE_BYTES      # own 2 texels + 4 child texels per BVH2 visit
-        alg = (node_bytes * cs["nodes_closest"] + TRI_BYTES * cs["tris_closest"]) / launches * samples_per_launch
-        # the segment kernel also walks the NEE shadow rays in place (no k_shadow launch): their visits are this launch's bytes too
+        # the segment kernel walks the NEE shadow rays in place (no k_shadow launch): their visits are this launch's work too
         fused_shadow = st["any_rays"] > 0 and float(np.median(any_ms)) == 0.0
-        if fused_shadow:
-            alg += (node_bytes * cs["nodes_any"] + TRI_BYTES * cs["tris_any"]) / launches * samples_per_launch
+        nodes = cs["nodes_closest"] + (cs["nodes_any"] if fused_shadow else 0)
+        tris = cs["tris_closest"] + (cs["tris_any"] if fused_shadow else 0)
+        alg_bytes = (node_bytes * nodes + TRI_BYTES * tris) / launches * samples_per_launch
         t_launch = launch_ms_timed * 1e-3
-        achieved = alg / t_launch / 1e9 if t_launch > 0 else 0.0
-        if fused_shadow:
-            kernel_label = "k_segment (raygen / queue fetch + CWBVH closest hit + shading + in-place NEE any-hit walk), mean per path segment"
-        else:
-            kernel_label = "k_segment (raygen / queue fetch + CWBVH closest hit + shading + queue emission), mean per path segment"
-        # the counter passes run the host-built tree, Lambert, 1920x1080: other blocks carry no counter figures of their own
-        pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and not device_built and materials in (None, "lambert")) else {}
-        traffic = pmc.get("l2_fabric_bytes_per_launch", pmc.get("hbm_bytes_per_launch"))
+        # counter passes exist per (workload, depth) at 1920x1080 on the host-built tree with the reference's materials
+        pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and (not device_built or name == HBM_RESIDENT) and materials in (None, "lambert")) else {}
+        traffic = pmc.get("l2_fabric_bytes_per_launch")
         if traffic is not None:      # a pass that rendered fewer samples per launch than this block's launches: scaled to the same unit
             traffic = int(traffic * samples_per_launch / max(1, pmc.get("samples_per_launch", 1)))
-        roofline = {
-            "bound": "hbm", "kernel": kernel_label, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "traffic_source": pmc.get("source"),
-            "traffic_is": "L2<->fabric bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes of this workload ("
-                          + ("run by this bench.py invocation as child processes before its own measurements" if pmc.get("source") == "live"
-                             else "the committed ones, profiles/pmc_traffic.json")
-                          + "); the scene sits in the 256 MiB Infinity Cache, so true HBM bytes are lower still",
-            "limiter": "valu_issue",
-            "valu_issue": pmc.get("valu_issue"),
-            "algorithmic_bytes_per_launch": int(alg),
-            "bytes_per_ray": round(alg / samples_per_launch / max(1, (cs["closest_rays"] + (cs["any_rays"] if fused_shadow else 0)) / launches), 2),
-            "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3),
-            "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
-            "any_hit_nodes_per_ray": round(cs["nodes_any"] / max(1, cs["any_rays"]), 3),
-            "any_hit_tris_per_ray": round(cs["tris_any"] / max(1, cs["any_rays"]), 3),
+        counters = {"primary_rays": int(n_primary), "closest_rays": int(cs["closest_rays"]), "any_rays": int(cs["any_rays"]),
+                    "closest_hits": int(cs["closest_hits"]), "nodes_closest": int(cs["nodes_closest"]), "tris_closest": int(cs["tris_closest"]),
+                    "nodes_any": int(cs["nodes_any"]), "tris_any": int(cs["tris_any"])}
+        roofline = valu_roofline(counters, t_launch, launches, samples_per_launch, args.accel)
+        vi = pmc.get("valu_issue") or {}
+        roofline.update({
+            "traffic": traffic, "traffic_source": pmc.get("source"),
+            # bytes crossing L2 <-> fabric per second; for a scene larger than the 256 MiB Infinity Cache (the hbm_resident blocks) this is
+            # HBM bandwidth, for the cache-resident BASELINE scenes mostly MALL hits
+            "traffic_gbps": round(traffic / t_launch / 1e9, 1) if traffic and t_launch > 0 else None,
+            "algorithmic_gbps": round(alg_bytes / t_launch / 1e9, 1) if t_launch > 0 else None,
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "issue_busy": vi.get("busy"), "lane_util": vi.get("lane_util"), "l2_hit_rate": pmc.get("l2_hit_rate"),
             "launch_ms": round(t_launch * 1e3, 4), "launches_timed": int(n_timed_launches), "samples_per_launch": int(samples_per_launch),
-            "any_hit_launch_ms": round(float(np.median(any_ms)), 4),
-            "frame_device_ms": round(float(np.median(total_ms)), 4),
-            "note": ("frac = SURVEY §8d algorithmic bytes / launch time / HBM peak; the kernel itself is bound by VALU issue (valu_issue.frac = "
-                     "issue slots busy x lanes enabled, from the PMC pass), not by HBM"
-                     + ("; this tree of %d nodes lives in L1, so the algorithmic-bytes rate says nothing about the memory system" % info["n_nodes8"]
-                        if info["n_nodes8"] < 64 else "")),
-        }
+            "path_segments": depth, "frame_device_ms": round(float(np.median(total_ms)), 4),
+            "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3), "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
+            "any_hit_nodes_per_ray": round(cs["nodes_any"] / max(1, cs["any_rays"]), 3), "any_hit_tris_per_ray": round(cs["tris_any"] / max(1, cs["any_rays"]), 3),
+            "counters": counters,
+        })
         out = {
             "value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling,
             "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": spp, "path_segments": depth,
-                       "rays_per_step": int(rays_all) * spp, "closest_rays_rank0": int(st["closest_rays"] // samples_per_launch),
-                       "any_rays_rank0": int(st["any_rays"] // samples_per_launch), "tile": tile, "parallelism": f"tiles/{world}", "settle_ms": args.settle_ms,
-                       "stack_overflows": int(st["stack_overflows"]),
+                       "rays_per_step": int(rays_all) * spp, "tile": tile, "parallelism": f"tiles/{world}",
+                       "n_nodes8": int(info["n_nodes8"]), "n_tris8": int(info["n_tris8"]), "stack_overflows": int(st["stack_overflows"]),
                        "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
             "roofline": roofline,
         }
+        if use_dist:
+            out["gather_ms"] = round(gather_ms, 4)
+            out["rank_device_ms_per_step"] = [round(x, 4) for x in rank_ms]
         if build_info:
             out["config"]["device_build"] = build_info
         if cpu_base and not args.no_cpu_baseline and args.accel == "cwbvh":
@@ -485,6 +517,32 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
     if takes_part:
         scene.close()
     return out
+
+
+_ISA = None
+
+
+def valu_roofline(c, t_launch, launches, samples_per_launch, accel="cwbvh"):
+    """The roof that binds the segment kernel: vector-instruction issue (tools/roofline.py has the definition and recomputes it).
+    achieved = algorithmic wave-instructions per launch / launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction."""
+    global _ISA
+    if _ISA is None:
+        try:
+            _ISA = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+        except Exception:
+            _ISA = {}
+    r = {"bound": "valu_issue", "kernel": "k_segment (ray generation / queue fetch + CWBVH closest hit + shading + in-place NEE any-hit walk), mean over the path's segments",
+         "achieved": None, "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Gwave-instr/s", "frac": None}
+    if _ISA.get("I_node") and accel == "cwbvh" and t_launch > 0:
+        n_first, n_bounce = c["primary_rays"], c["closest_rays"] - c["primary_rays"]
+        lane_instr = ((c["nodes_closest"] + c["nodes_any"]) * _ISA["I_node"] + (c["tris_closest"] + c["tris_any"]) * _ISA["I_tri"]
+                      + n_first * _ISA["I_ray_first"] + n_bounce * _ISA.get("I_ray_bounce", _ISA["I_ray_first"]) + c["closest_hits"] * _ISA["I_shade"])
+        w = lane_instr / 64.0 / launches * samples_per_launch
+        r["achieved"] = round(w / t_launch / 1e9, 1)
+        r["frac"] = round(r["achieved"] / VALU_PEAK_GINSTR, 4)
+        r["attainable"] = _ISA.get("attainable_gwave_instr_per_s")      # the same roof at the measured issue cost of this instruction mix
+        r["algorithmic_wave_instr_per_launch"] = int(w)
+    return r
 
 
 def cpu_baseline(data, cam, W, H, depth, rv, cs):
@@ -571,7 +629,8 @@ def main():
     if (args.gpus == 1 and "RANK" not in os.environ and args.workload == "auto" and args.accel == "cwbvh"
             and not (args.dry_run or args.no_live_pmc or args.option)):
         # hardware counters of this very run, from child processes, before this process makes its first GPU call
-        live_pmc([("cornell", args.depth, args.spp or 1)] + ([] if args.no_extra else [("mesh1m", 1, 4), ("mesh1m", 4, 4)]))
+        live_pmc([("mesh1m", args.depth, args.spp or 4)] + ([] if args.no_extra else [("mesh1m", 4, 4), ("cornell", 1, 1)])
+                 + ([] if args.no_extra or args.no_hbm_resident else [(HBM_RESIDENT, 1, 4, "--device-built", "sah"), (HBM_RESIDENT, 4, 4, "--device-built", "sah")]))
 
     ctx = Ctx(args)
     if ctx.world != args.gpus:
@@ -584,7 +643,7 @@ def main():
     N = ctx.world
     auto = args.workload == "auto"
     if N == 1:
-        name = "cornell" if auto else args.workload
+        name = "mesh1m" if auto else args.workload      # configs[2]: the workload BASELINE.json's targets are quoted on
         scaling = "weak"              # one GPU: per-GPU work is what it is
         W, H = 1920, 1080
     elif args.scaling == "strong":
@@ -603,48 +662,69 @@ def main():
         head = dry_block(ctx, W, H, spp, scaling)
         extra = {}
     else:
-        head = run_block(ctx, name, W, H, args.depth, spp, True, N == 1, scaling)
+        head = run_block(ctx, name, W, H, args.depth, spp, True, N == 1 and not args.device_built, scaling, device_built=args.device_built)
         extra = {}
         if auto and not args.no_extra and args.accel == "cwbvh":
             if N == 1:
-                extra["north_star"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, True, "weak")
-                extra["north_star_gpu_tree"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, False, "weak", device_built="sah")
+                extra["cornell"] = run_block(ctx, "cornell", 1920, 1080, 1, 1, True, False, "weak")
+                extra["gpu_tree"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, False, "weak", device_built="sah")
                 extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak")
                 extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak", materials="disney")
                 extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
-                extra["cornell_8_frames_per_launch"] = run_block(ctx, "cornell", 1920, 1080, 1, 8, True, False, "weak")
+                if not args.no_hbm_resident:
+                    # > 256 MiB of nodes + records: the one block whose `traffic` is HBM traffic.  Built on the GPU (binned SAH): the
+                    # reference's host builder would take minutes at this size.
+                    saved = args.steps
+                    args.steps = max(3, args.steps // 5)
+                    extra["hbm_resident"] = run_block(ctx, HBM_RESIDENT, 1920, 1080, 1, 4, True, False, "weak", device_built="sah")
+                    extra["hbm_resident_d4"] = run_block(ctx, HBM_RESIDENT, 1920, 1080, 4, 4, True, False, "weak", device_built="sah")
+                    args.steps = saved
             elif args.scaling == "strong":
                 ctx.barrier()
                 extra["n1_same_workload"] = run_block(ctx, name, W, H, args.depth, spp, False, False, "strong")
                 ctx.barrier()
 
     if ctx.rank == 0:
-        out = {"metric": METRIC, "value": head["value"], "unit": head["unit"], "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
+        out = {"metric": METRIC.replace("1920x1080", f"{W}x{H}"), "value": head["value"], "unit": head["unit"], "n_gpus": N, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
-        if "cpu_baseline" in head:
-            out["cpu_baseline"] = head["cpu_baseline"]
+        for k in ("cpu_baseline", "gather_ms", "rank_device_ms_per_step"):
+            if k in head:
+                out[k] = head[k]
         if head.get("dry_run"):
             out["dry_run"] = True
-        descr = {"north_star": "BASELINE.json configs[2] — the workload its targets (>= 1 Gray/s, >= 50 % HBM roofline) are quoted on",
-                 "north_star_gpu_tree": "configs[2] again, over a tree built on the GPU: crt_scene_create with CRT_BUILD_LBVH_ON_DEVICE | CRT_BUILD_SAH "
-                                        "(binned-SAH BVH2, CWBVH conversion and records all in HBM; config.device_build has the times) instead of the host SBVH",
-                 "incoherent": "BASELINE.json configs[3] ray mix with the reference's own (Lambert-only) integrator — 4 path segments on the same mesh, "
-                               "4 spp per step as in configs[2] (the step's four frames share each segment's launch: crt_render_frames)",
-                 "incoherent_disney": "BASELINE.json configs[3] as worded: 4 path segments with a mirror tall box and GGX / Disney-diffuse short "
-                                      "box and floor (the material model has no reference code: oracle-defined, HIP == oracle bit for bit)",
-                 "scale_base": "BASELINE.json configs[4] at N = 1: what the N > 1 lines of `bench.py --gpus N` divide by",
-                 "cornell_8_frames_per_launch": "NOT the headline: configs[1]'s scene with 8 frames handed to crt_render_frames per step, i.e. one launch per 8 "
-                                                "samples — what the top-level line (one launch per frame, as the reference's frame loop issues them) leaves "
-                                                "in launch gaps and kernel tails",
-                 "n1_same_workload": "the same frame rendered by rank 0 alone in this job (strong-scaling base)"}
-        for k, v in extra.items():
-            if v is not None:
-                v["what"] = descr[k]
-                out[k] = v
+        n1 = extra.pop("n1_same_workload", None)
+        if n1:
+            # the same frame rendered by rank 0 alone in this job: what N ranks are measured against
+            out["n1_same_workload"] = {"value": n1["value"], "ms_per_step": n1["ms_per_step"]}
+            out["scaling_efficiency"] = round(head["value"] / (N * n1["value"]), 4)
+        ex = {k: compact(v) for k, v in extra.items() if v is not None}
+        if ex:
+            out["extras"] = ex
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (json.dumps(out, separators=(",", ":")) + "\n").encode())
     ctx.close()
+
+
+HBM_RESIDENT = "mesh520"      # tessellation n = 520: 8,112,002 triangles, 16.2 M BVH2 nodes (below the 2^24 a float link can index)
+
+
+def compact(b):
+    """An extra block of the line: what it is, its throughput and its roofline figures, nothing else (README.md explains the fields)."""
+    r, c = b["roofline"], b["config"]
+    e = {"workload": c["workload"].split(",")[0].replace("procedural tessellated Cornell ", "") + f" {c['resolution']} d{c['path_segments']} spp{c['spp_per_step']}"
+                     + (" disney" if "Disney" in c["workload"] else "") + (" gpu-built" if "device_build" in c else ""),
+         "value": b["value"], "ms_per_step": b["ms_per_step"], "launch_ms": r["launch_ms"], "samples_per_launch": r["samples_per_launch"],
+         "frac": r["frac"], "achieved": r["achieved"], "algorithmic_gbps": r["algorithmic_gbps"]}
+    for k in ("traffic", "traffic_gbps", "lane_util", "issue_busy", "l2_hit_rate"):
+        if r.get(k) is not None:
+            e[k] = r[k]
+    if "device_build" in c:
+        e["device_build"] = c["device_build"]
+    if c["workload"].find(f"n={HBM_RESIDENT[4:]}:") >= 0 and r.get("traffic_gbps"):
+        e["hbm_frac"] = round(r["traffic_gbps"] / HBM_PEAK_GBS, 4)      # this scene does not fit the Infinity Cache: traffic is HBM traffic
+        e["scene_mb"] = round((80 * c["n_nodes8"] + 48 * c["n_tris8"]) / 1e6, 1)
+    return e
 
 
 if __name__ == "__main__":

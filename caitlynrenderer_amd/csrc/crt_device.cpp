@@ -143,7 +143,7 @@ struct crt_scene {
     bool have_camera = false;
     uint32_t jitter = 1;
     bool count_visits = false;
-    unsigned long long* d_visit_totals = nullptr;   // [0..3] lane visits: closest nodes/tris, any nodes/tris; [4..7] wave-level steps of the same blocks
+    unsigned long long* d_visit_totals = nullptr;   // [0..3] lane visits: closest nodes/tris, any nodes/tris; [4..7] wave-level steps of the same blocks; [8] closest-hit rays that hit
     unsigned long long* h_visit_totals = nullptr;   // pinned
 
     // scratch for crt_trace (host rays)
@@ -358,6 +358,7 @@ int collect_stats(crt_scene* s) {
         st.nodes_any = s->h_visit_totals[2]; st.tris_any = s->h_visit_totals[3];
         st.wave_steps_closest_nodes = s->h_visit_totals[4]; st.wave_steps_closest_tris = s->h_visit_totals[5];
         st.wave_steps_any_nodes = s->h_visit_totals[6]; st.wave_steps_any_tris = s->h_visit_totals[7];
+        st.closest_hits = s->h_visit_totals[8];
     }
     s->stats = st;
     s->stats_pending = false;
@@ -629,7 +630,7 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
 // of FlatNodes over PCIe twice at 1 M triangles).  Temporaries of both builders come from one arena allocation.
 static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
     const auto t_begin = std::chrono::steady_clock::now();
-    if (d->n_triangles >= (1u << 21)) return fail(CRT_ERR_LIMIT, "crt_scene_create: more than 2^21 triangles (FlatNode.h:24 start field)");
+    if (d->n_triangles >= (1u << 23)) return fail(CRT_ERR_LIMIT, "crt_scene_create: more than 2^23 triangles (the 2 n - 1 FlatNode links are floats, exact below 2^24)");
     const bool have_tex = d->albedo_textures && d->n_textures > 0;
     std::unique_ptr<crt_scene> owner(new (std::nothrow) crt_scene);
     crt_scene* s = owner.get();
@@ -828,10 +829,10 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
     if (!s->timing_accumulate) s->n_spans = 0;
     if (s->count_visits) {
         if (!s->d_visit_totals) {
-            if ((rc = dev_alloc(&s->d_visit_totals, 8))) return rc;
-            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 8 * sizeof(unsigned long long)));
+            if ((rc = dev_alloc(&s->d_visit_totals, 16))) return rc;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 16 * sizeof(unsigned long long)));
         }
-        HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 8 * sizeof(unsigned long long), s->stream));
+        HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 16 * sizeof(unsigned long long), s->stream));
     }
     // counter banks alternate per frame; k_segment<FIRST> clears the other bank for the frame after this one, so a
     // memset is only needed for the very first frame (or after a failed launch left the banks in an unknown state)
@@ -964,7 +965,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
     }
     if (deferred) crt::launch_accumulate_samples(s->d_sum, s->d_lfinal, P, n_samples, s->stream);
     if (s->count_visits)
-        HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     if (measure_tiles) {
         HIPCHK(hipMemcpyAsync(s->h_tile_cost, s->d_tile_cost, s->n_local_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipEventRecord(s->ev_tile_cost, s->stream));

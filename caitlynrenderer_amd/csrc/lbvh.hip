@@ -1335,7 +1335,7 @@ int crt_lbvh_build(const crt_triangle* tris, size_t n_tris, const float* vertice
     if (!out) return fail(CRT_ERR_INVALID, "crt_lbvh_build: null out");
     *out = nullptr;
     if (!tris || !vertices || n_tris == 0) return fail(CRT_ERR_INVALID, "crt_lbvh_build: empty input");
-    if (n_tris >= (1u << 21)) return fail(CRT_ERR_LIMIT, "crt_lbvh_build: more than 2^21 triangles (FlatNode.h:24 start field)");
+    if (n_tris >= (1u << 23)) return fail(CRT_ERR_LIMIT, "crt_lbvh_build: more than 2^23 triangles (the 2 n - 1 FlatNode links are floats, exact below 2^24)");
     if (flags & ~(uint32_t)(CRT_GPU_BUILD_PLOC | CRT_GPU_BUILD_SAH | 0xff00u)) return fail(CRT_ERR_INVALID, "crt_lbvh_build: unknown flags");
     for (size_t i = 0; i < n_tris; ++i)
         for (int j = 0; j < 3; ++j)

@@ -25,6 +25,15 @@ namespace crt {
 
 // ------------------------------------------------------------------ traversal --------
 
+// `make asm` builds with -DCRT_ISA_MARKS: comment lines in the assembly bracket the traversal loop and its node / triangle steps so
+// that tools/roofline.py can count the vector instructions one node visit and one triangle test cost (the roofline's
+// algorithmic instruction count).  The product build carries no markers: an inline-asm statement is a scheduling barrier.
+#ifdef CRT_ISA_MARKS
+#define CRT_MARK(name) asm volatile("; CRT_MARK " name)
+#else
+#define CRT_MARK(name) ((void)0)
+#endif
+
 __device__ __forceinline__ uint32_t sign_extend_s8x4(uint32_t x) { return ((x >> 7) & 0x01010101u) * 0xffu; }   // cwbvh.fs:369-372
 
 __device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }          // v_cvt_f32_ubyteN
@@ -136,9 +145,11 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
     float max_t = tmax_in;
     int sp = 0;
     uint2 cur = make_uint2(0u, 0x80000000u);
+    CRT_MARK("loop_begin plain");
     for (;;) {
         uint2 tg;
         if (cur.y & 0xff000000u) {
+            CRT_MARK("node_begin");
             const uint32_t hits_imask = cur.y;
             const int off = 31 - __builtin_clz(hits_imask);
             const uint32_t base = cur.x;
@@ -158,11 +169,13 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             tg.x = n1.y;
             cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
             tg.y = hitmask & 0x00ffffffu;
+            CRT_MARK("node_end");
         } else {
             tg = cur;
             cur = make_uint2(0u, 0u);
         }
         while (tg.y) {
+            CRT_MARK("tri_begin");
             const int b = 31 - __builtin_clz(tg.y);
             tg.y &= ~(1u << b);
             const uint32_t ti = tg.x + (uint32_t)b;
@@ -172,7 +185,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             float u, v, t;
             if (mt_test(ta, tb, tc, o, d, u, v, t)) {
                 if (ANY) {
-                    if (t < max_t) { best.tri = (int)ti; return true; }
+                    if (t < max_t) { best.tri = (int)ti; CRT_MARK("tri_end"); CRT_MARK("loop_end"); return true; }
                 } else {
                     const int id = __float_as_int(ta.w);
                     // SURVEY appendix C tie rule: nearer wins, equal t -> lower original id
@@ -182,6 +195,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
                     }
                 }
             }
+            CRT_MARK("tri_end");
         }
         if (!(cur.y & 0xff000000u)) {
             if (sp == 0) break;
@@ -189,6 +203,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             cur = stk[sp * 64];
         }
     }
+    CRT_MARK("loop_end");
     return best.tri >= 0;
 }
 
@@ -232,6 +247,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
     best.t = 0.f; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
     int sp = 0;
     uint2 cur = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    CRT_MARK("loop_begin voting");
     for (;;) {
         const unsigned long long idle = next < pool_end ? __ballot(!busy) : 0ull;     // a drained pool skips the refill logic
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
@@ -282,6 +298,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
         bool finished = false;
         if (node_phase) {
             if (can_node) {
+                CRT_MARK("node_begin");
                 const uint32_t hits_imask = cur.y;
                 const int off = 31 - __builtin_clz(hits_imask);
                 const uint32_t base = cur.x;
@@ -301,9 +318,11 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 tg.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
                 tg.y = hitmask & 0x00ffffffu;
+                CRT_MARK("node_end");
             }
         } else if (SHARE) {
             // ---- shared triangle step (the whole wave takes part, waiting or not) ----
+            CRT_MARK("share_begin");
             const unsigned long long act = __ballot(true), lt = (1ull << lane) - 1ull;
             const uint32_t n_cons = (uint32_t)__builtin_popcountll(act), rank = (uint32_t)__builtin_popcountll(act & lt);
             const uint32_t pend = has_tri ? (uint32_t)__builtin_popcount(tg.y) : 0u;
@@ -358,7 +377,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 tg.y = finished ? 0u : bits;
                 __builtin_amdgcn_wave_barrier();                 // results are consumed before the next step's items overwrite the strip
             }
+            CRT_MARK("share_end");
         } else if (has_tri) {
+            CRT_MARK("tri_begin");
             const int b = 31 - __builtin_clz(tg.y);
             tg.y &= ~(1u << b);
             const uint32_t ti = tg.x + (uint32_t)b;
@@ -377,6 +398,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                     }
                 }
             }
+            CRT_MARK("tri_end");
         }
         // a lane with neither a triangle group nor inner hits left pops its stack, or is done
         if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
@@ -388,6 +410,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             busy = false;
         }
     }
+    CRT_MARK("loop_end");
 }
 
 // ------------------------------------------------------------------ scheduling -------
@@ -865,6 +888,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
     const FrameArgs& f = a.f;
     uint32_t nn = 0, nt = 0, nn_any = 0, nt_any = 0;
     uint32_t wn = 0, wt = 0, wn_any = 0, wt_any = 0;     // wave-level step counts of the same blocks (counting kernels)
+    uint32_t n_hits = 0;                                 // closest-hit rays that hit something, i.e. lanes that ran the shading code
     // Queue counters are double-banked by frame parity: the first kernel of a frame clears the bank the next
     // frame will append to (last touched by the previous frame, which stream order has retired).
     if (FIRST && a.zero_counts && blockIdx.x == 0)   // 64 or 256 threads, either works
@@ -982,6 +1006,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         float pend_pdf = 0.f;
         float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, nx0 = sh0, nx1 = sh0;
         if (active && hit.tri >= 0) {
+            CRT_MARK("shade_begin");
+            if (STATS) ++n_hits;
             const float t = hit.t, bu = hit.u, bv = hit.v;
             const float4 tb = recs[3 * (size_t)hit.tri + 1], tc = recs[3 * (size_t)hit.tri + 2];
             const int slot = __float_as_int(tb.w), mtl = __float_as_int(tc.w);
@@ -1254,6 +1280,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
     }
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
     if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any, wn_any, wt_any);
+    if (STATS) flush_visit_totals(a.visit_totals + 8, n_hits, 0u);
     (void)stk; (void)stk2;
 }
 

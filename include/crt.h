@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 2   /* 2: crt_frame_stats.stack_overflows + wave_steps_*, crt_scene_desc.build_flags, crt_bvh_info build times */
+#define CRT_ABI_VERSION 3   /* 3: crt_frame_stats.closest_hits, crt_set_devices (one process, several GPUs), crt_has_experiments;
+                              * 2: crt_frame_stats.stack_overflows + wave_steps_*, crt_scene_desc.build_flags, crt_bvh_info build times */
 
 typedef enum crt_status {
     CRT_OK = 0,
@@ -255,6 +256,9 @@ typedef struct crt_frame_stats {
      * any-hit walks (each execution offers 64 lane slots), so nodes_closest / (64 * wave_steps_closest_nodes) is the lane
      * utilisation of that block — the quantity the traversal loops are tuned for */
     uint64_t wave_steps_closest_nodes, wave_steps_closest_tris, wave_steps_any_nodes, wave_steps_any_tris;
+    /* with "count_visits": closest-hit rays of the frame that hit something, i.e. the lanes that ran the shading code
+     * (path_trace.fs:872-1018); bench.py's instruction model charges the shading instructions to these only */
+    uint64_t closest_hits;
 } crt_frame_stats;
 int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out);
 /* structural facts about the device-resident CWBVH */

@@ -6,10 +6,10 @@ Per workload (cornell_d1, mesh1m_d1, mesh1m_d4), over the non-counting k_segment
   l2_fabric_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts half of the fetched bytes
       (MI355X_MICROARCH.md, HBM section); both counters are in KiB.  These are bytes crossing L2 <-> Infinity Fabric; with the
       scene resident in the 256 MiB Infinity Cache the bytes that reach HBM are fewer still.
-  valu_issue: busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8)   (SQ_* count quad-cycles; a wave64 VALU instruction
-      holds its SIMD's issue port ~4 cycles — measured, scratch/ubench in DESIGN.md §5; GRBM_GUI_ACTIVE is summed over the 8 XCDs);
-      lane_util = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); frac = busy * lane_util = the share of the chip's
-      lane-cycles doing enabled VALU work.  This, not HBM, is what bounds the kernel.
+  valu_issue: busy = 2 * SQ_INSTS_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8): the share of the vector issue slots used (a SIMD-32 issues one
+      wave64 instruction per 2 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs); busy_vs_mix_floor = the same against the 3.3 cycles
+      this kernel's instruction mix needs at best (tools/ubench/valu_issue_cycles.hip); lane_util = SQ_THREAD_CYCLES_VALU /
+      (64 * SQ_ACTIVE_INST_VALU); frac = busy * lane_util = the share of the chip's lane-cycles doing enabled VALU work.
 """
 import collections, csv, glob, json, os, sys
 
@@ -52,28 +52,33 @@ def entry_from_dirs(dirs, wl):
     insts, _ = total("SQ_INSTS_VALU")
     waves, _ = total("SQ_WAVES")
     gui, n_g = total("GRBM_GUI_ACTIVE")
-    if n_sq and n_g and act > 0:
-        busy_raw = 4.0 * (act / n_sq) / (N_SIMD * (gui / n_g) / 8.0)
-        # 4 cycles per wave64 VALU instruction is the nominal figure; the microbenchmark measures 3.6 - 4.3 (profiles/r02_valu_rate_ubench.txt),
-        # so a launch that keeps every SIMD issuing can come out a little above 1: reported as 1, with the raw value next to it
-        busy = min(1.0, busy_raw)
+    if n_sq and n_g and act > 0 and insts > 0:
+        # Issue slots: a SIMD-32 needs 2 cycles for a wave64 VALU instruction (MI355X_MICROARCH.md), so the share of the chip's issue
+        # slots a launch used is 2 x wave-instructions / (SIMDs x shader cycles).  (Round 2 divided 4 x SQ_ACTIVE_INST_VALU by the SIMD
+        # cycles and got 1.19: that counter adds up the quad-cycles during which EACH wave has a vector instruction in flight, and two
+        # waves of a SIMD overlap theirs, so it is not bounded by 1.)  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+        cycles = (gui / n_g) / 8.0
+        per_launch = insts / n_sq
+        busy = 2.0 * per_launch / (N_SIMD * cycles)
         lane = thr / (64.0 * act)
-        e["valu_issue"] = {"busy": round(busy, 3), "busy_raw": round(busy_raw, 3), "lane_util": round(lane, 3), "frac": round(busy * lane, 3),
-                           "valu_instructions_per_wave": round(insts / max(1.0, waves), 1),
-                           "source": "rocprofv3 --pmc passes of `bench.py --workload %s --depth %s --spp 1`; formulae in tools/pmc_traffic.py"
+        e["valu_issue"] = {"busy": round(busy, 3), "busy_vs_mix_floor": round(busy * 3.3 / 2.0, 3), "lane_util": round(lane, 3), "frac": round(busy * lane, 3),
+                           "cycles_per_instr_per_simd": round(N_SIMD * cycles / per_launch, 2),
+                           "valu_instructions_per_launch": int(per_launch), "valu_instructions_per_wave": round(insts / max(1.0, waves), 1),
+                           "shader_cycles_per_launch": int(cycles),
+                           "source": "rocprofv3 --pmc passes of `bench.py --workload %s --depth %s`; formulae in tools/pmc_traffic.py"
                                      % tuple(wl.split("_d"))}
     return e
 
 
-# the four counter groups, one rocprofv3 pass each (MI355X_MICROARCH.md: separate --pmc passes)
-PASSES = {"fetch": ["FETCH_SIZE", "TCC_HIT_sum"], "write": ["WRITE_SIZE", "TCC_MISS_sum"],
-          "sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"],
-          "grbm": ["GRBM_GUI_ACTIVE", "GRBM_TA_BUSY"]}
+# three counter groups, one rocprofv3 pass each (MI355X_MICROARCH.md, "rocprofv3 PMC slots": FETCH_SIZE takes 3 of the 4 TCC slots and
+# WRITE_SIZE 2, so they cannot share a pass; the two GRBM counters are independent of SQ / TCC and ride with the fetch pass)
+PASSES = {"fetch": ["FETCH_SIZE", "TCC_HIT_sum", "GRBM_GUI_ACTIVE", "GRBM_TA_BUSY"], "write": ["WRITE_SIZE", "TCC_MISS_sum"],
+          "sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]}
 
 
 def main(round_dir, out):
     res = {}
-    for wl in ("cornell_d1", "mesh1m_d1", "mesh1m_d4"):
+    for wl in ("cornell_d1", "mesh1m_d1", "mesh1m_d4", "mesh520_d1", "mesh520_d4"):
         e = entry_from_dirs({kind: os.path.join(round_dir, f"pmc_{kind}_{wl}") for kind in PASSES}, wl)
         if e:
             res[wl] = e

@@ -39,6 +39,38 @@ __global__ void k(float* out, unsigned long long* stamps, int iters, float seed)
                 asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                              "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                              : "+v"(a0) : "v"(b), "v"(c));
+            } else if (KIND == 5) { // 8 v_cvt_f32_ubyteN
+                asm volatile("v_cvt_f32_ubyte0 %0, %8\n v_cvt_f32_ubyte1 %1, %8\n v_cvt_f32_ubyte2 %2, %8\n v_cvt_f32_ubyte3 %3, %8\n"
+                             "v_cvt_f32_ubyte0 %4, %9\n v_cvt_f32_ubyte1 %5, %9\n v_cvt_f32_ubyte2 %6, %9\n v_cvt_f32_ubyte3 %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 6) { // 8 v_max3_f32 / v_min3_f32 (3 register sources)
+                asm volatile("v_max3_f32 %0, %0, %8, %9\n v_min3_f32 %1, %1, %8, %9\n v_max3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n"
+                             "v_max3_f32 %4, %4, %8, %9\n v_min3_f32 %5, %5, %8, %9\n v_max3_f32 %6, %6, %8, %9\n v_min3_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 7) { // 4 x (v_cmp_le_f32 vcc + v_cndmask_b32)
+                asm volatile("v_cmp_le_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_le_f32 vcc, %4, %5\n v_cndmask_b32 %6, %6, %7, vcc\n"
+                             "v_cmp_le_f32 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc\n v_cmp_le_f32 vcc, %5, %4\n v_cndmask_b32 %7, %7, %6, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            } else if (KIND == 8) { // 8 integer ops: and, lshl, or, lshl_or, and_or, bfe, add, xor
+                asm volatile("v_and_b32 %0, %0, %8\n v_lshlrev_b32 %1, 3, %1\n v_or_b32 %2, %2, %8\n v_lshl_or_b32 %3, %3, 3, %8\n"
+                             "v_and_or_b32 %4, %4, %8, %9\n v_bfe_u32 %5, %5, 3, 8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 9) { // 8 v_fma_f32 with two SGPR/constant operands (1 register source)
+                asm volatile("v_fma_f32 %0, %0, 2.0, 0.5\n v_fma_f32 %1, %1, 2.0, 0.5\n v_fma_f32 %2, %2, 2.0, 0.5\n v_fma_f32 %3, %3, 2.0, 0.5\n"
+                             "v_fma_f32 %4, %4, 2.0, 0.5\n v_fma_f32 %5, %5, 2.0, 0.5\n v_fma_f32 %6, %6, 2.0, 0.5\n v_fma_f32 %7, %7, 2.0, 0.5\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 10) { // 4 x (v_cmp_le_f32 into an SGPR pair + s_and/or use): compare results kept as scalar masks
+                asm volatile("v_cmp_le_f32 s[20:21], %0, %1\n v_cmp_le_f32 s[22:23], %2, %3\n v_cmp_le_f32 s[24:25], %4, %5\n v_cmp_le_f32 s[26:27], %6, %7\n"
+                             "v_cmp_gt_f32 s[20:21], %1, %0\n v_cmp_gt_f32 s[22:23], %3, %2\n v_cmp_gt_f32 s[24:25], %5, %4\n v_cmp_gt_f32 s[26:27], %7, %6\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+            } else if (KIND == 11) { // 8 v_max_f32 / v_min_f32 (2 sources)
+                asm volatile("v_max_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n"
+                             "v_max_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_min_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            } else if (KIND == 12) { // 8 v_mul_f32 / v_sub_f32 (the Moller-Trumbore block's bulk)
+                asm volatile("v_mul_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
             } else if (KIND == 4) { // 8 independent v_mov_b32 (1 source)
                 asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
                              "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n"
@@ -89,6 +121,16 @@ int main(int argc, char** argv) {
         run<4>("v_mov_b32 x8 independent", 8, grid, d_out, d_st);
         run<2>("node-test mix (16 per child)", 16, grid, d_out, d_st);
         run<3>("v_fma_f32 dependent chain", 8, grid, d_out, d_st);
+        if (grid == 1) {
+            run<5>("v_cvt_f32_ubyte0..3 x8", 8, grid, d_out, d_st);
+            run<6>("v_max3/min3_f32 x8", 8, grid, d_out, d_st);
+            run<11>("v_max/min_f32 x8 (2 sources)", 8, grid, d_out, d_st);
+            run<12>("v_mul/sub_f32 x8", 8, grid, d_out, d_st);
+            run<7>("v_cmp vcc + v_cndmask x4", 8, grid, d_out, d_st);
+            run<10>("v_cmp into SGPR pairs x8", 8, grid, d_out, d_st);
+            run<8>("integer and/shift/or/bfe/add x8", 8, grid, d_out, d_st);
+            run<9>("v_fma_f32 x8, constant operands", 8, grid, d_out, d_st);
+        }
     }
     return 0;
 }
