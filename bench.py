@@ -98,6 +98,12 @@ def parse_args(argv=None):
                     help="explicit workload: crt_scene_create builds the tree itself on the GPU from the source-order arrays (lbvh, ploc<r>, sah)")
     ap.add_argument("--no-extra", action="store_true", help="auto workload: only the headline block")
     ap.add_argument("--no-hbm-resident", action="store_true", help="auto workload: skip the 8 M-triangle (> Infinity Cache) blocks")
+    ap.add_argument("--one-process", action="store_true",
+                    help="N GPUs behind ONE scene handle in this one process (crt_set_devices: replication, tile sharding and the RCCL gather "
+                         "inside the C ABI) instead of one process per GPU under torch.distributed; the timed region ends with crt_sum_device")
+    ap.add_argument("--virtual-devices", type=int, default=0, metavar="K",
+                    help="with --one-process: K logical devices on GPU 0 (shards, streams and gather buffers as on K GPUs; copies instead of RCCL) — "
+                         "rehearses the path on a one-GPU machine; the number it prints is NOT a scaling figure")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
                          "(what the CPU tests exercise); the line says dry_run and reports no throughput")
@@ -208,6 +214,10 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.use_dist = "RANK" in os.environ       # launched by torch.distributed.run (also at N = 1: same code path)
+        # --one-process: the N devices sit behind one scene handle in this process (the gather is crt_sum_device's business)
+        self.one_proc_ids = None
+        if args.one_process and not args.dry_run:
+            self.one_proc_ids = [0] * args.virtual_devices if args.virtual_devices > 0 else list(range(max(1, args.gpus)))
         self.device = "cpu" if args.dry_run else "cuda"
 
     def init(self):
@@ -362,7 +372,12 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         else:
             data, cam, label, build_s = build_workload(name, args.builder, args.convert, materials or args.materials)
             scene = cr.Scene(data, W, H, depth)
-        scene.set_shard(rank, world, args.tile)
+        one_proc = ctx.one_proc_ids if sharded else None     # N devices behind this one handle (crt_set_devices) instead of N ranks
+        if one_proc:
+            scene.set_devices(one_proc, args.tile)
+            world = len(one_proc)
+        else:
+            scene.set_shard(rank, world, args.tile)
         for kv in args.option:
             k, v = kv.split("=")
             scene.set_option(k, int(v))
@@ -391,6 +406,9 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
 
         def read_back():
             """RCCL gather over xGMI of the per-tile radiance to rank 0 (at read-back only)."""
+            if one_proc:
+                scene.sum_device()           # gather + un-tile inside the C ABI, the frame stays in device 0's memory
+                return
             scene.copy_packed_device(gather_buf.data_ptr(), n_floats)
             tiles.gather_packed_to_root(gather_buf, recv, world)
 
@@ -414,7 +432,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         for k in range(Wu):
             step(k)
         scene.sync()
-        if use_dist:    # warm the collective too
+        if use_dist or one_proc:    # warm the collective too
             read_back()
         # HIP events on every segment launch of the timed region, on the scene's own stream (attached to the dispatch:
         # they take the kernel's own start/stop timestamps)
@@ -431,7 +449,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             step(Wu + k)
         scene.sync()
         render_s = time.perf_counter() - t0            # this rank's rendering, without the gather
-        if use_dist:
+        if use_dist or one_proc:
             read_back()
             torch.cuda.synchronize()
             gather_ms = (time.perf_counter() - t0 - render_s) * 1e3
@@ -463,7 +481,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         rays_all = ctx.sum_over_ranks(rays_frame) if sharded else float(rays_frame)
         value = rays_all * K * spp / dt / 1e6
         # primary rays of one frame of this rank = its in-frame pixels
-        n_primary = sum(min(tile, W - tx * tile) * min(tile, H - ty * tile) for tx, ty in tiles.local_tiles(W, H, tile, rank, world))
+        n_primary = W * H if one_proc else sum(min(tile, W - tx * tile) * min(tile, H - ty * tile) for tx, ty in tiles.local_tiles(W, H, tile, rank, world))
         rank_ms = ctx.gather_floats(render_s / K * 1e3) if use_dist else [render_s / K * 1e3]
 
     if takes_part and ctx.rank == 0:
@@ -504,12 +522,16 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": spp, "path_segments": depth,
                        "rays_per_step": int(rays_all) * spp, "tile": tile, "parallelism": f"tiles/{world}",
                        "n_nodes8": int(info["n_nodes8"]), "n_tris8": int(info["n_tris8"]), "stack_overflows": int(st["stack_overflows"]),
-                       "gather": "one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else "none"},
+                       "gather": ("one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else
+                                  f"inside the C ABI (crt_sum_device, one process, {scene.devices()['transport']}), once per timed region" if one_proc else "none")},
             "roofline": roofline,
         }
         if use_dist:
             out["gather_ms"] = round(gather_ms, 4)
             out["rank_device_ms_per_step"] = [round(x, 4) for x in rank_ms]
+        if one_proc:
+            out["gather_ms"] = round(gather_ms, 4)
+            out["config"]["devices"] = scene.devices()["devices"]
         if build_info:
             out["config"]["device_build"] = build_info
         if cpu_base and not args.no_cpu_baseline and args.accel == "cwbvh":
@@ -618,7 +640,7 @@ def dry_block(ctx, W, H, spp, scaling):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if args.gpus > 1 and "RANK" not in os.environ and not args.one_process:
         sys.exit(self_launch(args))
 
     # stdout carries exactly ONE JSON line: anything a library prints there (RCCL's version banner at
@@ -633,14 +655,14 @@ def main():
                  + ([] if args.no_extra or args.no_hbm_resident else [(HBM_RESIDENT, 1, 4, "--device-built", "sah"), (HBM_RESIDENT, 4, 4, "--device-built", "sah")]))
 
     ctx = Ctx(args)
-    if ctx.world != args.gpus:
+    if ctx.world != args.gpus and not args.one_process:
         args.gpus = ctx.world
     ctx.init()
     if not args.dry_run:
         import __graft_entry__ as g
         g.build()
 
-    N = ctx.world
+    N = len(ctx.one_proc_ids) if ctx.one_proc_ids else ctx.world
     auto = args.workload == "auto"
     if N == 1:
         name = "mesh1m" if auto else args.workload      # configs[2]: the workload BASELINE.json's targets are quoted on

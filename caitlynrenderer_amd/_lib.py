@@ -77,12 +77,15 @@ SYMBOLS = {
     "crt_reset": (_I, [_P]),
     "crt_read_sum": (_I, [_P, _P, _SZ]),
     "crt_resolve": (_I, [_P, _F, _P, _SZ]),
+    "crt_sum_device": (_I, [_P, C.POINTER(_P)]),
     "crt_trace": (_I, [_P, _P, _SZ, _P, _I, _P]),
     "crt_trace_device": (_I, [_P, _P, _SZ, _P, _I, _P, _I]),
     "crt_debug_read_queue": (_I, [_P, _I, _U32, _P, _SZ, C.POINTER(_SZ)]),
     "crt_debug_time_graph": (_I, [_P, _U32, _P, _U32, C.POINTER(_F), C.POINTER(_F)]),
     "crt_debug_launch_form": (_I, [_P, C.POINTER(C.c_int32)]),
     "crt_set_shard": (_I, [_P, _U32, _U32, _U32]),
+    "crt_set_devices": (_I, [_P, C.POINTER(C.c_int32), _U32, _U32]),
+    "crt_get_devices": (_I, [_P, C.POINTER(_U32), C.POINTER(C.c_int32), _U32, C.POINTER(C.c_int32), C.POINTER(_F)]),
     "crt_packed_info": (_I, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_SZ)]),
     "crt_read_packed": (_I, [_P, _P, _SZ]),
     "crt_copy_packed_device": (_I, [_P, _P, _SZ, _I]),

@@ -3,6 +3,7 @@
 // stream; every kernel of a frame is enqueued there, queue lengths stay on the device, and the
 // host synchronises once per call (never inside the frame).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -179,7 +180,22 @@ struct crt_scene {
     uint32_t timing = 2;                     // event spans: 2 = every launch, 1 = closest-hit launches only, 0 = none
     bool timing_accumulate = false;          // spans pile up over frames (crt_frame_stats then holds sums) instead of per frame
 
+    // ---- several GPUs behind ONE handle (crt_set_devices): this scene is logical device 0, `peers` are devices 1..n-1, each a
+    // complete scene on its own GPU (replicated buffers, own stream, own shard of the tiles).  Every entry point fans out to them;
+    // crt_read_sum / crt_resolve gather their packed tile buffers to this device and un-tile the whole frame here.
+    std::vector<crt_scene*> peers;           // owned
+    crt_scene* primary = nullptr;            // set in a peer
+    std::vector<std::pair<size_t, size_t>> scene_bufs;   // (offset of the pointer member, bytes): what a replica needs copied
+    std::vector<float*> d_gather;            // per peer, on THIS device: its packed sum buffer as received
+    std::vector<uint2*> d_peer_tiles;        // per peer, on THIS device: its local tile list (for the un-tiling launch)
+    std::vector<hipEvent_t> ev_peer;         // per peer: "your slice has arrived" (copy transport)
+    void* rccl_lib = nullptr;                // dlopen handle; comms[k] = communicator of logical device k
+    std::vector<void*> rccl_comms;
+    uint32_t gather_transport = 0;           // 0 = RCCL send/recv over xGMI, 1 = hipMemcpyPeerAsync (also: virtual devices, RCCL absent)
+    float last_gather_ms = 0.f;
+
     ~crt_scene() {
+        drop_peers();
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
@@ -195,6 +211,8 @@ struct crt_scene {
         for (EventSpan& s : spans) { if (s.a) hipEventDestroy(s.a); if (s.b) hipEventDestroy(s.b); }
         if (stream) hipStreamDestroy(stream);
     }
+
+    void drop_peers();      // defined with crt_set_devices
 
     // grid of a traversal kernel (always a multiple of 8: one slice per XCD group); persistent variant bounded by LDS and registers
     // (the XCD-aware schedule in rt_kernels.hip groups workgroups by blockIdx & 7)
@@ -389,6 +407,11 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     for (size_t m = 0; m < d->n_materials; ++m)
         s->special_materials = s->special_materials || d->materials[m].albedo[3] == 1.0f || d->materials[m].albedo[3] == 17.0f;
     return CRT_OK;
+}
+
+// What a replica on another GPU needs copied (crt_set_devices): the scene-level device buffers and their sizes.
+static void note_buf(crt_scene* s, const void* member, size_t bytes) {
+    s->scene_bufs.emplace_back((size_t)(reinterpret_cast<const char*>(member) - reinterpret_cast<const char*>(s)), bytes);
 }
 
 static int finish_scene_setup(crt_scene* s) {
@@ -620,6 +643,20 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
         if (hipMemcpy(s->d_tris2, rec2.data(), rec2.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));
     }
+    note_buf(s, &s->d_nodes, n_nodes8 * sizeof(crt_node8));
+    note_buf(s, &s->d_tris, recs.size() * sizeof(float4));
+    note_buf(s, &s->d_triangles, d->n_triangles * sizeof(crt_triangle));
+    note_buf(s, &s->d_normals, d->n_normals * 3 * sizeof(float));
+    note_buf(s, &s->d_materials, d->n_materials * sizeof(crt_material));
+    note_buf(s, &s->d_lights, d->n_lights * sizeof(crt_light));
+    if (have_tex) {
+        note_buf(s, &s->d_texcoords, d->n_texcoords * sizeof(float2));
+        note_buf(s, &s->d_textures, (size_t)d->tex_width * d->tex_height * d->n_textures * 3 * sizeof(float));
+    }
+    if (d->bvh) {
+        note_buf(s, &s->d_bvh2, d->n_bvh * sizeof(crt_flatnode));
+        note_buf(s, &s->d_tris2, d->n_triangles * 3 * sizeof(float4));
+    }
     if ((rc = finish_scene_setup(s))) return bail(rc);
     *out = owner.release();
     return CRT_OK;
@@ -718,6 +755,20 @@ static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
     s->info.n_nodes8 = n8; s->info.n_tris8 = n; s->info.n_bvh2_nodes = n2; s->info.max_depth8 = depth8;
     s->info.built_on_device = 1u; s->info.bvh2_depth = depth2;
     s->info.build_upload_ms = upload_ms; s->info.build_lbvh_device_ms = lbvh_ms; s->info.build_convert_device_ms = conv_ms;
+    note_buf(s, &s->d_nodes, (size_t)n8 * sizeof(crt_node8));
+    note_buf(s, &s->d_tris, (size_t)n * 3 * sizeof(float4));
+    note_buf(s, &s->d_triangles, (size_t)n * sizeof(crt_triangle));
+    note_buf(s, &s->d_normals, d->n_normals * 3 * sizeof(float));
+    note_buf(s, &s->d_materials, d->n_materials * sizeof(crt_material));
+    note_buf(s, &s->d_lights, d->n_lights * sizeof(crt_light));
+    if (have_tex) {
+        note_buf(s, &s->d_texcoords, d->n_texcoords * sizeof(float2));
+        note_buf(s, &s->d_textures, (size_t)d->tex_width * d->tex_height * d->n_textures * 3 * sizeof(float));
+    }
+    if (keep_bvh2) {
+        note_buf(s, &s->d_bvh2, (size_t)n2 * sizeof(crt_flatnode));
+        note_buf(s, &s->d_tris2, (size_t)n * 3 * sizeof(float4));
+    }
     if ((rc = finish_scene_setup(s))) return rc;
     s->info.build_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     *out = owner.release();
@@ -734,6 +785,7 @@ int crt_set_camera(crt_scene* s, const crt_camera* cam) {
     if (!s->have_camera || std::memcmp(&s->cam, cam, sizeof *cam) != 0) s->tile_state = crt_scene::TILES_WANT;   // a new view: new tile costs
     s->cam = *cam;
     s->have_camera = true;
+    for (crt_scene* p : s->peers) { const int rc = crt_set_camera(p, cam); if (rc) return rc; }
     return CRT_OK;
 }
 
@@ -741,6 +793,7 @@ int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_set_shard: null scene");
     if (world == 0 || rank >= world) return fail(CRT_ERR_INVALID, "crt_set_shard: rank/world");
     if (tile < 8 || (tile & 7u) || tile > 1024) return fail(CRT_ERR_INVALID, "crt_set_shard: tile must be a multiple of 8 in 8..1024");
+    if (!s->peers.empty() || s->primary) return fail(CRT_ERR_INVALID, "crt_set_shard: this scene deals its tiles to its own devices (crt_set_devices)");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->rank = rank; s->world = world; s->tile = tile;
@@ -759,6 +812,7 @@ int crt_reset(crt_scene* s) {
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(s->d_sum, 0, 3 * (size_t)std::max<uint32_t>(s->n_local_pixels, 1) * sizeof(float), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    for (crt_scene* p : s->peers) { rc = crt_reset(p); if (rc) return rc; }
     return CRT_OK;
 }
 
@@ -806,7 +860,15 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "debug_fail_batch_alloc")) s->debug_fail_batch_alloc = value ? 1u : 0u;
     else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: plain per-lane closest-hit loop (what trees of a few nodes get)
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
+    else if (!std::strcmp(name, "gather_transport")) {
+        if (value != 0 && value != 1) return fail(CRT_ERR_INVALID, "crt_set_option: gather_transport is 0 (RCCL send / recv) or 1 (hipMemcpyPeerAsync)");
+        if (value == 0 && !s->peers.empty() && s->rccl_comms.empty())
+            return fail(CRT_ERR_INVALID, "crt_set_option: this scene's devices have no RCCL communicators (virtual devices, or librccl.so could not be loaded)");
+        s->gather_transport = (uint32_t)value;
+        return CRT_OK;
+    }
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
+    for (crt_scene* p : s->peers) { const int rc = crt_set_option(p, name, value); if (rc) return rc; }
     return CRT_OK;
 }
 
@@ -949,9 +1011,12 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         } else
 #endif
         if (sp) crt::set_launch_events(sp->a, sp->b);
-        // bounce launches of a batched frame may find up to n_samples rays per pixel in their queue
-        const uint32_t items = (b > 0 && deferred) ? P * n_samples : P;
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, s->trace_grid(items, sa.wide_first ? 6 : 5), s->waves_per_workgroup, s->stream);
+        // A workgroup renders ONE chunk (CRT_CHUNK_LOOP), so the grid has to cover every chunk a sub-queue can hold: a group's
+        // sub-queue gets the rays of that group's units of 4096 pixels — ceil(units / 8) of them — times the samples of the launch.
+        // (P * n_samples spread evenly over the 8 groups is fewer chunks than that when the units do not divide by 8.)
+        uint32_t grid = s->trace_grid(P, sa.wide_first ? 6 : 5);
+        if (b > 0 && deferred) grid *= n_samples;
+        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, grid, s->waves_per_workgroup, s->stream);
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};
@@ -1031,7 +1096,18 @@ static uint32_t batch_limit(const crt_scene* s) {
     return (uint32_t)std::min<uint64_t>(8ull, std::max<uint64_t>(1ull, fit));         // 1 M triangles, 4 segments: 1.78 / 1.61 / 1.50 / 1.45 ms per frame at 1 / 2 / 4 / 8 frames per launch
 }
 
-int crt_render_frame_async(crt_scene* s, float rx, float ry) { return render_batch_async(s, 1u, &rx, &ry); }
+// one batch on every device of the scene: each enqueues on its own stream and returns, so the devices render concurrently
+static int render_batch_all(crt_scene* s, uint32_t n_samples, const float* rxs, const float* rys) {
+    int rc = render_batch_async(s, n_samples, rxs, rys);
+    if (rc) return rc;
+    for (crt_scene* p : s->peers) if ((rc = render_batch_async(p, n_samples, rxs, rys))) return rc;
+    return CRT_OK;
+}
+
+int crt_render_frame_async(crt_scene* s, float rx, float ry) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_render_frame: null scene");
+    return render_batch_all(s, 1u, &rx, &ry);
+}
 
 int crt_render_frames_async(crt_scene* s, uint32_t n, const float* rx, const float* ry) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_render_frames: null scene");
@@ -1039,7 +1115,7 @@ int crt_render_frames_async(crt_scene* s, uint32_t n, const float* rx, const flo
     const uint32_t lim = batch_limit(s);
     for (uint32_t i = 0; i < n;) {
         const uint32_t k = std::min(lim, n - i);
-        const int rc = render_batch_async(s, k, rx + i, ry + i);
+        const int rc = render_batch_all(s, k, rx + i, ry + i);
         if (rc) return rc;
         i += k;
     }
@@ -1057,6 +1133,8 @@ int crt_sync(crt_scene* s) {
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipGetLastError());
+    for (crt_scene* p : s->peers) { const int rc = crt_sync(p); if (rc) return rc; }
+    if (!s->peers.empty()) HIPCHK(hipSetDevice(s->device));
     return CRT_OK;
 }
 
@@ -1088,6 +1166,20 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
         HIPCHK(hipMemcpy(&s->stats.stack_overflows, s->d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     *out = s->stats;
+    // several devices: ray and visit counts are sums over the devices, times the slowest device's (they run side by side)
+    for (crt_scene* p : s->peers) {
+        crt_frame_stats ps{};
+        const int rc = crt_get_frame_stats(p, &ps);
+        if (rc) return rc;
+        out->closest_rays += ps.closest_rays; out->any_rays += ps.any_rays;
+        out->nodes_closest += ps.nodes_closest; out->tris_closest += ps.tris_closest; out->nodes_any += ps.nodes_any; out->tris_any += ps.tris_any;
+        out->wave_steps_closest_nodes += ps.wave_steps_closest_nodes; out->wave_steps_closest_tris += ps.wave_steps_closest_tris;
+        out->wave_steps_any_nodes += ps.wave_steps_any_nodes; out->wave_steps_any_tris += ps.wave_steps_any_tris;
+        out->closest_hits += ps.closest_hits; out->stack_overflows += ps.stack_overflows;
+        out->ms_total = std::max(out->ms_total, ps.ms_total); out->ms_trace_closest = std::max(out->ms_trace_closest, ps.ms_trace_closest);
+        out->ms_trace_any = std::max(out->ms_trace_any, ps.ms_trace_any); out->ms_shade = std::max(out->ms_shade, ps.ms_shade);
+    }
+    if (!s->peers.empty()) HIPCHK(hipSetDevice(s->device));
     return CRT_OK;
 }
 
@@ -1130,6 +1222,8 @@ int crt_copy_packed_device(crt_scene* s, void* d_dst, size_t n_floats, int sync)
     return CRT_OK;
 }
 
+static int gather_peers(crt_scene* s);
+
 static int untile_to_linear(crt_scene* s) {
     const size_t n = 3 * (size_t)s->width * s->height;
     if (!s->d_linear) { int rc = dev_alloc(&s->d_linear, n); if (rc) return rc; }
@@ -1137,6 +1231,20 @@ static int untile_to_linear(crt_scene* s) {
     if (s->n_local_pixels) {
         const crt::FrameArgs f = frame_args(s, 0.f, 0.f);
         crt::launch_untile(f, s->d_sum, s->d_linear, s->flat_grid(s->n_local_pixels), s->stream);
+    }
+    if (!s->peers.empty()) {
+        // the other devices' packed tile buffers come to this device ("multi-GPU gather happens inside these"), then
+        // every slice is un-tiled into the one linear frame with its own tile list; tiles are disjoint, so the order does not matter
+        int rc = gather_peers(s);
+        if (rc) return rc;
+        for (size_t k = 0; k < s->peers.size(); ++k) {
+            const crt_scene* p = s->peers[k];
+            if (!p->n_local_pixels) continue;
+            crt::FrameArgs f = frame_args(p, 0.f, 0.f);
+            f.tile_xy = s->d_peer_tiles[k];
+            f.tile_order = nullptr;
+            crt::launch_untile(f, s->d_gather[k], s->d_linear, s->flat_grid(p->n_local_pixels), s->stream);
+        }
     }
     return CRT_OK;
 }
@@ -1153,6 +1261,18 @@ int crt_read_sum(crt_scene* s, float* rgb, size_t n_floats) {
     return CRT_OK;
 }
 
+int crt_sum_device(crt_scene* s, const float** d_rgb) {
+    if (!s || !d_rgb) return fail(CRT_ERR_INVALID, "crt_sum_device: null argument");
+    *d_rgb = nullptr;
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if ((rc = untile_to_linear(s))) return rc;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *d_rgb = s->d_linear;
+    return CRT_OK;
+}
+
 int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
     if (!s || !rgba) return fail(CRT_ERR_INVALID, "crt_resolve: null argument");
     const size_t npx = (size_t)s->width * s->height;
@@ -1165,6 +1285,205 @@ int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
     crt::launch_resolve(s->d_linear, (uint32_t)npx, inv_count, s->d_rgba, s->flat_grid(npx), s->stream);
     HIPCHK(hipMemcpyAsync(rgba, s->d_rgba, n_bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    return CRT_OK;
+}
+
+// ------------------------------------------------------------------ several GPUs, one handle ----
+
+namespace {
+
+// The slice of RCCL this file uses, resolved from librccl.so at crt_set_devices time: the library is a dependency only of scenes
+// that span several GPUs (and a process that already carries an RCCL — PyTorch ships its own — keeps exactly that one).
+struct Rccl {
+    typedef int (*InitAll)(void**, int, const int*);
+    typedef int (*Destroy)(void*);
+    typedef int (*Group)(void);
+    typedef int (*SendRecv)(void*, size_t, int, int, void*, hipStream_t);      // ncclSend's buffer is const void*: same ABI
+    typedef const char* (*ErrStr)(int);
+    InitAll init_all = nullptr; Destroy destroy = nullptr; Group group_start = nullptr, group_end = nullptr;
+    SendRecv send = nullptr, recv = nullptr; ErrStr err = nullptr;
+    bool load(void** lib) {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+            if ((*lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!*lib) return false;
+        init_all = (InitAll)dlsym(*lib, "ncclCommInitAll"); destroy = (Destroy)dlsym(*lib, "ncclCommDestroy");
+        group_start = (Group)dlsym(*lib, "ncclGroupStart"); group_end = (Group)dlsym(*lib, "ncclGroupEnd");
+        send = (SendRecv)dlsym(*lib, "ncclSend"); recv = (SendRecv)dlsym(*lib, "ncclRecv"); err = (ErrStr)dlsym(*lib, "ncclGetErrorString");
+        return init_all && destroy && group_start && group_end && send && recv;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclFloat = 7;       // ncclFloat32 (rccl.h ncclDataType_t)
+
+}  // namespace
+
+void crt_scene::drop_peers() {
+    if (!rccl_comms.empty() && g_rccl.destroy)
+        for (void* c : rccl_comms) if (c) (void)g_rccl.destroy(c);
+    rccl_comms.clear();
+    for (crt_scene* p : peers) delete p;
+    peers.clear();
+    if (!d_gather.empty() || !d_peer_tiles.empty() || !ev_peer.empty()) (void)hipSetDevice(device);
+    for (float* b : d_gather) if (b) (void)hipFree(b);
+    for (uint2* b : d_peer_tiles) if (b) (void)hipFree(b);
+    for (hipEvent_t e : ev_peer) if (e) (void)hipEventDestroy(e);
+    d_gather.clear(); d_peer_tiles.clear(); ev_peer.clear();
+}
+
+// a complete copy of `src` on another device: configuration by value, scene buffers over the fabric (hipMemcpyPeer), own stream,
+// counters and events; frame buffers follow with its shard
+static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    std::unique_ptr<crt_scene> owner(new (std::nothrow) crt_scene);
+    crt_scene* r = owner.get();
+    if (!r) return fail(CRT_ERR_NOMEM, "crt_set_devices: out of memory");
+    r->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) r->n_cu = prop.multiProcessorCount;
+    HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    r->width = src->width; r->height = src->height; r->max_depth = src->max_depth; r->n_lights = src->n_lights;
+    r->tex_width = src->tex_width; r->tex_height = src->tex_height; r->n_textures = src->n_textures;
+    r->info = src->info; r->bvh2_stack = src->bvh2_stack; r->stack_entries = src->stack_entries; r->special_materials = src->special_materials;
+    r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
+    r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min;
+    r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
+    r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
+    r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
+    r->scene_bufs = src->scene_bufs;
+    if (device != src->device) {          // direct xGMI copies where the platform allows them; staged through the host otherwise
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(src->device, 0);
+        (void)hipGetLastError();          // "already enabled" is not an error to report later
+    }
+    for (const auto& b : src->scene_bufs) {
+        const void* from = *reinterpret_cast<void* const*>(reinterpret_cast<const char*>(src) + b.first);
+        void** to = reinterpret_cast<void**>(reinterpret_cast<char*>(r) + b.first);
+        if (!from) continue;
+        hipError_t e = hipMalloc(to, b.second ? b.second : 16);
+        if (e != hipSuccess) return fail(CRT_ERR_NOMEM, std::string("crt_set_devices: hipMalloc: ") + hipGetErrorString(e));
+        if (b.second && device == src->device) HIPCHK(hipMemcpy(*to, from, b.second, hipMemcpyDeviceToDevice));       // a virtual device
+        else if (b.second) HIPCHK(hipMemcpyPeer(*to, device, from, src->device, b.second));
+    }
+    int rc = finish_scene_setup(r);
+    if (rc) return rc;
+    *out = owner.release();
+    return CRT_OK;
+}
+
+int crt_set_devices(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile) {
+    if (!s || !devices) return fail(CRT_ERR_INVALID, "crt_set_devices: null argument");
+    if (s->primary) return fail(CRT_ERR_INVALID, "crt_set_devices: not on a replica");
+    if (n_devices == 0 || n_devices > 64) return fail(CRT_ERR_INVALID, "crt_set_devices: 1..64 devices");
+    if (tile < 8 || (tile & 7u) || tile > 1024) return fail(CRT_ERR_INVALID, "crt_set_devices: tile must be a multiple of 8 in 8..1024");
+    if (devices[0] != s->device) return fail(CRT_ERR_INVALID, "crt_set_devices: devices[0] must be the device the scene was created on");
+    int n_visible = 0;
+    if (hipGetDeviceCount(&n_visible) != hipSuccess || n_visible <= 0) return fail(CRT_ERR_NO_DEVICE, "crt_set_devices: no HIP device visible");
+    bool distinct = true;
+    for (uint32_t k = 0; k < n_devices; ++k) {
+        if (devices[k] < 0 || devices[k] >= n_visible) return fail(CRT_ERR_INVALID, "crt_set_devices: no such device");
+        for (uint32_t j = 0; j < k; ++j) distinct = distinct && devices[j] != devices[k];
+    }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->drop_peers();
+    int rc = CRT_OK;
+    auto undo = [&](int code) { s->drop_peers(); (void)hipSetDevice(s->device); s->rank = 0; s->world = 1; (void)alloc_frame_buffers(s); return code; };
+    try {
+        for (uint32_t k = 1; k < n_devices; ++k) {
+            crt_scene* p = nullptr;
+            if ((rc = replicate_scene(s, devices[k], &p))) return undo(rc);
+            p->primary = s;
+            s->peers.push_back(p);
+            p->rank = k; p->world = n_devices; p->tile = tile;
+            if ((rc = alloc_frame_buffers(p))) return undo(rc);
+        }
+        HIPCHK(hipSetDevice(s->device));
+        s->rank = 0; s->world = n_devices; s->tile = tile;
+        if ((rc = alloc_frame_buffers(s))) return undo(rc);
+        for (crt_scene* p : s->peers) {                      // where a peer's slice lands on this device, and its tile list
+            float* g = nullptr; uint2* t = nullptr; hipEvent_t e = nullptr;
+            if ((rc = dev_alloc(&g, 3 * (size_t)p->n_local_pixels))) return undo(rc);
+            s->d_gather.push_back(g);
+            if ((rc = dev_alloc(&t, p->n_local_tiles))) return undo(rc);
+            s->d_peer_tiles.push_back(t);
+            if (p->n_local_tiles && hipMemcpy(t, p->tiles.data(), p->tiles.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)
+                return undo(fail(CRT_ERR_HIP, "crt_set_devices: hipMemcpy H2D failed"));
+            // recorded on the peer's stream, waited for on this device's: an event belongs to the device it was created on
+            if (hipSetDevice(p->device) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+                return undo(fail(CRT_ERR_HIP, "crt_set_devices: hipEventCreate failed"));
+            s->ev_peer.push_back(e);
+            if (hipSetDevice(s->device) != hipSuccess) return undo(fail(CRT_ERR_HIP, "crt_set_devices: hipSetDevice failed"));
+        }
+    } catch (const std::exception& e) {
+        return undo(fail(CRT_ERR_NOMEM, std::string("crt_set_devices: ") + e.what()));
+    }
+    // RCCL communicators, one per device, created by this one thread (ncclCommInitAll).  Virtual devices (the same GPU listed more
+    // than once: a test arrangement) cannot have them; a missing library is not an error either: the copies below do the same job.
+    s->gather_transport = 1;
+    if (n_devices > 1 && distinct) {
+        if (!g_rccl.init_all && !g_rccl.load(&s->rccl_lib)) {
+            (void)fail(CRT_OK, "crt_set_devices: librccl.so not loadable, gathering with hipMemcpyPeerAsync");
+        } else {
+            std::vector<int> ids(devices, devices + n_devices);
+            s->rccl_comms.assign(n_devices, nullptr);
+            const int nr = g_rccl.init_all(s->rccl_comms.data(), (int)n_devices, ids.data());
+            if (nr != 0) {
+                s->rccl_comms.clear();
+                (void)fail(CRT_OK, std::string("crt_set_devices: ncclCommInitAll failed (") + (g_rccl.err ? g_rccl.err(nr) : "?") + "), gathering with hipMemcpyPeerAsync");
+            } else {
+                s->gather_transport = 0;
+            }
+            HIPCHK(hipSetDevice(s->device));
+        }
+    }
+    return CRT_OK;
+}
+
+int crt_get_devices(crt_scene* s, uint32_t* n_devices, int32_t* devices, uint32_t capacity, int32_t* transport, float* last_gather_ms) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_get_devices: null scene");
+    if (n_devices) *n_devices = (uint32_t)s->peers.size() + 1u;
+    if (devices)
+        for (uint32_t k = 0; k < capacity && k <= s->peers.size(); ++k) devices[k] = k == 0 ? s->device : s->peers[k - 1]->device;
+    if (transport) *transport = (int32_t)s->gather_transport;
+    if (last_gather_ms) *last_gather_ms = s->last_gather_ms;
+    return CRT_OK;
+}
+
+// every peer's packed sum buffer -> d_gather[k] on the primary device, complete in the primary's stream order when this returns
+static int gather_peers(crt_scene* s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (s->gather_transport == 0 && !s->rccl_comms.empty()) {
+        // grouped point-to-point: device k sends on its own stream (after its frames), device 0 receives on its stream; each slice
+        // crosses the one xGMI link between its GPU and this one
+        int nr = g_rccl.group_start();
+        for (size_t k = 0; k < s->peers.size() && nr == 0; ++k) {
+            crt_scene* p = s->peers[k];
+            const size_t count = 3 * (size_t)p->n_local_pixels;
+            if (!count) continue;
+            nr = g_rccl.send(p->d_sum, count, kNcclFloat, 0, s->rccl_comms[k + 1], p->stream);
+            if (nr == 0) nr = g_rccl.recv(s->d_gather[k], count, kNcclFloat, (int)k + 1, s->rccl_comms[0], s->stream);
+        }
+        const int ne = g_rccl.group_end();
+        if (nr == 0) nr = ne;
+        if (nr != 0) return fail(CRT_ERR_HIP, std::string("crt_read_sum: RCCL gather failed: ") + (g_rccl.err ? g_rccl.err(nr) : "?"));
+        HIPCHK(hipSetDevice(s->device));
+    } else {
+        for (size_t k = 0; k < s->peers.size(); ++k) {
+            crt_scene* p = s->peers[k];
+            const size_t bytes = 3 * (size_t)p->n_local_pixels * sizeof(float);
+            if (!bytes) continue;
+            HIPCHK(hipSetDevice(p->device));
+            if (p->device == s->device) HIPCHK(hipMemcpyAsync(s->d_gather[k], p->d_sum, bytes, hipMemcpyDeviceToDevice, p->stream));   // a virtual device
+            else HIPCHK(hipMemcpyPeerAsync(s->d_gather[k], s->device, p->d_sum, p->device, bytes, p->stream));
+            HIPCHK(hipEventRecord(s->ev_peer[k], p->stream));
+        }
+        HIPCHK(hipSetDevice(s->device));
+        for (size_t k = 0; k < s->peers.size(); ++k)
+            if (s->peers[k]->n_local_pixels) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_peer[k], 0));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->last_gather_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return CRT_OK;
 }
 
@@ -1278,10 +1597,8 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
         crt::Bvh2Args ba{};
         ba.nodes = s->d_bvh2; ba.tris = s->d_tris2; ba.rays = ta.rays; ba.hits = ta.hits; ba.stats = ta.stats;
         ba.n = (uint32_t)n; ba.tie = (mode & CRT_TRACE_TIE_LOWEST_ID) ? 1u : 0u; ba.stack_entries = s->bvh2_stack; ba.overflow = s->d_overflow;
-        const uint64_t lds = (uint64_t)(CRT_TRACE_BLOCK / 64) * ba.stack_entries * 64 * 4;
-        uint64_t g = std::min<uint64_t>((n + 255) / 256, (uint64_t)s->n_cu * std::max<uint64_t>(1, std::min<uint64_t>(8, 160 * 1024 / lds)));
-        g = (std::max<uint64_t>(g, 8) + 7) / 8 * 8;
-        crt::launch_trace_bvh2(ba, any_hit, d_stats != nullptr, (uint32_t)g, s->waves_per_workgroup, s->stream);
+        const uint32_t g = s->trace_grid(n, 8);          // every chunk has its workgroup (CRT_CHUNK_LOOP)
+        crt::launch_trace_bvh2(ba, any_hit, d_stats != nullptr, g, s->waves_per_workgroup, s->stream);
     } else {
         crt::launch_trace(ta, any_hit ? 1 : 0, d_stats != nullptr, s->trace_grid(n, 8, 1024), s->waves_per_workgroup, s->stream);
     }

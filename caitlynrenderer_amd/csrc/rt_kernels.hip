@@ -36,6 +36,7 @@ namespace crt {
 
 __device__ __forceinline__ uint32_t sign_extend_s8x4(uint32_t x) { return ((x >> 7) & 0x01010101u) * 0xffu; }   // cwbvh.fs:369-372
 
+
 __device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xffu); }          // v_cvt_f32_ubyteN
 
 // 8-wide quantised child-box test (cwbvh.fs:376-446, corrected: far = min(min()), tmin clamped to 0,
@@ -43,6 +44,13 @@ __device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x 
 // min3, 2 clamps, compare, shift, select); pairing the near/far fmas of an axis into v_pk_fma_f32 (24 instead of
 // 48) was measured twice: 0.224 vs 0.217 ms (200-frame averages) and 9 more VGPRs, so the scalar form stays.  Returns the hit mask: inner children in the top
 // byte at bit (24+slot)^oct, leaf triangles as unary-count bits in the low 24.
+// Round 3 measured what each instruction kind costs (profiles/r03_valu_issue_cycles.txt: only fma / mul / add / mov issue at ~2.5
+// cycles per wave64 instruction, conversions, min / max, compares and integer ops at ~4.2) and tried the obvious answer — a 128-byte
+// device copy of the node with the planes widened to IEEE halves, so that the conversion rides inside v_fma_mix_f32 and the ray picks
+// near / far plane rows by address instead of 12 v_cndmask (55 fewer instructions per node, same arithmetic, bit-identical).  It
+// lost: v_fma_mix_f32 is a 4.3-cycle instruction itself, and 8 row loads per node instead of 5 saturate the CU's vector-memory path
+// (1,004,672 triangles 12,574 vs 12,365 Mray/s at 96 VGPRs but the 80-VGPR build spills in the loop, 4 segments 4,995 vs 5,047,
+// the 8 M-triangle scene 6,942 vs 8,588).  The patch is kept as profiles/r03_f16_planes_experiment.patch.
 __device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3,
                                                     const uint4 n4, vec3 o, vec3 inv, bool negx, bool negy, bool negz,
                                                     uint32_t oct4, float max_t) {
@@ -434,6 +442,14 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
 // chunk on a per-group counter, stealing from other groups when drained) was measured and dropped: equal
 // on the 1 M-triangle scenes (0.404 vs 0.396 ms) and 1.8x slower on Cornell (0.132 vs 0.074 ms), where the
 // per-chunk atomic + two barriers sit on the critical path of very short rays.
+// The pass loop of a workgroup over its chunks.  The default build launches one workgroup per chunk (the hardware dispatcher is the
+// scheduler), so the loop body runs once — and is written as a loop the compiler can see runs once: around a real loop it hoists
+// every wave-uniform value and constant of the body into SGPRs that then live (or spill into VGPR lanes) across the whole kernel.
+#ifdef CRT_EXPERIMENTS
+#define CRT_CHUNK_LOOP(it) for (uint32_t it = 0;; ++it)          // persistent grids (option "oversubscribe")
+#else
+#define CRT_CHUNK_LOOP(it) for (uint32_t it = 0; it < 1u; ++it)
+#endif
 #define CRT_COUNTER_STRIDE 32u   // uint32 slots between two per-group counters (128 B)
 #define CRT_NO_WORK 0xffffffffu
 
@@ -522,7 +538,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
     uint32_t nn_total = 0, nt_total = 0;
-    for (uint32_t it = 0;; ++it) {
+    CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_pool_chunk<true>(wid, nullptr, n, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t first = dense_pool_first(v, wave);
@@ -646,7 +662,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace_bvh2(Bvh2Args a) {
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
     int* stk = s_stk2 + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
-    for (uint32_t it = 0;; ++it) {
+    CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_chunk<true>(wid, nullptr, a.n, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t i = dense_item(v, wave, lane);
@@ -682,6 +698,11 @@ __device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
 
 // local pixel index -> frame pixel.  Pixels are laid out tile-major; inside a tile, 8x8 blocks
 // row-major, so one 64-lane wave covers an 8x8 pixel block (coherent primary rays).
+// A wave-uniform value passed through an empty asm statement: what is computed from it (the reciprocal of an integer divisor, an
+// int -> float conversion) is computed where it is used instead of being hoisted to the top of the kernel, where it would hold a
+// VGPR across every loop (wave-uniform floats and division constants live in VGPRs: there is no scalar float unit).
+__device__ __forceinline__ uint32_t here(uint32_t uniform) { asm volatile("" : "+s"(uniform)); return uniform; }
+
 __device__ __forceinline__ bool pixel_of(const FrameArgs& f, uint32_t i, uint32_t& px, uint32_t& py) {
     uint32_t t, bx, by;
     const uint32_t k = i & 63u;
@@ -691,10 +712,10 @@ __device__ __forceinline__ bool pixel_of(const FrameArgs& f, uint32_t i, uint32_
         const uint32_t blk = (i & ((1u << s2) - 1u)) >> 6;
         bx = blk & ((1u << sb) - 1u); by = blk >> sb;
     } else {
-        const uint32_t tile_px = f.tile * f.tile;
+        const uint32_t tile_px = here(f.tile * f.tile);
         t = i / tile_px;
-        const uint32_t blk = (i % tile_px) >> 6, blocks_per_row = f.tile >> 3;
-        bx = blk % blocks_per_row; by = blk / blocks_per_row;
+        const uint32_t blk = (i - t * tile_px) >> 6, blocks_per_row = here(f.tile >> 3);
+        by = blk / blocks_per_row; bx = blk - by * blocks_per_row;
     }
     const uint2 txy = f.tile_xy[t];
     px = txy.x * f.tile + bx * 8u + (k & 7u);
@@ -893,7 +914,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
     // frame will append to (last touched by the previous frame, which stream order has retired).
     if (FIRST && a.zero_counts && blockIdx.x == 0)   // 64 or 256 threads, either works
         for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x) a.zero_counts[i] = 0u;
-    for (uint32_t it = 0;; ++it) {
+    CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_chunk<FIRST>(wid, a.count_in, f.n_local_pixels, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t g = v >> 28;                         // owner group of this chunk: its sub-queues get the output
@@ -903,7 +924,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         float4* const next_q = a.rays_next + 2 * (size_t)g * a.sub_capacity;
         uint32_t e, n;
         uint32_t cost_tile = 0;
-        unsigned long long cost_t0 = 0;
+        bool cost_valid = false;
+        uint32_t cost_t0 = 0;                               // low word of the cycle counter, wave-uniform: lives in an SGPR, not in a VGPR pair
         if (FIRST) {
             e = dense_item(v, wave, lane);
             n = f.n_local_pixels;
@@ -912,11 +934,15 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             // Cornell 0.082 -> 0.076 ms with nothing but a centre-out order).  A batch of 64 items never straddles two tiles.
             if (f.tile_order && e < n) {
                 const uint32_t tile_px = f.tile * f.tile;
-                const uint32_t slot = f.tile_log2 ? e >> (2u * f.tile_log2) : e / tile_px;
+                const uint32_t slot = f.tile_log2 ? e >> (2u * f.tile_log2) : e / here(tile_px);
                 cost_tile = f.tile_order[slot];
                 e = cost_tile * tile_px + (e - slot * tile_px);
             }
-            if (a.tile_cost) cost_t0 = __builtin_readcyclecounter();
+            if (a.tile_cost) cost_t0 = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_readcyclecounter());
+            // lane 0 reports the batch's cost for its tile (a batch never straddles two tiles): its tile and whether it has a pixel
+            // at all, as wave-uniform scalars — a per-lane copy would sit in VGPRs across every loop of the kernel
+            cost_tile = __builtin_amdgcn_readlane(cost_tile, 0);
+            cost_valid = __builtin_amdgcn_readlane((uint32_t)(e < n), 0) != 0u;
         } else {
             e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
             n = a.count_in[g * CRT_COUNTER_STRIDE];
@@ -927,7 +953,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         // the loop-carried state costs the single-sample kernel 50 bytes of scratch per lane otherwise.
         const uint32_t ws_waves = blockDim.x >> 6;           // wave_samples: wave w renders samples w, w + W, w + 2 W, ...
         const uint32_t n_smp = BATCH ? (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : a.n_samples) : 1u;
+        const uint32_t e_of_chunk = e;
         for (uint32_t smp_it = 0; smp_it < n_smp; ++smp_it) {
+        // BATCH: the pixel index goes through an empty asm statement at the top of every sample, so that what is derived from it
+        // (pixel coordinates, the camera-space direction before jitter, tile addresses) is recomputed per sample — a few dozen
+        // instructions — instead of being hoisted out of the sample loop and kept in registers across both traversal loops
+        if (BATCH) { e = e_of_chunk; asm volatile("" : "+v"(e)); }
         const uint32_t smp = wave_samples ? smp_it * ws_waves + wid.lds_wave : smp_it;
         float rv = BATCH ? a.rv_s[smp & 7u] : f.rv;
         bool active = e < n && (!wave_samples || smp < a.n_samples);
@@ -941,7 +972,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             pix = BATCH ? smp * f.n_local_pixels + e : e;     // the path's id: its pixel, or (sample, pixel) when a launch renders several samples
             active = active && pixel_of(f, e, px, py);
             sx = (float)px + 0.5f; sy = (float)py + 0.5f;
-            const float W = (float)f.width, H = (float)f.height;
+            const float W = (float)here(f.width), H = (float)here(f.height);
             float jx = 0.f, jy = 0.f;
             if (f.jitter) {
                 const float r1 = 2.0f * shader_rand(sx, sy, rv);
@@ -1088,7 +1119,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
                         if (a.n_lights <= 0) {
                             shader_rand(sx, sy, rv); shader_rand(sx, sy, rv); shader_rand(sx, sy, rv);
                         } else {
-                            int li = (int)(shader_rand(sx, sy, rv) * (float)a.n_lights);
+                            int li = (int)(shader_rand(sx, sy, rv) * (float)(int)here((uint32_t)a.n_lights));
                             if (li > a.n_lights - 1) li = a.n_lights - 1;
                             const float* Lt = a.lights + 18 * (size_t)li;
                             const float sq = sqrt_ieee(shader_rand(sx, sy, rv));    // :843-855
@@ -1275,8 +1306,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         const uint32_t ni = wave_append(emit_next, count_next);
         if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
         }   // samples
-        if (FIRST && a.tile_cost && lane == 0u && e < n)
-            atomicAdd(a.tile_cost + cost_tile, (uint32_t)(__builtin_readcyclecounter() - cost_t0));
+        if (FIRST && a.tile_cost && lane == 0u && cost_valid)
+            atomicAdd(a.tile_cost + cost_tile, (uint32_t)__builtin_readcyclecounter() - cost_t0);     // a wave lives far less than 2^32 cycles
     }
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
     if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any, wn_any, wt_any);
@@ -1294,7 +1325,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
     const uint32_t lane = wid.lane, wave = wid.wave;
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
-    for (uint32_t it = 0;; ++it) {
+    CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_pool_chunk<false>(wid, a.count, 0u, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t g = v >> 28;
@@ -1332,7 +1363,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
     const uint32_t lane = wid.lane, wave = wid.wave;
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
-    for (uint32_t it = 0;; ++it) {
+    CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_chunk<false>(wid, a.count, 0u, it);
         if (v == CRT_NO_WORK) break;
         const uint32_t g = v >> 28;

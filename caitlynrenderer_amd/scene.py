@@ -182,6 +182,25 @@ class Scene:
     def set_shard(self, rank, world, tile=16):
         check(lib().crt_set_shard(self._h, int(rank), int(world), int(tile)))
 
+    def sum_device(self):
+        """crt_sum_device: device pointer (int) of the whole frame's running sum on the first device (gathered when there are several)."""
+        ptr = C.c_void_p()
+        check(lib().crt_sum_device(self._h, C.byref(ptr)))
+        return ptr.value
+
+    def set_devices(self, devices, tile=16):
+        """crt_set_devices: this one handle renders on all of `devices` (HIP device ids, the scene's own first); read_sum / resolve
+        gather the other devices' tiles to the first.  The same id more than once = virtual devices on one GPU (tests)."""
+        ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        check(lib().crt_set_devices(self._h, ids, len(devices), int(tile)))
+
+    def devices(self):
+        """{"devices": [...], "transport": "rccl" | "copy", "last_gather_ms": ms of the last gather}"""
+        n, tr, ms = C.c_uint32(), C.c_int32(), C.c_float()
+        ids = (C.c_int32 * 64)()
+        check(lib().crt_get_devices(self._h, C.byref(n), ids, 64, C.byref(tr), C.byref(ms)))
+        return {"devices": [int(ids[k]) for k in range(n.value)], "transport": "rccl" if tr.value == 0 else "copy", "last_gather_ms": float(ms.value)}
+
     def packed_info(self):
         nt, tile, nf = C.c_uint32(), C.c_uint32(), C.c_size_t()
         check(lib().crt_packed_info(self._h, C.byref(nt), C.byref(tile), C.byref(nf)))

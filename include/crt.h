@@ -189,6 +189,8 @@ int crt_sync(crt_scene* s);
  *                         1 = for 6 (80 VGPRs), 2 (default) = 6 where the launch is bound by throughput, 5 where its longest
  *                         waves set its length (the same measure as "wave_samples"); the 6-wave build exists for the batched
  *                         launches of crt_render_frames on Lambert scenes
+ *     "gather_transport"  scenes on several devices (crt_set_devices): 0 = RCCL send / recv (default when librccl.so loads and the
+ *                         devices are distinct), 1 = hipMemcpyPeerAsync
  *   experimental (a library built with `make EXPERIMENTS=1`, crt_has_experiments() != 0; otherwise only the default value is
  *   accepted) — variants that lost every measurement and are kept for re-measurement, bit-identical like the rest:
  *     "bounce_refill"     segments >= 1: 0 = lock-step segment kernel (default), 1 = closest hits through lane-refill
@@ -206,6 +208,10 @@ int crt_reset(crt_scene* s);
 /* path_trace_texture read-back: n_floats must be width*height*3 (bottom row first).
  * With a shard set, returns this rank's pixels only (others 0). */
 int crt_read_sum(crt_scene* s, float* rgb, size_t n_floats);
+/* the same frame left where the reference keeps it — in device memory, as the texture the output pass samples
+ * (Scene.h:1226-1230): width*height*3 floats, bottom row first, on the scene's (first) device; with several devices this
+ * is the gather + un-tile without the copy to the host.  The pointer stays valid until the next read-back call. */
+int crt_sum_device(crt_scene* s, const float** d_rgb);
 /* replaces the output pass, Shader/output.fs:9-20 + Scene.h:1226-1230:
  * rgba8 = pow(tonemap(sum*inv_count), 1/2.2), alpha 255; n_bytes = width*height*4 */
 int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes);
@@ -233,6 +239,27 @@ int crt_debug_launch_form(crt_scene* s, int32_t* form);
  * schedule (option "adaptive_tiles"): smaller tiles schedule finer (1 M triangles, 1080p: 0.273 / 0.261 / 0.257 / 0.254 ms
  * per frame at 64 / 32 / 16 / 8). */
 int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile);
+/* Several GPUs behind ONE handle, one process, one frame loop — the shape of the reference (main.cpp:262-300 calls
+ * Scene::update / Scene::Render once per frame, Scene.h:1158-1231) with the tile sharding and the gather done inside
+ * the library ("Outputs": "multi-GPU gather happens inside these").  `devices` lists n_devices HIP device
+ * ids; devices[0] must be the device the scene lives on.  The scene's device buffers are copied to every other device
+ * over the fabric (hipMemcpyPeer: nothing is re-uploaded from the host, and a scene built on the device is replicated
+ * as built), the tiles (tile x tile pixels, Morton order) are dealt round-robin to the devices exactly as crt_set_shard
+ * deals them to ranks, and from then on every entry point acts on all of them: crt_set_camera / crt_set_option /
+ * crt_reset fan out, crt_render_frame[s][_async] enqueues the frame on each device's own stream (the devices run side
+ * by side), crt_sync waits for all, crt_get_frame_stats adds the counts up (times: the slowest device).  crt_read_sum
+ * and crt_resolve gather the packed per-tile radiance of devices 1..n-1 to device 0 — grouped RCCL send / recv over
+ * xGMI, one slice per link, librccl.so loaded on first use; hipMemcpyPeerAsync when RCCL cannot be loaded or option
+ * "gather_transport" is 1 — and un-tile the whole frame there.  Sums are bit-identical to one device rendering the whole
+ * frame (a pixel's samples depend on its coordinates and the frame's randomVector only).  n_devices = 1 returns to a
+ * single device.  The same id may appear more than once ("virtual devices": separate streams and shards on one GPU,
+ * gathered by copies) — that is how the path is tested on a one-GPU machine.  crt_set_shard is refused on such a scene;
+ * crt_trace*, crt_packed_info / crt_read_packed act on device 0 alone.  One process per GPU with crt_set_shard and the
+ * caller's own collective (caitlynrenderer_amd/tiles.py, bench.py --gpus N) remains the other way to use several GPUs. */
+int crt_set_devices(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile);
+/* what crt_set_devices left: the device list (up to `capacity` entries), how the gather travels (0 RCCL, 1 peer copies)
+ * and the host milliseconds the last gather took (enqueue to completion on device 0); any pointer may be NULL */
+int crt_get_devices(crt_scene* s, uint32_t* n_devices, int32_t* devices, uint32_t capacity, int32_t* transport, float* last_gather_ms);
 /* packed tile-major sum buffer of this rank: n_local_tiles * tile*tile*3 floats. */
 int crt_packed_info(crt_scene* s, uint32_t* n_local_tiles, uint32_t* tile, size_t* n_floats);
 int crt_read_packed(crt_scene* s, float* dst_host, size_t n_floats);

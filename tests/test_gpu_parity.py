@@ -516,6 +516,68 @@ def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data, T)
     full.close()
 
 
+@pytest.mark.parametrize("name,depth,n_dev", [("cornell", 1, 2), ("tess8", 3, 4), ("tess8", 2, 3)])
+def test_one_handle_several_devices_gather_inside_the_c_abi(cr, ob, cornell, scenes, name, depth, n_dev):
+    """crt_set_devices: ONE scene handle and one frame loop, as the reference has them (main.cpp:262-300), rendering on several
+    devices; crt_read_sum / crt_resolve gather the other devices' tiles to the first and return the whole frame.  On
+    this one-GPU box the devices are virtual — the same GPU listed n times: separate replicas, streams, shards and gather buffers,
+    copies instead of RCCL — which exercises everything but the transport.  Frames one by one and batched, camera change, reset,
+    options and statistics: bit-identical to the oracle and to the single-device scene."""
+    from caitlynrenderer_amd import _lib
+    _, _, data = scenes[name]
+    _, cam = cornell
+    W, H = 250, 140                                   # ragged tiles
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(7)]
+    orc = ob.Oracle(data, W, H, depth, cam)
+    ref = np.zeros((H, W, 3), np.float32)
+    cnt_last = None
+    for r in rvs:
+        _, cnt_last = orc.render_frame(r[0], r[1], ref, threads=8)
+    multi = cr.Scene(data, W, H, depth)
+    multi.set_devices([0] * n_dev, 16)
+    info = multi.devices()
+    assert info["devices"] == [0] * n_dev and info["transport"] == "copy"
+    multi.set_option("count_visits", 1)
+    for r in rvs[:3]:
+        multi.render_frame(*r)
+    multi.set_option("count_visits", 0)
+    multi.render_frames(rvs[3:6])
+    multi.set_option("count_visits", 1)
+    multi.render_frame(*rvs[6])
+    st = multi.frame_stats()
+    assert (st["closest_rays"], st["any_rays"]) == (cnt_last[0], cnt_last[1]) and st["stack_overflows"] == 0      # summed over the devices
+    assert st["nodes_closest"] + st["nodes_any"] == cnt_last[2] and st["tris_closest"] + st["tris_any"] == cnt_last[3]
+    out = multi.read_sum()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), float(np.abs(out - ref).max())
+    assert multi.devices()["last_gather_ms"] > 0
+    single = cr.Scene(data, W, H, depth)
+    for r in rvs:
+        single.render_frame(*r)
+    assert np.array_equal(multi.resolve(1.0 / 7).view(np.uint32), single.resolve(1.0 / 7).view(np.uint32))
+    # a shard of its own is refused; reset and a new camera reach every device; back to one device
+    with pytest.raises(cr.CrtError) as e:
+        multi.set_shard(0, 2, 16)
+    assert e.value.code == _lib.CRT_ERR_INVALID
+    cam2 = cr.Camera((2.0, 2.5, 9.0), (2.8, 2.7, 0.0), 50.0)
+    for s in (multi, single):
+        s.reset()
+        s.update(cam2)
+        s.render_frame(*rvs[0])
+    assert np.array_equal(multi.read_sum().view(np.uint32), single.read_sum().view(np.uint32)) and single.read_sum().max() > 0
+    multi.set_devices([0], 16)
+    assert multi.devices()["devices"] == [0]
+    multi.reset(); single.reset()
+    for s in (multi, single):
+        s.render_frame(*rvs[1])
+    assert np.array_equal(multi.read_sum().view(np.uint32), single.read_sum().view(np.uint32))
+    with pytest.raises(cr.CrtError):
+        multi.set_devices([0, 99], 16)
+    with pytest.raises(cr.CrtError):
+        multi.set_devices([], 16)
+    multi.close(); single.close()
+
+
 def test_device_resident_trace_and_torch_interop(cr, ob, cornell, scenes):
     """crt_trace_device on torch-owned HBM buffers (the bench path): same bits as the host-buffer entry."""
     import torch
@@ -770,15 +832,15 @@ def test_config5_4k_frame_of_the_million_triangle_mesh(cr, ob, mesh1m):
         shard.close()
 
 
-def test_config4_with_mirror_and_disney_materials_at_full_size(cr, ob, mesh1m):
+def test_config4_with_mirror_and_disney_materials_at_full_size(cr, ob, mesh1m, cornell):
     """BASELINE configs[3] as worded — "4-bounce Disney BSDF" — on the mesh the bench's `incoherent_disney` block runs: the
     1,004,672-triangle tree with the mirror tall box and the GGX / Disney-diffuse short box and floor, 4 path segments, 1920x1080.
     One frame against the oracle bit for bit (sum, ray counts, visit totals), then a step as the bench renders it (4 frames per
     crt_render_frames call) against the same frames one by one."""
     import copy
-    from caitlynrenderer_amd.meshgen import with_disney_materials
-    big, data0, cam = mesh1m
-    mesh = with_disney_materials(big)                       # same geometry and tree: only the material table and the material ids change
+    from caitlynrenderer_amd.meshgen import tessellated_cornell, with_disney_materials
+    _, data0, cam = mesh1m
+    mesh = tessellated_cornell(with_disney_materials(cornell[0]), 183)   # same geometry and tree: only the material table and the material ids change
     data = copy.copy(data0)
     data.materials = mesh.materials
     data.triangles = data0.triangles.copy()
@@ -1544,4 +1606,23 @@ def test_bench_self_launch_under_rccl_on_one_gpu(tmp_path):
     assert len(lines) == 1, run.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["resolution"] == "3840x2160" and d["config"]["spp_per_step"] == 4
-    assert "RCCL gather" in d["config"]["gather"] and d["value"] > 1000
+    assert "RCCL gather" in d["config"]["gather"] and d["value"] > 1000 and "3840x2160" in d["metric"]
+    assert d["gather_ms"] >= 0 and len(d["rank_device_ms_per_step"]) == 1 and d["rank_device_ms_per_step"][0] > 0
+
+
+def test_bench_one_process_several_devices(tmp_path):
+    """`bench.py --one-process`: the N devices behind ONE scene handle (crt_set_devices), gather inside the C ABI at the end of the
+    timed region — here with 4 virtual devices on the one GPU (copies, not RCCL), configs[4]'s frame on a smaller mesh."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--one-process", "--virtual-devices", "4", "--workload", "mesh40",
+                          "--resolution", "3840x2160", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc"],
+                         capture_output=True, text=True, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 4 and d["config"]["devices"] == [0, 0, 0, 0] and d["config"]["parallelism"] == "tiles/4"
+    assert "inside the C ABI" in d["config"]["gather"] and d["gather_ms"] > 0 and d["value"] > 500
+    assert d["roofline"]["counters"]["primary_rays"] == 3840 * 2160

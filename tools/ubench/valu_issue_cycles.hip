@@ -71,6 +71,34 @@ __global__ void k(float* out, unsigned long long* stamps, int iters, float seed)
                 asm volatile("v_mul_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
                              "v_mul_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            } else if (KIND == 13) { // 8 v_fma_mix_f32: src0 an f16 half of a packed register (converted inside the fma), src1/src2 f32
+                asm volatile("v_fma_mix_f32 %0, %8, %9, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %2, %8, %9, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %9, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %4, %8, %9, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %6, %8, %9, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 14) { // 8 v_cvt_f32_f16
+                asm volatile("v_cvt_f32_f16 %0, %8\n v_cvt_f32_f16 %1, %8\n v_cvt_f32_f16 %2, %8\n v_cvt_f32_f16 %3, %8\n"
+                             "v_cvt_f32_f16 %4, %9\n v_cvt_f32_f16 %5, %9\n v_cvt_f32_f16 %6, %9\n v_cvt_f32_f16 %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 15) { // 8 three-operand integer ops: perm, or3, bfi, lshl_add, and_or, lshl_or, mad_u32_u24, add3
+                asm volatile("v_perm_b32 %0, %0, %8, %9\n v_or3_b32 %1, %1, %8, %9\n v_bfi_b32 %2, %2, %8, %9\n v_lshl_add_u32 %3, %3, 3, %8\n"
+                             "v_and_or_b32 %4, %4, %8, %9\n v_lshl_or_b32 %5, %5, 3, %8\n v_mad_u32_u24 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 16) { // 8 v_cndmask_b32 on an SGPR-pair mask
+                asm volatile("v_cndmask_b32 %0, %0, %8, s[20:21]\n v_cndmask_b32 %1, %1, %8, s[20:21]\n v_cndmask_b32 %2, %2, %8, s[20:21]\n v_cndmask_b32 %3, %3, %8, s[20:21]\n"
+                             "v_cndmask_b32 %4, %4, %8, s[20:21]\n v_cndmask_b32 %5, %5, %8, s[20:21]\n v_cndmask_b32 %6, %6, %8, s[20:21]\n v_cndmask_b32 %7, %7, %8, s[20:21]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s20", "s21");
+            } else if (KIND == 17) { // 8 v_pk_mul_f32 / v_pk_add_f32 on register pairs (16 flops per 8 instructions... counted as 4 instructions below)
+                asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                             : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(const double*)&b));
+            } else if (KIND == 18) { // the node test per child with f16 planes: 6 v_fma_mix_f32, max3, min3, max, min, cmp, cndmask, or (13 instr)
+                asm volatile("v_fma_mix_f32 %0, %4, %8, %9 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %2, %5, %8, %9 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %5, %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %6, %4, %9, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %5, %9, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_max3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %3, %6, %7\n v_max_f32 %0, %0, %9\n v_min_f32 %1, %1, %8\n"
+                             "v_cmp_le_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %4, vcc\n v_or_b32 %3, %3, %2\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
             } else if (KIND == 4) { // 8 independent v_mov_b32 (1 source)
                 asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
                              "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n"
@@ -130,6 +158,12 @@ int main(int argc, char** argv) {
             run<10>("v_cmp into SGPR pairs x8", 8, grid, d_out, d_st);
             run<8>("integer and/shift/or/bfe/add x8", 8, grid, d_out, d_st);
             run<9>("v_fma_f32 x8, constant operands", 8, grid, d_out, d_st);
+            run<13>("v_fma_mix_f32 x8 (f16 src0)", 8, grid, d_out, d_st);
+            run<14>("v_cvt_f32_f16 x8", 8, grid, d_out, d_st);
+            run<15>("3-operand integer ops x8", 8, grid, d_out, d_st);
+            run<16>("v_cndmask_b32 x8 (SGPR mask)", 8, grid, d_out, d_st);
+            run<17>("v_pk_mul/add_f32 x4", 4, grid, d_out, d_st);
+            run<18>("node test per child, f16 planes (13)", 13, grid, d_out, d_st);
         }
     }
     return 0;
