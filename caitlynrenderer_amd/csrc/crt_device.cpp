@@ -174,6 +174,24 @@ struct crt_scene {
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
+    // bounce rays regrouped by (direction octant, origin cell) between segments (rt_kernels.hpp RayBins).  Tables per segment a ray
+    // can enter (1..16), capacities / offsets twice (frame parity: the launch that consumes a segment's rays reads the layout its
+    // producer used while k_bin_scan already writes the next frame's).
+    // option "ray_bins": 0 (default) = per-group sub-queues in emission order; 1 = bins, the lanes of a wave that share a key take their
+    // places with one atomic; 2 = bins, one atomic per ray; 3 = 1 for the first segment's emission, 2 for the bounce segments'.
+    // Measured on the 1 M-triangle frame, 4 segments, 4 samples per launch: wave-level traversal steps -10 % (lane utilisation of
+    // the closest-hit node block 46.5 -> 51.7 %), frame time +3.6 % / +31 % / +5 % for 1 / 2 / 3 — what the append costs
+    // (a wave of bounce rays holds ~50 different keys) exceeds what the walk gains; profiles/r03_experiments.md.
+    uint32_t ray_bins = 0;
+    bool rays_doubled = false;               // the path-ray queues have their overflow half (allocated when the bins are first used)
+    uint32_t* d_bins = nullptr;              // one allocation: count [17][B] | cap [2][17][B] | off [2][17][B] | start [17][B + 1] | ovf [17 x 32]
+    float bounds_lo[3] = {0.f, 0.f, 0.f}, bounds_hi[3] = {1.f, 1.f, 1.f};   // of the vertices: the cell grid of the bins
+    uint32_t* bin_count(uint32_t seg) const { return d_bins + (size_t)seg * CRT_RAY_BINS; }
+    uint32_t* bin_cap(uint32_t par, uint32_t seg) const { return d_bins + (size_t)(17 + par * 17 + seg) * CRT_RAY_BINS; }
+    uint32_t* bin_off(uint32_t par, uint32_t seg) const { return d_bins + (size_t)(17 * 3 + par * 17 + seg) * CRT_RAY_BINS; }
+    uint32_t* bin_start(uint32_t seg) const { return d_bins + (size_t)17 * 5 * CRT_RAY_BINS + (size_t)seg * (CRT_RAY_BINS + 1u); }
+    uint32_t* bin_ovf(uint32_t seg) const { return d_bins + (size_t)17 * 5 * CRT_RAY_BINS + (size_t)17 * (CRT_RAY_BINS + 1u) + (size_t)seg * 32u; }
+    static size_t bins_words() { return (size_t)17 * 5 * CRT_RAY_BINS + (size_t)17 * (CRT_RAY_BINS + 1u) + 17u * 32u; }
     uint32_t debug_fail_batch_alloc = 0;     // test hook (option of the same name): the next growth of the batch buffers fails before it allocates
     uint32_t batch_cap = 1;                  // samples the path state, the ray queues and d_lfinal are sized for (1 until crt_render_frames needs more)
     uint32_t samples_in_stats = 1;           // samples per pixel of the launch the pending stats describe (crt_render_frames batches)
@@ -200,7 +218,7 @@ struct crt_scene {
         if (stream) hipStreamSynchronize(stream);
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
-                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal};
+                        d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal, d_bins};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_tile_cost) hipHostFree(h_tile_cost);
         if (h_tile_order) hipHostFree(h_tile_order);
@@ -282,6 +300,8 @@ void free_frame_buffers(crt_scene* s) {
                      (void**)&s->d_lfinal};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     s->batch_cap = 1;
+    // the bins' capacities and offsets describe the queues that were just freed: back to "everything overflows"
+    if (s->d_bins) (void)hipMemset(s->d_bins, 0, crt_scene::bins_words() * sizeof(uint32_t));
     if (s->h_tile_cost) { (void)hipHostFree(s->h_tile_cost); s->h_tile_cost = nullptr; }
     if (s->h_tile_order) { (void)hipHostFree(s->h_tile_order); s->h_tile_order = nullptr; }
     s->frame_buffers_ready = false;
@@ -323,6 +343,7 @@ int alloc_frame_buffers(crt_scene* s) {
     if (s->max_depth > 1) {                      // path state and ray queues exist only for multi-segment paths
         if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
         if ((rc = dev_alloc(&s->d_rays[1], 2 * Q))) return rc;
+        s->rays_doubled = false;
         if ((rc = dev_alloc(&s->pb.L, P))) return rc;
         if ((rc = dev_alloc(&s->pb.T, P))) return rc;
         if ((rc = dev_alloc(&s->pb.seed, P))) return rc;
@@ -397,6 +418,7 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
     if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
 #endif
+    if (const char* e = std::getenv("CRT_RAY_BINS")) s->ray_bins = (uint32_t)std::min(3, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(3, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
@@ -404,6 +426,14 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return (fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
+    if (d->n_vertices) {
+        for (int k = 0; k < 3; ++k) s->bounds_lo[k] = s->bounds_hi[k] = d->vertices[k];
+        for (size_t i = 1; i < d->n_vertices; ++i)
+            for (int k = 0; k < 3; ++k) {
+                s->bounds_lo[k] = std::min(s->bounds_lo[k], d->vertices[3 * i + k]);
+                s->bounds_hi[k] = std::max(s->bounds_hi[k], d->vertices[3 * i + k]);
+            }
+    }
     for (size_t m = 0; m < d->n_materials; ++m)
         s->special_materials = s->special_materials || d->materials[m].albedo[3] == 1.0f || d->materials[m].albedo[3] == 17.0f;
     return CRT_OK;
@@ -857,6 +887,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
             s->spans.push_back(sp);
         }
     }
+    else if (!std::strcmp(name, "ray_bins")) s->ray_bins = (uint32_t)std::min(3, std::max(0, value));
     else if (!std::strcmp(name, "debug_fail_batch_alloc")) s->debug_fail_batch_alloc = value ? 1u : 0u;
     else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: plain per-lane closest-hit loop (what trees of a few nodes get)
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
@@ -976,6 +1007,35 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.tri_share = s->tri_share == 3u ? (b == 0 ? 0u : 2u) : s->tri_share;
         if (s->info.n_tris8 > (1ull << 24)) sa.tri_share = 0u;     // a shared item is (triangle index | owner lane << 24)
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
+        // bounce rays binned between the segments (option "ray_bins"): big trees, CWBVH walks, the lock-step segment kernels
+        const bool bins = s->ray_bins != 0u && s->max_depth > 1u && !small_tree && !bvh2 && !s->bounce_refill;
+        if (bins && !s->d_bins) {
+            if ((rc = dev_alloc(&s->d_bins, crt_scene::bins_words()))) return rc;
+            HIPCHK(hipMemsetAsync(s->d_bins, 0, crt_scene::bins_words() * sizeof(uint32_t), s->stream));     // capacities 0: a first launch overflows entirely
+        }
+        const uint32_t Qe = 8u * s->sub_capacity;        // entries of the bins' half of a queue = what the sub-queue form holds
+        if (bins && !s->rays_doubled) {
+            // twice the entries any launch can emit: the bins' places in the first half, the overflow region — in the worst case every
+            // ray of a launch, e.g. the first one after the view changed — in the second.  Between two frames the queues hold nothing.
+            HIPCHK(hipStreamSynchronize(s->stream));
+            float4 *r0 = nullptr, *r1 = nullptr;
+            if ((rc = dev_alloc(&r0, 4 * (size_t)Qe)) || (rc = dev_alloc(&r1, 4 * (size_t)Qe))) { if (r0) (void)hipFree(r0); return rc; }
+            (void)hipFree(s->d_rays[0]); (void)hipFree(s->d_rays[1]);
+            s->d_rays[0] = r0; s->d_rays[1] = r1;
+            s->rays_doubled = true;
+        }
+        if (bins && b + 1 < s->max_depth) {
+            crt::RayBins& o = sa.bins_out;
+            o.count = s->bin_count(b + 1); o.cap = s->bin_cap(s->bank, b + 1); o.off = s->bin_off(s->bank, b + 1);
+            o.ovf_count = s->bin_ovf(b + 1); o.ovf_base = Qe;
+            o.per_lane = s->ray_bins == 2u ? 1u : s->ray_bins == 3u ? (b > 0 ? 1u : 0u) : 0u;
+            for (int k = 0; k < 3; ++k) {
+                const float ext = s->bounds_hi[k] - s->bounds_lo[k];
+                o.origin[k] = s->bounds_lo[k];
+                o.scale[k] = ext > 0.f ? 8.0f / ext : 0.f;
+            }
+        }
+        if (bins && b > 0) { sa.bin_start = s->bin_start(b); sa.bin_off_in = s->bin_off(s->bank, b); sa.ovf_base_in = Qe; }
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
         sa.shadow = s->d_shadow; sa.count_shadow = cnt + counter_index(b, 1, 0);
@@ -1017,6 +1077,15 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         uint32_t grid = s->trace_grid(P, sa.wide_first ? 6 : 5);
         if (b > 0 && deferred) grid *= n_samples;
         crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, grid, s->waves_per_workgroup, s->stream);
+        if (sa.bins_out.count) {
+            // fill counts -> the next launch's index space and ray count, and the next frame's capacities (the other parity)
+            crt::BinScanArgs ba{};
+            ba.count = s->bin_count(b + 1); ba.cap = s->bin_cap(s->bank, b + 1); ba.start = s->bin_start(b + 1); ba.ovf_count = s->bin_ovf(b + 1);
+            ba.n_in = cnt + counter_index(b + 1, 0, 0);
+            ba.cap_next = s->bin_cap(s->bank ^ 1u, b + 1); ba.off_next = s->bin_off(s->bank ^ 1u, b + 1);
+            ba.queue_entries = Qe;
+            crt::launch_bin_scan(ba, s->stream);
+        }
 
         if (inplace) continue;                       // shadow rays were traced inside k_segment
         crt::ShadowArgs sh{};
@@ -1075,6 +1144,8 @@ static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
     s->d_rays[0] = rays0; s->d_rays[1] = rays1; s->pb.L = L; s->pb.T = T; s->pb.seed = seed; s->d_lfinal = lfinal;
     s->sub_capacity = sub_capacity;
     s->batch_cap = cap;
+    s->rays_doubled = false;
+    if (s->d_bins) HIPCHK(hipMemset(s->d_bins, 0, crt_scene::bins_words() * sizeof(uint32_t)));     // new queues: the bins start empty-handed again
     return CRT_OK;
 }
 
@@ -1350,6 +1421,8 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
     r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
+    r->ray_bins = src->ray_bins;
+    for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }
     r->scene_bufs = src->scene_bufs;
     if (device != src->device) {          // direct xGMI copies where the platform allows them; staged through the host otherwise
         int can = 0;
@@ -1552,6 +1625,7 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
     if (!s->frame_buffers_ready || segment > 16) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: no frame rendered");
     std::vector<uint32_t> counts(kCounters);
     HIPCHK(hipMemcpy(counts.data(), s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (which != 2 && s->d_bins && s->ray_bins) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: the path-ray queue is binned (option ray_bins 0 gives the sub-queue form this reads)");
     const float4* src = which == 2 ? s->d_shadow : s->d_rays[segment & 1];
     if (!src) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: that queue does not exist (shadow queue: only with inplace_shadow = 0; path queues: max_depth > 1)");
     const size_t entry = which == 2 ? 3 * sizeof(float4) : sizeof(crt_ray);

@@ -696,6 +696,58 @@ __device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
     return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
 }
 
+// ---- bounce-ray bins (rt_kernels.hpp RayBins) ----
+__device__ __forceinline__ uint32_t ray_bin_key(const RayBins& b, float4 o, float4 d) {
+    // NaN coordinates fall into cell 0 (v_max ignores a NaN operand); the key only decides where the ray waits, never what it hits
+    const float cx = __builtin_fminf(__builtin_fmaxf((o.x - b.origin[0]) * b.scale[0], 0.0f), 7.0f);
+    const float cy = __builtin_fminf(__builtin_fmaxf((o.y - b.origin[1]) * b.scale[1], 0.0f), 7.0f);
+    const float cz = __builtin_fminf(__builtin_fmaxf((o.z - b.origin[2]) * b.scale[2], 0.0f), 7.0f);
+    const uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+    return (oct << 9) | ((uint32_t)cz << 6) | ((uint32_t)cy << 3) | (uint32_t)cx;      // octant-major: neighbouring bins share the octant
+}
+// Queue entry for this lane's ray (meaningless where !want).  The lanes of a wave that share a key are found with one ballot per
+// distinct key (a bounce off one 8 x 8 pixel patch spreads over a handful of cells and 4 - 8 octants), each such set takes its places
+// with ONE atomic (all sets' atomics issue together), and what does not fit its bin takes a place in the overflow region.
+__device__ __forceinline__ uint32_t bin_append(const RayBins& b, bool want, uint32_t key) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t idx = 0;
+    if (b.per_lane) {
+        // a wave of bounce rays holds about as many keys as rays (its rays left one cell in one octant and landed all over the
+        // scene): finding the few lanes that share one costs more than their atomics
+        if (want) idx = atomicAdd(b.count + key, 1u);
+    } else {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        unsigned long long todo = __ballot(want);
+        uint32_t rank = 0, n_same = 0, leader = lane;
+        while (todo) {                                               // wave-uniform: one pass per distinct key
+            const int l = __builtin_ctzll(todo);
+            const uint32_t k = __builtin_amdgcn_readlane(key, l);
+            const unsigned long long m = __ballot(want && key == k);
+            if (want && key == k) { rank = (uint32_t)__builtin_popcountll(m & below); n_same = (uint32_t)__builtin_popcountll(m); leader = (uint32_t)l; }
+            todo &= ~m;
+        }
+        uint32_t base = 0;
+        if (want && lane == leader) base = atomicAdd(b.count + key, n_same);
+        base = __shfl(base, (int)leader);
+        idx = base + rank;
+    }
+    const uint32_t cap = want ? b.cap[key] : 0u;
+    const bool fits = want && idx < cap;
+    const uint32_t ov = wave_append(want && !fits, b.ovf_count);
+    return fits ? b.off[key] + idx : b.ovf_base + ov;
+}
+// consumer index -> queue entry: the bin whose range [start[b], start[b + 1]) holds e (binary search, 12 steps), or the overflow region
+__device__ __forceinline__ uint32_t binned_entry(const uint32_t* __restrict__ start, const uint32_t* __restrict__ off, uint32_t ovf_base, uint32_t e) {
+    const uint32_t in_bins = start[CRT_RAY_BINS];
+    if (e >= in_bins) return ovf_base + (e - in_bins);
+    uint32_t lo = 0u, hi = CRT_RAY_BINS;                             // invariant: start[lo] <= e < start[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (start[mid] <= e) lo = mid; else hi = mid;
+    }
+    return off[lo] + (e - start[lo]);
+}
+
 // local pixel index -> frame pixel.  Pixels are laid out tile-major; inside a tile, 8x8 blocks
 // row-major, so one 64-lane wave covers an 8x8 pixel block (coherent primary rays).
 // A wave-uniform value passed through an empty asm statement: what is computed from it (the reciprocal of an integer divisor, an
@@ -915,7 +967,17 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
     if (FIRST && a.zero_counts && blockIdx.x == 0)   // 64 or 256 threads, either works
         for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x) a.zero_counts[i] = 0u;
     CRT_CHUNK_LOOP(it) {
-        const uint32_t v = static_chunk<FIRST>(wid, a.count_in, f.n_local_pixels, it);
+        uint32_t v;
+        if (!FIRST && a.bin_start) {
+            // binned input: ONE queue in consumer order (bin after bin — octant-major — then the overflow entries); workgroup group
+            // x (one XCD, as far as the round-robin dispatch goes) takes the x-th eighth of its chunks, i.e. about one direction
+            // octant, so an L2 sees rays that head the same way
+            const uint32_t n_chunks = queue_chunks(a.count_in[0]), per_group = (n_chunks + 7u) >> 3;
+            const uint32_t grp = wid.vblock & 7u, c = (wid.vblock >> 3) + it * (wid.vgrid >> 3);
+            v = (c < per_group && grp * per_group + c < n_chunks) ? (grp << 28) | (grp * per_group + c) : CRT_NO_WORK;
+        } else {
+            v = static_chunk<FIRST>(wid, a.count_in, f.n_local_pixels, it);
+        }
         if (v == CRT_NO_WORK) break;
         const uint32_t g = v >> 28;                         // owner group of this chunk: its sub-queues get the output
         uint32_t* const count_shadow = a.count_shadow + g * CRT_COUNTER_STRIDE;
@@ -945,7 +1007,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             cost_valid = __builtin_amdgcn_readlane((uint32_t)(e < n), 0) != 0u;
         } else {
             e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
-            n = a.count_in[g * CRT_COUNTER_STRIDE];
+            n = a.bin_start ? a.count_in[0] : a.count_in[g * CRT_COUNTER_STRIDE];
         }
         // BATCH (crt_render_frames on a one-segment path): the lane renders a.n_samples samples of its pixel one after the
         // other — exactly what the same number of launches would do to this pixel, without their launch gaps and kernel
@@ -993,7 +1055,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             d = normalize((right * dx + up * dy) + fwd);
             o = V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         } else if (active) {
-            const float4* rq = a.rays_in + 2 * ((size_t)g * a.sub_capacity + e);
+            const float4* rq = a.bin_start ? a.rays_in + 2 * (size_t)binned_entry(a.bin_start, a.bin_off_in, a.ovf_base_in, e)
+                                           : a.rays_in + 2 * ((size_t)g * a.sub_capacity + e);
             const float4 r0 = rq[0], r1 = rq[1];
             o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z);
             pix = __float_as_uint(r1.w);
@@ -1303,8 +1366,13 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
                 if (!emit_next && a.pb.L) a.pb.L[pix] = make_float4(L.x, L.y, L.z, 0.f);
             }
         }
-        const uint32_t ni = wave_append(emit_next, count_next);
-        if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
+        if (a.bins_out.count) {
+            const uint32_t ni = bin_append(a.bins_out, emit_next, ray_bin_key(a.bins_out, nx0, nx1));
+            if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
+        } else {
+            const uint32_t ni = wave_append(emit_next, count_next);
+            if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
+        }
         }   // samples
         if (FIRST && a.tile_cost && lane == 0u && cost_valid)
             atomicAdd(a.tile_cost + cost_tile, (uint32_t)__builtin_readcyclecounter() - cost_t0);     // a wave lives far less than 2^32 cycles
@@ -1393,6 +1461,64 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
         }
     }
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
+}
+
+// Between the launch that fills the bins of a segment and the launch that walks them (RayBins in rt_kernels.hpp): fill counts ->
+// consumer index space, ray count of the consuming launch, next frame's capacities and offsets, counters back to zero.
+__global__ void __launch_bounds__(1024) k_bin_scan(BinScanArgs a) {
+    __shared__ uint32_t s_wave[2][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t PER = CRT_RAY_BINS / 1024u;
+    uint32_t filled[PER], want[PER], f_sum = 0, w_sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t b = tid * PER + k, c = a.count[b], cap = a.cap[b];
+        filled[k] = c < cap ? c : cap;
+        want[k] = c + (c >> 3) + 16u;                    // what the bin received, an eighth more, and room for a bin that was empty
+        f_sum += filled[k]; w_sum += want[k];
+        a.count[b] = 0u;
+    }
+    // exclusive prefix of (f_sum, w_sum) over the 1024 threads: inside the wave by shuffles, across waves through LDS
+    uint32_t f_inc = f_sum, w_inc = w_sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t fu = __shfl_up(f_inc, d), wu = __shfl_up(w_inc, d);
+        if ((int)lane >= d) { f_inc += fu; w_inc += wu; }
+    }
+    if (lane == 63u) { s_wave[0][wave] = f_inc; s_wave[1][wave] = w_inc; }
+    __syncthreads();
+    uint32_t f_base = 0, w_base = 0, f_all = 0, w_all = 0;
+    for (uint32_t w = 0; w < 16u; ++w) {
+        if (w < wave) { f_base += s_wave[0][w]; w_base += s_wave[1][w]; }
+        f_all += s_wave[0][w]; w_all += s_wave[1][w];
+    }
+    uint32_t f_at = f_base + f_inc - f_sum, w_at = w_base + w_inc - w_sum;
+    // the capacities asked for may exceed the bins' share of the queue (a launch of more samples than the last one): scaled down
+    const float shrink = w_all > a.queue_entries ? (float)a.queue_entries / (float)w_all : 1.0f;
+    if (shrink < 1.0f) {
+        // rescale and redo the offsets' prefix on the scaled values
+        uint32_t s_sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) { want[k] = (uint32_t)((float)want[k] * shrink); s_sum += want[k]; }
+        uint32_t s_inc = s_sum;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(s_inc, d); if ((int)lane >= d) s_inc += u; }
+        __syncthreads();
+        if (lane == 63u) s_wave[1][wave] = s_inc;
+        __syncthreads();
+        w_base = 0;
+        for (uint32_t w = 0; w < wave; ++w) w_base += s_wave[1][w];
+        w_at = w_base + s_inc - s_sum;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t b = tid * PER + k;
+        a.start[b] = f_at; f_at += filled[k];
+        a.cap_next[b] = want[k]; a.off_next[b] = w_at; w_at += want[k];
+    }
+    if (tid == 0u) {
+        a.start[CRT_RAY_BINS] = f_all;
+        *a.n_in = f_all + *a.ovf_count;
+        *a.ovf_count = 0u;
+    }
 }
 
 // packed tile-major -> linear frame (bottom row first); pixels of other ranks stay untouched.
@@ -1653,6 +1779,9 @@ void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t wave
     const size_t lds = waves * stack_bytes(a.stack_entries);
     if (stats) launch(k_shadow<true>, g, b, lds, stream, a);
     else       launch(k_shadow<false>, g, b, lds, stream, a);
+}
+void launch_bin_scan(const BinScanArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, a);
 }
 void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pixels, uint32_t n_samples, hipStream_t stream) {
     hipLaunchKernelGGL(k_accumulate_samples, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, sum, l_final, n_pixels, n_samples);

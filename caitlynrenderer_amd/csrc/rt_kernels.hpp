@@ -56,6 +56,36 @@ struct FrameArgs {
     float cam_pos[3], cam_right[3], cam_up[3], cam_forward[3];
 };
 
+// Bounce rays regrouped between two segments (BASELINE configs[3], "divergence / sorting stress"): the rays a launch emits are
+// appended to one of CRT_RAY_BINS bins keyed by (direction octant, 8 x 8 x 8 cell of the origin) instead of to its group's
+// sub-queue, so that the next launch's 64-ray batches hold rays that start in the same region and head the same way.  No sort
+// pass: every bin has a fixed place in the queue whose size is what the bin received in the PREVIOUS launch of the same segment
+// (+ 1/8 + 16; a progressive renderer repeats its distribution frame after frame), a ray that does not fit goes to an overflow
+// region behind the bins (all of them in the first launch of a scene), and one tiny kernel between the two launches turns the
+// bins' fill counts into the consumer's index space and next frame's capacities (k_bin_scan).  Per-ray work is unchanged and a
+// pixel's radiance is added in frame order as before, so sums, ray counts and visit counters keep their bits.
+#define CRT_RAY_BINS 4096u
+struct RayBins {
+    uint32_t* count;            // [CRT_RAY_BINS] rays this launch appended per bin (also those that overflowed); null = sub-queues
+    const uint32_t* cap;        // [CRT_RAY_BINS] places of each bin in the queue
+    const uint32_t* off;        // [CRT_RAY_BINS] first queue entry of each bin
+    uint32_t* ovf_count;        // rays that found their bin full: entry ovf_base + k
+    uint32_t ovf_base;
+    uint32_t per_lane;          // 1: every ray takes its place with its own atomic (launches whose waves hold ~64 different keys: bounce
+                                // segments); 0: the lanes of a wave that share a key take theirs with one (coherent first segment)
+    float origin[3], scale[3];  // cell coordinate = clamp((p - origin) * scale, 0, 7)
+};
+struct BinScanArgs {             // k_bin_scan: one workgroup of 1024 threads between the emitting and the consuming launch
+    uint32_t* count;             // in: fill attempts per bin; zeroed for the next launch
+    const uint32_t* cap;         // in: the capacities the emitting launch used
+    uint32_t* start;             // out [CRT_RAY_BINS + 1]: first consumer index of each bin; [last] = rays that sit in bins
+    uint32_t* ovf_count;         // in: overflow entries; zeroed
+    uint32_t* n_in;              // out: rays the consuming launch will find (in bins + overflow)
+    uint32_t* cap_next;          // out: capacities and offsets for the next launch that emits into this segment
+    uint32_t* off_next;
+    uint32_t queue_entries;      // places available to the bins (the overflow region lies behind them)
+};
+
 struct SegmentArgs {
     const uint4* nodes;
     const float4* tris;
@@ -97,6 +127,10 @@ struct SegmentArgs {
                                // renders its pixels' samples one after the other
     uint32_t n_samples;        // FIRST: samples per pixel rendered by this launch (>= 1); > 1 only for one-segment paths walked in place
     float rv_s[8];             // randomVector.x * randomVector.y of each of them (f.rv = rv_s[0])
+    RayBins bins_out;          // where the rays this launch emits go (count == null: rays_next's sub-queues)
+    const uint32_t* bin_start; // segments >= 1, rays_in binned: [CRT_RAY_BINS + 1] consumer index -> bin; null = sub-queues
+    const uint32_t* bin_off_in;
+    uint32_t ovf_base_in;
 };
 
 struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-written path-ray queue
@@ -138,6 +172,7 @@ void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, ui
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
+void launch_bin_scan(const BinScanArgs& a, hipStream_t stream);
 void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pixels, uint32_t n_samples, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);

@@ -181,6 +181,12 @@ int crt_sync(crt_scene* s);
  *     "tri_share"         triangle steps of the voting loop hand the waiting lanes' pending triangles (up to 3 each) to ALL lanes
  *                         of the wave through a wave-private LDS strip, in bounce segments (the coherent first segment is faster
  *                         without): 0 off, 1 closest-hit walk, 2 or 3 (default) also the in-place shadow rays
+ *     "ray_bins"          bounce rays regrouped between segments (BASELINE configs[3], "sorting stress"): 0 (default) = per-group
+ *                         sub-queues in emission order; 1 = the rays a segment emits are appended to 4096 bins keyed by (direction
+ *                         octant, 8^3 cell of the origin) whose places in the queue follow the previous frame's counts, so the next
+ *                         segment's 64-ray batches hold rays that start together and head the same way (wave-level traversal steps
+ *                         -10 % on the 1 M-triangle frame; the append costs more than that saves: frame time +3.6 %); 2 / 3 = variants
+ *                         of the append (one atomic per ray)
  *     "wave_samples"      crt_render_frames, first segment: where the samples of a 64-pixel batch run.  0 = one after the other
  *                         in one wave; 1 = side by side on the 2 to 4 waves of one workgroup, added to the sum in sample order
  *                         through LDS (the same bits); 2 (default) = 1 when the launch would otherwise be bound by its longest

@@ -160,7 +160,8 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
                                (2, {}, None), (1, {"waves_per_workgroup": 4}, (1, 3)), (4, {}, None), (3, {"tri_share": 1}, (0, 2)),
                                (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None),
                                (1, {"wave_samples": 0}, None), (3, {"wave_samples": 0}, (1, 2)), (1, {"wave_samples": 1, "accel": 1}, (2, 3)),
-                               (4, {"wave_samples": 1, "tri_share": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2))):
+                               (4, {"wave_samples": 1, "tri_share": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2)),
+                               (3, {"ray_bins": 1}, None), (4, {"ray_bins": 1}, (1, 2)), (2, {"ray_bins": 3, "wave_samples": 0}, None)):
         if name in ("tess8_mat",) and opts.get("accel"):
             continue                                                          # the BVH2 frame mode is the Lambert-only shader
         if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(opts):
@@ -443,7 +444,7 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
                     {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
                     {"tri_share": 0, "waves_per_workgroup": 2}, {"tri_share": 2, "tri_min": 1}, {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
                     {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
-                    {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5},
+                    {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5}, {"ray_bins": 1}, {"ray_bins": 2}, {"ray_bins": 3, "tri_share": 0}, {"ray_bins": 1, "inplace_shadow": 0},
                     {"bounce_refill": 1}, {"bounce_refill": 1, "refill_min": 1}, {"bounce_refill": 1, "refill_min": 40}, {"inplace_shadow": 0},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
         if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):
@@ -778,6 +779,22 @@ def test_config4_million_triangles_four_segments(cr, ob, mesh1m):
         assert np.array_equal(batched.read_sum().view(np.uint32), ref.view(np.uint32)), ws
         assert batched.frame_stats()["stack_overflows"] == 0
         batched.close()
+    # configs[3]'s "sorting" half: the bounce rays regrouped by (direction octant, origin cell) between the segments (option
+    # ray_bins; from the second frame on the bins have their places).  Same sums, same ray counts and visit totals — only the
+    # number of wave-level traversal steps drops.
+    steps = {}
+    for bins in (0, 1):
+        s = cr.Scene(data, W, H, depth)
+        s.set_option("ray_bins", bins)
+        for r in rvs[:2]:
+            s.render_frame(*r)
+        s.set_option("count_visits", 1)
+        s.render_frame(*rvs[2])
+        st = s.frame_stats()
+        assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32)), bins
+        steps[bins] = (st["closest_rays"], st["any_rays"], st["nodes_closest"], st["tris_closest"], st["nodes_any"], st["tris_any"], st["wave_steps_closest_nodes"])
+        s.close()
+    assert steps[0][:6] == steps[1][:6] and steps[1][6] < 0.95 * steps[0][6]
 
 
 def test_config5_4k_frame_of_the_million_triangle_mesh(cr, ob, mesh1m):

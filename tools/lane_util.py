@@ -13,6 +13,9 @@ scene = cr.Scene(data, 1920, 1080, depth)
 for kv in sys.argv[3:]:
     k, v = kv.split("=")
     scene.set_option(k, int(v))
+# two frames first: the bins of the bounce rays (option ray_bins) take their places from the previous frame's counts
+for _ in range(2):
+    scene.render_frame(0.6591631174087524, 0.9108020067214966)
 scene.set_option("count_visits", 1)
 scene.render_frame(0.6591631174087524, 0.9108020067214966)
 st = scene.frame_stats()
