@@ -331,7 +331,7 @@ def live_pmc(workloads, budget_s=330.0):
                     return                                           # counters do not work here: do not spend minutes finding out twice
                 dirs[kind] = d
             if ok:
-                e = pt.entry_from_dirs(dirs, key)
+                e = pt.entry_from_dirs(dirs, key, tail=min(10, 5 * spp) * depth)     # without the children's own single-sample tail frames
                 if e and "l2_fabric_bytes_per_launch" in e:
                     e["samples_per_launch"] = spp                              # what one launch of the pass rendered (crt_render_frames)
                     _LIVE_PMC[key] = e

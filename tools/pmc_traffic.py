@@ -16,20 +16,33 @@ import collections, csv, glob, json, os, sys
 N_SIMD = 256 * 4
 
 
-def per_kernel(dirname):
-    agg = collections.defaultdict(list)
+def per_kernel(dirname, tail=0):
+    """{(kernel, counter): [value per dispatch]} of one pass.  `tail` = how many of the LAST dispatches of the non-counting segment
+    kernels to leave out: bench.py ends every run with min(10, steps x spp) single-sample frames rendered with full event timing, and
+    those launches — a quarter of the work of a 4-sample launch, some of them by the same kernel — must not be averaged in."""
+    rows = []
     for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        rows += list(csv.DictReader(open(f)))
+
+    def is_seg(r):
+        n = r["Kernel_Name"].split("(")[0]
+        return n.startswith("void crt::k_segment<") and n.split(",")[1].strip() == "false"
+    if tail:
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows if is_seg(r)})
+        drop = set(ids[-tail:])
+        rows = [r for r in rows if not (is_seg(r) and int(r["Dispatch_Id"]) in drop)]
+    agg = collections.defaultdict(list)
+    for r in rows:
+        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return agg
 
 
-def entry_from_dirs(dirs, wl):
-    """dirs: {"fetch" | "write" | "sq" | "grbm": directory of that --pmc pass}; wl = "<workload>_d<depth>".  None if no pass
+def entry_from_dirs(dirs, wl, tail=0):
+    """dirs: {"fetch" | "write" | "sq": directory of that --pmc pass}; wl = "<workload>_d<depth>"; tail: see per_kernel.  None if no pass
     saw the segment kernels."""
     agg = {}
     for d in dirs.values():
-        agg.update(per_kernel(d))
+        agg.update(per_kernel(d, tail))
     names = sorted({k for k, _ in agg if k.startswith("void crt::k_segment<") and k.split(",")[1].strip() == "false"})
     if not names:
         return None
@@ -76,11 +89,13 @@ PASSES = {"fetch": ["FETCH_SIZE", "TCC_HIT_sum", "GRBM_GUI_ACTIVE", "GRBM_TA_BUS
           "sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]}
 
 
-def main(round_dir, out):
+def main(round_dir, out, steps=5):
     res = {}
-    for wl in ("cornell_d1", "mesh1m_d1", "mesh1m_d4", "mesh520_d1", "mesh520_d4"):
-        e = entry_from_dirs({kind: os.path.join(round_dir, f"pmc_{kind}_{wl}") for kind in PASSES}, wl)
+    for wl, spp in (("cornell_d1", 1), ("mesh1m_d1", 4), ("mesh1m_d4", 4), ("mesh520_d1", 4), ("mesh520_d4", 4)):
+        depth = int(wl.split("_d")[1])
+        e = entry_from_dirs({kind: os.path.join(round_dir, f"pmc_{kind}_{wl}") for kind in PASSES}, wl, tail=min(10, steps * spp) * depth)
         if e:
+            e["samples_per_launch"] = spp
             res[wl] = e
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
