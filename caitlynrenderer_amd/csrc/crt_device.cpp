@@ -183,6 +183,7 @@ struct crt_scene {
     // the closest-hit node block 46.5 -> 51.7 %), frame time +3.6 % / +31 % / +5 % for 1 / 2 / 3 — what the append costs
     // (a wave of bounce rays holds ~50 different keys) exceeds what the walk gains; profiles/r03_experiments.md.
     uint32_t ray_bins = 0;
+    bool rows_padded = false;                // d_nodes / d_tris are at the build's stride (CRT_NODE_ROWS / CRT_TRI_ROWS)
     bool rays_doubled = false;               // the path-ray queues have their overflow half (allocated when the bins are first used)
     uint32_t* d_bins = nullptr;              // one allocation: count [17][B] | cap [2][17][B] | off [2][17][B] | start [17][B + 1] | ovf [17 x 32]
     float bounds_lo[3] = {0.f, 0.f, 0.f}, bounds_hi[3] = {1.f, 1.f, 1.f};   // of the vertices: the cell grid of the bins
@@ -444,8 +445,27 @@ static void note_buf(crt_scene* s, const void* member, size_t bytes) {
     s->scene_bufs.emplace_back((size_t)(reinterpret_cast<const char*>(member) - reinterpret_cast<const char*>(s)), bytes);
 }
 
+// The traversal's copies of nodes and records at the build's stride (CRT_NODE_ROWS / CRT_TRI_ROWS): packed input -> padded copy.
+template <typename T>
+static int pad_rows(crt_scene* s, T** buf, uint32_t rows_in, uint32_t rows_out, size_t n_items) {
+    if (rows_in == rows_out || !*buf) return CRT_OK;
+    T* padded = nullptr;
+    int rc = dev_alloc(&padded, n_items * rows_out);
+    if (rc) return rc;
+    crt::launch_restride(*buf, rows_in, padded, rows_out, n_items, s->stream);
+    if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(padded); return fail(CRT_ERR_HIP, "crt_scene_create: re-striding failed"); }
+    (void)hipFree(*buf);
+    *buf = padded;
+    return CRT_OK;
+}
+
 static int finish_scene_setup(crt_scene* s) {
     int rc;
+    if (!s->rows_padded) {           // a replica's buffers arrive padded (crt_set_devices copies them as they are)
+        if ((rc = pad_rows(s, &s->d_nodes, 5u, (uint32_t)CRT_NODE_ROWS, (size_t)s->info.n_nodes8))) return rc;
+        if ((rc = pad_rows(s, &s->d_tris, 3u, (uint32_t)CRT_TRI_ROWS, (size_t)s->info.n_tris8))) return rc;
+        s->rows_padded = true;
+    }
     if ((rc = dev_alloc(&s->d_overflow, 1))) return rc;
     if (hipMemset(s->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) return fail(CRT_ERR_HIP, "hipMemset failed");
     if ((rc = dev_alloc(&s->d_counts, 2 * kCounters))) return rc;
@@ -673,8 +693,8 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
         if (hipMemcpy(s->d_tris2, rec2.data(), rec2.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(CRT_ERR_HIP, "hipMemcpy H2D failed"));
     }
-    note_buf(s, &s->d_nodes, n_nodes8 * sizeof(crt_node8));
-    note_buf(s, &s->d_tris, recs.size() * sizeof(float4));
+    note_buf(s, &s->d_nodes, n_nodes8 * (size_t)CRT_NODE_ROWS * 16);
+    note_buf(s, &s->d_tris, n_tris8 * (size_t)CRT_TRI_ROWS * 16);
     note_buf(s, &s->d_triangles, d->n_triangles * sizeof(crt_triangle));
     note_buf(s, &s->d_normals, d->n_normals * 3 * sizeof(float));
     note_buf(s, &s->d_materials, d->n_materials * sizeof(crt_material));
@@ -785,8 +805,8 @@ static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
     s->info.n_nodes8 = n8; s->info.n_tris8 = n; s->info.n_bvh2_nodes = n2; s->info.max_depth8 = depth8;
     s->info.built_on_device = 1u; s->info.bvh2_depth = depth2;
     s->info.build_upload_ms = upload_ms; s->info.build_lbvh_device_ms = lbvh_ms; s->info.build_convert_device_ms = conv_ms;
-    note_buf(s, &s->d_nodes, (size_t)n8 * sizeof(crt_node8));
-    note_buf(s, &s->d_tris, (size_t)n * 3 * sizeof(float4));
+    note_buf(s, &s->d_nodes, (size_t)n8 * CRT_NODE_ROWS * 16);
+    note_buf(s, &s->d_tris, (size_t)n * CRT_TRI_ROWS * 16);
     note_buf(s, &s->d_triangles, (size_t)n * sizeof(crt_triangle));
     note_buf(s, &s->d_normals, d->n_normals * 3 * sizeof(float));
     note_buf(s, &s->d_materials, d->n_materials * sizeof(crt_material));
@@ -1421,7 +1441,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
     r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
-    r->ray_bins = src->ray_bins;
+    r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }
     r->scene_bufs = src->scene_bufs;
     if (device != src->device) {          // direct xGMI copies where the platform allows them; staged through the host otherwise

@@ -169,7 +169,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             }
             const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-            const uint4* np = nodes + (size_t)(base + rel) * 5;
+            const uint4* np = nodes + (size_t)(base + rel) * CRT_NODE_ROWS;
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
             if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
             const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
@@ -187,7 +187,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const int b = 31 - __builtin_clz(tg.y);
             tg.y &= ~(1u << b);
             const uint32_t ti = tg.x + (uint32_t)b;
-            const float4* tp = tris + (size_t)ti * 3;
+            const float4* tp = tris + (size_t)ti * CRT_TRI_ROWS;
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
             if (STATS) { ++n_tris; count_wave_step(w_tris); }
             float u, v, t;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 }
                 const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
                 const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-                const uint4* np = nodes + (size_t)nidx * 5;
+                const uint4* np = nodes + (size_t)nidx * CRT_NODE_ROWS;
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                 if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
@@ -356,7 +356,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                     const uint32_t item = share.items[rank];
                     const uint32_t src = item >> 24, ti = item & 0x00ffffffu;
                     const float4 ro = share.ray[src], rd = share.ray[64u + src];
-                    const float4* tp = tris + (size_t)ti * 3;
+                    const float4* tp = tris + (size_t)ti * CRT_TRI_ROWS;
                     const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                     float u, v, t;
                     const bool hit = mt_test(ta, tb, tc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), u, v, t);
@@ -391,7 +391,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             const int b = 31 - __builtin_clz(tg.y);
             tg.y &= ~(1u << b);
             const uint32_t ti = tg.x + (uint32_t)b;
-            const float4* tp = tris + (size_t)ti * 3;
+            const float4* tp = tris + (size_t)ti * CRT_TRI_ROWS;
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
             if (STATS) { ++n_tris; count_wave_step(w_tris); }
             float u, v, t;
@@ -1103,7 +1103,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             CRT_MARK("shade_begin");
             if (STATS) ++n_hits;
             const float t = hit.t, bu = hit.u, bv = hit.v;
-            const float4 tb = recs[3 * (size_t)hit.tri + 1], tc = recs[3 * (size_t)hit.tri + 2];
+            const size_t rec_rows = BVH2 ? 3u : (size_t)CRT_TRI_ROWS;            // the BVH2 walk's slot-ordered records stay packed
+            const float4 tb = recs[rec_rows * (size_t)hit.tri + 1], tc = recs[rec_rows * (size_t)hit.tri + 2];
             const int slot = __float_as_int(tb.w), mtl = __float_as_int(tc.w);
             const int4 vn = a.triangles[3 * (size_t)slot + 1];                    // path_trace.fs:440-454
             vec3 n;

@@ -58,6 +58,15 @@ __global__ void k_gather_records(const crt_triangle* __restrict__ in, const uint
     recs[3 * (size_t)i] = a; recs[3 * (size_t)i + 1] = b; recs[3 * (size_t)i + 2] = c;
 }
 
+// dst[i * rows_out + r] = src[i * rows_in + r] for r < rows_in; the padding rows are zeroed (never read)
+__global__ void k_restride(const uint4* __restrict__ src, uint32_t rows_in, uint4* __restrict__ dst, uint32_t rows_out, uint64_t n_items) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = t / rows_out;
+    const uint32_t r = (uint32_t)(t % rows_out);
+    if (i >= n_items) return;
+    dst[t] = r < rows_in ? src[i * rows_in + r] : make_uint4(0u, 0u, 0u, 0u);
+}
+
 inline dim3 grid_for(uint32_t n) { return dim3((n + 255u) / 256u ? (n + 255u) / 256u : 1u); }
 
 }  // namespace
@@ -66,6 +75,11 @@ void launch_validate_triangles(const crt_triangle* d_tris, uint32_t n, uint32_t 
                                uint32_t n_texcoords, const float* d_materials, int have_tex, uint32_t* d_flag, hipStream_t stream) {
     hipLaunchKernelGGL(k_validate_triangles, grid_for(n), dim3(256), 0, stream, d_tris, n, n_vertices, n_materials, n_normals, n_texcoords, d_materials,
                        have_tex, d_flag);
+}
+void launch_restride(const void* d_src, uint32_t rows_in, void* d_dst, uint32_t rows_out, uint64_t n_items, hipStream_t stream) {
+    const uint64_t threads = n_items * rows_out;
+    hipLaunchKernelGGL(k_restride, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, stream, static_cast<const uint4*>(d_src), rows_in,
+                       static_cast<uint4*>(d_dst), rows_out, n_items);
 }
 void launch_gather_slots(const crt_triangle* d_in, const uint32_t* d_tri_order, const float* d_verts, uint32_t n_slots, crt_triangle* d_slot_tris,
                          float4* d_recs2, hipStream_t stream) {

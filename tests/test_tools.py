@@ -1,0 +1,117 @@
+"""The measurement tooling behind the bench line's `roofline` object, without a GPU: the ISA counter of tools/roofline.py on a small
+hand-written assembly, the instruction model against the committed bench line, and the counter summary's rule that the single-sample
+tail frames of a profiled bench run are not averaged into the per-launch figures (tools/pmc_traffic.py)."""
+import csv
+import importlib.util
+import json
+import os
+
+from conftest import ROOT
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+ASM = """
+_ZN3crt9k_segmentILb1ELb0ELb0ELb0ELb1ELb0ELb0ELb0ELb0ELb0ELb0EEEvNS_11SegmentArgsE:
+	s_load_dwordx2 s[0:1], s[4:5], 0x0
+	v_mov_b32_e32 v0, 0
+	v_add_f32_e32 v1, v0, v0
+	; CRT_MARK loop_begin voting
+.LBB0_1:
+	v_cmp_eq_u32_e32 vcc, 0, v0
+	s_and_saveexec_b64 s[2:3], vcc
+	s_cbranch_execz .LBB0_3
+	; CRT_MARK node_begin
+	global_load_dwordx4 v[4:7], v8, s[0:1]
+	v_cvt_f32_ubyte0_e32 v2, v4
+	v_fma_f32 v2, v2, v1, v1
+	v_max3_f32 v2, v2, v1, v0
+.LBB0_3:
+	s_or_b64 exec, exec, s[2:3]
+	v_cmp_eq_u32_e32 vcc, 1, v0
+	s_and_saveexec_b64 s[2:3], vcc
+	s_cbranch_execz .LBB0_5
+	; CRT_MARK tri_begin
+	v_mul_f32_e32 v3, v1, v1
+	v_sub_f32_e32 v3, v3, v1
+.LBB0_5:
+	s_or_b64 exec, exec, s[2:3]
+	s_cbranch_scc1 .LBB0_1
+	; CRT_MARK loop_end
+	v_cmp_lt_f32_e32 vcc, 0, v3
+	s_and_saveexec_b64 s[2:3], vcc
+	s_cbranch_execz .LBB0_7
+	; CRT_MARK shade_begin
+	v_mul_f32_e32 v9, v3, v3
+	v_add_f32_e32 v9, v9, v3
+	v_add_f32_e32 v9, v9, v3
+.LBB0_7:
+	s_endpgm
+	.end_amdhsa_kernel
+"""
+
+
+def test_isa_regions_are_counted_between_the_guarding_branch_and_its_join_label(tmp_path):
+    r = _load("roofline")
+    p = tmp_path / "k.s"
+    p.write_text(ASM)
+    k = r.parse_asm(str(p))
+    (name, e), = k.items()
+    assert r.demangle_args(name) == [1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0] and r.label_of(name) == "k_segment<FIRST,INPLACE>"
+    regs = {kind: n for kind, _, n in e["regions"]}
+    assert regs["node"] == 3 and regs["tri"] == 2 and regs["shade"] == 3            # vector instructions under each block's lane mask
+    assert regs["loop"] == 7                                                          # 2 compares + 3 + 2 inside the loop
+    assert e["valu_total"] == 13 and e["valu_outside_loops"] == 6 and e["vmem_total"] == 1
+
+
+def test_the_committed_bench_line_is_recomputable_from_its_counters_and_the_isa_counts():
+    r = _load("roofline")
+    isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+    line = [l for l in open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) if l.startswith("{")][-1]
+    assert len(line) < 6000
+    d = json.loads(line)
+    ro = d["roofline"]
+    got = r.roofline_block(ro["counters"], isa, ro["launch_ms"], ro["path_segments"], ro["samples_per_launch"])
+    assert abs(got["frac"] - ro["frac"]) < 2e-3 and ro["bound"] == "valu_issue" and ro["peak"] == r.PEAK_GINSTR
+    assert "1004672 tris" in d["config"]["workload"] and d["config"]["spp_per_step"] == 4
+    for name, e in d["extras"].items():
+        assert 0 < e["frac"] <= 1.0, name                                             # no block above its roof
+    assert d["extras"]["hbm_resident"]["scene_mb"] > 256 * 1.048576 and 0 < d["extras"]["hbm_resident_d4"]["hbm_frac"] < 1
+
+
+def test_counter_summary_leaves_the_single_sample_tail_out(tmp_path):
+    """bench.py ends a run with single-sample frames (full event timing); under rocprofv3 --pmc those dispatches — a quarter of the
+    work, partly the same kernels — must not be averaged with the steps' 4-sample launches."""
+    pt = _load("pmc_traffic")
+    seg = "void crt::k_segment<true, false, false, false, true, false, false, false, false, true, true>(crt::SegmentArgs)"
+    stats = "void crt::k_segment<true, true, true, false, true, false, true, false, false, false, false>(crt::SegmentArgs)"
+    cols = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
+
+    def write(kind, counters):
+        d = tmp_path / f"pmc_{kind}"
+        (d / "run").mkdir(parents=True)
+        with open(d / "run" / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.DictWriter(f, cols)
+            w.writeheader()
+            disp = 0
+            for n, val in [(stats, 999.0)] + [(seg, 400.0)] * 7 + [(seg, 100.0)] * 10:     # counting frame, 7 step launches, 10 tail frames
+                disp += 1
+                for c, scale in counters.items():
+                    w.writerow({"Dispatch_Id": disp, "Kernel_Name": n, "Counter_Name": c, "Counter_Value": val * scale})
+        return str(d)
+    dirs = {"fetch": write("fetch", {"FETCH_SIZE": 1.0, "TCC_HIT_sum": 3.0, "GRBM_GUI_ACTIVE": 8000.0, "GRBM_TA_BUSY": 1.0}),
+            "write": write("write", {"WRITE_SIZE": 0.5, "TCC_MISS_sum": 1.0}),
+            "sq": write("sq", {"SQ_WAVES": 1.0, "SQ_INSTS_VALU": 1000.0, "SQ_ACTIVE_INST_VALU": 10.0, "SQ_THREAD_CYCLES_VALU": 320.0})}
+    mixed = pt.entry_from_dirs(dirs, "mesh1m_d1")
+    steps = pt.entry_from_dirs(dirs, "mesh1m_d1", tail=10)
+    assert steps["dispatches"] == 7 and mixed["dispatches"] == 17
+    assert steps["l2_fabric_bytes_per_launch"] == int((2 * 400.0 + 200.0) * 1024)       # (2 FETCH_SIZE + WRITE_SIZE) KiB of a step launch
+    assert mixed["l2_fabric_bytes_per_launch"] < steps["l2_fabric_bytes_per_launch"]
+    assert steps["l2_hit_rate"] == 0.75 and abs(steps["valu_issue"]["lane_util"] - 0.5) < 1e-9
+    # issue_busy = 2 x wave-instructions / (SIMDs x shader cycles), bounded by 1 by construction
+    assert abs(steps["valu_issue"]["busy"] - 2 * 400e3 / (1024 * 400 * 8000.0 / 8)) < 1e-3
