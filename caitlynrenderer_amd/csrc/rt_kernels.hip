@@ -462,11 +462,22 @@ __device__ __forceinline__ uint32_t queue_chunks(uint32_t n) { return (((n + 63u
 // (group << 28 | chunk) for iteration `it` of this workgroup, or CRT_NO_WORK; uniform over the workgroup.
 // A workgroup is 4 waves (256 threads), 2 waves or a single wave: with fewer than 4 waves per workgroup, 4 / W
 // consecutive workgroups of the same XCD stand for one chunk, so the dispatcher refills CUs (half-)wave-pair by wave.
-struct WaveId { uint32_t lane, wave, lds_wave, vblock, vgrid; };
-__device__ __forceinline__ WaveId wave_id(bool one_batch_per_workgroup = false) {
+struct WaveId { uint32_t lane, wave, lds_wave, vblock, vgrid, quadrant; };
+// four_per_batch (lane_samples): four consecutive single-wave workgroups of an XCD slice stand for ONE batch, one 4 x 4 pixel quadrant each
+__device__ __forceinline__ WaveId wave_id(bool one_batch_per_workgroup = false, bool four_per_batch = false) {
     WaveId w;
     w.lane = threadIdx.x & 63u;
     w.lds_wave = threadIdx.x >> 6;
+    if (four_per_batch) {
+        const uint32_t qq = blockIdx.x >> 3;
+        w.quadrant = qq & 3u;
+        const uint32_t q = qq >> 2;
+        w.wave = q & 3u;
+        w.vblock = ((q >> 2) << 3) | (blockIdx.x & 7u);
+        w.vgrid = gridDim.x >> 4;
+        return w;
+    }
+    w.quadrant = 0u;
     // W = 1, 2 or 4 waves per workgroup: 4 / W consecutive workgroups of the same XCD slice stand for one 4-batch chunk.
     // one_batch_per_workgroup (wave_samples): the workgroup's waves all work on ONE batch, so it maps like a single wave.
     const uint32_t W = one_batch_per_workgroup ? 1u : blockDim.x >> 6, per_log2 = W == 1u ? 2u : W == 2u ? 1u : 0u;
@@ -943,8 +954,11 @@ template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool B
           bool BATCH = false, bool WIDE = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
-    const bool wave_samples = BATCH && a.wave_samples != 0u;      // uniform: the workgroup's waves are the samples of one 64-pixel batch
-    const WaveId wid = wave_id(wave_samples);
+    const bool wave_samples = BATCH && a.wave_samples == 1u;      // uniform: the workgroup's waves are the samples of one 64-pixel batch
+    // uniform: a wave is one 4 x 4 pixel quadrant of a batch x 4 samples (lane = sample * 16 + pixel): the 64 rays of a wave leave a
+    // quarter of the area, i.e. agree on their nodes like the rays of a frame of twice the resolution
+    const bool lane_samples = BATCH && a.wave_samples == 2u;
+    const WaveId wid = wave_id(wave_samples, lane_samples);
     const uint32_t lane = wid.lane, wave = wid.wave;
     // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
     const uint32_t wave_stride = (COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) * 64u;
@@ -990,6 +1004,11 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         uint32_t cost_t0 = 0;                               // low word of the cycle counter, wave-uniform: lives in an SGPR, not in a VGPR pair
         if (FIRST) {
             e = dense_item(v, wave, lane);
+            if (lane_samples) {
+                // pixel j = lane & 15 of quadrant q of the batch's 8 x 8 block (items of a batch are row-major in the block)
+                const uint32_t j = lane & 15u, q = wid.quadrant;
+                e = dense_item(v, wave, 0u) + (((q >> 1) * 4u + (j >> 2)) * 8u + (q & 1u) * 4u + (j & 3u));
+            }
             n = f.n_local_pixels;
             // the unit of work says WHEN a tile is rendered, tile_order says WHICH tile that is: expensive tiles first, so that the
             // launch does not end on a few long waves (the same pixels, the same sums; 1 M triangles 0.356 -> 0.331 ms,
@@ -1014,15 +1033,19 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         // tails (1 M triangles, 4 samples: 0.299 -> 0.276 ms per frame; Cornell 0.080 -> 0.064).  A separate instantiation:
         // the loop-carried state costs the single-sample kernel 50 bytes of scratch per lane otherwise.
         const uint32_t ws_waves = blockDim.x >> 6;           // wave_samples: wave w renders samples w, w + W, w + 2 W, ...
-        const uint32_t n_smp = BATCH ? (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : a.n_samples) : 1u;
+        const uint32_t n_smp = BATCH ? (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : lane_samples ? a.n_samples >> 2 : a.n_samples) : 1u;
         const uint32_t e_of_chunk = e;
         for (uint32_t smp_it = 0; smp_it < n_smp; ++smp_it) {
         // BATCH: the pixel index goes through an empty asm statement at the top of every sample, so that what is derived from it
         // (pixel coordinates, the camera-space direction before jitter, tile addresses) is recomputed per sample — a few dozen
         // instructions — instead of being hoisted out of the sample loop and kept in registers across both traversal loops
         if (BATCH) { e = e_of_chunk; asm volatile("" : "+v"(e)); }
-        const uint32_t smp = wave_samples ? smp_it * ws_waves + wid.lds_wave : smp_it;
+        const uint32_t smp = wave_samples ? smp_it * ws_waves + wid.lds_wave : lane_samples ? smp_it * 4u + (lane >> 4) : smp_it;
         float rv = BATCH ? a.rv_s[smp & 7u] : f.rv;
+        if (lane_samples) {                                  // per-lane sample: a select chain, not an indexed read of the argument block
+            rv = a.rv_s[0];
+            for (uint32_t k = 1; k < 8u; ++k) rv = smp == k ? a.rv_s[k] : rv;
+        }
         bool active = e < n && (!wave_samples || smp < a.n_samples);
         uint32_t pix = 0;
         vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f);
@@ -1297,7 +1320,19 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             // several samples per launch on a path of several segments: the samples of a pixel finish in different launches, so each
             // leaves its radiance at its own place and k_accumulate_samples adds them in the order the frames would have come
             if (a.l_final) a.l_final[pix] = make_float4(L.x, L.y, L.z, 0.f);
-            else if (!wave_samples && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, (FIRST && BATCH) ? e : pix, L);
+            else if (!wave_samples && !lane_samples && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, (FIRST && BATCH) ? e : pix, L);
+        }
+        if (lane_samples && !a.l_final) {
+            // the four samples of a pixel sit in lanes j, j + 16, j + 32, j + 48: lane j adds them in sample order — what the frames one
+            // after the other would add, zero radiance skipped as everywhere
+            const bool mine = finished && !pending;
+            const float mx = mine ? L.x : 0.f, my = mine ? L.y : 0.f, mz = mine ? L.z : 0.f;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const int src = (int)((lane & 15u) + 16u * k);
+                const float rx = __shfl(mx, src), ry = __shfl(my, src), rz = __shfl(mz, src);
+                if (lane < 16u && e < n && (rx != 0.f || ry != 0.f || rz != 0.f)) add_to_sum(a.sum, e, V3(rx, ry, rz));
+            }
         }
         if (wave_samples && !a.l_final) {
             // the waves' samples of this batch, added in sample order by wave 0 (what the frames one after the other would add)
@@ -1654,9 +1689,11 @@ void launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool i
         const size_t lds4 = ws * per_wave + ws * 64 * sizeof(float4);
         SegmentArgs v = a;
         if (a.wave_samples && lds4 > 64u * 1024u) v.wave_samples = 0u;     // the sequential form, should the stacks and the result strip not fit
-        const bool side_by_side = v.wave_samples != 0u;
-        // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups
-        const dim3 gg = side_by_side ? dim3(grid * 4u) : g, bb = side_by_side ? dim3(ws * 64u) : b;
+        if (v.wave_samples == 2u && (a.n_samples & 3u)) v.wave_samples = 0u;   // samples in lanes come four at a time
+        const bool side_by_side = v.wave_samples == 1u, in_lanes = v.wave_samples == 2u;
+        // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups;
+        // in the lanes of four single-wave workgroups per batch (one 4 x 4 pixel quadrant x 4 samples each): 16 * grid workgroups
+        const dim3 gg = side_by_side ? dim3(grid * 4u) : in_lanes ? dim3(grid * 16u) : g, bb = side_by_side ? dim3(ws * 64u) : b;
         const size_t ll = side_by_side ? lds4 : lds;
         if (feat == 2)      launch(CRT_K(true, false, true, true, false, true, false, true, false), gg, bb, ll, stream, v);
         else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, true, false), gg, bb, ll, stream, v);
@@ -1724,6 +1761,16 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
         const size_t lds4 = ws * per_wave + ws * 64 * sizeof(float4);
         SegmentArgs seq = a;                         // the sequential form, should the stacks and the result strip not fit
         seq.wave_samples = 0u;
+        if (a.wave_samples == 2u) {
+            // the samples in the lanes of four single-wave workgroups per batch; in this build with the plain batched kernels only
+            if ((a.n_samples & 3u) || bvh2 || share || waves != 1u) return launch_segment(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
+            const dim3 g16(grid * 16u), b1(64u);
+#define CRT_LAUNCH_LS(T, M) launch(CRT_KSEG(true, false, T, false, true, false, M, false, false, true), g16, b1, per_wave, stream, a)
+            if (mat) { if (tex) CRT_LAUNCH_LS(true, true); else CRT_LAUNCH_LS(false, true); }
+            else     { if (tex) CRT_LAUNCH_LS(true, false); else CRT_LAUNCH_LS(false, false); }
+#undef CRT_LAUNCH_LS
+            return;
+        }
         if (a.wave_samples && lds4 > 64u * 1024u) return launch_segment(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
         if (a.wave_samples) {
             // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups

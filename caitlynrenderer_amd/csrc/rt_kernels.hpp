@@ -131,7 +131,9 @@ struct SegmentArgs {
                                // the path state by sample * n_local_pixels + pixel; k_accumulate_samples adds them to `sum` in sample order
     uint32_t* tile_cost;       // FIRST, optional: += the clock ticks every wave spent on a tile's pixels, per local tile (feeds tile_order)
     uint32_t wide_first;       // FIRST: 1 = the 6-waves-per-SIMD build of the kernel (launches bound by throughput), 0 = the 5-wave one
-    uint32_t wave_samples;     // BATCH, one-segment paths: 1 = the launch's samples (2..4) sit on the waves of a 4-wave workgroup, one sample of
+    uint32_t wave_samples;     // BATCH: 2 = a wave renders a 4 x 4 pixel quadrant of a batch x 4 samples (lane = sample * 16 + pixel; n_samples a
+                               // multiple of 4, four times the waves), the samples of a pixel added in order through lane shuffles;
+                               // 1 = the launch's samples (2..4) sit on the waves of a 4-wave workgroup, one sample of
                                // the workgroup's 64 pixels each, and are added to the sum in sample order through LDS; 0 = one wave
                                // renders its pixels' samples one after the other
     uint32_t n_samples;        // FIRST: samples per pixel rendered by this launch (>= 1); > 1 only for one-segment paths walked in place

@@ -187,10 +187,14 @@ int crt_sync(crt_scene* s);
  *                         segment's 64-ray batches hold rays that start together and head the same way (wave-level traversal steps
  *                         -10 % on the 1 M-triangle frame; the append costs more than that saves: frame time +3.6 %); 2 / 3 = variants
  *                         of the append (one atomic per ray)
- *     "wave_samples"      crt_render_frames, first segment: where the samples of a 64-pixel batch run.  0 = one after the other
- *                         in one wave; 1 = side by side on the 2 to 4 waves of one workgroup, added to the sum in sample order
- *                         through LDS (the same bits); 2 (default) = 1 when the launch would otherwise be bound by its longest
- *                         waves — a shard of a frame, a small frame — as judged from the measured tile costs, else 0
+ *     "wave_samples"      crt_render_frames, first segment: where the samples of a launch run.  0 = one after the other in the wave
+ *                         that owns the 8x8 pixel batch; 1 = side by side on the 2 to 4 waves of one workgroup, added to the sum in
+ *                         sample order through LDS; 3 = four samples of a 4x4 pixel quadrant in the lanes of one wave (lane = sample x 16
+ *                         + pixel; launches of 4 or 8 samples on trees of 64+ nodes, else 0), added in sample order through lane
+ *                         shuffles: a wave's rays leave a quarter of the area, so they agree on their nodes like the rays of a frame of
+ *                         twice the resolution (1 M triangles: +8.5 % / +12 % at 4 / 8 samples per launch); 2 (default) = 3 where it
+ *                         applies, otherwise 1 when the launch would be bound by its longest waves — a shard of a frame, a small
+ *                         frame — as judged from the measured tile costs, else 0.  The same bits every way.
  *     "wide_first"        which build of the first-segment kernel a launch runs: 0 = compiled for 5 waves per SIMD (96 VGPRs),
  *                         1 = for 6 (80 VGPRs), 2 (default) = 6 where the launch is bound by throughput, 5 where its longest
  *                         waves set its length (the same measure as "wave_samples"); the 6-wave build exists for the batched

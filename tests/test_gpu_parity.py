@@ -161,6 +161,7 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
                                (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None),
                                (1, {"wave_samples": 0}, None), (3, {"wave_samples": 0}, (1, 2)), (1, {"wave_samples": 1, "accel": 1}, (2, 3)),
                                (4, {"wave_samples": 1, "tri_share": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2)),
+                               (1, {"wave_samples": 3}, None), (1, {"wave_samples": 3, "wide_first": 1}, (1, 2)), (3, {"wave_samples": 3}, None),
                                (3, {"ray_bins": 1}, None), (4, {"ray_bins": 1}, (1, 2)), (2, {"ray_bins": 3, "wave_samples": 0}, None)):
         if name in ("tess8_mat",) and opts.get("accel"):
             continue                                                          # the BVH2 frame mode is the Lambert-only shader
@@ -209,17 +210,19 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
     c.close()
 
 
-def test_launch_form_follows_the_size_of_the_launch(cr, cornell, tess8):
-    """wave_samples = 2 (default): a launch of crt_render_frames runs its samples side by side on the waves of a workgroup when it
-    has too few 64-pixel batches to fill the GPU's wave slots with their samples one after the other — a shard, a small frame —
-    and keeps them in one wave when it is bound by throughput (the whole 1080p frame: 32,400 batches on 5,120 slots).  The choice is
-    made from the measured tile costs once there are any; 0 and 1 force either form; a single frame has nothing to choose."""
+def test_launch_form_follows_the_size_of_the_launch(cr, cornell, cornell_data, tess8):
+    """wave_samples = 2 (default).  A launch of 4 or 8 samples on a tree of 64+ nodes puts four samples of a 4x4 pixel quadrant in the
+    lanes of one wave (form 2).  Otherwise (6 samples here; any launch on the 32-triangle box) it runs its samples side by side on the
+    waves of a workgroup (form 1) when it has too few 64-pixel batches to fill the GPU's wave slots with their samples one after the
+    other — a shard, a small frame — and keeps them in one wave (form 0) when it is bound by throughput (the whole 1080p frame: 32,400
+    batches on 5,120 slots); that choice is made from the measured tile costs once there are any.  0, 1 and 3 force a form; a single
+    frame has nothing to choose."""
     _, data = tess8
     _, cam = cornell
     rnd = cr.Rnd()
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(8)]
-    def forms(W, H, shard=None, option=None):
-        s = cr.Scene(data, W, H, 1)
+    def forms(W, H, shard=None, option=None, n=8, d=None):
+        s = cr.Scene(d if d is not None else data, W, H, 1)
         s.update(cam)
         if option is not None:
             s.set_option("wave_samples", option)
@@ -227,17 +230,23 @@ def test_launch_form_follows_the_size_of_the_launch(cr, cornell, tess8):
             s.set_shard(shard[0], shard[1], 16)
         out = []
         for _ in range(4):                      # the first launch measures the tiles; a later one has adopted the costs
-            s.render_frames(rvs)
+            s.render_frames(rvs[:n])
             out.append(s.debug_launch_form())
         s.render_frame(*rvs[0])
         out.append(s.debug_launch_form())
         s.close()
         return out
-    assert forms(1920, 1080) == [0, 0, 0, 0, 0]
-    assert forms(1920, 1080, (3, 8)) == [1, 1, 1, 1, 0]
-    assert forms(320, 200) == [1, 1, 1, 1, 0]
+    assert forms(1920, 1080) == [2, 2, 2, 2, 0]
+    assert forms(1920, 1080, (3, 8)) == [2, 2, 2, 2, 0]
+    # 6 samples go as 4 + 2: the last launch of the call is the pair, in the form the launch's size asks for
+    assert forms(1920, 1080, n=6) == [0, 0, 0, 0, 0]
+    assert forms(1920, 1080, (3, 8), n=6) == [1, 1, 1, 1, 0]
+    assert forms(320, 200, n=3) == [1, 1, 1, 1, 0]
+    assert forms(1920, 1080, d=cornell_data) == [0, 0, 0, 0, 0]              # a 3-node tree: more, shorter waves cost more than they save
+    assert forms(1920, 1080, (3, 8), d=cornell_data) == [1, 1, 1, 1, 0]
     assert forms(1920, 1080, (3, 8), option=0) == [0, 0, 0, 0, 0]
     assert forms(1920, 1080, option=1) == [1, 1, 1, 1, 0]
+    assert forms(1920, 1080, option=3, n=6) == [0, 0, 0, 0, 0]               # 3 = lanes or nothing: the trailing pair runs one after the other
 
 
 def test_edge_cases(cr, ob, scenes, cornell):

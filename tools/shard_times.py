@@ -1,7 +1,7 @@
 """Per-rank cost of a sharded frame, measured on ONE GPU: rank world // 2 of `world` renders its tiles of the 1 M-triangle frame
 through crt_render_frames, and the time per frame is set against perfect division of the whole frame's.  Columns: the samples of a
-launch one after the other in each wave (wave_samples 0), side by side on the waves of a workgroup (1), and what the library picks
-by itself (2).  The sums of the three are compared bit for bit first.
+launch one after the other in each wave (wave_samples 0), side by side on the waves of a workgroup (1), what the library picks
+by itself (2), and four samples of a 4 x 4 pixel quadrant in the lanes of one wave (3).  The sums of all are compared bit for bit first.
 
     python tools/shard_times.py [WxH] [depth ...]        (default 3840x2160, depths 1 4)
 
@@ -24,7 +24,7 @@ rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(160)]
 
 for depth in depths:
     sums = []
-    for ws in (0, 1, 2):
+    for ws in (0, 1, 2, 3):
         scene = cr.Scene(data, 640, 360, depth)
         scene.set_option("wave_samples", ws)
         scene.set_shard(1, 3, 16)
@@ -34,12 +34,12 @@ for depth in depths:
         sums.append(scene.read_sum().copy())
         scene.close()
     same = all(np.array_equal(sums[0].view(np.uint32), s.view(np.uint32)) for s in sums[1:])
-    print(f"depth {depth}: sums of the three forms identical: {same}", flush=True)
+    print(f"depth {depth}: sums of the four forms identical: {same}", flush=True)
     assert same
     whole = {}
     for world in (1, 2, 4, 8):
         cells = []
-        for ws in (0, 1, 2):
+        for ws in (0, 1, 3, 2):
             scene = cr.Scene(data, W, H, depth)
             scene.set_option("wave_samples", ws)
             if world > 1:

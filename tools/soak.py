@@ -54,7 +54,7 @@ for case in range(n_cases):
                         waves_per_workgroup=int(rng.choice([1, 1, 2, 4])), compact_shadow=int(rng.random() < 0.5))
     opts["ray_bins"] = int(rng.choice([0, 0, 1, 1, 2, 3]))     # bounce rays in emission order or binned by (octant, origin cell)
     opts["adaptive_tiles"] = int(rng.random() < 0.7)          # cost-sorted or centre-out tile order: the same pixels either way
-    opts["wave_samples"] = int(rng.choice([0, 1, 2]))         # the samples of a launch in one wave or on the waves of a workgroup
+    opts["wave_samples"] = int(rng.choice([0, 1, 2, 2, 3]))   # the samples of a launch in one wave, on the waves of a workgroup, or four in the lanes of a wave
     opts["wide_first"] = int(rng.choice([0, 1, 2]))           # the 5- or the 6-waves-per-SIMD build of the first-segment kernel
     for k, v in opts.items():
         scene.set_option(k, v)
@@ -76,7 +76,15 @@ for case in range(n_cases):
         last = np.zeros(2, np.int64)
         per_launch = 8 if (((accel != 0 and EXPERIMENTS) or (accel == 0 and opts.get("inplace_shadow", 1) == 1)) and (depth == 1 or not opts.get("bounce_refill", 0))
                            and not (opts.get("compact_shadow", 1) and opts.get("tri_share", 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
-        in_last = n_fr - ((n_fr - 1) // per_launch) * per_launch
+        # the library's own split of a call into launches (crt_render_frames_async): up to per_launch frames each, and where four samples
+        # can sit in the lanes of a wave (wave_samples >= 2, a tree of 64+ nodes, CWBVH) a launch of 5..7 frames goes as 4 + the rest
+        fours = opts.get("wave_samples", 2) >= 2 and scene.bvh_info()["n_nodes8"] >= 64 and accel == 0
+        left, in_last = n_fr, 0
+        while left:
+            k = min(per_launch, left)
+            if fours and per_launch > 1 and k > 4 and k % 4:
+                k -= k % 4
+            in_last, left = k, left - k
         for k, (rx, ry) in enumerate(rvs):
             _, cnt = orc.render_frame(rx, ry, ref, accel=o_accel, tie=o_tie, threads=16)
             if k >= n_fr - in_last:
