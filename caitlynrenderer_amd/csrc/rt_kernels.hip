@@ -1078,8 +1078,14 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             d = normalize((right * dx + up * dy) + fwd);
             o = V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         } else if (active) {
-            const float4* rq = a.bin_start ? a.rays_in + 2 * (size_t)binned_entry(a.bin_start, a.bin_off_in, a.ovf_base_in, e)
-                                           : a.rays_in + 2 * ((size_t)g * a.sub_capacity + e);
+            const float4* rq;
+            if (a.bin_start) {
+                CRT_MARK("loop_begin bins");
+                rq = a.rays_in + 2 * (size_t)binned_entry(a.bin_start, a.bin_off_in, a.ovf_base_in, e);
+                CRT_MARK("loop_end");
+            } else {
+                rq = a.rays_in + 2 * ((size_t)g * a.sub_capacity + e);
+            }
             const float4 r0 = rq[0], r1 = rq[1];
             o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z);
             pix = __float_as_uint(r1.w);
@@ -1403,8 +1409,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             }
         }
         if (a.bins_out.count) {
+            CRT_MARK("loop_begin bins");      // the optional bins are not part of the instruction model (tools/roofline.py): bracketed like a loop
             const uint32_t ni = bin_append(a.bins_out, emit_next, ray_bin_key(a.bins_out, nx0, nx1));
             if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
+            CRT_MARK("loop_end");
         } else {
             const uint32_t ni = wave_append(emit_next, count_next);
             if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
