@@ -161,6 +161,12 @@ struct crt_scene {
     uint32_t inplace_shadow = 1;             // NEE shadow rays walked inside k_segment (0: shadow queue + k_shadow)
     uint32_t accel = 0;                      // frames: 0 CWBVH; 1 BVH2 walked as the shipped shader does (first visited wins); 2 BVH2, lowest id wins
     uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
+    // crt_trace: rays per wave (its refill pool): 64, 128 or 256.  64 = one lock-step batch per single-wave workgroup: four times the
+    // workgroups for the dispatcher to balance, which is what a launch of a few million rays needs (tools/refill_probe.py, 1 M
+    // triangles: 2.07 M primary rays 0.153 ms against 0.346 with 256-ray pools, whose 8,100 waves all start at once and end with the
+    // slowest; 0.81 M shadow rays 0.192 / 0.202 / 0.230 ms for 64 / 128 / 256; 1.16 M bounce rays 0.332 / 0.320 / 0.321 — the one
+    // case where refill beats the finer grain, by 4 %)
+    uint32_t trace_pool = 64;
     uint32_t trace_occupancy = 8;            // persistent grids only (oversubscribe >= 1): workgroups per CU
     // 0: one chunk per workgroup, the hardware dispatcher hands chunks to CUs as they drain (measured 13 % faster than
     // a persistent grid on the 1 M mesh: per-chunk cost varies 10x between sky and grazing rays);
@@ -917,6 +923,10 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "debug_fail_batch_alloc")) s->debug_fail_batch_alloc = value ? 1u : 0u;
     else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: plain per-lane closest-hit loop (what trees of a few nodes get)
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
+    else if (!std::strcmp(name, "trace_pool")) {
+        if (value != 64 && value != 128 && value != 256) return fail(CRT_ERR_INVALID, "crt_set_option: trace_pool is 64, 128 or 256");
+        s->trace_pool = (uint32_t)value;
+    }
     else if (!std::strcmp(name, "gather_transport")) {
         if (value != 0 && value != 1) return fail(CRT_ERR_INVALID, "crt_set_option: gather_transport is 0 (RCCL send / recv) or 1 (hipMemcpyPeerAsync)");
         if (value == 0 && !s->peers.empty() && s->rccl_comms.empty())
@@ -1454,7 +1464,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->tex_width = src->tex_width; r->tex_height = src->tex_height; r->n_textures = src->n_textures;
     r->info = src->info; r->bvh2_stack = src->bvh2_stack; r->stack_entries = src->stack_entries; r->special_materials = src->special_materials;
     r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
-    r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min;
+    r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
     r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
@@ -1700,6 +1710,7 @@ int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, i
     ta.refill_min = s->refill_min;
     ta.tri_min = s->tri_min;
     ta.overflow = s->d_overflow;
+    ta.pool_split_log2 = s->trace_pool == 64u ? 2u : s->trace_pool == 128u ? 1u : 0u;
     s->n_spans = 0;
     if ((mode & CRT_TRACE_BVH2) && !s->d_bvh2) return fail(CRT_ERR_INVALID, "crt_trace: the scene was created without a BVH2 (desc.bvh)");
     EventSpan* sp = s->new_span(any_hit ? 2 : 1);

@@ -462,12 +462,15 @@ __device__ __forceinline__ uint32_t queue_chunks(uint32_t n) { return (((n + 63u
 // (group << 28 | chunk) for iteration `it` of this workgroup, or CRT_NO_WORK; uniform over the workgroup.
 // A workgroup is 4 waves (256 threads), 2 waves or a single wave: with fewer than 4 waves per workgroup, 4 / W
 // consecutive workgroups of the same XCD stand for one chunk, so the dispatcher refills CUs (half-)wave-pair by wave.
-struct WaveId { uint32_t lane, wave, lds_wave, vblock, vgrid, quadrant; };
+struct WaveId { uint32_t lane, wave, lds_wave, vblock, vgrid, quadrant, sub; };
 // four_per_batch (lane_samples): four consecutive single-wave workgroups of an XCD slice stand for ONE batch, one 4 x 4 pixel quadrant each
-__device__ __forceinline__ WaveId wave_id(bool one_batch_per_workgroup = false, bool four_per_batch = false) {
+// sub_log2 (k_trace, single-wave workgroups): 1 << sub_log2 consecutive workgroups of an XCD slice stand for ONE wave of the mapping
+// below, `sub` says which of them this is
+__device__ __forceinline__ WaveId wave_id(bool one_batch_per_workgroup = false, bool four_per_batch = false, uint32_t sub_log2 = 0u) {
     WaveId w;
     w.lane = threadIdx.x & 63u;
     w.lds_wave = threadIdx.x >> 6;
+    w.sub = 0u;
     if (four_per_batch) {
         const uint32_t qq = blockIdx.x >> 3;
         w.quadrant = qq & 3u;
@@ -481,10 +484,11 @@ __device__ __forceinline__ WaveId wave_id(bool one_batch_per_workgroup = false, 
     // W = 1, 2 or 4 waves per workgroup: 4 / W consecutive workgroups of the same XCD slice stand for one 4-batch chunk.
     // one_batch_per_workgroup (wave_samples): the workgroup's waves all work on ONE batch, so it maps like a single wave.
     const uint32_t W = one_batch_per_workgroup ? 1u : blockDim.x >> 6, per_log2 = W == 1u ? 2u : W == 2u ? 1u : 0u;
-    const uint32_t q = blockIdx.x >> 3;
+    w.sub = (blockIdx.x >> 3) & ((1u << sub_log2) - 1u);
+    const uint32_t q = blockIdx.x >> (3u + sub_log2);
     w.wave = (q & ((1u << per_log2) - 1u)) * W + (one_batch_per_workgroup ? 0u : w.lds_wave);
     w.vblock = ((q >> per_log2) << 3) | (blockIdx.x & 7u);
-    w.vgrid = gridDim.x >> per_log2;
+    w.vgrid = gridDim.x >> (per_log2 + sub_log2);
     return w;
 }
 
@@ -540,11 +544,11 @@ __device__ __forceinline__ void flush_visit_totals(unsigned long long* totals, u
     }
 }
 
-// Trace kernel over an explicit ray buffer (crt_trace / crt_trace_device): 256-ray pools with lane refill.
+// Trace kernel over an explicit ray buffer (crt_trace / crt_trace_device): pools of 256 >> a.pool_split_log2 rays per wave, lane refill.
 template <bool ANY, bool STATS>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
-    const WaveId wid = wave_id();
+    const WaveId wid = wave_id(false, false, a.pool_split_log2);
     const uint32_t lane = wid.lane, wave = wid.wave;
     uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
     const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
@@ -552,9 +556,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_pool_chunk<true>(wid, nullptr, n, it);
         if (v == CRT_NO_WORK) break;
-        const uint32_t first = dense_pool_first(v, wave);
+        const uint32_t pool = 256u >> a.pool_split_log2;
+        const uint32_t first = dense_pool_first(v, wave) + wid.sub * pool;
         if (first >= n) continue;
-        const uint32_t last = first + 256u < n ? first + 256u : n;
+        const uint32_t last = first + pool < n ? first + pool : n;
         uint32_t nn = 0, nt = 0, wn_unused = 0, wt_unused = 0;
         // per-ray counters need the count of ONE ray: sample the running totals at load and at completion
         uint32_t nn0 = 0, nt0 = 0;
@@ -1641,9 +1646,11 @@ static inline size_t stack_bytes(uint32_t entries) { return (size_t)entries * 64
 static inline dim3 grid_dim(uint32_t grid, uint32_t waves) { return dim3(grid * (4u / waves)); }
 static inline dim3 block_dim(uint32_t waves) { return dim3(waves * 64u); }
 
-void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
-    waves = fit_waves(waves, stack_bytes(a.stack_entries));
-    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
+void launch_trace(const TraceArgs& a_in, int mode, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+    waves = fit_waves(waves, stack_bytes(a_in.stack_entries));
+    TraceArgs a = a_in;
+    if (waves != 1u || a.pool_split_log2 > 2u) a.pool_split_log2 = 0u;       // sub-pools are single-wave workgroups
+    const dim3 g = grid_dim(grid << a.pool_split_log2, waves), b = block_dim(waves);
     const size_t lds = waves * stack_bytes(a.stack_entries);
     if (mode == 1) {
         if (stats) launch(k_trace<true, true>, g, b, lds, stream, a);

@@ -32,6 +32,7 @@ struct TraceArgs {
     uint32_t refill_min;       // idle lanes that trigger a pool refill (traverse_pool)
     uint32_t tri_min;          // vote ratio of traverse_pool: node step while node-ready lanes >= tri_min x triangle-waiting lanes
     uint32_t* overflow;        // += 1 per dropped stack push (never happens for a tree crt_scene_create accepted)
+    uint32_t pool_split_log2;  // a wave's 256-ray slot of the index space is walked by 1 << this single-wave workgroups (pools of 256, 128, 64)
 };
 
 struct Bvh2Args {               // the reference's live BVH2 walk (path_trace.fs:511-819) for crt_trace

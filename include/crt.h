@@ -199,6 +199,10 @@ int crt_sync(crt_scene* s);
  *                         1 = for 6 (80 VGPRs), 2 (default) = 6 where the launch is bound by throughput, 5 where its longest
  *                         waves set its length (the same measure as "wave_samples"); the 6-wave build exists for the batched
  *                         launches of crt_render_frames on Lambert scenes
+ *     "trace_pool"        crt_trace / crt_trace_device: rays per wave, 64 (default: one lock-step batch per single-wave workgroup, the
+ *                         finest grain for the dispatcher — 2.07 M primary rays of the 1 M-triangle scene 0.153 ms against 0.346),
+ *                         128 or 256 (a pool: a lane whose ray has finished takes the pool's next ray once "refill_min" lanes
+ *                         (default 8, 1..64) are idle; worth 4 % on incoherent bounce rays, tools/refill_probe.py)
  *     "gather_transport"  scenes on several devices (crt_set_devices): 0 = RCCL send / recv (default when librccl.so loads and the
  *                         devices are distinct), 1 = hipMemcpyPeerAsync
  *   experimental (a library built with `make EXPERIMENTS=1`, crt_has_experiments() != 0; otherwise only the default value is

@@ -283,6 +283,32 @@ def test_zero_components_and_non_finite_rays(cr, ob, scenes):
     assert np.array_equal(got["tri"] >= 0, orc.trace(rays, ob.BVH8, ob.ANY, threads=8)["tri"] >= 0)
 
 
+def test_trace_pool_sizes_and_refill_thresholds_agree(cr, ob, scenes):
+    """crt_trace walks its rays in pools of 64 (default), 128 or 256 per wave, refilled once `refill_min` lanes are idle: hits and
+    per-ray visit counters are those of the oracle whatever the pool, the threshold or the (ragged) ray count."""
+    scene, orc, _ = scenes["tess40"]
+    rng = np.random.default_rng(11)
+    for n in (1, 63, 64, 65, 129, 1000, 4096 + 257, 3 * 4096 + 70):
+        rays = np.zeros(n, cr.RAY_DT)
+        rays["o"] = (0.3 + 4.9 * rng.random((n, 3))).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        rays["tmax"] = np.float32(1e9)
+        want, wst = orc.trace(rays, ob.BVH8, ob.CLOSEST, ob.TIE_LOWEST_ID, stats=True, threads=8)
+        occ = orc.trace(rays, ob.BVH8, ob.ANY, threads=8)["tri"] >= 0
+        for pool, refill in ((64, 8), (128, 8), (128, 64), (256, 1), (256, 40)):
+            scene.set_option("trace_pool", pool)
+            scene.set_option("refill_min", refill)
+            got, gst = scene.trace(rays, cr.CRT_TRACE_CLOSEST, stats=True)
+            _assert_hits_equal(got, want)
+            assert np.array_equal(gst["nodes"], wst["nodes"]) and np.array_equal(gst["tris"], wst["tris"]), (n, pool, refill)
+            assert np.array_equal(scene.trace(rays, cr.CRT_TRACE_ANY)["tri"] >= 0, occ), (n, pool, refill)
+    scene.set_option("trace_pool", 64)
+    scene.set_option("refill_min", 8)
+    with pytest.raises(cr.CrtError):
+        scene.set_option("trace_pool", 100)
+
+
 def test_exact_ties_resolve_to_lowest_original_id(cr, ob):
     """Two coincident triangles: every hit is an exact tie; the lower original id must win."""
     v = np.array([[0, 0, 0], [4, 0, 0], [0, 4, 0], [0, 0, 0], [4, 0, 0], [0, 4, 0], [0, 0, 1], [4, 0, 1], [0, 4, 1]], np.float32)
