@@ -104,6 +104,9 @@ def parse_args(argv=None):
     ap.add_argument("--virtual-devices", type=int, default=0, metavar="K",
                     help="with --one-process: K logical devices on GPU 0 (shards, streams and gather buffers as on K GPUs; copies instead of RCCL) — "
                          "rehearses the path on a one-GPU machine; the number it prints is NOT a scaling figure")
+    ap.add_argument("--streams", type=int, default=0, metavar="K",
+                    help="tile shards of a rank's frame rendered side by side on K streams of its GPU (crt_set_option streams); default: 2 for "
+                         "multi-segment paths on an unsharded scene, else 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
                          "(what the CPU tests exercise); the line says dry_run and reports no throughput")
@@ -319,7 +322,7 @@ def live_pmc(workloads, budget_s=330.0):
                 d = os.path.join(top, f"pmc_{kind}_{key}")
                 cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
                        "--workload", name, "--depth", str(depth), "--spp", str(spp), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-live-pmc",
-                       "--settle-ms", "0"] + [str(x) for x in more]
+                       "--settle-ms", "0", "--streams", "1"] + [str(x) for x in more]     # one stream: a dispatch is a whole segment of the frame
                 try:
                     run = subprocess.run(cmd, cwd=top, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=150)
                 except subprocess.TimeoutExpired:
@@ -378,6 +381,11 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             world = len(one_proc)
         else:
             scene.set_shard(rank, world, args.tile)
+        # a multi-segment frame is a chain of dependent launches: two tile shards of this rank's frame on two streams of the GPU fill each
+        # other's launch tails (option "streams", bit-identical; 1 M triangles, 4 segments: +6 %).  One launch per step gains nothing.
+        streams = args.streams if args.streams > 0 else (2 if depth > 1 and world == 1 and not one_proc and args.accel == "cwbvh" else 1)
+        if streams > 1:
+            scene.set_option("streams", streams)
         for kv in args.option:
             k, v = kv.split("=")
             scene.set_option(k, int(v))
@@ -398,7 +406,9 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         scene.set_option("count_visits", 0)
         scene.reset()
 
-        _, tile, n_floats = scene.packed_info()
+        tile, n_floats = args.tile, 0
+        if use_dist:
+            _, tile, n_floats = scene.packed_info()
         gather_buf = recv = None
         if use_dist:
             gather_buf = torch.zeros(tiles.max_local_tiles(W, H, tile, world) * tile * tile * 3, dtype=torch.float32, device="cuda")
@@ -521,7 +531,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             "value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling,
             "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": spp, "path_segments": depth,
                        "rays_per_step": int(rays_all) * spp, "tile": tile, "parallelism": f"tiles/{world}",
-                       "n_nodes8": int(info["n_nodes8"]), "n_tris8": int(info["n_tris8"]), "stack_overflows": int(st["stack_overflows"]),
+                       "n_nodes8": int(info["n_nodes8"]), "n_tris8": int(info["n_tris8"]), "stack_overflows": int(st["stack_overflows"]), "streams": int(streams),
                        "gather": ("one RCCL gather of the packed tiles to rank 0 per timed region" if use_dist else
                                   f"inside the C ABI (crt_sum_device, one process, {scene.devices()['transport']}), once per timed region" if one_proc else "none")},
             "roofline": roofline,

@@ -211,6 +211,8 @@ struct crt_scene {
     std::vector<crt_scene*> peers;           // owned
     crt_scene* primary = nullptr;            // set in a peer
     std::vector<std::pair<size_t, size_t>> scene_bufs;   // (offset of the pointer member, bytes): what a replica needs copied
+    uint32_t streams = 1;                    // option "streams": this many tile shards of the frame on streams of their own, on this one GPU
+    bool shares_scene = false;               // a replica on its primary's own device: the scene buffers are the primary's, not copies
     std::vector<float*> d_gather;            // per peer, on THIS device: its packed sum buffer as received
     std::vector<uint2*> d_peer_tiles;        // per peer, on THIS device: its local tile list (for the un-tiling launch)
     std::vector<hipEvent_t> ev_peer;         // per peer: "your slice has arrived" (copy transport)
@@ -223,6 +225,8 @@ struct crt_scene {
         drop_peers();
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
+        if (shares_scene)                    // borrowed from the primary, which frees them
+            for (const auto& b : scene_bufs) *reinterpret_cast<void**>(reinterpret_cast<char*>(this) + b.first) = nullptr;
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal, d_bins};
@@ -849,6 +853,11 @@ int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_set_shard: null scene");
     if (world == 0 || rank >= world) return fail(CRT_ERR_INVALID, "crt_set_shard: rank/world");
     if (tile < 8 || (tile & 7u) || tile > 1024) return fail(CRT_ERR_INVALID, "crt_set_shard: tile must be a multiple of 8 in 8..1024");
+    if (s->streams > 1u) {                   // the caller shards the frame itself now: its shard runs on one stream
+        const int32_t one = s->device;
+        const int rc = crt_set_devices(s, &one, 1, tile);
+        if (rc) return rc;
+    }
     if (!s->peers.empty() || s->primary) return fail(CRT_ERR_INVALID, "crt_set_shard: this scene deals its tiles to its own devices (crt_set_devices)");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -893,6 +902,21 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         if (!is_default) return fail(CRT_ERR_INVALID, std::string("crt_set_option: ") + name + " is an experimental variant: this library was built without CRT_EXPERIMENTS");
     }
 #endif
+    else if (!std::strcmp(name, "streams")) {
+        // k tile shards of the frame, each with its own stream, queues and path state, on this one GPU: the segment launches of one
+        // shard fill the tails and gaps of the others' (a multi-segment frame is a chain of dependent launches).  The machinery is
+        // crt_set_devices' with the same GPU listed k times; the scene buffers are shared, not copied.
+        if (value < 1 || value > 4) return fail(CRT_ERR_INVALID, "crt_set_option: streams is 1..4");
+        if (s->primary) return fail(CRT_ERR_INVALID, "crt_set_option: streams is set on the scene, not on a replica");
+        if ((uint32_t)value == s->streams) return CRT_OK;
+        if (s->streams == 1u && (!s->peers.empty() || s->world != 1u))
+            return fail(CRT_ERR_INVALID, "crt_set_option: streams needs an unsharded scene (crt_set_shard / crt_set_devices already deal its tiles)");
+        const std::vector<int32_t> ids((size_t)value, (int32_t)s->device);
+        const int rc = crt_set_devices(s, ids.data(), (uint32_t)value, s->tile ? s->tile : 16u);
+        if (rc) return rc;
+        s->streams = (uint32_t)value;
+        return CRT_OK;                       // nothing to pass on to the replicas
+    }
     else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(3u, (uint32_t)value);
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
     else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(3, std::max(0, value));
@@ -1309,6 +1333,7 @@ int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out) {
 
 int crt_packed_info(crt_scene* s, uint32_t* n_local_tiles, uint32_t* tile, size_t* n_floats) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_packed_info: null scene");
+    if (s->streams > 1u) return fail(CRT_ERR_INVALID, "crt_packed_info: the packed buffer is per shard; this scene splits its frame over streams (option streams)");
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
@@ -1320,6 +1345,7 @@ int crt_packed_info(crt_scene* s, uint32_t* n_local_tiles, uint32_t* tile, size_
 
 int crt_read_packed(crt_scene* s, float* dst, size_t n_floats) {
     if (!s || !dst) return fail(CRT_ERR_INVALID, "crt_read_packed: null argument");
+    if (s->streams > 1u) return fail(CRT_ERR_INVALID, "crt_read_packed: the packed buffer is per shard; this scene splits its frame over streams (option streams)");
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
@@ -1331,6 +1357,7 @@ int crt_read_packed(crt_scene* s, float* dst, size_t n_floats) {
 
 int crt_copy_packed_device(crt_scene* s, void* d_dst, size_t n_floats, int sync) {
     if (!s || !d_dst) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: null argument");
+    if (s->streams > 1u) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: the packed buffer is per shard; this scene splits its frame over streams (option streams)");
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
@@ -1464,13 +1491,14 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->tex_width = src->tex_width; r->tex_height = src->tex_height; r->n_textures = src->n_textures;
     r->info = src->info; r->bvh2_stack = src->bvh2_stack; r->stack_entries = src->stack_entries; r->special_materials = src->special_materials;
     r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
-    r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool;
+    r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
     r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
     r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }
     r->scene_bufs = src->scene_bufs;
+    r->shares_scene = device == src->device;
     if (device != src->device) {          // direct xGMI copies where the platform allows them; staged through the host otherwise
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(src->device, 0);
@@ -1480,10 +1508,10 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
         const void* from = *reinterpret_cast<void* const*>(reinterpret_cast<const char*>(src) + b.first);
         void** to = reinterpret_cast<void**>(reinterpret_cast<char*>(r) + b.first);
         if (!from) continue;
+        if (device == src->device) { *to = const_cast<void*>(from); continue; }      // the same GPU again: one copy of the scene serves both
         hipError_t e = hipMalloc(to, b.second ? b.second : 16);
         if (e != hipSuccess) return fail(CRT_ERR_NOMEM, std::string("crt_set_devices: hipMalloc: ") + hipGetErrorString(e));
-        if (b.second && device == src->device) HIPCHK(hipMemcpy(*to, from, b.second, hipMemcpyDeviceToDevice));       // a virtual device
-        else if (b.second) HIPCHK(hipMemcpyPeer(*to, device, from, src->device, b.second));
+        if (b.second) HIPCHK(hipMemcpyPeer(*to, device, from, src->device, b.second));
     }
     int rc = finish_scene_setup(r);
     if (rc) return rc;
@@ -1507,6 +1535,7 @@ int crt_set_devices(crt_scene* s, const int32_t* devices, uint32_t n_devices, ui
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->drop_peers();
+    s->streams = 1;
     int rc = CRT_OK;
     auto undo = [&](int code) { s->drop_peers(); (void)hipSetDevice(s->device); s->rank = 0; s->world = 1; (void)alloc_frame_buffers(s); return code; };
     try {

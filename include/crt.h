@@ -199,6 +199,12 @@ int crt_sync(crt_scene* s);
  *                         1 = for 6 (80 VGPRs), 2 (default) = 6 where the launch is bound by throughput, 5 where its longest
  *                         waves set its length (the same measure as "wave_samples"); the 6-wave build exists for the batched
  *                         launches of crt_render_frames on Lambert scenes
+ *     "streams"           1 (default) .. 4: that many tile shards of the frame rendered side by side on streams of their own on this one GPU
+ *                         (own queues and path state, the scene buffers shared).  A multi-segment frame is a chain of dependent
+ *                         launches; another shard's launches fill their tails: 1 M triangles, 4 segments, 2 streams +6 %, 8 M triangles
+ *                         +4 %; a one-segment frame gains nothing.  It is crt_set_devices with this GPU listed k times: the accumulated
+ *                         sum restarts, crt_read_sum / crt_resolve / crt_sum_device assemble the frame, the per-shard packed-buffer calls
+ *                         are refused meanwhile, and crt_set_shard / crt_set_devices take the split away again.  Needs an unsharded scene.
  *     "trace_pool"        crt_trace / crt_trace_device: rays per wave, 64 (default: one lock-step batch per single-wave workgroup, the
  *                         finest grain for the dispatcher — 2.07 M primary rays of the 1 M-triangle scene 0.153 ms against 0.346),
  *                         128 or 256 (a pool: a lane whose ray has finished takes the pool's next ray once "refill_min" lanes

@@ -552,6 +552,53 @@ def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data, T)
     full.close()
 
 
+@pytest.mark.parametrize("name,depth,k", [("tess8", 3, 2), ("tess40", 4, 2), ("tess8", 2, 3), ("cornell", 1, 2)])
+def test_streams_option_splits_the_frame_over_streams_of_one_gpu(cr, ob, cornell, scenes, name, depth, k):
+    """Option "streams": k tile shards of the frame on k streams of the one GPU (a multi-segment frame is a chain of dependent launches;
+    another shard's launches fill their tails), the scene buffers shared.  Same sums as the oracle and the same statistics, frame by
+    frame and batched; the per-shard packed buffer is refused while the split is on; crt_set_shard and streams = 1 undo it."""
+    _, _, data = scenes[name]
+    _, cam = cornell
+    W, H = 250, 140
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(6)]
+    orc = ob.Oracle(data, W, H, depth, cam)
+    ref = np.zeros((H, W, 3), np.float32)
+    cnt_last = None
+    for r in rvs:
+        _, cnt_last = orc.render_frame(r[0], r[1], ref, threads=8)
+    sc = cr.Scene(data, W, H, depth)
+    sc.set_option("streams", k)
+    assert sc.devices()["devices"] == [0] * k
+    sc.render_frame(*rvs[0])
+    sc.render_frames(rvs[1:5])
+    sc.set_option("count_visits", 1)
+    sc.render_frame(*rvs[5])
+    st = sc.frame_stats()
+    assert (st["closest_rays"], st["any_rays"]) == (cnt_last[0], cnt_last[1]) and st["stack_overflows"] == 0
+    assert st["nodes_closest"] + st["nodes_any"] == cnt_last[2] and st["tris_closest"] + st["tris_any"] == cnt_last[3]
+    out = sc.read_sum()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), float(np.abs(out - ref).max())
+    with pytest.raises(cr.CrtError):
+        sc.packed_info()
+    with pytest.raises(cr.CrtError):
+        sc.set_option("streams", 5)
+    # back to one stream: a plain scene again (the sum restarts, as with every re-sharding)
+    sc.set_option("streams", 1)
+    assert sc.devices()["devices"] == [0]
+    sc.render_frame(*rvs[0])
+    one = np.zeros((H, W, 3), np.float32)
+    orc.render_frame(rvs[0][0], rvs[0][1], one, threads=8)
+    assert np.array_equal(sc.read_sum().view(np.uint32), one.view(np.uint32))
+    # a caller that shards the frame itself takes the split away
+    sc.set_option("streams", 2)
+    sc.set_shard(0, 2, 16)
+    assert sc.devices()["devices"] == [0] and sc.packed_info()[0] > 0
+    with pytest.raises(cr.CrtError):
+        sc.set_option("streams", 2)          # its tiles are already dealt
+    sc.close()
+
+
 @pytest.mark.parametrize("name,depth,n_dev", [("cornell", 1, 2), ("tess8", 3, 4), ("tess8", 2, 3)])
 def test_one_handle_several_devices_gather_inside_the_c_abi(cr, ob, cornell, scenes, name, depth, n_dev):
     """crt_set_devices: ONE scene handle and one frame loop, as the reference has them (main.cpp:262-300), rendering on several

@@ -18,7 +18,7 @@ done
 echo "kernel stats done"
 for CFG in "mesh1m 1 4" "mesh1m 4 4" "cornell 1 1" "mesh520 1 4 --device-built sah" "mesh520 4 4 --device-built sah"; do
   set -- $CFG; WL=$1; D=$2; S=$3; shift 3
-  ARGS="--no-cpu-baseline --no-live-pmc --settle-ms 0 --steps 5 --warmup 2 --workload $WL --depth $D --spp $S $*"
+  ARGS="--no-cpu-baseline --no-live-pmc --settle-ms 0 --steps 5 --warmup 2 --streams 1 --workload $WL --depth $D --spp $S $*"
   rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY --output-format csv -d $O/pmc_fetch_${WL}_d$D -- python3 $R/bench.py $ARGS > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum --output-format csv -d $O/pmc_write_${WL}_d$D -- python3 $R/bench.py $ARGS > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq_${WL}_d$D -- python3 $R/bench.py $ARGS > /dev/null 2>&1

@@ -46,7 +46,8 @@ for case in range(n_cases):
     scene.set_option("count_visits", 1)
     # pipeline variants: all must give the oracle's bits
     accel = 0 if name.endswith("_mat") else int(rng.choice([0, 0, 0, 1, 2]))      # the BVH2 frame mode is the Lambert-only shader
-    opts = {"accel": accel}
+    opts = {"streams": int(rng.choice([1, 1, 1, 2, 2, 3]))}      # the frame on one stream, or its tile shards side by side on two or three
+    opts["accel"] = accel
     if accel == 0:
         opts.update(inplace_shadow=int(rng.random() < 0.7), tri_min=int(rng.choice([0, 1, 2, 2, 3])), tri_share=int(rng.choice([0, 1, 2, 3, 3])))
         if EXPERIMENTS:          # variants of a `make EXPERIMENTS=1` library only
