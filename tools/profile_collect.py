@@ -8,8 +8,10 @@ O, P = os.path.join(ROOT, "gpurun_out", f"round_{tag}"), os.path.join(ROOT, "pro
 
 
 def first(pattern):
+    """the newest match: gpurun merges a run's files into gpurun_out/ without removing those of earlier runs (rocprofv3 names its
+    files after the process id)"""
     g = glob.glob(pattern, recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None
 
 
 def cp(src, name):
