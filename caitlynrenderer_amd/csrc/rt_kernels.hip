@@ -51,6 +51,10 @@ __device__ __forceinline__ float ubyte_f(uint32_t x, int j) { return (float)((x 
 // lost: v_fma_mix_f32 is a 4.3-cycle instruction itself, and 8 row loads per node instead of 5 saturate the CU's vector-memory path
 // (1,004,672 triangles 12,574 vs 12,365 Mray/s at 96 VGPRs but the 80-VGPR build spills in the loop, 4 segments 4,995 vs 5,047,
 // the 8 M-triangle scene 6,942 vs 8,588).  The patch is kept as profiles/r03_f16_planes_experiment.patch.
+// Also tried: the mask assembly (54 of the 230 instructions, all of the 4.2-cycle kind) with the byte extractions folded into SDWA
+// operand selects by inline assembly (v_lshlrev_b32_sdwa: child_bits << bit_index in one instruction per child, the exponent bytes
+// likewise): 223 instructions per visit instead of 230 and SLOWER — 13,120 vs 13,660 Mray/s, 4 segments 5,357 vs 5,402, Cornell
+// 45,250 vs 44,640: an SDWA instruction costs more issue time than the two plain ones it replaces.
 __device__ __forceinline__ uint32_t node8_intersect(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3,
                                                     const uint4 n4, vec3 o, vec3 inv, bool negx, bool negy, bool negz,
                                                     uint32_t oct4, float max_t) {
