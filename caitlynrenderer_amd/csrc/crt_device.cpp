@@ -612,6 +612,9 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
                 return fail(CRT_ERR_INVALID, "crt_scene_create: bvh8_tri_slots entry out of range");
     }
 
+    // the traversal loops address node and record rows as base + a 32-bit byte offset (rt_kernels.hip node_rows / tri_rows)
+    if (n_nodes8 * (uint64_t)(CRT_NODE_ROWS * 16) >= (1ull << 32) || n_tris8 * (uint64_t)(CRT_TRI_ROWS * 16) >= (1ull << 32))
+        return fail(CRT_ERR_LIMIT, "crt_scene_create: CWBVH node or triangle-record array of 4 GiB or more (53 M nodes / 89 M records)");
     std::unique_ptr<crt_scene> owner(new (std::nothrow) crt_scene);   // freed on every early return and on a throw
     crt_scene* s = owner.get();
     if (!s) return fail(CRT_ERR_NOMEM, "crt_scene_create: out of memory");

@@ -137,6 +137,21 @@ __device__ __forceinline__ bool mt_test(const float4 a, const float4 b, const fl
     return (uu >= 0.0f) & (vv >= 0.0f) & (tt >= 0.0f) & (w >= 0.0f);
 }
 
+// Row address of a node / triangle record as uniform base + a 32-bit byte offset: the load then takes the base from an SGPR pair and the
+// offset from one VGPR (global_load ... v_off, s[base]) instead of a 64-bit v_mad_u64_u32 per visit — an instruction that costs 8.9
+// issue cycles against 4.4 for the 32-bit multiply (profiles/r03_valu_issue_cycles.txt).  crt_scene_create refuses arrays beyond 4 GiB.
+#ifndef CRT_ADDR64
+__device__ __forceinline__ const uint4* node_rows(const uint4* nodes, uint32_t idx) {
+    return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + (size_t)(idx * (uint32_t)(CRT_NODE_ROWS * 16)));
+}
+__device__ __forceinline__ const float4* tri_rows(const float4* tris, uint32_t idx) {
+    return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + (size_t)(idx * (uint32_t)(CRT_TRI_ROWS * 16)));
+}
+#else
+__device__ __forceinline__ const uint4* node_rows(const uint4* nodes, uint32_t idx) { return nodes + (size_t)idx * CRT_NODE_ROWS; }
+__device__ __forceinline__ const float4* tri_rows(const float4* tris, uint32_t idx) { return tris + (size_t)idx * CRT_TRI_ROWS; }
+#endif
+
 // One ray through the CWBVH (cwbvh.fs:448-536 closest, :538-616 any).  `stk` is this lane's column
 // of the wave's LDS stack: stk[level * 64]; stack_entries (<= CRT_STACK_ENTRIES) is sized from the
 // CWBVH's depth at scene creation so shallow trees leave more LDS for occupancy.
@@ -173,7 +188,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             }
             const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-            const uint4* np = nodes + (size_t)(base + rel) * CRT_NODE_ROWS;
+            const uint4* np = node_rows(nodes, base + rel);
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
             if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
             const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
@@ -191,7 +206,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const int b = 31 - __builtin_clz(tg.y);
             tg.y &= ~(1u << b);
             const uint32_t ti = tg.x + (uint32_t)b;
-            const float4* tp = tris + (size_t)ti * CRT_TRI_ROWS;
+            const float4* tp = tri_rows(tris, ti);
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
             if (STATS) { ++n_tris; count_wave_step(w_tris); }
             float u, v, t;
@@ -322,7 +337,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 }
                 const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
                 const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-                const uint4* np = nodes + (size_t)nidx * CRT_NODE_ROWS;
+                const uint4* np = node_rows(nodes, nidx);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                 if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
@@ -360,7 +375,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                     const uint32_t item = share.items[rank];
                     const uint32_t src = item >> 24, ti = item & 0x00ffffffu;
                     const float4 ro = share.ray[src], rd = share.ray[64u + src];
-                    const float4* tp = tris + (size_t)ti * CRT_TRI_ROWS;
+                    const float4* tp = tri_rows(tris, ti);
                     const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                     float u, v, t;
                     const bool hit = mt_test(ta, tb, tc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), u, v, t);
@@ -395,7 +410,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             const int b = 31 - __builtin_clz(tg.y);
             tg.y &= ~(1u << b);
             const uint32_t ti = tg.x + (uint32_t)b;
-            const float4* tp = tris + (size_t)ti * CRT_TRI_ROWS;
+            const float4* tp = tri_rows(tris, ti);
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
             if (STATS) { ++n_tris; count_wave_step(w_tris); }
             float u, v, t;

@@ -99,6 +99,35 @@ __global__ void k(float* out, unsigned long long* stamps, int iters, float seed)
                              "v_max3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %3, %6, %7\n v_max_f32 %0, %0, %9\n v_min_f32 %1, %1, %8\n"
                              "v_cmp_le_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %4, vcc\n v_or_b32 %3, %3, %2\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+            } else if (KIND == 19) { // 8 v_mul_lo_u32 (the node test has two, the address arithmetic more)
+                asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                             "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            } else if (KIND == 20) { // 4 v_mad_u64_u32 (index * stride + 64-bit base: how hipcc forms every global address)
+                asm volatile("v_mad_u64_u32 %0, s[20:21], %4, %5, %0\n v_mad_u64_u32 %1, s[20:21], %4, %5, %1\n v_mad_u64_u32 %2, s[20:21], %4, %5, %2\n v_mad_u64_u32 %3, s[20:21], %4, %5, %3\n"
+                             : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(b), "v"(c) : "s20", "s21");
+            } else if (KIND == 21) { // 8 v_lshlrev_b32 with SDWA byte selects on both operands
+                asm volatile("v_lshlrev_b32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n v_lshlrev_b32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n"
+                             "v_lshlrev_b32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n v_lshlrev_b32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n"
+                             "v_lshlrev_b32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n v_lshlrev_b32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n"
+                             "v_lshlrev_b32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n v_lshlrev_b32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 22) { // 8 of: bitop3, bfe, lshrrev, variable lshlrev, bcnt, ffbh, mbcnt_lo, mbcnt_hi (the loop's bookkeeping)
+                asm volatile("v_bitop3_b32 %0, %0, %8, %9 bitop3:0x6c\n v_bfe_u32 %1, %1, 5, 3\n v_lshrrev_b32 %2, 8, %2\n v_lshlrev_b32 %3, %8, %3\n"
+                             "v_bcnt_u32_b32 %4, %4, %8\n v_ffbh_u32 %5, %5\n v_mbcnt_lo_u32_b32 %6, %8, %6\n v_mbcnt_hi_u32_b32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 23) { // 8 v_mul_u32_u24 / v_mad_u32_u24
+                asm volatile("v_mul_u32_u24 %0, %0, %8\n v_mad_u32_u24 %1, %1, %8, %9\n v_mul_u32_u24 %2, %2, %8\n v_mad_u32_u24 %3, %3, %8, %9\n"
+                             "v_mul_u32_u24 %4, %4, %8\n v_mad_u32_u24 %5, %5, %8, %9\n v_mul_u32_u24 %6, %6, %8\n v_mad_u32_u24 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 24) { // 8 of the division / square-root helpers: rcp, sqrt, div_scale, div_fmas-free fma, div_fixup, rcp, sqrt, rsq
+                asm volatile("v_rcp_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_div_scale_f32 %2, vcc, %2, %8, %2\n v_div_fixup_f32 %3, %3, %8, %9\n"
+                             "v_rcp_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_rsq_f32 %6, %6\n v_div_fixup_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+            } else if (KIND == 25) { // 8 v_fma_f64 (the pinned sine)
+                asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                             "v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                             : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(const double*)&b), "v"(*(const double*)&b));
             } else if (KIND == 4) { // 8 independent v_mov_b32 (1 source)
                 asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
                              "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n"
@@ -164,6 +193,13 @@ int main(int argc, char** argv) {
             run<16>("v_cndmask_b32 x8 (SGPR mask)", 8, grid, d_out, d_st);
             run<17>("v_pk_mul/add_f32 x4", 4, grid, d_out, d_st);
             run<18>("node test per child, f16 planes (13)", 13, grid, d_out, d_st);
+            run<19>("v_mul_lo_u32 x8", 8, grid, d_out, d_st);
+            run<20>("v_mad_u64_u32 x4", 4, grid, d_out, d_st);
+            run<21>("v_lshlrev_b32_sdwa x8 (byte selects)", 8, grid, d_out, d_st);
+            run<22>("bitop3/bfe/shifts/bcnt/ffbh/mbcnt x8", 8, grid, d_out, d_st);
+            run<23>("v_mul/mad_u32_u24 x8", 8, grid, d_out, d_st);
+            run<24>("rcp/sqrt/rsq/div_scale/div_fixup x8", 8, grid, d_out, d_st);
+            run<25>("v_fma_f64 x8", 8, grid, d_out, d_st);
         }
     }
     return 0;
