@@ -106,7 +106,7 @@ def parse_args(argv=None):
                          "rehearses the path on a one-GPU machine; the number it prints is NOT a scaling figure")
     ap.add_argument("--streams", type=int, default=0, metavar="K",
                     help="tile shards of a rank's frame rendered side by side on K streams of its GPU (crt_set_option streams); default: 2 for "
-                         "multi-segment paths on an unsharded scene, else 1")
+                         "multi-segment paths, else 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
                          "(what the CPU tests exercise); the line says dry_run and reports no throughput")
@@ -381,9 +381,10 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             world = len(one_proc)
         else:
             scene.set_shard(rank, world, args.tile)
-        # a multi-segment frame is a chain of dependent launches: two tile shards of this rank's frame on two streams of the GPU fill each
-        # other's launch tails (option "streams", bit-identical; 1 M triangles, 4 segments: +6 %).  One launch per step gains nothing.
-        streams = args.streams if args.streams > 0 else (2 if depth > 1 and world == 1 and not one_proc and args.accel == "cwbvh" else 1)
+        # a multi-segment frame is a chain of dependent launches: two tile shards of this rank's part of the frame on two streams of the GPU
+        # fill each other's launch tails (option "streams", bit-identical; 1 M triangles, 4 segments: +6 % on the whole frame, +12 % on an
+        # eighth of the 4K frame).  One launch per step gains nothing on a whole frame and 0..2 % on a shard.
+        streams = args.streams if args.streams > 0 else (2 if depth > 1 and not one_proc and args.accel == "cwbvh" else 1)
         if streams > 1:
             scene.set_option("streams", streams)
         for kv in args.option:

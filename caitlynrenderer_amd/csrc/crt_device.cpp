@@ -211,6 +211,7 @@ struct crt_scene {
     std::vector<crt_scene*> peers;           // owned
     crt_scene* primary = nullptr;            // set in a peer
     std::vector<std::pair<size_t, size_t>> scene_bufs;   // (offset of the pointer member, bytes): what a replica needs copied
+    uint32_t shard_rank = 0, shard_world = 1; // the caller's shard of the frame (crt_set_shard); rank / world below are this stream's share of it
     uint32_t streams = 1;                    // option "streams": this many tile shards of the frame on streams of their own, on this one GPU
     bool shares_scene = false;               // a replica on its primary's own device: the scene buffers are the primary's, not copies
     std::vector<float*> d_gather;            // per peer, on THIS device: its packed sum buffer as received
@@ -852,6 +853,8 @@ int crt_set_camera(crt_scene* s, const crt_camera* cam) {
     return CRT_OK;
 }
 
+static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile, uint32_t base_rank, uint32_t base_world);
+
 int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_set_shard: null scene");
     if (world == 0 || rank >= world) return fail(CRT_ERR_INVALID, "crt_set_shard: rank/world");
@@ -865,6 +868,7 @@ int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile) {
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->rank = rank; s->world = world; s->tile = tile;
+    s->shard_rank = rank; s->shard_world = world;
     return alloc_frame_buffers(s);
 }
 
@@ -912,10 +916,10 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         if (value < 1 || value > 4) return fail(CRT_ERR_INVALID, "crt_set_option: streams is 1..4");
         if (s->primary) return fail(CRT_ERR_INVALID, "crt_set_option: streams is set on the scene, not on a replica");
         if ((uint32_t)value == s->streams) return CRT_OK;
-        if (s->streams == 1u && (!s->peers.empty() || s->world != 1u))
-            return fail(CRT_ERR_INVALID, "crt_set_option: streams needs an unsharded scene (crt_set_shard / crt_set_devices already deal its tiles)");
+        if (s->streams == 1u && !s->peers.empty())
+            return fail(CRT_ERR_INVALID, "crt_set_option: streams is for a scene on one device (crt_set_devices already deals its tiles to several)");
         const std::vector<int32_t> ids((size_t)value, (int32_t)s->device);
-        const int rc = crt_set_devices(s, ids.data(), (uint32_t)value, s->tile ? s->tile : 16u);
+        const int rc = set_devices_of_shard(s, ids.data(), (uint32_t)value, s->tile ? s->tile : 16u, s->shard_rank, s->shard_world);
         if (rc) return rc;
         s->streams = (uint32_t)value;
         return CRT_OK;                       // nothing to pass on to the replicas
@@ -1334,24 +1338,49 @@ int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out) {
     return CRT_OK;
 }
 
+// Option "streams": the caller's shard lives in k parts, one per stream; tile i of stream j is tile i * k + j of the shard's own list
+// (set_devices_of_shard), so the shard's packed buffer is the parts interleaved tile by tile.
+static size_t shard_tiles_of_streams(const crt_scene* s) {
+    size_t n = s->n_local_tiles;
+    for (const crt_scene* p : s->peers) n += p->n_local_tiles;
+    return n;
+}
+static int copy_packed_of_streams(crt_scene* s, void* dst, hipMemcpyKind kind) {
+    const size_t tile_bytes = 3 * (size_t)s->tile * s->tile * sizeof(float);
+    const size_t k = s->peers.size() + 1;
+    for (crt_scene* p : s->peers) HIPCHK(hipStreamSynchronize(p->stream));     // their frames are in their sums before these are read
+    for (size_t j = 0; j < k; ++j) {
+        const crt_scene* q = j == 0 ? s : s->peers[j - 1];
+        if (!q->n_local_tiles) continue;
+        HIPCHK(hipMemcpy2DAsync(static_cast<char*>(dst) + j * tile_bytes, k * tile_bytes, q->d_sum, tile_bytes, tile_bytes, q->n_local_tiles, kind, s->stream));
+    }
+    return CRT_OK;
+}
+
 int crt_packed_info(crt_scene* s, uint32_t* n_local_tiles, uint32_t* tile, size_t* n_floats) {
     if (!s) return fail(CRT_ERR_INVALID, "crt_packed_info: null scene");
-    if (s->streams > 1u) return fail(CRT_ERR_INVALID, "crt_packed_info: the packed buffer is per shard; this scene splits its frame over streams (option streams)");
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
-    if (n_local_tiles) *n_local_tiles = s->n_local_tiles;
+    // option "streams": the caller's shard is what its streams hold together
+    const size_t tiles = s->streams > 1u ? shard_tiles_of_streams(s) : s->n_local_tiles;
+    if (n_local_tiles) *n_local_tiles = (uint32_t)tiles;
     if (tile) *tile = s->tile;
-    if (n_floats) *n_floats = 3 * (size_t)s->n_local_pixels;
+    if (n_floats) *n_floats = 3 * tiles * s->tile * s->tile;
     return CRT_OK;
 }
 
 int crt_read_packed(crt_scene* s, float* dst, size_t n_floats) {
     if (!s || !dst) return fail(CRT_ERR_INVALID, "crt_read_packed: null argument");
-    if (s->streams > 1u) return fail(CRT_ERR_INVALID, "crt_read_packed: the packed buffer is per shard; this scene splits its frame over streams (option streams)");
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
+    if (s->streams > 1u) {
+        if (n_floats != 3 * shard_tiles_of_streams(s) * s->tile * s->tile) return fail(CRT_ERR_INVALID, "crt_read_packed: size mismatch");
+        if ((rc = copy_packed_of_streams(s, dst, hipMemcpyDeviceToHost))) return rc;
+        HIPCHK(hipStreamSynchronize(s->stream));
+        return CRT_OK;
+    }
     if (n_floats != 3 * (size_t)s->n_local_pixels) return fail(CRT_ERR_INVALID, "crt_read_packed: size mismatch");
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(dst, s->d_sum, n_floats * sizeof(float), hipMemcpyDeviceToHost));
@@ -1360,10 +1389,15 @@ int crt_read_packed(crt_scene* s, float* dst, size_t n_floats) {
 
 int crt_copy_packed_device(crt_scene* s, void* d_dst, size_t n_floats, int sync) {
     if (!s || !d_dst) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: null argument");
-    if (s->streams > 1u) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: the packed buffer is per shard; this scene splits its frame over streams (option streams)");
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
+    if (s->streams > 1u) {
+        if (n_floats != 3 * shard_tiles_of_streams(s) * s->tile * s->tile) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: size mismatch");
+        if ((rc = copy_packed_of_streams(s, d_dst, hipMemcpyDeviceToDevice))) return rc;
+        if (sync) HIPCHK(hipStreamSynchronize(s->stream));
+        return CRT_OK;
+    }
     if (n_floats != 3 * (size_t)s->n_local_pixels) return fail(CRT_ERR_INVALID, "crt_copy_packed_device: size mismatch");
     HIPCHK(hipMemcpyAsync(d_dst, s->d_sum, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     if (sync) HIPCHK(hipStreamSynchronize(s->stream));
@@ -1522,7 +1556,15 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     return CRT_OK;
 }
 
+// base_rank / base_world: the shard of the frame the devices divide among themselves — the whole frame (0 of 1) for crt_set_devices,
+// the caller's own shard (crt_set_shard) when option "streams" splits it over streams of one GPU: device k takes the tiles
+// base_rank + k * base_world, + n * base_world, ... of the Morton order, i.e. every n-th tile of that shard's list starting at its k-th
 int crt_set_devices(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile) {
+    if (s) { s->shard_rank = 0u; s->shard_world = 1u; }      // the devices divide the whole frame
+    return set_devices_of_shard(s, devices, n_devices, tile, 0u, 1u);
+}
+
+static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile, uint32_t base_rank, uint32_t base_world) {
     if (!s || !devices) return fail(CRT_ERR_INVALID, "crt_set_devices: null argument");
     if (s->primary) return fail(CRT_ERR_INVALID, "crt_set_devices: not on a replica");
     if (n_devices == 0 || n_devices > 64) return fail(CRT_ERR_INVALID, "crt_set_devices: 1..64 devices");
@@ -1540,18 +1582,18 @@ int crt_set_devices(crt_scene* s, const int32_t* devices, uint32_t n_devices, ui
     s->drop_peers();
     s->streams = 1;
     int rc = CRT_OK;
-    auto undo = [&](int code) { s->drop_peers(); (void)hipSetDevice(s->device); s->rank = 0; s->world = 1; (void)alloc_frame_buffers(s); return code; };
+    auto undo = [&](int code) { s->drop_peers(); (void)hipSetDevice(s->device); s->rank = base_rank; s->world = base_world; (void)alloc_frame_buffers(s); return code; };
     try {
         for (uint32_t k = 1; k < n_devices; ++k) {
             crt_scene* p = nullptr;
             if ((rc = replicate_scene(s, devices[k], &p))) return undo(rc);
             p->primary = s;
             s->peers.push_back(p);
-            p->rank = k; p->world = n_devices; p->tile = tile;
+            p->rank = base_rank + k * base_world; p->world = base_world * n_devices; p->tile = tile;
             if ((rc = alloc_frame_buffers(p))) return undo(rc);
         }
         HIPCHK(hipSetDevice(s->device));
-        s->rank = 0; s->world = n_devices; s->tile = tile;
+        s->rank = base_rank; s->world = base_world * n_devices; s->tile = tile;
         if ((rc = alloc_frame_buffers(s))) return undo(rc);
         for (crt_scene* p : s->peers) {                      // where a peer's slice lands on this device, and its tile list
             float* g = nullptr; uint2* t = nullptr; hipEvent_t e = nullptr;

@@ -203,8 +203,11 @@ int crt_sync(crt_scene* s);
  *                         (own queues and path state, the scene buffers shared).  A multi-segment frame is a chain of dependent
  *                         launches; another shard's launches fill their tails: 1 M triangles, 4 segments, 2 streams +6 %, 8 M triangles
  *                         +4 %; a one-segment frame gains nothing.  It is crt_set_devices with this GPU listed k times: the accumulated
- *                         sum restarts, crt_read_sum / crt_resolve / crt_sum_device assemble the frame, the per-shard packed-buffer calls
- *                         are refused meanwhile, and crt_set_shard / crt_set_devices take the split away again.  Needs an unsharded scene.
+ *                         sum restarts, crt_read_sum / crt_resolve / crt_sum_device assemble the frame.  A scene that renders a shard
+ *                         (crt_set_shard, one process per GPU) can split that shard the same way — set the option after crt_set_shard;
+ *                         its tiles are dealt to the streams and crt_packed_info / crt_read_packed / crt_copy_packed_device hand out the
+ *                         shard's packed buffer assembled from the streams' parts (an eighth of the 4K frame, 4 segments: 88 -> 99 % of
+ *                         perfect division).  crt_set_shard and crt_set_devices take the split away again.
  *     "trace_pool"        crt_trace / crt_trace_device: rays per wave, 64 (default: one lock-step batch per single-wave workgroup, the
  *                         finest grain for the dispatcher — 2.07 M primary rays of the 1 M-triangle scene 0.153 ms against 0.346),
  *                         128 or 256 (a pool: a lane whose ray has finished takes the pool's next ray once "refill_min" lanes

@@ -556,7 +556,8 @@ def test_tile_shards_compose_to_the_full_frame(cr, ob, cornell, cornell_data, T)
 def test_streams_option_splits_the_frame_over_streams_of_one_gpu(cr, ob, cornell, scenes, name, depth, k):
     """Option "streams": k tile shards of the frame on k streams of the one GPU (a multi-segment frame is a chain of dependent launches;
     another shard's launches fill their tails), the scene buffers shared.  Same sums as the oracle and the same statistics, frame by
-    frame and batched; the per-shard packed buffer is refused while the split is on; crt_set_shard and streams = 1 undo it."""
+    frame and batched; the packed buffer of the caller's shard is assembled from the streams' parts; a shard set with crt_set_shard can
+    be split the same way (its own tiles dealt to the streams); crt_set_shard and streams = 1 undo the split."""
     _, _, data = scenes[name]
     _, cam = cornell
     W, H = 250, 140
@@ -579,8 +580,12 @@ def test_streams_option_splits_the_frame_over_streams_of_one_gpu(cr, ob, cornell
     assert st["nodes_closest"] + st["nodes_any"] == cnt_last[2] and st["tris_closest"] + st["tris_any"] == cnt_last[3]
     out = sc.read_sum()
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), float(np.abs(out - ref).max())
-    with pytest.raises(cr.CrtError):
-        sc.packed_info()
+    plain = cr.Scene(data, W, H, depth)
+    for r in rvs:
+        plain.render_frame(*r)
+    assert sc.packed_info() == plain.packed_info()
+    assert np.array_equal(sc.read_packed().view(np.uint32), plain.read_packed().view(np.uint32))      # tile for tile, in the shard's own order
+    plain.close()
     with pytest.raises(cr.CrtError):
         sc.set_option("streams", 5)
     # back to one stream: a plain scene again (the sum restarts, as with every re-sharding)
@@ -590,13 +595,31 @@ def test_streams_option_splits_the_frame_over_streams_of_one_gpu(cr, ob, cornell
     one = np.zeros((H, W, 3), np.float32)
     orc.render_frame(rvs[0][0], rvs[0][1], one, threads=8)
     assert np.array_equal(sc.read_sum().view(np.uint32), one.view(np.uint32))
-    # a caller that shards the frame itself takes the split away
+    # a caller that shards the frame itself takes the split away, and may split its own shard again
     sc.set_option("streams", 2)
-    sc.set_shard(0, 2, 16)
-    assert sc.devices()["devices"] == [0] and sc.packed_info()[0] > 0
-    with pytest.raises(cr.CrtError):
-        sc.set_option("streams", 2)          # its tiles are already dealt
-    sc.close()
+    sc.set_shard(1, 3, 16)
+    assert sc.devices()["devices"] == [0]
+    ref_shard = cr.Scene(data, W, H, depth)
+    ref_shard.set_shard(1, 3, 16)
+    sc.set_option("streams", k)
+    assert sc.devices()["devices"] == [0] * k
+    for s_ in (sc, ref_shard):
+        s_.render_frame(*rvs[0])
+        s_.render_frames(rvs[1:4])
+    assert sc.packed_info() == ref_shard.packed_info()
+    assert np.array_equal(sc.read_packed().view(np.uint32), ref_shard.read_packed().view(np.uint32)) and ref_shard.read_packed().max() > 0
+    assert np.array_equal(sc.read_sum().view(np.uint32), ref_shard.read_sum().view(np.uint32))      # the shard's tiles in the frame, nothing else
+    import torch
+    n_floats = sc.packed_info()[2]
+    d_buf = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+    sc.copy_packed_device(d_buf.data_ptr(), n_floats)
+    assert np.array_equal(d_buf.cpu().numpy().view(np.uint32), ref_shard.read_packed().view(np.uint32))
+    sc.set_option("streams", 1)                     # the caller's shard again, on one stream
+    sc.render_frame(*rvs[0])
+    ref_shard.reset(); ref_shard.render_frame(*rvs[0])
+    assert sc.packed_info() == ref_shard.packed_info()
+    assert np.array_equal(sc.read_packed().view(np.uint32), ref_shard.read_packed().view(np.uint32))
+    sc.close(); ref_shard.close()
 
 
 @pytest.mark.parametrize("name,depth,n_dev", [("cornell", 1, 2), ("tess8", 3, 4), ("tess8", 2, 3)])
@@ -690,6 +713,8 @@ def _shard_worker(rank, world, port, W, H, T, out_dir):
     mesh, cam = g._cornell()
     scene = cr.Scene(cr.SceneData.build(mesh, cam), W, H, 3)
     scene.set_shard(rank, world, T)
+    if rank == 1:
+        scene.set_option("streams", 2)             # this rank renders its shard as two tile sets on two streams: the same packed buffer
     rnd = cr.Rnd()
     for _ in range(2):
         scene.render_frame(rnd.randf2(), rnd.randf2())
