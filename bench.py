@@ -33,7 +33,7 @@ simply is one of the ranks.
 Prints ONE JSON line (< 6 KB) on rank 0 with the driver's keys plus
   "roofline": the dominant kernel (the fused segment kernel) against the roof that binds it — VECTOR-INSTRUCTION ISSUE, not HBM (every
       BASELINE scene is cache-resident: SURVEY §8d's algorithmic bytes / time exceeds the HBM peak and is reported as
-      `algorithmic_gbps`, never as a fraction).  achieved = algorithmic wave-instructions of a launch / its mean HIP-event duration;
+      `algorithmic_gbps`, never as a fraction).  achieved = algorithmic wave-instructions of a launch / its mean HIP-event duration (blocks that render tile shards side by side on several streams — `config.streams` > 1: multi-segment paths and few-node scenes — take the step's wall time / its launches per shard instead: the time a segment of the WHOLE frame takes);
       peak = 1024 SIMDs x 2.4 GHz / 2 cycles; definitions, instruction counts and the script that recomputes every frac:
       tools/roofline.py, profiles/isa_counts.json.  `traffic` = L2<->fabric bytes per launch, (2 FETCH_SIZE + WRITE_SIZE) x 1024 from
       rocprofv3 --pmc passes this invocation runs itself as child processes before its own first GPU call (`traffic_source:
@@ -105,8 +105,8 @@ def parse_args(argv=None):
                     help="with --one-process: K logical devices on GPU 0 (shards, streams and gather buffers as on K GPUs; copies instead of RCCL) — "
                          "rehearses the path on a one-GPU machine; the number it prints is NOT a scaling figure")
     ap.add_argument("--streams", type=int, default=0, metavar="K",
-                    help="tile shards of a rank's frame rendered side by side on K streams of its GPU (crt_set_option streams); default: 2 for "
-                         "multi-segment paths, else 1")
+                    help="tile shards of a rank's frame rendered side by side on K streams of its GPU (crt_set_option streams); default: 3 for "
+                         "scenes of a few nodes, 2 for multi-segment paths, else 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
                          "(what the CPU tests exercise); the line says dry_run and reports no throughput")
@@ -384,7 +384,10 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         # a multi-segment frame is a chain of dependent launches: two tile shards of this rank's part of the frame on two streams of the GPU
         # fill each other's launch tails (option "streams", bit-identical; 1 M triangles, 4 segments: +6 % on the whole frame, +12 % on an
         # eighth of the 4K frame).  One launch per step gains nothing on a whole frame and 0..2 % on a shard.
-        streams = args.streams if args.streams > 0 else (2 if depth > 1 and not one_proc and args.accel == "cwbvh" else 1)
+        # ... and a frame of a few-node scene (the 32-triangle Cornell box: 58 us per launch) is bound by the gaps between launches: three
+        # tile shards on three streams keep the GPU busy through them (+13 %; four streams are bound by the host's launch rate)
+        tiny = scene.bvh_info()["n_nodes8"] < 64
+        streams = args.streams if args.streams > 0 else ((3 if tiny else 2 if depth > 1 else 1) if not one_proc and args.accel == "cwbvh" else 1)
         if streams > 1:
             scene.set_option("streams", streams)
         for kv in args.option:
@@ -504,6 +507,10 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         tris = cs["tris_closest"] + (cs["tris_any"] if fused_shadow else 0)
         alg_bytes = (node_bytes * nodes + TRI_BYTES * tris) / launches * samples_per_launch
         t_launch = launch_ms_timed * 1e-3
+        if streams > 1:
+            # the shards' launches run side by side: a segment of the WHOLE frame takes the step's wall time / its launches per shard (a
+            # single launch's own duration would count the time it shares the GPU with the other shards' launches more than once)
+            t_launch = dt / max(1.0, K * spp * max(1, depth) / samples_per_launch)
         # counter passes exist per (workload, depth) at 1920x1080 on the host-built tree with the reference's materials
         pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and (not device_built or name == HBM_RESIDENT) and materials in (None, "lambert")) else {}
         traffic = pmc.get("l2_fabric_bytes_per_launch")
