@@ -448,10 +448,21 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         scene.sync()
         if use_dist or one_proc:    # warm the collective too
             read_back()
-        # HIP events on every segment launch of the timed region, on the scene's own stream (attached to the dispatch:
-        # they take the kernel's own start/stop timestamps)
+        # launches one step makes (a probe step with events on its launches): the samples of a step share launches where the path allows
         scene.set_option("timing", 1)
-        scene.set_option("timing_accumulate", K * spp * max(1, depth))
+        scene.set_option("timing_accumulate", spp * max(1, depth))
+        step(0)
+        scene.sync()
+        launches_per_step = max(1, int(scene.frame_stats()["n_trace_launches"]))
+        scene.set_option("timing_accumulate", 0)
+        if streams == 1:
+            # HIP events on every segment launch of the timed region, on the scene's own stream (attached to the dispatch:
+            # they take the kernel's own start/stop timestamps)
+            scene.set_option("timing_accumulate", K * spp * max(1, depth))
+        else:
+            # several streams: the launch time of the roofline is the step's wall time / launches (below), and an event-carrying dispatch
+            # would only keep its neighbours on the other streams from overlapping it
+            scene.set_option("timing", 0)
     if sharded:
         ctx.barrier(scene)
     elif takes_part:
@@ -479,8 +490,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         # ray counts of the LAST timed frame (every frame does identical work up to the per-frame random vector) and
         # the mean launch time over the timed region; then a short event-timed tail for the per-kernel split
         st = scene.frame_stats()
-        launch_ms_timed = st["ms_trace_closest"] / max(1, st["n_trace_launches"])
-        n_timed_launches = st["n_trace_launches"]
+        n_timed_launches = st["n_trace_launches"] if streams == 1 else launches_per_step * K
+        launch_ms_timed = st["ms_trace_closest"] / max(1, n_timed_launches)
         # samples per pixel one launch rendered: 1, or the step's spp where crt_render_frames batched them
         samples_per_launch = max(1, round(K * spp * max(1, depth) / max(1, n_timed_launches)))
         scene.set_option("timing_accumulate", 0)

@@ -169,9 +169,9 @@ int crt_sync(crt_scene* s);
  *     "adaptive_tiles"    1 (default): the order in which the tiles of the frame (16x16 pixels unless crt_set_shard says otherwise) are handed to the GPU follows their
  *                         measured cost, most expensive first (one frame per new view is timed, tile by tile); 0: centre-out
  *                         order only.  Which pixel lands where — in the image and in the sum buffer — does not depend on it.
- *     "timing"            HIP events behind crt_frame_stats.ms_*: 2 = every traversal launch (default), 1 = closest-hit
- *                         launches only, 0 = none.  The events ride on the dispatches; a timed dispatch costs ~5 us of
- *                         stream time because it cannot overlap its neighbours
+ *     "timing"            HIP events behind crt_frame_stats.ms_* and n_trace_launches: 0 = none (default: the fields stay 0), 1 = closest-hit
+ *                         launches only, 2 = every traversal launch.  The events ride on the dispatches; a timed dispatch costs ~5 us
+ *                         of stream time because it cannot overlap its neighbours (8 % of a 1080p frame of the 32-triangle box)
  *     "timing_accumulate" n > 0: keep the spans of the next n launches instead of restarting every frame
  *                         (crt_frame_stats.ms_* are then sums over n_trace_launches launches); 0: per frame
  *   tuning

@@ -412,6 +412,11 @@ def test_async_frames_and_timing_options_do_not_change_results(cr, scenes, inpla
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(frames)]
     a = cr.Scene(data, W, H, depth)
     a.set_option("inplace_shadow", inplace)
+    a.render_frame(*rvs[0])
+    st0 = a.frame_stats()                      # launches carry no events unless asked to: nothing timed, nothing counted
+    assert st0["n_trace_launches"] == 0 and st0["ms_trace_closest"] == 0 and st0["ms_total"] == 0
+    a.reset()
+    a.set_option("timing", 2)
     for rx, ry in rvs:
         a.render_frame(rx, ry)
     want, want_st = a.read_sum(), a.frame_stats()
@@ -692,10 +697,12 @@ def test_device_resident_trace_and_torch_interop(cr, ob, cornell, scenes):
     d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1, 32)).cuda()
     d_hits = torch.empty((len(rays), 16), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
+    scene.set_option("timing", 2)
     scene.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), cr.CRT_TRACE_CLOSEST)
     got = d_hits.cpu().numpy().view(cr.HIT_DT).ravel()
-    _assert_hits_equal(got, scene.trace(rays))
     assert scene.frame_stats()["ms_trace_closest"] > 0
+    scene.set_option("timing", 0)
+    _assert_hits_equal(got, scene.trace(rays))
 
 
 def _shard_worker(rank, world, port, W, H, T, out_dir):
