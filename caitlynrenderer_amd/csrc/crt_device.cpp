@@ -347,7 +347,7 @@ int alloc_frame_buffers(crt_scene* s) {
         s->tiles_measured_once = false;
         s->tile_cost_spread = 0.f;
     }
-    if ((rc = dev_alloc(&s->d_sum, 3 * P))) return rc;
+    if ((rc = dev_alloc(&s->d_sum, 3 * std::max<size_t>(P, 1)))) return rc;     // a shard may hold no tile at all (more devices or streams than tiles)
     HIPCHK(hipMemset(s->d_sum, 0, 3 * std::max<size_t>(P, 1) * sizeof(float)));
     // a workgroup group handles every 8th unit of 4096 pixels/rays, so it can emit at most this many rays per segment
     s->sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096);

@@ -627,6 +627,35 @@ def test_streams_option_splits_the_frame_over_streams_of_one_gpu(cr, ob, cornell
     sc.close(); ref_shard.close()
 
 
+def test_more_streams_or_devices_than_tiles(cr, ob, cornell, cornell_data):
+    """A frame of one or two tiles on up to four streams (or virtual devices): some shards hold no tile at all and still take part in
+    every call; sums, packed buffer and resolve are those of the plain scene."""
+    _, cam = cornell
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(5)]
+    for (W, H) in ((8, 8), (17, 9), (1, 1), (40, 8)):
+        for depth in (1, 3):
+            orc = ob.Oracle(cornell_data, W, H, depth, cam)
+            ref = np.zeros((H, W, 3), np.float32)
+            for r in rvs:
+                orc.render_frame(r[0], r[1], ref, threads=2)
+            plain = cr.Scene(cornell_data, W, H, depth)
+            plain.render_frame(*rvs[0]); plain.render_frames(rvs[1:5])
+            for k in (2, 3, 4):
+                sc = cr.Scene(cornell_data, W, H, depth)
+                if k == 4:
+                    sc.set_devices([0] * k, 16)
+                else:
+                    sc.set_option("streams", k)
+                sc.render_frame(*rvs[0]); sc.render_frames(rvs[1:5])
+                assert np.array_equal(sc.read_sum().view(np.uint32), ref.view(np.uint32)), (W, H, depth, k)
+                assert np.array_equal(sc.resolve(0.2), plain.resolve(0.2))
+                if k < 4:
+                    assert np.array_equal(sc.read_packed().view(np.uint32), plain.read_packed().view(np.uint32))
+                sc.close()
+            plain.close()
+
+
 @pytest.mark.parametrize("name,depth,n_dev", [("cornell", 1, 2), ("tess8", 3, 4), ("tess8", 2, 3)])
 def test_one_handle_several_devices_gather_inside_the_c_abi(cr, ob, cornell, scenes, name, depth, n_dev):
     """crt_set_devices: ONE scene handle and one frame loop, as the reference has them (main.cpp:262-300), rendering on several
