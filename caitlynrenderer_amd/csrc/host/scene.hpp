@@ -94,6 +94,13 @@ struct Scene {
         update(0.0f);
     }
 
+    // tuning passthrough (crt.h "Options"), e.g. set_option("streams", 2) for multi-segment paths; false + `error` if refused
+    bool set_option(const char* name, int value) {
+        if (!gpu) return false;
+        if (crt_set_option(gpu, name, value) != CRT_OK) { error = crt_last_error(); return false; }
+        return true;
+    }
+
     void Render() {                                  // Scene.h:1158-1231
         if (!gpu) return;
         if (camera.isMoving) {                       // Scene.h:1160-1172

@@ -21,6 +21,8 @@ int main(int argc, char** argv) {
     crt::Scene scn(argv[1], w, h, depth);                 // init_scene, main.cpp:28-67
     if (!scn.ok()) { std::fprintf(stderr, "scene failed: %s\n", scn.error.c_str()); return 1; }
     const bool batched = std::getenv("RENDER_OBJ_BATCHED") != nullptr;   // all frames through one crt_render_frames call
+    if (const char* k = std::getenv("RENDER_OBJ_STREAMS"))               // tile shards of the frame side by side on k streams of the GPU
+        if (!scn.set_option("streams", std::atoi(k))) { std::fprintf(stderr, "streams refused: %s\n", scn.error.c_str()); return 1; }
     scn.update(0.0f);
     if (batched) scn.RenderFrames(frames);
     else for (int i = 0; i < frames; ++i) {               // main.cpp:262-300: update(dt); render();

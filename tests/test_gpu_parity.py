@@ -796,6 +796,11 @@ def test_cpp_host_scene_matches_python_path(cr, ob, cornell, tmp_path):
                           str(depth), str(tmp_path / "sum.f32")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     got = np.fromfile(tmp_path / "sum.f32", np.float32).reshape(H, W, 3)
+    # the same frames as two tile shards on two streams (crt::Scene::set_option): the same sum
+    out2 = subprocess.run([os.path.join(ROOT, "examples", "render_obj"), obj, str(tmp_path / "o2.ppm"), str(W), str(H), str(frames),
+                           str(depth), str(tmp_path / "sum2.f32")], capture_output=True, text=True, env=dict(os.environ, RENDER_OBJ_STREAMS="2"))
+    assert out2.returncode == 0, out2.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "sum2.f32", np.float32).view(np.uint32), got.reshape(-1).view(np.uint32))
     cam = cr.Camera((-2.755610, 2.745992, 7.58545), (-2.755610, 2.745992, 6.58545), 40.0)   # Scene.h:468
     data = cr.SceneData.from_obj(obj, cam)
     orc = ob.Oracle(data, W, H, depth, cam)
