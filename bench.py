@@ -105,8 +105,8 @@ def parse_args(argv=None):
                     help="with --one-process: K logical devices on GPU 0 (shards, streams and gather buffers as on K GPUs; copies instead of RCCL) — "
                          "rehearses the path on a one-GPU machine; the number it prints is NOT a scaling figure")
     ap.add_argument("--streams", type=int, default=0, metavar="K",
-                    help="tile shards of a rank's frame rendered side by side on K streams of its GPU (crt_set_option streams); default: 3 for "
-                         "scenes of a few nodes, 2 for multi-segment paths, else 1")
+                    help="tile shards of a rank's frame rendered side by side on K streams of its GPU (crt_set_option streams); default 0 = the "
+                         "library's pick: 3 for scenes of a few nodes, 2 for multi-segment paths, else 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU and no rendering: launcher, process group (gloo), shard bookkeeping, gather and the JSON line only "
                          "(what the CPU tests exercise); the line says dry_run and reports no throughput")
@@ -386,10 +386,10 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         # eighth of the 4K frame).  One launch per step gains nothing on a whole frame and 0..2 % on a shard.
         # ... and a frame of a few-node scene (the 32-triangle Cornell box: 58 us per launch) is bound by the gaps between launches: three
         # tile shards on three streams keep the GPU busy through them (+13 %; four streams are bound by the host's launch rate)
-        tiny = scene.bvh_info()["n_nodes8"] < 64
-        streams = args.streams if args.streams > 0 else ((3 if tiny else 2 if depth > 1 else 1) if not one_proc and args.accel == "cwbvh" else 1)
-        if streams > 1:
-            scene.set_option("streams", streams)
+        streams = 1
+        if not one_proc and args.accel == "cwbvh":
+            scene.set_option("streams", args.streams)            # 0 (the default here): the library's own pick, as described above
+            streams = len(scene.devices()["devices"])
         for kv in args.option:
             k, v = kv.split("=")
             scene.set_option(k, int(v))

@@ -915,7 +915,10 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         // k tile shards of the frame, each with its own stream, queues and path state, on this one GPU: the segment launches of one
         // shard fill the tails and gaps of the others' (a multi-segment frame is a chain of dependent launches).  The machinery is
         // crt_set_devices' with the same GPU listed k times; the scene buffers are shared, not copied.
-        if (value < 1 || value > 4) return fail(CRT_ERR_INVALID, "crt_set_option: streams is 1..4");
+        if (value < 0 || value > 4) return fail(CRT_ERR_INVALID, "crt_set_option: streams is 0 (pick for me) or 1..4");
+        // 0: what the measurements say — a frame of a few-node scene is bound by the gaps between its launches (3 streams), a multi-segment
+        // frame by the tails of its chain of launches (2), a one-segment frame of a large scene by neither (1)
+        if (value == 0) value = s->info.n_nodes8 < 64 ? 3 : s->max_depth > 1 ? 2 : 1;
         if (s->primary) return fail(CRT_ERR_INVALID, "crt_set_option: streams is set on the scene, not on a replica");
         if ((uint32_t)value == s->streams) return CRT_OK;
         if (s->streams == 1u && !s->peers.empty())

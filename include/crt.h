@@ -199,7 +199,7 @@ int crt_sync(crt_scene* s);
  *                         1 = for 6 (80 VGPRs), 2 (default) = 6 where the launch is bound by throughput, 5 where its longest
  *                         waves set its length (the same measure as "wave_samples"); the 6-wave build exists for the batched
  *                         launches of crt_render_frames on Lambert scenes
- *     "streams"           1 (default) .. 4: that many tile shards of the frame rendered side by side on streams of their own on this one GPU
+ *     "streams"           1 (default) .. 4, or 0 = pick for me (3 for scenes of a few nodes, 2 for max_depth > 1, else 1): that many tile shards of the frame rendered side by side on streams of their own on this one GPU
  *                         (own queues and path state, the scene buffers shared).  A multi-segment frame is a chain of dependent
  *                         launches; another shard's launches fill their tails: 1 M triangles, 4 segments, 2 streams +6 %, 8 M triangles
  *                         +4 %; a one-segment frame gains nothing.  It is crt_set_devices with this GPU listed k times: the accumulated

@@ -593,6 +593,8 @@ def test_streams_option_splits_the_frame_over_streams_of_one_gpu(cr, ob, cornell
     plain.close()
     with pytest.raises(cr.CrtError):
         sc.set_option("streams", 5)
+    sc.set_option("streams", 0)                     # the library's own pick: 3 for a few-node scene, 2 for a multi-segment path, else 1
+    assert len(sc.devices()["devices"]) == (3 if name == "cornell" else 2 if depth > 1 else 1)
     # back to one stream: a plain scene again (the sum restarts, as with every re-sharding)
     sc.set_option("streams", 1)
     assert sc.devices()["devices"] == [0]
