@@ -770,6 +770,8 @@ def compact(b):
     for k in ("traffic", "traffic_gbps", "lane_util", "issue_busy", "l2_hit_rate"):
         if r.get(k) is not None:
             e[k] = r[k]
+    if c.get("streams", 1) > 1:
+        e["streams"] = c["streams"]       # tile shards side by side: launch_ms is the step's wall time / launches per shard
     if "device_build" in c:
         e["device_build"] = c["device_build"]
     if c["workload"].find(f"n={HBM_RESIDENT[4:]}:") >= 0 and r.get("traffic_gbps"):
