@@ -1130,7 +1130,14 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             else if (s->wave_samples != 3u && s->use_wave_samples()) sa.wave_samples = 1u;
         }
         // the first segment's 6-wave build where the launch is bound by throughput, the 5-wave build where its longest waves set its length
-        sa.wide_first = (b == 0 && (s->wide_first == 2u ? !s->bound_by_longest_waves() : s->wide_first != 0u)) ? 1u : 0u;
+        // (with four samples in the lanes of a wave a launch has four times the waves, each a quarter as long, and the measure above —
+        // made for samples that follow each other in a wave — flips too early: the 6-wave build wins down to about a million pixels,
+        // i.e. while the launch fills the chip's 6,144 wave slots eight times over; an eighth of the 4K frame 0.405 -> 0.396 ms, half a
+        // 1080p frame 0.435 -> 0.421, a quarter 0.225 against 0.231 the other way)
+        bool wide_auto = !s->bound_by_longest_waves();
+        if (sa.wave_samples == 2u)
+            wide_auto = (double)(s->n_local_pixels / 16u) * (double)(n_samples / 4u) >= 8.0 * (double)s->n_cu * 4.0 * 6.0;
+        sa.wide_first = (b == 0 && (s->wide_first == 2u ? wide_auto : s->wide_first != 0u)) ? 1u : 0u;
         if (b == 0) s->last_launch_form = (int)sa.wave_samples;
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
