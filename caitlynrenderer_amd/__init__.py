@@ -17,5 +17,10 @@ def has_experiments():
     return bool(_lib.lib().crt_has_experiments())
 
 
-__all__ = ["has_experiments", "Scene", "SceneData", "Camera", "Mesh", "SBVH", "CWBVH", "Rnd", "pcg_hash", "CrtError",
+def warmup():
+    """crt_warmup: HIP context + the library's code objects on the current device, so that the first scene does not pay for them."""
+    _lib.check(_lib.lib().crt_warmup())
+
+
+__all__ = ["has_experiments", "warmup", "Scene", "SceneData", "Camera", "Mesh", "SBVH", "CWBVH", "Rnd", "pcg_hash", "CrtError",
            "RAY_DT", "HIT_DT", "STATS_DT", "CRT_TRACE_CLOSEST", "CRT_TRACE_ANY", "CRT_TRACE_BVH2", "CRT_TRACE_TIE_LOWEST_ID"]

@@ -83,6 +83,7 @@ SYMBOLS = {
     "crt_debug_read_queue": (_I, [_P, _I, _U32, _P, _SZ, C.POINTER(_SZ)]),
     "crt_debug_time_graph": (_I, [_P, _U32, _P, _U32, C.POINTER(_F), C.POINTER(_F)]),
     "crt_debug_launch_form": (_I, [_P, C.POINTER(C.c_int32)]),
+    "crt_debug_launch_info": (_I, [_P, C.POINTER(C.c_int32)]),
     "crt_set_shard": (_I, [_P, _U32, _U32, _U32]),
     "crt_set_devices": (_I, [_P, C.POINTER(C.c_int32), _U32, _U32]),
     "crt_get_devices": (_I, [_P, C.POINTER(_U32), C.POINTER(C.c_int32), _U32, C.POINTER(C.c_int32), C.POINTER(_F)]),
@@ -93,6 +94,7 @@ SYMBOLS = {
     "crt_get_bvh_info": (_I, [_P, C.POINTER(crt_bvh_info)]),
     "crt_device_count": (_I, []),
     "crt_has_experiments": (_I, []),
+    "crt_warmup": (_I, []),
     "crt_camera_look_at": (_I, [C.POINTER(_F), C.POINTER(_F), _F, C.POINTER(crt_camera)]),
     "crt_pcg_hash": (_U32, [_U32]),
     "crt_randf2": (_F, [C.POINTER(_U32)]),

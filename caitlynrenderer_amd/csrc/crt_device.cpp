@@ -119,6 +119,7 @@ struct crt_scene {
     uint32_t wide_first = 2;            // first-segment kernels built for 6 waves per SIMD: 0 never, 1 always, 2 by the same measure
     float tile_cost_spread = 0.f;       // 99th percentile of the measured tile costs over their mean; 0 = nothing measured yet
     int last_launch_form = 0;           // crt_debug_launch_form
+    int last_launch_wide = 0, last_launch_samples = 1;      // crt_debug_launch_info
     bool use_wave_samples() const { return wave_samples == 2u ? bound_by_longest_waves() : wave_samples == 1u; }
     bool bound_by_longest_waves() const {
         // One wave renders the n samples of its 64 pixels one after the other: the launch cannot end before the most expensive
@@ -497,6 +498,20 @@ int crt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// Everything a first crt_scene_create would otherwise pay for once per process and device, paid here instead: the HIP context of the
+// current device and the library's four code objects (traversal kernels, the GPU builders with their sort / scan kernels, the CWBVH
+// converter, the scene-assembly kernels).  HIP loads a code object when one of its kernels is first looked up — measured on MI355X at
+// 1,004,672 triangles: the first crt_scene_create(... CRT_BUILD_SAH) of a process 22 ms, the second 8.7 (profiles/r04_build_probe.txt).
+int crt_warmup(void) {
+    int rc = require_device();
+    if (rc) return rc;
+    HIPCHK(hipFree(nullptr));                          // creates the context
+    int e;
+    if ((e = crt::warm_rt_kernels()) || (e = crt::warm_lbvh_kernels()) || (e = crt::warm_cwbvh_kernels()) || (e = crt::warm_scene_build_kernels()))
+        return fail(CRT_ERR_HIP, std::string("crt_warmup: loading a code object failed: ") + hipGetErrorString((hipError_t)e));
+    return CRT_OK;
 }
 
 int crt_has_experiments(void) {
@@ -1138,7 +1153,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         if (sa.wave_samples == 2u)
             wide_auto = (double)(s->n_local_pixels / 16u) * (double)(n_samples / 4u) >= 8.0 * (double)s->n_cu * 4.0 * 6.0;
         sa.wide_first = (b == 0 && (s->wide_first == 2u ? wide_auto : s->wide_first != 0u)) ? 1u : 0u;
-        if (b == 0) s->last_launch_form = (int)sa.wave_samples;
+        if (b == 0) { s->last_launch_form = (int)sa.wave_samples; s->last_launch_samples = (int)n_samples; }
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
 #ifdef CRT_EXPERIMENTS
@@ -1164,7 +1179,8 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         // (P * n_samples spread evenly over the 8 groups is fewer chunks than that when the units do not divide by 8.)
         uint32_t grid = s->trace_grid(P, sa.wide_first ? 6 : 5);
         if (b > 0 && deferred) grid *= n_samples;
-        crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, grid, s->waves_per_workgroup, s->stream);
+        const int wide_ran = crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, grid, s->waves_per_workgroup, s->stream);
+        if (b == 0) s->last_launch_wide = wide_ran;
         if (sa.bins_out.count) {
             // fill counts -> the next launch's index space and ray count, and the next frame's capacities (the other parity)
             crt::BinScanArgs ba{};
@@ -1698,6 +1714,12 @@ static int gather_peers(crt_scene* s) {
 int crt_debug_launch_form(crt_scene* s, int32_t* form) {
     if (!s || !form) return fail(CRT_ERR_INVALID, "crt_debug_launch_form: null argument");
     *form = s->last_launch_form;
+    return CRT_OK;
+}
+
+int crt_debug_launch_info(crt_scene* s, int32_t info[4]) {
+    if (!s || !info) return fail(CRT_ERR_INVALID, "crt_debug_launch_info: null argument");
+    info[0] = s->last_launch_form; info[1] = s->last_launch_wide; info[2] = s->last_launch_samples; info[3] = (int32_t)s->peers.size() + 1;
     return CRT_OK;
 }
 

@@ -353,6 +353,22 @@ int cwbvh_convert_on_device(const crt_flatnode* d_bvh2, uint32_t n2, uint32_t ns
     return CRT_OK;
 }
 
+// crt_warmup: load this translation unit's code object on the current device (device_build.hpp)
+int warm_cwbvh_kernels() {
+    hipFuncAttributes a;
+    hipError_t e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_parents))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_depths))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_level_starts))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_costs_level))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_discover))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sizes))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_place))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_emit))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_cover))) != hipSuccess) return (int)e;
+    return 0;
+}
+
 }  // namespace crt
 
 extern "C" {

@@ -69,4 +69,11 @@ void launch_gather_slots(const crt_triangle* d_in, const uint32_t* d_tri_order, 
 void launch_gather_records(const crt_triangle* d_in, const uint32_t* d_tri_order, const int32_t* d_tri_slots, const float* d_verts, uint32_t n_tris8,
                            float4* d_recs, hipStream_t stream);
 
+// ---- code-object warm-up (crt_warmup) ----
+// HIP loads a code object the first time one of its kernels is looked up; each of these asks for the attributes of its
+// translation unit's kernels, which loads that unit's code object on the current device (~ms each) without launching anything.
+int warm_lbvh_kernels();
+int warm_cwbvh_kernels();
+int warm_scene_build_kernels();
+
 }  // namespace crt

@@ -1327,6 +1327,41 @@ int lbvh_build_on_device(const int32_t* d_vidx, uint32_t stride, const float* d_
     return CRT_OK;
 }
 
+// crt_warmup: load this translation unit's code object on the current device (device_build.hpp)
+int warm_lbvh_kernels() {
+    hipFuncAttributes a;
+    hipError_t e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_tri_order))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_tri_bounds))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_morton))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_radix_tree))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_bfs_keys))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_bfs_pos))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_flatten))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_level_starts))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_refit_level))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_init))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_nn))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_flags))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_apply))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_tail))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_bfs_keys))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_ploc_flatten))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_init))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_cbounds))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_bin))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_advance))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_sweep))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_flags))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_scatter))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_small_counts))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_small<8>))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_small<16>))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_small<SAH_SMALL>))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sah_flatten))) != hipSuccess) return (int)e;
+    return 0;
+}
+
 }  // namespace crt
 
 extern "C" {

@@ -978,7 +978,9 @@ template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool B
           bool BATCH = false, bool WIDE = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
-    const bool wave_samples = BATCH && a.wave_samples == 1u;      // uniform: the workgroup's waves are the samples of one 64-pixel batch
+    // uniform: the workgroup's waves are the samples of one 64-pixel batch.  The 6-waves-per-SIMD build is never launched in that form
+    // (launch_segment), and compiling the form out of it frees the registers its LDS result strip and wave index would hold
+    const bool wave_samples = BATCH && !WIDE && a.wave_samples == 1u;
     // uniform: a wave is one 4 x 4 pixel quadrant of a batch x 4 samples (lane = sample * 16 + pixel): the 64 rays of a wave leave a
     // quarter of the area, i.e. agree on their nodes like the rays of a frame of twice the resolution
     const bool lane_samples = BATCH && a.wave_samples == 2u;
@@ -1707,8 +1709,7 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 // -DCRT_EXPERIMENTS (make EXPERIMENTS=1), where the GPU suite still checks it bit for bit.
 //               k_segment<FIRST, STATS, TEX, PRETRACED, INPLACE, BVH2, MAT, COMPACT, SHARE, BATCH, WIDE>
 #define CRT_K(F, S, T, Y, B2, M, SH, BA, WI) k_segment<F, S, T, false, Y, B2, M, false, SH, BA, WI>
-void launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool inplace, bool bvh2, bool mat, bool /*compact*/, bool stats, uint32_t grid, uint32_t /*waves*/,
-                    hipStream_t stream) {
+static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, bool bvh2, bool mat, bool stats, uint32_t grid, hipStream_t stream, int& wide_ran) {
     const bool tex = a.textures != nullptr;
     const bool share = !first && a.tri_share != 0u && a.tri_min != 0u && inplace && !bvh2;
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
@@ -1731,7 +1732,7 @@ void launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool i
         const size_t ll = side_by_side ? lds4 : lds;
         if (feat == 2)      launch(CRT_K(true, false, true, true, false, true, false, true, false), gg, bb, ll, stream, v);
         else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, true, false), gg, bb, ll, stream, v);
-        else if (v.wide_first && !side_by_side) launch(CRT_K(true, false, false, true, false, false, false, true, true), gg, bb, ll, stream, v);
+        else if (v.wide_first && !side_by_side) { wide_ran = 1; launch(CRT_K(true, false, false, true, false, false, false, true, true), gg, bb, ll, stream, v); }
         else                launch(CRT_K(true, false, false, true, false, false, false, true, false), gg, bb, ll, stream, v);
         return;
     }
@@ -1772,12 +1773,19 @@ void launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool i
     }
 }
 #undef CRT_K
+// returns 1 when the launch ran the 6-waves-per-SIMD (WIDE) build of the first-segment kernel, else 0 (crt_debug_launch_info)
+int launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool inplace, bool bvh2, bool mat, bool /*compact*/, bool stats, uint32_t grid, uint32_t /*waves*/,
+                   hipStream_t stream) {
+    int wide_ran = 0;
+    launch_segment_impl(a, first, inplace, bvh2, mat, stats, grid, stream, wide_ran);
+    return wide_ran;
+}
 #else   // CRT_EXPERIMENTS: every variant the kernel's template parameters describe
 #define CRT_KSEG(F, S, T, P, Y, B, M, C, SH, BA) \
     (a.wide_first ? k_segment<F, S, T, P, Y, B, M, C, SH, BA, (F) && !(S)> : k_segment<F, S, T, P, Y, B, M, C, SH, BA, false>)
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+static void launch_segment_impl(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
     const bool share = a.tri_share != 0u && a.tri_min != 0u && inplace && !pretraced && !bvh2 && !compact;
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
     size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
@@ -1797,7 +1805,7 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
         seq.wave_samples = 0u;
         if (a.wave_samples == 2u) {
             // the samples in the lanes of four single-wave workgroups per batch; in this build with the plain batched kernels only
-            if ((a.n_samples & 3u) || bvh2 || share || waves != 1u) return launch_segment(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
+            if ((a.n_samples & 3u) || bvh2 || share || waves != 1u) return launch_segment_impl(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
             const dim3 g16(grid * 16u), b1(64u);
 #define CRT_LAUNCH_LS(T, M) launch(CRT_KSEG(true, false, T, false, true, false, M, false, false, true), g16, b1, per_wave, stream, a)
             if (mat) { if (tex) CRT_LAUNCH_LS(true, true); else CRT_LAUNCH_LS(false, true); }
@@ -1805,7 +1813,7 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
 #undef CRT_LAUNCH_LS
             return;
         }
-        if (a.wave_samples && lds4 > 64u * 1024u) return launch_segment(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
+        if (a.wave_samples && lds4 > 64u * 1024u) return launch_segment_impl(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
         if (a.wave_samples) {
             // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups
             const dim3 g4(grid * 4u), b4(ws * 64u);
@@ -1845,6 +1853,10 @@ void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inpla
 #undef CRT_LAUNCH_SEG_T
 #undef CRT_LAUNCH_SEG
 }
+int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
+    launch_segment_impl(a, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
+    return (a.wide_first && first && !stats && (a.n_samples <= 1u || a.wave_samples == 2u)) ? 1 : 0;      // CRT_KSEG's choice; batched launches only in the lanes form
+}
 #endif  // CRT_EXPERIMENTS
 #ifdef CRT_EXPERIMENTS
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
@@ -1873,6 +1885,20 @@ void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint3
 }
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, stream, linear, n_pixels, inv_count, rgba);
+}
+
+// crt_warmup: load this translation unit's code object on the current device (asking for a kernel's attributes does that without
+// launching anything); the other kernels of the unit come with it
+int warm_rt_kernels() {
+    hipFuncAttributes a;
+    hipError_t e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_trace<false, false>))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_trace<true, false>))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_shadow<false>))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_untile))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_resolve))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_accumulate_samples))) != hipSuccess) return (int)e;
+    return 0;
 }
 
 }  // namespace crt

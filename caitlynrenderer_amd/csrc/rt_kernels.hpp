@@ -179,7 +179,8 @@ void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, uint3
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 // mat: the scene has Mirror / Disney materials (CWBVH lock-step segments only: not with pretraced or bvh2)
 // compact: gather the in-place shadow rays of a 2- or 4-wave workgroup into full waves before walking them
-void launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+// returns 1 when the launch ran the 6-waves-per-SIMD (WIDE) build of the first-segment kernel
+int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
@@ -188,5 +189,7 @@ void launch_bin_scan(const BinScanArgs& a, hipStream_t stream);
 void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pixels, uint32_t n_samples, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
+
+int warm_rt_kernels();      // crt_warmup: loads this unit's code object on the current device
 
 }  // namespace crt

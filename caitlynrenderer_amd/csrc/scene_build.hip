@@ -90,4 +90,15 @@ void launch_gather_records(const crt_triangle* d_in, const uint32_t* d_tri_order
     hipLaunchKernelGGL(k_gather_records, grid_for(n_tris8), dim3(256), 0, stream, d_in, d_tri_order, d_tri_slots, d_verts, n_tris8, d_recs);
 }
 
+// crt_warmup: load this translation unit's code object on the current device (device_build.hpp)
+int warm_scene_build_kernels() {
+    hipFuncAttributes a;
+    hipError_t e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_validate_triangles))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_gather_slots))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_gather_records))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_restride))) != hipSuccess) return (int)e;
+    return 0;
+}
+
 }  // namespace crt

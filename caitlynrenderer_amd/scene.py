@@ -179,6 +179,14 @@ class Scene:
         check(lib().crt_debug_launch_form(self._h, C.byref(form)))
         return form.value
 
+    def debug_launch_info(self):
+        """crt_debug_launch_info of the last first-segment launch: {"form": 0 | 1 | 2 (2 = four samples of a 4x4 pixel quadrant in the
+        lanes of a wave), "wide": the 6-waves-per-SIMD build ran, "samples": samples per pixel of the launch, "shards": tile shards
+        side by side (streams / devices)}"""
+        info = (C.c_int32 * 4)()
+        check(lib().crt_debug_launch_info(self._h, info))
+        return {"form": info[0], "wide": bool(info[1]), "samples": info[2], "shards": info[3]}
+
     def set_shard(self, rank, world, tile=16):
         check(lib().crt_set_shard(self._h, int(rank), int(world), int(tile)))
 

@@ -254,6 +254,10 @@ int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint
 /* test hook: how the last launch of crt_render_frame(s) ran the samples of its first segment: *form = 0 one sample, or several
  * one after the other in each wave; 1 = side by side on the waves of a workgroup (option "wave_samples") */
 int crt_debug_launch_form(crt_scene* s, int32_t* form);
+/* test hook: the same launch in full: info[0] = form as above (2 = four samples of a 4 x 4 pixel quadrant in the lanes of a wave),
+ * info[1] = 1 when the first segment ran its 6-waves-per-SIMD build (option "wide_first"), info[2] = samples per pixel of the launch,
+ * info[3] = tile shards rendering side by side (option "streams" / crt_set_devices) */
+int crt_debug_launch_info(crt_scene* s, int32_t info[4]);
 
 /* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is
  * cut into tile x tile squares dealt round-robin in Morton order to `world` ranks;
@@ -321,6 +325,11 @@ typedef struct crt_bvh_info {
 } crt_bvh_info;
 int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out);
 int crt_device_count(void);
+/* Optional, once per process and device (the current HIP device): creates the HIP context and loads the library's code objects —
+ * traversal kernels, GPU builders, CWBVH converter — so that the first crt_scene_create does not pay for it (HIP loads a code object
+ * at the first use of one of its kernels: ~10 ms of a first build-on-device scene at 1 M triangles).  The reference pays the
+ * equivalent in Scene::Scene, where its shaders are compiled before the first frame (Scene.h:1080-1083, Shader.h:18-97). */
+int crt_warmup(void);
 /* 1 when the library carries the experimental kernel variants (built with -DCRT_EXPERIMENTS), else 0 */
 int crt_has_experiments(void);
 
