@@ -14,6 +14,8 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
     "extras" (compact: value, ms_per_step, launch_ms, frac, algorithmic_gbps, traffic):
       "cornell"            configs[1]: Cornell box, CWBVH, 1 spp primary + shadow, 1920x1080 (one launch per frame);
       "gpu_tree"           configs[2] over a tree built on the GPU (binned SAH, everything assembled in HBM by crt_scene_create);
+      "d2"                 configs[2]'s mesh with 2 path segments: the other reading of the metric's "primary + 1 bounce" (the headline is
+                           primary + shadow, SURVEY 8d's reading);
       "incoherent"         configs[3]: same mesh, 4 path segments (incoherent bounce rays), the reference's Lambert integrator;
       "incoherent_disney"  configs[3] with the oracle-defined mirror + GGX / Disney-diffuse materials;
       "scale_base"         configs[4] at N = 1: the 3840x2160 frame of that mesh on one GPU (what the N > 1 lines divide by);
@@ -32,13 +34,17 @@ simply is one of the ranks.
 
 Prints ONE JSON line (< 6 KB) on rank 0 with the driver's keys plus
   "roofline": the dominant kernel (the fused segment kernel) against the roof that binds it — VECTOR-INSTRUCTION ISSUE, not HBM (every
-      BASELINE scene is cache-resident: SURVEY §8d's algorithmic bytes / time exceeds the HBM peak and is reported as
-      `algorithmic_gbps`, never as a fraction).  achieved = algorithmic wave-instructions of a launch / its mean HIP-event duration (blocks that render tile shards side by side on several streams — `config.streams` > 1: multi-segment paths and few-node scenes — take the step's wall time / its launches per shard instead: the time a segment of the WHOLE frame takes);
-      peak = 1024 SIMDs x 2.4 GHz / 2 cycles; definitions, instruction counts and the script that recomputes every frac:
-      tools/roofline.py, profiles/isa_counts.json.  `traffic` = L2<->fabric bytes per launch, (2 FETCH_SIZE + WRITE_SIZE) x 1024 from
-      rocprofv3 --pmc passes this invocation runs itself as child processes before its own first GPU call (`traffic_source:
-      "live"`; --no-live-pmc or a missing rocprofv3: the committed passes of profiles/pmc_traffic.json, "committed"); `issue_busy`,
-      `lane_util` from the SQ pass of the same.
+      BASELINE scene is cache-resident: SURVEY 8d's algorithmic bytes / time exceeds the HBM peak and is reported as `algorithmic_gbps`,
+      never as a fraction).  achieved = TRAVERSAL wave-instructions of a launch — (node visits x I_node + triangle tests x I_tri) / 64,
+      straight-line blocks counted in the ISA — / its mean HIP-event duration (blocks that render tile shards side by side on several
+      streams — `config.streams` > 1 — take the step's wall time / its launches per shard instead: the time a segment of the WHOLE
+      frame takes); peak = 1024 SIMDs x 2.4 GHz / 2 cycles.  `issue_busy`, `lane_util` and their product `counter_frac` come from
+      rocprofv3 --pmc passes this invocation runs itself as child processes before its own first GPU call (`traffic_source: "live"`;
+      --no-live-pmc or a missing rocprofv3: the committed passes of profiles/pmc_traffic.json, "committed"); frac <= counter_frac by
+      construction, `non_traversal_share` = 1 - frac / counter_frac is the ray's shell (ray generation, shading, NEE, bounce
+      sampling) plus the loop's bookkeeping.  `traffic` = L2<->fabric bytes per launch, (2 FETCH_SIZE + WRITE_SIZE) x 1024 from the
+      same passes; `hbm_frac` = traffic / time / 8 TB/s (HBM traffic proper only for the scene that exceeds the Infinity Cache).
+      Definitions and the script that recomputes every figure: tools/roofline.py, profiles/isa_counts.json.
   "cpu_baseline": the CPU oracle on the same workload, bounded sample, rank 0, N = 1.
 """
 import argparse
@@ -91,6 +97,9 @@ def parse_args(argv=None):
                     help="untimed rendering before the warm-up steps, in ms of wall time (default 100): clocks and caches reach the steady "
                          "state the metric is about; 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true",
+                    help="skip `sum_rows_match_oracle` (after the timed region every block renders one more step in the timed form and compares "
+                         "16 rows of the sum with the CPU oracle)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="auto workload at N = 1: do not run the rocprofv3 --pmc passes (roofline.traffic / valu_issue then come from the "
                          "committed profiles/pmc_traffic.json and say so)")
@@ -124,6 +133,7 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    env.setdefault("CRT_BUILD_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))      # every rank builds the SBVH: share the cores (host/sbvh.cpp usable_threads)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}")
@@ -489,6 +499,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
 
         # ray counts of the LAST timed frame (every frame does identical work up to the per-frame random vector) and
         # the mean launch time over the timed region; then a short event-timed tail for the per-kernel split
+        launch_info = scene.debug_launch_info()          # how the timed steps' first-segment launches ran (form, build, samples, shards)
         st = scene.frame_stats()
         n_timed_launches = st["n_trace_launches"] if streams == 1 else launches_per_step * K
         launch_ms_timed = st["ms_trace_closest"] / max(1, n_timed_launches)
@@ -530,16 +541,21 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         counters = {"primary_rays": int(n_primary), "closest_rays": int(cs["closest_rays"]), "any_rays": int(cs["any_rays"]),
                     "closest_hits": int(cs["closest_hits"]), "nodes_closest": int(cs["nodes_closest"]), "tris_closest": int(cs["tris_closest"]),
                     "nodes_any": int(cs["nodes_any"]), "tris_any": int(cs["tris_any"])}
-        roofline = valu_roofline(counters, t_launch, launches, samples_per_launch, args.accel)
-        vi = pmc.get("valu_issue") or {}
+        roofline = valu_roofline(counters, t_launch, launches, samples_per_launch, args.accel, pmc)
+        if one_proc and len(set(one_proc)) < len(one_proc):
+            # virtual devices share one GPU: a launch's duration there says nothing about the kernel (the number this mode prints is not a
+            # scaling figure either)
+            roofline["achieved"] = roofline["frac"] = None
+        traffic_gbps = round(traffic / t_launch / 1e9, 1) if traffic and t_launch > 0 else None
         roofline.update({
             "traffic": traffic, "traffic_source": pmc.get("source"),
             # bytes crossing L2 <-> fabric per second; for a scene larger than the 256 MiB Infinity Cache (the hbm_resident blocks) this is
             # HBM bandwidth, for the cache-resident BASELINE scenes mostly MALL hits
-            "traffic_gbps": round(traffic / t_launch / 1e9, 1) if traffic and t_launch > 0 else None,
+            "traffic_gbps": traffic_gbps,
+            "hbm_frac": round(traffic_gbps / HBM_PEAK_GBS, 4) if traffic_gbps else None,      # L2<->fabric bytes / s over the HBM peak: HBM traffic proper only when the scene exceeds the Infinity Cache
             "algorithmic_gbps": round(alg_bytes / t_launch / 1e9, 1) if t_launch > 0 else None,
             "algorithmic_bytes_per_launch": int(alg_bytes),
-            "issue_busy": vi.get("busy"), "lane_util": vi.get("lane_util"), "l2_hit_rate": pmc.get("l2_hit_rate"),
+            "l2_hit_rate": pmc.get("l2_hit_rate"),
             "launch_ms": round(t_launch * 1e3, 4), "launches_timed": int(n_timed_launches), "samples_per_launch": int(samples_per_launch),
             "path_segments": depth, "frame_device_ms": round(float(np.median(total_ms)), 4),
             "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3), "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
@@ -558,11 +574,21 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         if use_dist:
             out["gather_ms"] = round(gather_ms, 4)
             out["rank_device_ms_per_step"] = [round(x, 4) for x in rank_ms]
+            # what the collective library itself saw: the driver's record then shows RCCL with N ranks
+            out["collective"] = {"backend": ctx.dist.get_backend(), "ranks_seen": int(ctx.dist.get_world_size()), "transport": "torch.distributed gather of the packed tiles to rank 0 (RCCL grouped send / recv under the nccl backend)",
+                                 "build_threads_per_rank": int(os.environ.get("CRT_BUILD_THREADS", "0") or 0)}
         if one_proc:
             out["gather_ms"] = round(gather_ms, 4)
-            out["config"]["devices"] = scene.devices()["devices"]
+            dv = scene.devices()
+            out["config"]["devices"] = dv["devices"]
+            out["collective"] = {"backend": "libcrt (crt_set_devices)", "ranks_seen": len(dv["devices"]), "transport": dv["transport"]}
         if build_info:
             out["config"]["device_build"] = build_info
+        out["config"]["launch"] = launch_info
+        if not args.no_oracle_check and args.accel == "cwbvh" and (world == 1 or one_proc):
+            # after the clock has stopped: ONE more step, exactly as the timed region ran it, on a cleared sum, and 16 rows of the result
+            # against the CPU oracle on the same frames (the checker, never the thing measured)
+            out["sum_rows_match_oracle"] = rows_match_oracle(scene, step, Wu, spp, rvs, data, name, device_built, materials or args.materials, cam, W, H, depth)
         if cpu_base and not args.no_cpu_baseline and args.accel == "cwbvh":
             out["cpu_baseline"] = cpu_baseline(data, cam, W, H, depth, rvs[0], cs)
     if takes_part:
@@ -570,12 +596,55 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
     return out
 
 
+def rows_match_oracle(scene, step, Wu, spp, rvs, data, name, device_built, materials, cam, W, H, depth):
+    """True / False: the sum buffer after one step of the timed form equals the oracle's on 16 pixel rows through the image centre, bit
+    for bit.  A scene crt_scene_create built on the GPU is checked against the oracle walking the same builder's tree (downloaded through
+    the host-array entry points).  None when the check could not run."""
+    import numpy as np
+    import caitlynrenderer_amd as cr
+    try:
+        from oracle import binding as ob
+        if data is None:
+            key = (name, device_built, "device", "lambert")
+            if key not in _SCENE_CACHE:
+                mesh, _ = source_mesh(name)
+                t0 = time.time()
+                _SCENE_CACHE[key] = (cr.SceneData.build(mesh, cam, builder=device_built, convert="device"), cam, "", time.time() - t0)
+            data = _SCENE_CACHE[key][0]
+        scene.set_option("timing", 0)
+        scene.reset()
+        step(Wu)                                      # the first timed step's frames
+        scene.sync()
+        got = scene.read_sum()
+        y0 = (H // 2 - 8) // 8 * 8
+        orc = ob.Oracle(data, W, H, depth, cam)
+        rows = np.zeros((H, W, 3), np.float32)
+        for rx, ry in rvs[1 + Wu * spp:1 + (Wu + 1) * spp]:
+            orc.render_rows(rx, ry, y0, y0 + 16, rows)
+        return bool(np.array_equal(got[y0:y0 + 16].view(np.uint32), rows[y0:y0 + 16].view(np.uint32)) and rows[y0:y0 + 16].max() > 0)
+    except Exception as e:                             # the check must never take the measurement down with it
+        log(f"[bench] oracle row check did not run: {e!r}")
+        return None
+
+
 _ISA = None
+_RL = None
 
 
-def valu_roofline(c, t_launch, launches, samples_per_launch, accel="cwbvh"):
+def roofline_module():
+    global _RL
+    if _RL is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("crt_roofline", os.path.join(ROOT, "tools", "roofline.py"))
+        _RL = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_RL)
+    return _RL
+
+
+def valu_roofline(c, t_launch, launches, samples_per_launch, accel="cwbvh", pmc=None):
     """The roof that binds the segment kernel: vector-instruction issue (tools/roofline.py has the definition and recomputes it).
-    achieved = algorithmic wave-instructions per launch / launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction."""
+    achieved = traversal wave-instructions per launch / launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction;
+    with counters (pmc): issue_busy, lane_util, counter_frac = their product (>= frac by construction), non_traversal_share."""
     global _ISA
     if _ISA is None:
         try:
@@ -585,14 +654,9 @@ def valu_roofline(c, t_launch, launches, samples_per_launch, accel="cwbvh"):
     r = {"bound": "valu_issue", "kernel": "k_segment (ray generation / queue fetch + CWBVH closest hit + shading + in-place NEE any-hit walk), mean over the path's segments",
          "achieved": None, "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Gwave-instr/s", "frac": None}
     if _ISA.get("I_node") and accel == "cwbvh" and t_launch > 0:
-        n_first, n_bounce = c["primary_rays"], c["closest_rays"] - c["primary_rays"]
-        lane_instr = ((c["nodes_closest"] + c["nodes_any"]) * _ISA["I_node"] + (c["tris_closest"] + c["tris_any"]) * _ISA["I_tri"]
-                      + n_first * _ISA["I_ray_first"] + n_bounce * _ISA.get("I_ray_bounce", _ISA["I_ray_first"]) + c["closest_hits"] * _ISA["I_shade"])
-        w = lane_instr / 64.0 / launches * samples_per_launch
-        r["achieved"] = round(w / t_launch / 1e9, 1)
-        r["frac"] = round(r["achieved"] / VALU_PEAK_GINSTR, 4)
-        r["attainable"] = _ISA.get("attainable_gwave_instr_per_s")      # the same roof at the measured issue cost of this instruction mix
-        r["algorithmic_wave_instr_per_launch"] = int(w)
+        got = roofline_module().roofline_block(c, _ISA, t_launch * 1e3, launches, samples_per_launch, pmc)
+        r.update({k: got[k] for k in ("achieved", "frac", "attainable", "traversal_wave_instr_per_launch", "shell_static_wave_instr_per_launch",
+                                      "issue_busy", "lane_util", "counter_frac", "non_traversal_share") if k in got})
     return r
 
 
@@ -686,6 +750,10 @@ def main():
     ctx = Ctx(args)
     if ctx.world != args.gpus and not args.one_process:
         args.gpus = ctx.world
+    if ctx.world > 1:
+        # launched under torch.distributed.run by someone else: the ranks of this node share its cores for the host SBVH build
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", ctx.world))
+        os.environ.setdefault("CRT_BUILD_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, local_world))))
     ctx.init()
     if not args.dry_run:
         import __graft_entry__ as g
@@ -719,6 +787,7 @@ def main():
             if N == 1:
                 extra["cornell"] = run_block(ctx, "cornell", 1920, 1080, 1, 1, True, False, "weak")
                 extra["gpu_tree"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, False, "weak", device_built="sah")
+                extra["d2"] = run_block(ctx, "mesh1m", 1920, 1080, 2, 4, True, False, "weak")      # the other reading of the metric's "primary + 1 bounce": two path segments
                 extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak")
                 extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak", materials="disney")
                 extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
@@ -739,7 +808,7 @@ def main():
         out = {"metric": METRIC.replace("1920x1080", f"{W}x{H}"), "value": head["value"], "unit": head["unit"], "n_gpus": N, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
-        for k in ("cpu_baseline", "gather_ms", "rank_device_ms_per_step"):
+        for k in ("cpu_baseline", "gather_ms", "rank_device_ms_per_step", "sum_rows_match_oracle", "collective"):
             if k in head:
                 out[k] = head[k]
         if head.get("dry_run"):
@@ -767,16 +836,17 @@ def compact(b):
                      + (" disney" if "Disney" in c["workload"] else "") + (" gpu-built" if "device_build" in c else ""),
          "value": b["value"], "ms_per_step": b["ms_per_step"], "launch_ms": r["launch_ms"], "samples_per_launch": r["samples_per_launch"],
          "frac": r["frac"], "achieved": r["achieved"], "algorithmic_gbps": r["algorithmic_gbps"]}
-    for k in ("traffic", "traffic_gbps", "lane_util", "issue_busy", "l2_hit_rate"):
+    for k in ("traffic", "traffic_gbps", "hbm_frac", "issue_busy", "lane_util", "counter_frac", "non_traversal_share", "l2_hit_rate"):
         if r.get(k) is not None:
             e[k] = r[k]
+    if b.get("sum_rows_match_oracle") is not None:
+        e["sum_rows_match_oracle"] = b["sum_rows_match_oracle"]
     if c.get("streams", 1) > 1:
         e["streams"] = c["streams"]       # tile shards side by side: launch_ms is the step's wall time / launches per shard
     if "device_build" in c:
         e["device_build"] = c["device_build"]
-    if c["workload"].find(f"n={HBM_RESIDENT[4:]}:") >= 0 and r.get("traffic_gbps"):
-        e["hbm_frac"] = round(r["traffic_gbps"] / HBM_PEAK_GBS, 4)      # this scene does not fit the Infinity Cache: traffic is HBM traffic
-        e["scene_mb"] = round((80 * c["n_nodes8"] + 48 * c["n_tris8"]) / 1e6, 1)
+    if c["workload"].find(f"n={HBM_RESIDENT[4:]}:") >= 0:
+        e["scene_mb"] = round((80 * c["n_nodes8"] + 48 * c["n_tris8"]) / 1e6, 1)      # this scene does not fit the Infinity Cache: its traffic is HBM traffic
     return e
 
 

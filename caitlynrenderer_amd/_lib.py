@@ -86,6 +86,7 @@ SYMBOLS = {
     "crt_debug_launch_info": (_I, [_P, C.POINTER(C.c_int32)]),
     "crt_set_shard": (_I, [_P, _U32, _U32, _U32]),
     "crt_set_devices": (_I, [_P, C.POINTER(C.c_int32), _U32, _U32]),
+    "crt_shard_tiles": (_I, [_U32] * 7 + [_P, _SZ, C.POINTER(_SZ)]),
     "crt_get_devices": (_I, [_P, C.POINTER(_U32), C.POINTER(C.c_int32), _U32, C.POINTER(C.c_int32), C.POINTER(_F)]),
     "crt_packed_info": (_I, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_SZ)]),
     "crt_read_packed": (_I, [_P, _P, _SZ]),

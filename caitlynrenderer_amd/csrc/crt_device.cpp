@@ -8,9 +8,12 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -113,8 +116,10 @@ struct crt_scene {
     // segments >= 1: 0 = fused lock-step k_segment (default: with the shadow rays walked in place it beats the pools,
     // 1.87 vs 2.09 ms for 4 segments at 1 M triangles); 1 = closest hits through lane-refill pools (k_closest_queue) + shade-only pass
     uint32_t bounce_refill = 0;
-    // crt_render_frames: the samples of a launch on the waves of a workgroup (0 never, 1 always, 2 when the launch is bound by its
-    // longest waves rather than by throughput)
+    // crt_render_frames, how the samples of a launch sit on the hardware (include/crt.h, option "wave_samples"): 0 = one after the other in
+    // each wave; 1 = side by side on the waves of a workgroup; 2 (default) = four samples of a 4 x 4 pixel quadrant in the lanes of a wave
+    // where the launch allows it (a multiple of 4 samples, a tree of >= 64 nodes, CWBVH), otherwise 1 when the launch is bound by its longest
+    // waves rather than by throughput (use_wave_samples) and 0 when not; 3 = lanes where allowed, else 0
     uint32_t wave_samples = 2;
     uint32_t wide_first = 2;            // first-segment kernels built for 6 waves per SIMD: 0 never, 1 always, 2 by the same measure
     float tile_cost_spread = 0.f;       // 99th percentile of the measured tile costs over their mean; 0 = nothing measured yet
@@ -286,24 +291,37 @@ int require_device() {
     return CRT_OK;
 }
 
-int build_shard(crt_scene* s) {
-    const uint32_t T = s->tile;
-    const uint32_t tx_n = (s->width + T - 1) / T, ty_n = (s->height + T - 1) / T;
+// The tiles of shard `rank` of `world`: the frame's tile x tile squares in Morton order, every world-th one starting at the rank-th
+// (SURVEY 8e).  Pure host arithmetic: crt_set_shard, crt_set_devices, option "streams" and the [host] entry crt_shard_tiles share it.
+void deal_tiles(uint32_t width, uint32_t height, uint32_t T, uint32_t rank, uint32_t world, std::vector<uint2>& tiles, uint64_t* pixels_in_frame) {
+    const uint32_t tx_n = (width + T - 1) / T, ty_n = (height + T - 1) / T;
     struct Item { uint32_t code, x, y; };
     std::vector<Item> all;
     all.reserve((size_t)tx_n * ty_n);
     for (uint32_t y = 0; y < ty_n; ++y)
         for (uint32_t x = 0; x < tx_n; ++x) all.push_back({morton2(x, y), x, y});
     std::sort(all.begin(), all.end(), [](const Item& a, const Item& b) { return a.code < b.code; });
-    s->tiles.clear();
-    s->n_local_in_frame = 0;
-    for (size_t k = s->rank; k < all.size(); k += s->world) {
-        s->tiles.push_back(make_uint2(all[k].x, all[k].y));
-        const uint32_t w = std::min(T, s->width - all[k].x * T), h = std::min(T, s->height - all[k].y * T);
-        s->n_local_in_frame += (uint64_t)w * h;
+    tiles.clear();
+    uint64_t in_frame = 0;
+    for (size_t k = rank; k < all.size(); k += world) {
+        tiles.push_back(make_uint2(all[k].x, all[k].y));
+        const uint32_t w = std::min(T, width - all[k].x * T), h = std::min(T, height - all[k].y * T);
+        in_frame += (uint64_t)w * h;
     }
+    if (pixels_in_frame) *pixels_in_frame = in_frame;
+}
+
+// Logical device k of n_devices, dividing shard base_rank of base_world among themselves (set_devices_of_shard): every n-th tile of that
+// shard's list starting at its k-th, i.e. shard base_rank + k * base_world of base_world * n_devices of the whole frame.
+inline void device_share(uint32_t k, uint32_t n_devices, uint32_t base_rank, uint32_t base_world, uint32_t* rank, uint32_t* world) {
+    *rank = base_rank + k * base_world;
+    *world = base_world * n_devices;
+}
+
+int build_shard(crt_scene* s) {
+    deal_tiles(s->width, s->height, s->tile, s->rank, s->world, s->tiles, &s->n_local_in_frame);
     s->n_local_tiles = (uint32_t)s->tiles.size();
-    const uint64_t px = (uint64_t)s->n_local_tiles * T * T;
+    const uint64_t px = (uint64_t)s->n_local_tiles * s->tile * s->tile;
     if (px >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "framebuffer shard too large for 32-bit pixel indices");
     s->n_local_pixels = (uint32_t)px;
     return CRT_OK;
@@ -500,18 +518,71 @@ int crt_device_count(void) {
     return n;
 }
 
-// Everything a first crt_scene_create would otherwise pay for once per process and device, paid here instead: the HIP context of the
-// current device and the library's four code objects (traversal kernels, the GPU builders with their sort / scan kernels, the CWBVH
-// converter, the scene-assembly kernels).  HIP loads a code object when one of its kernels is first looked up — measured on MI355X at
-// 1,004,672 triangles: the first crt_scene_create(... CRT_BUILD_SAH) of a process 22 ms, the second 8.7 (profiles/r04_build_probe.txt).
+// HIP loads a code object when one of its kernels is first looked up.  The library has four (traversal kernels; the GPU builders
+// with their sort / scan kernels; the CWBVH converter; scene assembly), and the builders' alone costs 12.5 ms on MI355X — more than the
+// whole build of a million triangles it then runs (profiles/r04_build_probe.txt: the first crt_scene_create(... CRT_BUILD_SAH) of a
+// process that had already rendered took 22.2 ms, every later one 8.4).  So the first scene a process creates on a device starts a
+// thread that loads all four while the caller uploads and renders; a build-on-device creation waits for it instead of loading
+// the same code objects itself.  crt_warmup() does the same synchronously.
+namespace {
+struct Warmer {
+    std::mutex m;
+    std::thread t;
+    bool started[64] = {};                         // per HIP device
+    int rc = 0;
+    static int load_all() {
+        int e;
+        if ((e = crt::warm_rt_kernels()) || (e = crt::warm_lbvh_kernels()) || (e = crt::warm_cwbvh_kernels()) || (e = crt::warm_scene_build_kernels())) return e;
+        return 0;
+    }
+    void start(int device) {                       // returns at once
+        std::lock_guard<std::mutex> g(m);
+        if (device < 0 || device >= 64 || started[device]) return;
+        started[device] = true;
+        if (t.joinable()) t.join();
+        try {
+            t = std::thread([this, device] { if (hipSetDevice(device) == hipSuccess) rc = load_all(); });
+        } catch (const std::exception&) { /* no thread: the code objects load at first use, as before */ }
+    }
+    void wait() {
+        std::lock_guard<std::mutex> g(m);
+        if (t.joinable()) t.join();
+    }
+    ~Warmer() { if (t.joinable()) t.join(); }
+};
+Warmer g_warmer;
+}  // namespace
+
+// Optional, synchronous: the HIP context of the current device, the library's code objects, and the runtime's own first-use set-up
+// (first stream, first host-to-device copy, first event, first kernel dispatch: ~85 ms in a fresh process, profiles/r04_build_probe.txt)
+// — what the first crt_scene_create of a process otherwise pays.
 int crt_warmup(void) {
     int rc = require_device();
     if (rc) return rc;
     HIPCHK(hipFree(nullptr));                          // creates the context
-    int e;
-    if ((e = crt::warm_rt_kernels()) || (e = crt::warm_lbvh_kernels()) || (e = crt::warm_cwbvh_kernels()) || (e = crt::warm_scene_build_kernels()))
-        return fail(CRT_ERR_HIP, std::string("crt_warmup: loading a code object failed: ") + hipGetErrorString((hipError_t)e));
-    return CRT_OK;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    g_warmer.wait();
+    const int e = Warmer::load_all();
+    if (e) return fail(CRT_ERR_HIP, std::string("crt_warmup: loading a code object failed: ") + hipGetErrorString((hipError_t)e));
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    uint4* d = nullptr;
+    std::vector<uint4> h(4096, make_uint4(1u, 2u, 3u, 4u));           // 64 KB: through the pageable-copy staging path
+    auto done = [&](int code) { if (ev) (void)hipEventDestroy(ev); if (d) (void)hipFree(d); if (st) (void)hipStreamDestroy(st); return code; };
+#define W_CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(CRT_ERR_HIP, std::string("crt_warmup: " #expr ": ") + hipGetErrorString(e_))); } while (0)
+    W_CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    W_CHK(hipEventCreate(&ev));
+    W_CHK(hipMalloc(reinterpret_cast<void**>(&d), 2 * h.size() * sizeof(uint4)));
+    W_CHK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice, st));
+    W_CHK(hipMemsetAsync(d + h.size(), 0, h.size() * sizeof(uint4), st));
+    crt::launch_restride(d, 1u, d + h.size(), 1u, h.size(), st);       // one dispatch of a library kernel
+    W_CHK(hipEventRecord(ev, st));
+    W_CHK(hipMemcpyAsync(h.data(), d + h.size(), 64, hipMemcpyDeviceToHost, st));
+    W_CHK(hipStreamSynchronize(st));
+    W_CHK(hipGetLastError());
+#undef W_CHK
+    return done(CRT_OK);
 }
 
 int crt_has_experiments(void) {
@@ -597,6 +668,10 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
     }
     int rc = require_device();
     if (rc) return rc;
+    {   // the library's other code objects load in the background while this scene is uploaded (see Warmer)
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) g_warmer.start(dev);
+    }
     if (d->build_flags & CRT_BUILD_LBVH_ON_DEVICE) return scene_create_device_built(d, out);
 
     // CWBVH: take the caller's, or convert the BVH2 (cwbvh.h:58)
@@ -808,6 +883,7 @@ static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
                                          " index out of range");
 
     // BVH2 (kept: it is the FlatNode array the BVH2 frame mode and CRT_TRACE_BVH2 walk) -> CWBVH
+    g_warmer.wait();                              // the builders' code objects: loaded by now, or being loaded by that thread
     if ((rc = dev_alloc(&s->d_bvh2, (size_t)n2 * 2))) return rc;
     uint32_t depth2 = 0, n8 = 0, depth8 = 0;
     float lbvh_ms = 0.f, conv_ms = 0.f;
@@ -901,8 +977,9 @@ int crt_reset(crt_scene* s) {
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(s->d_sum, 0, 3 * (size_t)std::max<uint32_t>(s->n_local_pixels, 1) * sizeof(float), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    for (crt_scene* p : s->peers) { rc = crt_reset(p); if (rc) return rc; }
-    return CRT_OK;
+    for (crt_scene* p : s->peers) { rc = crt_reset(p); if (rc) break; }
+    if (!s->peers.empty()) (void)hipSetDevice(s->device);
+    return rc;
 }
 
 int crt_set_option(crt_scene* s, const char* name, int value) {
@@ -971,7 +1048,13 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         }
     }
     else if (!std::strcmp(name, "ray_bins")) s->ray_bins = (uint32_t)std::min(3, std::max(0, value));
-    else if (!std::strcmp(name, "debug_fail_batch_alloc")) s->debug_fail_batch_alloc = value ? 1u : 0u;
+    else if (!std::strcmp(name, "debug_fail_batch_alloc")) {
+        // one injected failure, on ONE device: 1 = this scene's own, k >= 2 = its (k - 1)-th peer (streams / crt_set_devices); 0 disarms all
+        if (value >= 2 && (size_t)(value - 2) < s->peers.size()) s->peers[(size_t)(value - 2)]->debug_fail_batch_alloc = 1u;
+        else s->debug_fail_batch_alloc = value == 1 ? 1u : 0u;
+        if (value == 0) for (crt_scene* p : s->peers) p->debug_fail_batch_alloc = 0u;
+        return CRT_OK;
+    }
     else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: plain per-lane closest-hit loop (what trees of a few nodes get)
     else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
     else if (!std::strcmp(name, "trace_pool")) {
@@ -986,7 +1069,8 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         return CRT_OK;
     }
     else return fail(CRT_ERR_INVALID, std::string("crt_set_option: unknown option ") + name);
-    for (crt_scene* p : s->peers) { const int rc = crt_set_option(p, name, value); if (rc) return rc; }
+    for (crt_scene* p : s->peers) { const int rc = crt_set_option(p, name, value); if (rc) { (void)hipSetDevice(s->device); return rc; } }
+    if (!s->peers.empty()) (void)hipSetDevice(s->device);      // "timing_accumulate" visits the peers' devices
     return CRT_OK;
 }
 
@@ -994,33 +1078,61 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
 // whose shadow rays are walked in place: nothing is queued between launches): the same launch renders that many samples of
 // every pixel one after the other — what n_samples calls would do, bit for bit, without their launch gaps and kernel tails.
 static int ensure_batch_buffers(crt_scene* s, uint32_t cap);
-static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs, const float* rys) {
-    if (!s) return fail(CRT_ERR_INVALID, "crt_render_frame: null scene");
-    if (!s->have_camera) return fail(CRT_ERR_INVALID, "crt_render_frame: crt_set_camera was never called");
+static bool uses_ray_bins(const crt_scene* s) {
+    // bounce rays binned between the segments (option "ray_bins"): big trees, CWBVH walks, the lock-step segment kernels
+    return s->ray_bins != 0u && s->max_depth > 1u && s->info.n_nodes8 >= 64 && s->accel == 0u && !s->bounce_refill;
+}
+// Everything a batch of n_samples needs ALLOCATED on this device, and nothing enqueued: a scene on several devices or streams prepares
+// all of them before the first launch of any, so that an allocation failing on one leaves no device with half a batch in its sums.
+static int prepare_batch(crt_scene* s, uint32_t n_samples) {
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
     if (s->n_local_pixels == 0) return CRT_OK;
-    const uint32_t P = s->n_local_pixels;
     const bool deferred = n_samples > 1u && s->max_depth > 1u;       // finished paths leave their radiance in d_lfinal
     if (deferred && (rc = ensure_batch_buffers(s, n_samples))) return rc;   // grows to the largest batch ever asked for
+    if (s->count_visits && !s->d_visit_totals) {
+        if ((rc = dev_alloc(&s->d_visit_totals, 16))) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 16 * sizeof(unsigned long long)));
+    }
+    // the shadow queue (inplace_shadow = 0) and the hit buffer of the bounce pools (bounce_refill = 1): allocated by the first frame that needs them
+    const size_t Q = 8 * (size_t)s->sub_capacity;
+    if (!s->inplace_shadow && s->accel == 0u && !s->d_shadow && (rc = dev_alloc(&s->d_shadow, 3 * Q))) return rc;
+    if (s->bounce_refill && s->max_depth > 1 && !s->d_qhits && (rc = dev_alloc(&s->d_qhits, Q))) return rc;
+    if (uses_ray_bins(s)) {
+        if (!s->d_bins) {
+            if ((rc = dev_alloc(&s->d_bins, crt_scene::bins_words()))) return rc;
+            HIPCHK(hipMemsetAsync(s->d_bins, 0, crt_scene::bins_words() * sizeof(uint32_t), s->stream));     // capacities 0: a first launch overflows entirely
+        }
+        if (!s->rays_doubled) {
+            // twice the entries any launch can emit: the bins' places in the first half, the overflow region — in the worst case every
+            // ray of a launch, e.g. the first one after the view changed — in the second.  Between two frames the queues hold nothing.
+            const uint32_t Qe = 8u * s->sub_capacity;
+            HIPCHK(hipStreamSynchronize(s->stream));
+            float4 *r0 = nullptr, *r1 = nullptr;
+            if ((rc = dev_alloc(&r0, 4 * (size_t)Qe)) || (rc = dev_alloc(&r1, 4 * (size_t)Qe))) { if (r0) (void)hipFree(r0); return rc; }
+            (void)hipFree(s->d_rays[0]); (void)hipFree(s->d_rays[1]);
+            s->d_rays[0] = r0; s->d_rays[1] = r1;
+            s->rays_doubled = true;
+        }
+    }
+    return CRT_OK;
+}
+
+static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs, const float* rys) {
+    if (!s) return fail(CRT_ERR_INVALID, "crt_render_frame: null scene");
+    if (!s->have_camera) return fail(CRT_ERR_INVALID, "crt_render_frame: crt_set_camera was never called");
+    int rc = prepare_batch(s, n_samples);            // sets the device; a no-op when render_batch_all has prepared every device already
+    if (rc) return rc;
+    if (s->n_local_pixels == 0) return CRT_OK;
+    const uint32_t P = s->n_local_pixels;
+    const bool deferred = n_samples > 1u && s->max_depth > 1u;
     const float rx = rxs[0], ry = rys[0];
     const crt::FrameArgs f = frame_args(s, rx, ry);
     if (!s->timing_accumulate) s->n_spans = 0;
-    if (s->count_visits) {
-        if (!s->d_visit_totals) {
-            if ((rc = dev_alloc(&s->d_visit_totals, 16))) return rc;
-            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 16 * sizeof(unsigned long long)));
-        }
-        HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 16 * sizeof(unsigned long long), s->stream));
-    }
+    if (s->count_visits) HIPCHK(hipMemsetAsync(s->d_visit_totals, 0, 16 * sizeof(unsigned long long), s->stream));
     // counter banks alternate per frame; k_segment<FIRST> clears the other bank for the frame after this one, so a
     // memset is only needed for the very first frame (or after a failed launch left the banks in an unknown state)
-    {
-        const size_t Q = 8 * (size_t)s->sub_capacity;
-        if (!s->inplace_shadow && s->accel == 0u && !s->d_shadow && (rc = dev_alloc(&s->d_shadow, 3 * Q))) return rc;
-        if (s->bounce_refill && s->max_depth > 1 && !s->d_qhits && (rc = dev_alloc(&s->d_qhits, Q))) return rc;
-    }
     // tile order: adopt a finished measurement, start one if the view is new
     bool measure_tiles = false;
     if (s->adaptive_tiles && s->n_local_tiles > 1 && !s->capturing) {
@@ -1094,23 +1206,8 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.tri_share = s->tri_share == 3u ? (b == 0 ? 0u : 2u) : s->tri_share;
         if (s->info.n_tris8 > (1ull << 24)) sa.tri_share = 0u;     // a shared item is (triangle index | owner lane << 24)
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
-        // bounce rays binned between the segments (option "ray_bins"): big trees, CWBVH walks, the lock-step segment kernels
-        const bool bins = s->ray_bins != 0u && s->max_depth > 1u && !small_tree && !bvh2 && !s->bounce_refill;
-        if (bins && !s->d_bins) {
-            if ((rc = dev_alloc(&s->d_bins, crt_scene::bins_words()))) return rc;
-            HIPCHK(hipMemsetAsync(s->d_bins, 0, crt_scene::bins_words() * sizeof(uint32_t), s->stream));     // capacities 0: a first launch overflows entirely
-        }
+        const bool bins = uses_ray_bins(s);              // tables and the queues' overflow halves exist (prepare_batch)
         const uint32_t Qe = 8u * s->sub_capacity;        // entries of the bins' half of a queue = what the sub-queue form holds
-        if (bins && !s->rays_doubled) {
-            // twice the entries any launch can emit: the bins' places in the first half, the overflow region — in the worst case every
-            // ray of a launch, e.g. the first one after the view changed — in the second.  Between two frames the queues hold nothing.
-            HIPCHK(hipStreamSynchronize(s->stream));
-            float4 *r0 = nullptr, *r1 = nullptr;
-            if ((rc = dev_alloc(&r0, 4 * (size_t)Qe)) || (rc = dev_alloc(&r1, 4 * (size_t)Qe))) { if (r0) (void)hipFree(r0); return rc; }
-            (void)hipFree(s->d_rays[0]); (void)hipFree(s->d_rays[1]);
-            s->d_rays[0] = r0; s->d_rays[1] = r1;
-            s->rays_doubled = true;
-        }
         if (bins && b + 1 < s->max_depth) {
             crt::RayBins& o = sa.bins_out;
             o.count = s->bin_count(b + 1); o.cap = s->bin_cap(s->bank, b + 1); o.off = s->bin_off(s->bank, b + 1);
@@ -1273,10 +1370,18 @@ static uint32_t batch_limit(const crt_scene* s) {
 
 // one batch on every device of the scene: each enqueues on its own stream and returns, so the devices render concurrently
 static int render_batch_all(crt_scene* s, uint32_t n_samples, const float* rxs, const float* rys) {
-    int rc = render_batch_async(s, n_samples, rxs, rys);
-    if (rc) return rc;
-    for (crt_scene* p : s->peers) if ((rc = render_batch_async(p, n_samples, rxs, rys))) return rc;
-    return CRT_OK;
+    int rc = CRT_OK;
+    if (!s->peers.empty()) {
+        // phase 1: every device's buffers for this batch exist before any device renders (a failed growth leaves every sum as it was)
+        if (!s->have_camera) return fail(CRT_ERR_INVALID, "crt_render_frame: crt_set_camera was never called");
+        if ((rc = prepare_batch(s, n_samples))) { (void)hipSetDevice(s->device); return rc; }
+        for (crt_scene* p : s->peers) if ((rc = prepare_batch(p, n_samples))) { (void)hipSetDevice(s->device); return rc; }
+    }
+    // phase 2: enqueue everywhere
+    rc = render_batch_async(s, n_samples, rxs, rys);
+    for (size_t k = 0; !rc && k < s->peers.size(); ++k) rc = render_batch_async(s->peers[k], n_samples, rxs, rys);
+    if (!s->peers.empty()) (void)hipSetDevice(s->device);      // the caller's thread keeps the device the scene lives on
+    return rc;
 }
 
 int crt_render_frame_async(crt_scene* s, float rx, float ry) {
@@ -1512,14 +1617,22 @@ struct Rccl {
     typedef const char* (*ErrStr)(int);
     InitAll init_all = nullptr; Destroy destroy = nullptr; Group group_start = nullptr, group_end = nullptr;
     SendRecv send = nullptr, recv = nullptr; ErrStr err = nullptr;
+    bool loaded = false;                // every symbol below resolved: set last, so a partial resolve can never be taken for a loaded library
     bool load(void** lib) {
+        if (loaded) return true;
+        void* h = nullptr;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
-            if ((*lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-        if (!*lib) return false;
-        init_all = (InitAll)dlsym(*lib, "ncclCommInitAll"); destroy = (Destroy)dlsym(*lib, "ncclCommDestroy");
-        group_start = (Group)dlsym(*lib, "ncclGroupStart"); group_end = (Group)dlsym(*lib, "ncclGroupEnd");
-        send = (SendRecv)dlsym(*lib, "ncclSend"); recv = (SendRecv)dlsym(*lib, "ncclRecv"); err = (ErrStr)dlsym(*lib, "ncclGetErrorString");
-        return init_all && destroy && group_start && group_end && send && recv;
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return false;
+        Rccl r;
+        r.init_all = (InitAll)dlsym(h, "ncclCommInitAll"); r.destroy = (Destroy)dlsym(h, "ncclCommDestroy");
+        r.group_start = (Group)dlsym(h, "ncclGroupStart"); r.group_end = (Group)dlsym(h, "ncclGroupEnd");
+        r.send = (SendRecv)dlsym(h, "ncclSend"); r.recv = (SendRecv)dlsym(h, "ncclRecv"); r.err = (ErrStr)dlsym(h, "ncclGetErrorString");
+        if (!(r.init_all && r.destroy && r.group_start && r.group_end && r.send && r.recv)) { (void)dlclose(h); return false; }
+        r.loaded = true;
+        *this = r;
+        *lib = h;
+        return true;
     }
 };
 Rccl g_rccl;
@@ -1588,8 +1701,9 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
 // the caller's own shard (crt_set_shard) when option "streams" splits it over streams of one GPU: device k takes the tiles
 // base_rank + k * base_world, + n * base_world, ... of the Morton order, i.e. every n-th tile of that shard's list starting at its k-th
 int crt_set_devices(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile) {
-    if (s) { s->shard_rank = 0u; s->shard_world = 1u; }      // the devices divide the whole frame
-    return set_devices_of_shard(s, devices, n_devices, tile, 0u, 1u);
+    const int rc = set_devices_of_shard(s, devices, n_devices, tile, 0u, 1u);
+    if (rc == CRT_OK) { s->shard_rank = 0u; s->shard_world = 1u; }      // the devices divide the whole frame (a refused call changes nothing)
+    return rc;
 }
 
 static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile, uint32_t base_rank, uint32_t base_world) {
@@ -1617,11 +1731,13 @@ static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n
             if ((rc = replicate_scene(s, devices[k], &p))) return undo(rc);
             p->primary = s;
             s->peers.push_back(p);
-            p->rank = base_rank + k * base_world; p->world = base_world * n_devices; p->tile = tile;
+            device_share(k, n_devices, base_rank, base_world, &p->rank, &p->world);
+            p->tile = tile;
             if ((rc = alloc_frame_buffers(p))) return undo(rc);
         }
-        HIPCHK(hipSetDevice(s->device));
-        s->rank = base_rank; s->world = base_world * n_devices; s->tile = tile;
+        if (hipSetDevice(s->device) != hipSuccess) return undo(fail(CRT_ERR_HIP, "crt_set_devices: hipSetDevice failed"));
+        device_share(0u, n_devices, base_rank, base_world, &s->rank, &s->world);
+        s->tile = tile;
         if ((rc = alloc_frame_buffers(s))) return undo(rc);
         for (crt_scene* p : s->peers) {                      // where a peer's slice lands on this device, and its tile list
             float* g = nullptr; uint2* t = nullptr; hipEvent_t e = nullptr;
@@ -1644,7 +1760,10 @@ static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n
     // than once: a test arrangement) cannot have them; a missing library is not an error either: the copies below do the same job.
     s->gather_transport = 1;
     if (n_devices > 1 && distinct) {
-        if (!g_rccl.init_all && !g_rccl.load(&s->rccl_lib)) {
+        const char* env_tr = std::getenv("CRT_GATHER_TRANSPORT");     // "copy": peer copies even where RCCL would load
+        if (env_tr && !std::strcmp(env_tr, "copy")) {
+            (void)fail(CRT_OK, "crt_set_devices: CRT_GATHER_TRANSPORT=copy, gathering with hipMemcpyPeerAsync");
+        } else if (!g_rccl.load(&s->rccl_lib)) {
             (void)fail(CRT_OK, "crt_set_devices: librccl.so not loadable, gathering with hipMemcpyPeerAsync");
         } else {
             std::vector<int> ids(devices, devices + n_devices);
@@ -1656,9 +1775,28 @@ static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n
             } else {
                 s->gather_transport = 0;
             }
-            HIPCHK(hipSetDevice(s->device));
+            (void)hipSetDevice(s->device);                  // ncclCommInitAll visits every device; the scene is complete either way
         }
     }
+    return CRT_OK;
+}
+
+// [host] the tile list a scene would give logical device `device` of `n_devices` when those divide shard (rank of world) of a width x
+// height frame among themselves — crt_set_shard (n_devices = 1), crt_set_devices (rank 0 of world 1) and option "streams" all deal
+// tiles through this.  No GPU involved: the multi-GPU bookkeeping can be checked on any machine.
+int crt_shard_tiles(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t world, uint32_t device, uint32_t n_devices,
+                    uint32_t* tile_xy, size_t capacity, size_t* n_tiles) {
+    if (!n_tiles) return fail(CRT_ERR_INVALID, "crt_shard_tiles: null n_tiles");
+    if (width == 0 || height == 0 || width > 65535u * 8u || height > 65535u * 8u) return fail(CRT_ERR_INVALID, "crt_shard_tiles: bad resolution");
+    if (tile < 8 || (tile & 7u) || tile > 1024) return fail(CRT_ERR_INVALID, "crt_shard_tiles: tile must be a multiple of 8 in 8..1024");
+    if (world == 0 || rank >= world || n_devices == 0 || n_devices > 64 || device >= n_devices) return fail(CRT_ERR_INVALID, "crt_shard_tiles: rank/world/device");
+    uint32_t r = 0, w = 1;
+    device_share(device, n_devices, rank, world, &r, &w);
+    std::vector<uint2> tiles;
+    try { deal_tiles(width, height, tile, r, w, tiles, nullptr); } catch (const std::exception& e) { return fail(CRT_ERR_NOMEM, std::string("crt_shard_tiles: ") + e.what()); }
+    *n_tiles = tiles.size();
+    if (tile_xy)
+        for (size_t i = 0; i < tiles.size() && i < capacity; ++i) { tile_xy[2 * i] = tiles[i].x; tile_xy[2 * i + 1] = tiles[i].y; }
     return CRT_OK;
 }
 
@@ -1688,9 +1826,20 @@ static int gather_peers(crt_scene* s) {
         }
         const int ne = g_rccl.group_end();
         if (nr == 0) nr = ne;
-        if (nr != 0) return fail(CRT_ERR_HIP, std::string("crt_read_sum: RCCL gather failed: ") + (g_rccl.err ? g_rccl.err(nr) : "?"));
-        HIPCHK(hipSetDevice(s->device));
-    } else {
+        (void)hipSetDevice(s->device);
+        if (nr != 0) {
+            // a first run on real hardware must not end here: the peer copies below do the same job (the slices are disjoint buffers;
+            // whatever part of the grouped send / recv was enqueued wrote the same bytes to the same places)
+            (void)fail(CRT_OK, std::string("crt_read_sum: RCCL gather failed (") + (g_rccl.err ? g_rccl.err(nr) : "?") + "), gathering with hipMemcpyPeerAsync from now on");
+            std::fprintf(stderr, "[crt] %s\n", crt_last_error());
+            s->gather_transport = 1;
+            for (crt_scene* p : s->peers) { (void)hipSetDevice(p->device); (void)hipStreamSynchronize(p->stream); }
+            (void)hipSetDevice(s->device);
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipGetLastError();
+        }
+    }
+    if (s->gather_transport != 0 || s->rccl_comms.empty()) {
         for (size_t k = 0; k < s->peers.size(); ++k) {
             crt_scene* p = s->peers[k];
             const size_t bytes = 3 * (size_t)p->n_local_pixels * sizeof(float);
@@ -1726,6 +1875,8 @@ int crt_debug_launch_info(crt_scene* s, int32_t info[4]) {
 int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint32_t reps, float* ms_stream, float* ms_graph) {
     if (!s || !rxy || !ms_stream || !ms_graph || n_frames == 0 || (n_frames & 1u) || reps == 0)
         return fail(CRT_ERR_INVALID, "crt_debug_time_graph: bad argument (n_frames must be even: the counter banks alternate)");
+    if (!s->peers.empty() || s->primary)
+        return fail(CRT_ERR_INVALID, "crt_debug_time_graph: one stream only (option streams 1, no crt_set_devices): the capture records this scene's stream, not its peers'");
     HIPCHK(hipSetDevice(s->device));
     const uint32_t timing0 = s->timing;
     s->timing = 0;                                         // event-carrying launches are not capturable

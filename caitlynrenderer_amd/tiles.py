@@ -30,6 +30,18 @@ def local_tiles(width, height, tile, rank, world):
     return tile_order(width, height, tile)[rank::world]
 
 
+def shard_tiles_of_library(width, height, tile, rank=0, world=1, device=0, n_devices=1):
+    """crt_shard_tiles: the (tx, ty) list libcrt.so itself deals to logical device `device` of `n_devices` inside shard `rank` of `world`
+    (host arithmetic, no GPU) — what `local_tiles` must agree with."""
+    import ctypes as C
+    from . import _lib
+    n = C.c_size_t()
+    _lib.check(_lib.lib().crt_shard_tiles(width, height, tile, rank, world, device, n_devices, None, 0, C.byref(n)))
+    xy = np.zeros((n.value, 2), np.uint32)
+    _lib.check(_lib.lib().crt_shard_tiles(width, height, tile, rank, world, device, n_devices, xy.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+    return [(int(x), int(y)) for x, y in xy]
+
+
 def max_local_tiles(width, height, tile, world):
     n = len(tile_order(width, height, tile))
     return (n + world - 1) // world

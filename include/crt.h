@@ -284,6 +284,12 @@ int crt_set_shard(crt_scene* s, uint32_t rank, uint32_t world, uint32_t tile);
  * crt_trace*, crt_packed_info / crt_read_packed act on device 0 alone.  One process per GPU with crt_set_shard and the
  * caller's own collective (caitlynrenderer_amd/tiles.py, bench.py --gpus N) remains the other way to use several GPUs. */
 int crt_set_devices(crt_scene* s, const int32_t* devices, uint32_t n_devices, uint32_t tile);
+/* [host] Which tiles logical device `device` of `n_devices` renders when those devices divide shard `rank` of `world` of a width x height
+ * frame among themselves: tile_xy receives (x, y) pairs in the order of the device's packed buffer (up to `capacity` pairs), *n_tiles the
+ * count.  crt_set_shard is (rank, world, 0, 1); crt_set_devices (0, 1, k, n); option "streams" on a shard (rank, world, k, streams).
+ * No GPU needed: the bookkeeping of SURVEY 8e can be checked on any machine. */
+int crt_shard_tiles(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t world, uint32_t device, uint32_t n_devices,
+                    uint32_t* tile_xy, size_t capacity, size_t* n_tiles);
 /* what crt_set_devices left: the device list (up to `capacity` entries), how the gather travels (0 RCCL, 1 peer copies)
  * and the host milliseconds the last gather took (enqueue to completion on device 0); any pointer may be NULL */
 int crt_get_devices(crt_scene* s, uint32_t* n_devices, int32_t* devices, uint32_t capacity, int32_t* transport, float* last_gather_ms);
@@ -325,10 +331,13 @@ typedef struct crt_bvh_info {
 } crt_bvh_info;
 int crt_get_bvh_info(crt_scene* s, crt_bvh_info* out);
 int crt_device_count(void);
-/* Optional, once per process and device (the current HIP device): creates the HIP context and loads the library's code objects —
- * traversal kernels, GPU builders, CWBVH converter — so that the first crt_scene_create does not pay for it (HIP loads a code object
- * at the first use of one of its kernels: ~10 ms of a first build-on-device scene at 1 M triangles).  The reference pays the
- * equivalent in Scene::Scene, where its shaders are compiled before the first frame (Scene.h:1080-1083, Shader.h:18-97). */
+/* Optional, once per process and device (the current HIP device), synchronous: creates the HIP context, loads the library's code
+ * objects (traversal kernels, GPU builders, CWBVH converter, scene assembly) and runs the HIP runtime's own first-use set-up (first
+ * stream, first copy, first dispatch), so that the first crt_scene_create does not pay for them.  Without it the first
+ * crt_scene_create of a process starts a thread that loads the code objects while the scene is uploaded (HIP loads a code object at
+ * the first use of one of its kernels: 12.5 ms for the builders', more than the build of a million triangles that follows).  The
+ * reference pays the equivalent in Scene::gpu_data, where its shaders are compiled before the first frame (Scene.h:1080-1083,
+ * Shader.h:18-97). */
 int crt_warmup(void);
 /* 1 when the library carries the experimental kernel variants (built with -DCRT_EXPERIMENTS), else 0 */
 int crt_has_experiments(void);

@@ -720,6 +720,37 @@ def test_one_handle_several_devices_gather_inside_the_c_abi(cr, ob, cornell, sce
     multi.close(); single.close()
 
 
+def test_two_real_devices_rccl_and_copy_transports_agree(cr, ob, cornell, scenes):
+    """Only on a machine with >= 2 GPUs (skipped on the one-GPU test box): ONE handle on two distinct devices — replication over the
+    fabric, tile sharding, and the gather inside crt_read_sum through RCCL send / recv and through hipMemcpyPeerAsync — each
+    bit-identical to the single-device sum; the calling thread's current HIP device is the scene's own after every entry point."""
+    import torch
+    from caitlynrenderer_amd import _lib
+    if _lib.lib().crt_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _, _, data = scenes["tess8"]
+    W, H, depth = 250, 140, 3
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(5)]
+    single = cr.Scene(data, W, H, depth)
+    single.render_frame(*rvs[0]); single.render_frames(rvs[1:])
+    want = single.read_sum()
+    single.close()
+    for transport in (0, 1):
+        multi = cr.Scene(data, W, H, depth)
+        multi.set_devices([0, 1], 16)
+        if transport == 0 and multi.devices()["transport"] != "rccl":
+            multi.close()
+            continue                                                  # librccl.so not loadable here: the copies are all there is
+        multi.set_option("gather_transport", transport)
+        multi.render_frame(*rvs[0]); assert torch.cuda.current_device() == 0
+        multi.render_frames(rvs[1:]); assert torch.cuda.current_device() == 0
+        got = multi.read_sum(); assert torch.cuda.current_device() == 0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), transport
+        multi.reset(); assert torch.cuda.current_device() == 0
+        multi.close()
+
+
 def test_device_resident_trace_and_torch_interop(cr, ob, cornell, scenes):
     """crt_trace_device on torch-owned HBM buffers (the bench path): same bits as the host-buffer entry."""
     import torch
@@ -1060,6 +1091,69 @@ def test_wide_first_segment_build_on_the_whole_million_triangle_frame(cr, ob, me
         s.close()
 
 
+def _bench_step(scene, rvs):
+    """bench.py run_block's step(): crt_render_frames (async) of a step's frames, default options."""
+    scene.render_frames(rvs, sync=False)
+
+
+def test_the_launches_bench_times_equal_the_oracle_at_full_size(cr, ob, mesh1m):
+    """What bench.py's timed region runs on BASELINE configs[2], held to the oracle at full size: a step is ONE
+    crt_render_frames call of 4 frames with every option at its default — which must come out as launch form 2 (four samples of a 4x4
+    pixel quadrant in the lanes of a wave) on the 6-waves-per-SIMD build of the first-segment kernel — on (a) the host-built tree of the
+    1,004,672-triangle mesh (the headline block) and (b) the tree the GPU SAH builder makes of the same mesh inside crt_scene_create (the
+    `gpu_tree` block; the oracle walks the same builder's tree).  Two steps each — the second runs on the cost-sorted tile order the first
+    one measured — the whole 1920x1080 frame against the oracle bit for bit."""
+    big, data, cam = mesh1m
+    W, H = 1920, 1080
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(8)]
+    sah = cr.SceneData.build(big, cam, builder="sah", convert="device")
+    for label, make, tree in (("host-built", lambda: cr.Scene(data, W, H, 1), data),
+                              ("gpu-built", lambda: cr.Scene(cr.SceneData.for_device_build(big, cam, builder="sah"), W, H, 1), sah)):
+        orc = ob.Oracle(tree, W, H, 1, cam)
+        ref = np.zeros((H, W, 3), np.float32)
+        for r in rvs:
+            orc.render_frame(r[0], r[1], ref, threads=16)
+        s = make()
+        if label == "gpu-built":
+            assert s.bvh_info()["n_nodes8"] == sah.bvh8.shape[0] and s.bvh_info()["built_on_device"] == 1
+        for k in range(2):
+            _bench_step(s, rvs[4 * k:4 * k + 4])
+            s.sync()
+            info = s.debug_launch_info()
+            assert info == {"form": 2, "wide": True, "samples": 4, "shards": 1}, (label, k, info)
+        out = s.read_sum()
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (label, float(np.abs(out - ref).max()))
+        assert s.frame_stats()["stack_overflows"] == 0
+        s.close()
+
+
+def test_the_incoherent_blocks_of_the_bench_equal_the_oracle_at_full_size(cr, ob, mesh1m):
+    """bench.py's `incoherent` block (BASELINE configs[3], the reference's Lambert integrator): 4 path segments, a step = one
+    crt_render_frames call of 4 frames, option "streams" 0 — the library's pick, two tile shards of the frame on two streams — and the
+    two-segment block `d2` (the other reading of "primary + 1 bounce") the same way.  Whole 1920x1080 frames against the oracle."""
+    _, data, cam = mesh1m
+    W, H = 1920, 1080
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(4)]
+    for depth in (4, 2):
+        orc = ob.Oracle(data, W, H, depth, cam)
+        ref = np.zeros((H, W, 3), np.float32)
+        for r in rvs:
+            orc.render_frame(r[0], r[1], ref, threads=16)
+        s = cr.Scene(data, W, H, depth)
+        s.set_option("streams", 0)
+        assert len(s.devices()["devices"]) == 2
+        _bench_step(s, rvs)
+        s.sync()
+        info = s.debug_launch_info()
+        assert info["form"] == 2 and info["samples"] == 4 and info["shards"] == 2, info
+        out = s.read_sum()
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (depth, float(np.abs(out - ref).max()))
+        assert s.frame_stats()["stack_overflows"] == 0
+        s.close()
+
+
 def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
     """The bench's `hbm_resident` workload: the Cornell scene tessellated to 8,112,002 triangles (n = 520) — 390 MB of intersection
     records + 73 MB of nodes, more than the 256 MiB Infinity Cache, so its fetches are HBM fetches — built by the GPU SAH builder
@@ -1110,6 +1204,25 @@ def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
     dev.render_frame(RX1, RY1)
     assert np.array_equal(dev.read_sum().view(np.uint32), out.view(np.uint32))
     dev.close()
+    # the launches bench.py's hbm_resident blocks time: the device-built scene, a step = 4 frames through one crt_render_frames call with
+    # default options, at one segment (lanes form on the 6-wave build) and at four (two streams); 16 rows against the oracle
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(4)]
+    for depth, shards in ((1, 1), (4, 2)):
+        orc_d = ob.Oracle(data, W, H, depth, cam)
+        rows = np.zeros((H, W, 3), np.float32)
+        for r in rvs:
+            orc_d.render_rows(r[0], r[1], 536, 552, rows)
+        dev = cr.Scene(cr.SceneData.for_device_build(mesh, cam, builder="sah"), W, H, depth)
+        dev.set_option("streams", 0)
+        _bench_step(dev, rvs)
+        dev.sync()
+        li = dev.debug_launch_info()
+        assert li["form"] == 2 and li["samples"] == 4 and li["shards"] == shards and (li["wide"] or depth > 1), li
+        got = dev.read_sum()
+        assert np.array_equal(got[536:552].view(np.uint32), rows[536:552].view(np.uint32)) and rows[536:552].max() > 0, depth
+        assert dev.frame_stats()["stack_overflows"] == 0
+        dev.close()
 
 
 @pytest.fixture(scope="module")
@@ -1458,6 +1571,22 @@ def test_a_failed_growth_of_the_batch_buffers_leaves_the_scene_usable(cr, ob, co
         orc.render_frame(r[0], r[1], ref, threads=8)
     assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32))
     s.close()
+    # with tile shards on several streams (the default of crt::Scene for such paths) every shard's buffers are grown BEFORE any
+    # shard renders — a growth that fails on the second shard leaves the first shard's sums untouched, not half a batch ahead
+    for failing in (1, 2):                                          # the scene's own shard, its first peer
+        s = cr.Scene(data, W, H, depth)
+        s.set_option("streams", 2)
+        s.render_frame(*rvs[0])
+        before = s.read_sum()
+        s.set_option("debug_fail_batch_alloc", failing)
+        with pytest.raises(cr.CrtError) as e:
+            s.render_frames(rvs[1:5])
+        assert e.value.code == _lib.CRT_ERR_NOMEM
+        assert np.array_equal(s.read_sum().view(np.uint32), before.view(np.uint32)), failing
+        s.render_frame(*rvs[1])
+        s.render_frames(rvs[2:6])
+        assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32)), failing
+        s.close()
 
 
 def _same_cwbvh(a, b):

@@ -21,6 +21,32 @@ def test_tile_order_is_a_partition(cr):
     assert dy[:64].max() == 7 and dx[:64].max() == 7
 
 
+def test_library_deals_the_same_tiles_without_a_gpu(cr):
+    """The multi-GPU bookkeeping of libcrt.so itself (crt_shard_tiles, the arithmetic crt_set_shard / crt_set_devices / option "streams"
+    deal their tiles with) on no GPU at all: 8 ranks, and 8 devices behind one handle, get exactly the Python mirror's lists — a
+    partition of the 4K frame of BASELINE configs[4] —, and a shard split again over streams is that shard's list dealt round-robin."""
+    from caitlynrenderer_amd import tiles
+    for (W, H, T) in ((3840, 2160, 16), (3840, 2160, 64), (250, 140, 16), (8, 8, 8)):
+        order = tiles.tile_order(W, H, T)
+        for world in (1, 2, 8):
+            per_rank = [tiles.shard_tiles_of_library(W, H, T, r, world) for r in range(world)]              # crt_set_shard(r, world)
+            per_dev = [tiles.shard_tiles_of_library(W, H, T, 0, 1, k, world) for k in range(world)]         # crt_set_devices, device k of `world`
+            assert per_rank == per_dev == [tiles.local_tiles(W, H, T, r, world) for r in range(world)]
+            assert sorted(sum(per_rank, [])) == sorted(order)
+            assert max(map(len, per_rank)) - min(map(len, per_rank)) <= 1
+        # option "streams" = 3 on rank 5 of 8: stream j renders tiles j, j + 3, ... of that rank's own list
+        mine = tiles.local_tiles(W, H, T, 5, 8)
+        parts = [tiles.shard_tiles_of_library(W, H, T, 5, 8, j, 3) for j in range(3)]
+        assert parts == [mine[j::3] for j in range(3)]
+    import pytest
+    with pytest.raises(cr.CrtError):
+        tiles.shard_tiles_of_library(64, 64, 12)           # tile not a multiple of 8
+    with pytest.raises(cr.CrtError):
+        tiles.shard_tiles_of_library(64, 64, 16, 2, 2)     # rank >= world
+    with pytest.raises(cr.CrtError):
+        tiles.shard_tiles_of_library(64, 64, 16, 0, 1, 3, 3)
+
+
 def test_untile_roundtrip(cr):
     from caitlynrenderer_amd import tiles
     W, H, T = 100, 70, 16

@@ -1,34 +1,43 @@
 #!/usr/bin/env python3
 """The binding roofline of the segment kernels: VALU issue, and everything needed to recompute it from committed files.
 
-  tools/roofline.py isa     [asm] [remarks]   -> profiles/isa_counts.json, profiles/<round>_kernel_resources.txt
-  tools/roofline.py frac    bench.json [kernel_stats.csv]   -> every block's roofline.frac recomputed from the line's own counters
+  tools/roofline.py isa     [asm] [remarks] [tag]   -> profiles/isa_counts.json, profiles/<tag>_kernel_resources.txt
+  tools/roofline.py frac    bench.json [kernel_stats.csv]   -> every block's roofline recomputed from the line's own counters
                                                                (and, with a CSV, from rocprofv3's average duration of the kernel)
 
-Why VALU issue and not HBM.  SURVEY §8d prices a ray at 80 B per node + 52 B per triangle test and divides by 8 TB/s.  Every BASELINE
+Why VALU issue and not HBM.  SURVEY 8d prices a ray at 80 B per node + 52 B per triangle test and divides by 8 TB/s.  Every BASELINE
 scene (<= 110 MB) lives in L1 / L2 / the 256 MiB Infinity Cache, so those bytes never reach HBM and that quotient exceeds 1: it is
-kept as `algorithmic_gbps`, never as a fraction.  The kernel is bound by vector-instruction issue (rocprofv3: every SIMD issues all
-the time), so the roof is
+kept as `algorithmic_gbps`, never as a fraction; the bytes that do cross L2 <-> fabric are `traffic`, and `hbm_frac` = traffic / time /
+8 TB/s.  The kernel is bound by vector-instruction issue, so the roof is
 
     peak      = 1024 SIMDs x 2.4 GHz / 2 cycles            = 1228.8 G wave-instructions/s
                 (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction occupies the ALU for 2 cycles; the same figure as the
                 157.3 TFLOP/s fp32 vector peak)
-    achieved  = ALGORITHMIC wave-instructions / launch time
-    algorithmic wave-instructions of a launch
-              = (N_node x I_node + N_tri x I_tri + N_ray x I_ray + N_hit x I_shade) / 64
-                N_*  : node fetches, triangle tests and rays of the launch (the counting kernels; equal to the CPU oracle's
-                       counters on the same frame, asserted by the GPU tests and by bench.py's cpu_baseline leg)
-                I_*  : vector instructions ONE lane needs for one node visit / one triangle test / what every ray runs (ray generation or
-                       queue fetch, loop set-up, queue emission) / what a ray that hit something runs (shading, NEE set-up, bounce
-                       sampling), counted in the kernel's ISA at the CRT_MARK comment lines of a `make asm` build
-                       (profiles/isa_counts.json); static counts: both sides of a branch inside a block are included
+    achieved  = TRAVERSAL wave-instructions of a launch / its duration
+              = (N_node x I_node + N_tri x I_tri) / 64 / t
+                N_*  : node visits and triangle tests of the launch (the counting kernels; equal to the CPU oracle's counters on the
+                       same frame, asserted by the GPU tests and by bench.py's cpu_baseline leg)
+                I_*  : vector instructions ONE lane executes for one node visit (the 8-wide box test and the mask assembly) / one
+                       Moller-Trumbore test: straight-line blocks, counted in the kernel's ISA between the CRT_MARK lines of a
+                       `make asm` build (profiles/isa_counts.json)
     frac      = achieved / peak
 
-i.e. the fraction of the chip's vector issue slots that did work the algorithm asks for, as if every instruction ran with 64 useful
-lanes.  Idle lanes (divergence), the loop's own bookkeeping (votes, refill logic, stack traffic beyond the visit) and issue slots
-lost to waiting all lower it.  `attainable` is the same with the measured issue cost of this kernel's instruction mix
-(tools/ubench/valu_issue_cycles.hip: 3.3 cycles per wave-instruction per SIMD with 4 waves resident, against 2.5-2.7 for plain
-v_fma_f32 and the 2.0 of the datasheet) instead of 2 cycles.
+i.e. the share of the chip's vector lane-cycles spent inside node and triangle tests — the work SURVEY 8d's algorithmic bytes stand
+for — as 64-lane equivalents.  Every one of these instructions really was issued with those lanes enabled, so the hardware counters of
+the same run bound it from above:
+
+    counter_frac = issue_busy x lane_util      issue_busy = 2 x SQ_INSTS_VALU / (1024 SIMDs x shader cycles)
+                                               lane_util  = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+    frac <= counter_frac                       (asserted on the committed line by tests/test_tools.py)
+    non_traversal_share = 1 - frac / counter_frac
+
+`non_traversal_share` is everything the lanes executed that is not a node or triangle test: the ray's shell (ray generation or queue
+fetch, shading, NEE set-up, bounce sampling, queue emission) and the traversal loop's own bookkeeping (votes, stack, pops).  Round 3
+added a STATIC count of the shell to `achieved` (both sides of every branch): on the Cornell box that claimed more instructions than
+the launch issued altogether (frac 0.82 against a counter bound of 0.44) — the shell's executed cost is not a static count, so it is
+no longer part of `frac`; its static size stays on the line as `shell_static_wave_instr_per_launch` for reference.  `attainable` is the
+roof with the measured issue cost of this kernel's instruction mix (tools/ubench/valu_issue_cycles.hip: 3.3 cycles per wave-instruction
+per SIMD with 4 waves resident, against 2.5-2.7 for plain v_fma_f32 and the 2.0 of the datasheet) instead of 2 cycles.
 """
 import collections
 import csv
@@ -215,23 +224,45 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
         print("wrote", path)
 
 
-def algorithmic_wave_instr(cs, isa, depth=1, samples=1):
-    """Algorithmic wave-instructions of ONE launch: the frame's total over its `depth` segment launches / depth, x samples per launch.
-    cs: totals of one counting frame — primary_rays, closest_rays, closest_hits, nodes_closest, tris_closest, nodes_any, tris_any."""
-    n_first = cs["primary_rays"]
-    n_bounce = cs["closest_rays"] - n_first
-    # hits are not split by segment: the first segment's shading count is used for all of them (the bounce kernels' differs by < 10 %)
-    lane_instr = ((cs["nodes_closest"] + cs["nodes_any"]) * isa["I_node"] + (cs["tris_closest"] + cs["tris_any"]) * isa["I_tri"]
-                  + n_first * isa["I_ray_first"] + n_bounce * isa.get("I_ray_bounce", isa["I_ray_first"]) + cs["closest_hits"] * isa["I_shade"])
+def traversal_wave_instr(cs, isa, depth=1, samples=1):
+    """Traversal wave-instructions of ONE launch (node visits and triangle tests only, 64-lane equivalents): the frame's total over its
+    `depth` segment launches / depth, x samples per launch.  cs: totals of one counting frame."""
+    lane_instr = (cs["nodes_closest"] + cs["nodes_any"]) * isa["I_node"] + (cs["tris_closest"] + cs["tris_any"]) * isa["I_tri"]
     return lane_instr / 64.0 / max(1, depth) * samples
 
 
-def roofline_block(cs, isa, launch_ms, depth, samples):
-    w = algorithmic_wave_instr(cs, isa, depth, samples)
+def shell_static_wave_instr(cs, isa, depth=1, samples=1):
+    """The per-ray shell as a STATIC instruction count (both sides of every branch): an upper bound of what it executes, for reference only."""
+    n_first = cs["primary_rays"]
+    n_bounce = cs["closest_rays"] - n_first
+    lane_instr = n_first * isa["I_ray_first"] + n_bounce * isa.get("I_ray_bounce", isa["I_ray_first"]) + cs["closest_hits"] * isa["I_shade"]
+    return lane_instr / 64.0 / max(1, depth) * samples
+
+
+def counter_figures(pmc, samples_per_launch):
+    """issue_busy, lane_util, their product and the executed lane-full wave-instructions per launch, from an entry of pmc_traffic.json /
+    a live pass (tools/pmc_traffic.py `valu_issue`), scaled to this block's samples per launch.  {} without counters."""
+    vi = (pmc or {}).get("valu_issue") or {}
+    if not vi.get("busy") or not vi.get("lane_util"):
+        return {}
+    scale = samples_per_launch / max(1, (pmc or {}).get("samples_per_launch", 1))
+    return {"issue_busy": vi["busy"], "lane_util": vi["lane_util"], "counter_frac": round(vi["busy"] * vi["lane_util"], 4),
+            "valu_instr_per_launch": int(vi.get("valu_instructions_per_launch", 0) * scale)}
+
+
+def roofline_block(cs, isa, launch_ms, depth, samples, pmc=None):
+    w = traversal_wave_instr(cs, isa, depth, samples)
     achieved = w / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    return {"achieved": round(achieved, 1), "peak": PEAK_GINSTR, "frac": round(achieved / PEAK_GINSTR, 4),
-            "attainable": round(ATTAINABLE_GINSTR, 1), "frac_of_attainable": round(achieved / ATTAINABLE_GINSTR, 4),
-            "algorithmic_wave_instr_per_launch": int(w)}
+    r = {"achieved": round(achieved, 1), "peak": PEAK_GINSTR, "frac": round(achieved / PEAK_GINSTR, 4),
+         "attainable": round(ATTAINABLE_GINSTR, 1), "frac_of_attainable": round(achieved / ATTAINABLE_GINSTR, 4),
+         "traversal_wave_instr_per_launch": int(w), "shell_static_wave_instr_per_launch": int(shell_static_wave_instr(cs, isa, depth, samples))}
+    c = counter_figures(pmc, samples)
+    if c:
+        r.update({"issue_busy": c["issue_busy"], "lane_util": c["lane_util"], "counter_frac": c["counter_frac"]})
+        if c["valu_instr_per_launch"]:
+            # executed lane-full wave-instructions of the launch (everything the lanes did) against the traversal's share of them
+            r["non_traversal_share"] = round(1.0 - w / (c["valu_instr_per_launch"] * c["lane_util"]), 4)
+    return r
 
 
 def cmd_frac(bench_json, stats_csv=None):
@@ -249,9 +280,12 @@ def cmd_frac(bench_json, stats_csv=None):
         cs = r.get("counters")
         if not cs:
             continue
-        got = roofline_block(cs, isa, r["launch_ms"], r.get("path_segments", 1), r.get("samples_per_launch", 1))
-        print(f"{name:22s} launch {r['launch_ms']:.4f} ms  frac {got['frac']:.4f} (line says {r.get('frac')})  achieved {got['achieved']} G wave-instr/s  "
-              f"algorithmic GB/s {r.get('algorithmic_gbps')}")
+        pmc = {"valu_issue": {"busy": r.get("issue_busy"), "lane_util": r.get("lane_util")}} if r.get("issue_busy") else None
+        got = roofline_block(cs, isa, r["launch_ms"], r.get("path_segments", 1), r.get("samples_per_launch", 1), pmc)
+        bound = got.get("counter_frac")
+        print(f"{name:22s} launch {r['launch_ms']:.4f} ms  frac {got['frac']:.4f} (line says {r.get('frac')})"
+              + (f"  <= issue_busy x lane_util {bound:.4f}: {'ok' if got['frac'] <= bound else 'VIOLATED'}" if bound else "  (no counters on this block)")
+              + f"  achieved {got['achieved']} G wave-instr/s  algorithmic GB/s {r.get('algorithmic_gbps')}")
     if avg_us:
         for n, us in sorted(avg_us.items(), key=lambda kv: -kv[1])[:6]:
             print(f"  rocprofv3 average {us:10.1f} us  {n[:110]}")
