@@ -261,7 +261,7 @@ struct crt_scene {
         const uint64_t share = ((n + 4095) / 4096 + 7) / 8 * 4096;
         uint64_t g = 8 * ((share + chunk - 1) / chunk);
         if (oversubscribe != 0u) {
-            const uint64_t lds = (uint64_t)(CRT_TRACE_BLOCK / 64) * stack_entries * 64 * 8;
+            const uint64_t lds = (uint64_t)(CRT_TRACE_BLOCK / 64) * (stack_entries + CRT_HIT_SLOTS) * 64 * 8;
             const uint64_t per_cu = std::min<uint64_t>(std::min(trace_occupancy, reg_cap), std::max<uint64_t>(1, (160 * 1024) / lds));
             g = std::min(g, ((uint64_t)n_cu * per_cu * oversubscribe + 7) / 8 * 8);
         }

@@ -257,23 +257,43 @@ struct TriShare {
 };
 #define CRT_SHARE_BYTES (2 * 64 * 16 + 64 * 4 + 64 * 16)      // per wave
 
-template <bool ANY, bool STATS, bool SHARE = false, typename Load, typename Done>
+// Registers.  What a closest-hit walk carries besides the ray is (t, u, v, triangle, original id) of the best hit so far, yet u, v and
+// the id are written a handful of times per ray (when a nearer hit is accepted) and read once at the end — the id also when two hits tie
+// on t, which is rare.  They live in two extra entries of the lane's LDS stack column (CRT_HIT_SLOTS: stk[stack_entries * 64] =
+// (u, v), stk[(stack_entries + 1) * 64].x = id) instead of three VGPRs across a 600-instruction loop; same values, same comparisons.
+// UNIFORM_O: every ray of the pool starts at the same point (primary rays: the camera position, a kernel argument): the origin then
+// stays in scalar registers (`o_uniform`, never assigned under a lane mask) instead of three more VGPRs; load() still says, per lane,
+// whether it has a ray at all.
+//   bool load(idx, o, d, tmax)  fetches ray idx of the pool (false: no ray in this slot);  done(idx, best, occluded)  consumes its result.
+template <bool ANY, bool STATS, bool SHARE = false, bool UNIFORM_O = false, typename Load, typename Done>
 __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* stk,
                                               int stack_entries, uint32_t* overflow, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
                                               uint32_t tri_min, Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris,
-                                              uint32_t& w_nodes, uint32_t& w_tris, TriShare share = TriShare{nullptr, nullptr, nullptr}) {
+                                              uint32_t& w_nodes, uint32_t& w_tris, TriShare share = TriShare{nullptr, nullptr, nullptr},
+                                              vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t next = pool_begin;                     // wave-uniform
     bool busy = false;
     uint32_t idx = 0;
-    vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
+    vec3 o_lane = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
     bool negx = false, negy = false, negz = false;
     uint32_t oct4 = 0;
-    float max_t = 0.f;
-    HitState best;
-    best.t = 0.f; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
+    float best_t = 0.f;                             // closest hit so far (closest-hit walks: also the far clip of every box and triangle test)
+    int best_tri = -1;
+    uint2* const hit_uv = stk + stack_entries * 64;             // CRT_HIT_SLOTS
+    uint2* const hit_id = stk + (stack_entries + 1) * 64;
     int sp = 0;
     uint2 cur = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    // nearer wins; equal t -> lower original id; the stored id is fetched only when t ties
+    auto accept = [&](float t, float u, float v, int id, int ti) {
+        bool take = t < best_t;
+        if (t == best_t && best_tri >= 0) take = id < (int)hit_id->x;
+        if (take) {
+            best_t = t; best_tri = ti;
+            *hit_uv = make_uint2(__float_as_uint(u), __float_as_uint(v));
+            hit_id->x = (uint32_t)id;
+        }
+    };
     CRT_MARK("loop_begin voting");
     for (;;) {
         const unsigned long long idle = next < pool_end ? __ballot(!busy) : 0ull;     // a drained pool skips the refill logic
@@ -283,27 +303,28 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             if (!busy && mine < pool_end) {
                 idx = mine;
                 float tmax_in;
-                load(idx, o, d, tmax_in);
-                best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
-                max_t = tmax_in;
+                const bool has_ray = load(idx, o_lane, d, tmax_in);
+                best_t = tmax_in; best_tri = -1;
                 sp = 0;
                 busy = true;
                 // same prologue as traverse(): non-finite origin -> immediate miss; clamp zero direction components
-                const bool finite = __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z);
+                const vec3 oo = UNIFORM_O ? o_uniform : o_lane;
+                const bool finite = __builtin_isfinite(oo.x) && __builtin_isfinite(oo.y) && __builtin_isfinite(oo.z);
                 const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
                 negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
                 oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
                 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
-                cur = finite ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
+                cur = (finite && has_ray) ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
                 tg = make_uint2(0u, 0u);
                 if (SHARE) {                        // whoever tests this ray's triangles reads its operands from here
-                    share.ray[lane] = make_float4(o.x, o.y, o.z, 0.f);
+                    share.ray[lane] = make_float4(oo.x, oo.y, oo.z, 0.f);
                     share.ray[64u + lane] = make_float4(d.x, d.y, d.z, 0.f);
                 }
             }
             next = next + n_idle < pool_end ? next + n_idle : pool_end;
         }
         if (__ballot(busy) == 0ull) break;          // pool drained and every lane finished
+        const vec3 o = UNIFORM_O ? o_uniform : o_lane;
 
         // ---- one step per iteration: either a node step (lanes in state N: inner hits pending, no triangle
         // group pending) or a triangle step (lanes in state T: a triangle group pending).  The wave votes: triangle
@@ -340,7 +361,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 const uint4* np = node_rows(nodes, nidx);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                 if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
-                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
+                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
                 cur.x = n1.x;
                 tg.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -394,10 +415,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                         if (id >= 0) {
                             const uint32_t ti = tg.x + (uint32_t)b;
                             if (ANY) {
-                                if (r.x < max_t) { best.tri = (int)ti; finished = true; }
-                            } else if (r.x < best.t || (r.x == best.t && best.tri >= 0 && id < best.id)) {
-                                best.t = r.x; best.u = r.y; best.v = r.z; best.tri = (int)ti; best.id = id;
-                                max_t = r.x;
+                                if (r.x < best_t) { best_tri = (int)ti; finished = true; }
+                            } else {
+                                accept(r.x, r.y, r.z, id, (int)ti);
                             }
                         }
                     }
@@ -416,13 +436,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             float u, v, t;
             if (mt_test(ta, tb, tc, o, d, u, v, t)) {
                 if (ANY) {
-                    if (t < max_t) { best.tri = (int)ti; finished = true; tg.y = 0u; }
+                    if (t < best_t) { best_tri = (int)ti; finished = true; tg.y = 0u; }
                 } else {
-                    const int id = __float_as_int(ta.w);
-                    if (t < best.t || (t == best.t && best.tri >= 0 && id < best.id)) {
-                        best.t = t; best.u = u; best.v = v; best.tri = (int)ti; best.id = id;
-                        max_t = t;
-                    }
+                    accept(t, u, v, __float_as_int(ta.w), (int)ti);
                 }
             }
             CRT_MARK("tri_end");
@@ -433,7 +449,13 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             else { --sp; cur = stk[sp * 64]; }
         }
         if (finished) {
-            done(idx, best, best.tri >= 0);
+            HitState best;
+            best.t = best_t; best.tri = best_tri; best.u = 0.f; best.v = 0.f; best.id = -1;
+            if (!ANY && best_tri >= 0) {
+                const uint2 uv = *hit_uv;
+                best.u = __uint_as_float(uv.x); best.v = __uint_as_float(uv.y); best.id = (int)hit_id->x;
+            }
+            done(idx, best, best_tri >= 0);
             busy = false;
         }
     }
@@ -569,7 +591,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const WaveId wid = wave_id(false, false, a.pool_split_log2);
     const uint32_t lane = wid.lane, wave = wid.wave;
-    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * (a.stack_entries + CRT_HIT_SLOTS) * 64u + lane;
     const uint32_t n = a.count_ptr ? *a.count_ptr : a.n;
     uint32_t nn_total = 0, nt_total = 0;
     CRT_CHUNK_LOOP(it) {
@@ -586,6 +608,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
                 const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
                 o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
                 nn0 = nn; nt0 = nt;
+                return true;
             };
         auto done = [&](uint32_t i, const HitState& best, bool hit) {
                 float4 h;
@@ -987,7 +1010,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
     const WaveId wid = wave_id(wave_samples, lane_samples);
     const uint32_t lane = wid.lane, wave = wid.wave;
     // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
-    const uint32_t wave_stride = (COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) * 64u;
+    const uint32_t wave_stride = ((COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) + CRT_HIT_SLOTS) * 64u;
     uint2* stk = s_lds + (size_t)wid.lds_wave * wave_stride + lane;
     int* stk2 = reinterpret_cast<int*>(s_lds) + (size_t)wid.lds_wave * a.stack_entries2 * 64u + lane;   // BVH2 mode
     TriShare share{nullptr, nullptr, nullptr};
@@ -1114,19 +1137,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             }
             const float4 r0 = rq[0], r1 = rq[1];
             o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z);
-            pix = __float_as_uint(r1.w);
-            if (a.l_final) {                               // a batched frame: the path belongs to sample pix / n_local_pixels, with that frame's randomVector
-                const uint32_t smp_of = pix / f.n_local_pixels;
-                rv = a.rv_s[0];
-                for (uint32_t k = 1; k < 8u; ++k) rv = smp_of == k ? a.rv_s[k] : rv;
-            }
-            const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
-            const float2 sd = a.pb.seed[pix];
-            L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w;
-            T = V3(Tp.x, Tp.y, Tp.z);
-            is_specular = (__float_as_uint(Tp.w) & 1u) != 0u;
-            true_area = (__float_as_uint(Tp.w) & 2u) != 0u;
-            sx = sd.x; sy = sd.y;
+            pix = __float_as_uint(r1.w);                   // the path's state is fetched AFTER the walk (below): nothing of it is needed inside
         }
 
         HitState hit;
@@ -1142,15 +1153,33 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
             if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
-            // ray get a non-finite origin, which finishes immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
-            const float qnan = __uint_as_float(0x7fc00000u);
-            traverse_pool<false, STATS, SHARE>(
+            // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
+            // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
+            traverse_pool<false, STATS, SHARE, FIRST>(
                 a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
-                [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = active ? o : V3(qnan, qnan, qnan); rd = d; tmax = CRT_INF; },
+                [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = o; rd = d; tmax = CRT_INF; return active; },
                 [&](uint32_t, const HitState& best, bool) { hit = best; },
-                nn, nt, wn, wt, share);
+                nn, nt, wn, wt, share, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]));
         }
 
+        if (!FIRST && active) {
+            // Path state of a ray that came through the queue: radiance so far, throughput, RNG state, flags.  Fetched here, behind the
+            // closest-hit walk, instead of where the ray is fetched: a dozen values the walk never looks at would otherwise sit in
+            // VGPRs through its whole loop (the bounce kernels are the ones short of registers: 90-96 VGPRs at 5 waves per SIMD).
+            asm volatile("" : "+v"(pix));                  // keeps the loads below the loop (they depend on this copy of the index)
+            if (a.l_final) {                               // a batched frame: the path belongs to sample pix / n_local_pixels, with that frame's randomVector
+                const uint32_t smp_of = pix / f.n_local_pixels;
+                rv = a.rv_s[0];
+                for (uint32_t k = 1; k < 8u; ++k) rv = smp_of == k ? a.rv_s[k] : rv;
+            }
+            const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
+            const float2 sd = a.pb.seed[pix];
+            L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w;
+            T = V3(Tp.x, Tp.y, Tp.z);
+            is_specular = (__float_as_uint(Tp.w) & 1u) != 0u;
+            true_area = (__float_as_uint(Tp.w) & 2u) != 0u;
+            sx = sd.x; sy = sd.y;
+        }
         bool emit_shadow = false, emit_next = false, finished = active, pending = false;
         float pend_pdf = 0.f;
         float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, nx0 = sh0, nx1 = sh0;
@@ -1272,28 +1301,13 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
                                 }
                                 c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
                                 if (INPLACE) {
-                                    // the occlusion test of path_trace.fs:968 in place (what k_shadow does with a queue entry)
+                                    // the occlusion test of path_trace.fs:968 is walked in this kernel (what k_shadow does with a queue entry) —
+                                    // below, after the bounce ray has been sampled and queued: nothing but L, C and the path's index
+                                    // then sits in registers through the walk's loop (the shader walks it right here; the order of two
+                                    // independent computations is all that changes)
                                     const unsigned long long m = __ballot(true);
                                     if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
-                                    if (COMPACT) {
-                                        pending = true;                               // walked after the workgroup-wide compaction below
-                                    } else if (SHARE && a.tri_share == 2u) {
-                                        // the shadow rays of this wave's lit lanes as one lock-step batch of the voting, triangle-sharing loop
-                                        const uint32_t n_lit = (uint32_t)__builtin_popcountll(m);
-                                        bool occluded = false;
-                                        traverse_pool<true, STATS, true>(
-                                            a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, n_lit, n_lit, a.tri_min,
-                                            [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = hit_point; rd = ldir; tmax = len - CRT_EPS; },
-                                            [&](uint32_t, const HitState&, bool h) { occluded = h; },
-                                            nn_any, nt_any, wn_any, wt_any, share);
-                                        if (!occluded) L = L + c;
-                                    } else {
-                                        HitState sh;
-                                        const bool occluded = BVH2
-                                            ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, hit_point, ldir, len - CRT_EPS, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
-                                            : traverse<true, STATS>(a.nodes, a.tris, hit_point, ldir, len - CRT_EPS, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any);
-                                        if (!occluded) L = L + c;
-                                    }
+                                    pending = true;
                                 } else {
                                     emit_shadow = true;
                                 }
@@ -1329,7 +1343,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
                             T = T * albedo;
                         }
                         if (go_on) {
-                            if (COMPACT && pending) pend_pdf = bsdf_pdf;              // the lane that walks the shadow ray writes L (+ C) and this pdf
+                            if (INPLACE && pending) pend_pdf = bsdf_pdf;              // whoever walks the shadow ray writes L (+ C) and this pdf
                             else a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
                             a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(disney ? 2u : 0u));   // bit 0 is_specular, bit 1 true_area
                             a.pb.seed[pix] = make_float2(sx, sy);
@@ -1346,6 +1360,37 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
                     }
                 }
             }
+        }
+        if (a.bins_out.count) {
+            CRT_MARK("loop_begin bins");      // the optional bins are not part of the instruction model (tools/roofline.py): bracketed like a loop
+            const uint32_t ni = bin_append(a.bins_out, emit_next, ray_bin_key(a.bins_out, nx0, nx1));
+            if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
+            CRT_MARK("loop_end");
+        } else {
+            const uint32_t ni = wave_append(emit_next, count_next);
+            if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
+        }
+        if (INPLACE && !COMPACT) {
+            // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
+            if (!BVH2 && SHARE && a.tri_share == 2u) {
+                // one lock-step batch of the voting, triangle-sharing loop: every lane of the wave tests triangles, lanes without a shadow ray only that
+                bool occluded = false;
+                traverse_pool<true, STATS, true>(
+                    a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
+                    [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = V3(sh0.x, sh0.y, sh0.z); rd = V3(sh1.x, sh1.y, sh1.z); tmax = sh0.w; return pending; },
+                    [&](uint32_t, const HitState&, bool h) { occluded = h; },
+                    nn_any, nt_any, wn_any, wt_any, share);
+                if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
+            } else if (pending) {
+                HitState sh;
+                const vec3 so = V3(sh0.x, sh0.y, sh0.z), sd = V3(sh1.x, sh1.y, sh1.z);
+                const bool occluded = BVH2
+                    ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, so, sd, sh0.w, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
+                    : traverse<true, STATS>(a.nodes, a.tris, so, sd, sh0.w, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any);
+                if (!occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
+            }
+            if (pending && emit_next) a.pb.L[pix] = make_float4(L.x, L.y, L.z, pend_pdf);     // the path goes on: its radiance so far waits in the path state
+            pending = false;                                                                   // a path that ended here adds L below
         }
         // a path that ends here with nothing pending adds its radiance to the running sum now
         if (finished && !pending) {
@@ -1434,15 +1479,6 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
                 if (!emit_next && a.pb.L) a.pb.L[pix] = make_float4(L.x, L.y, L.z, 0.f);
             }
         }
-        if (a.bins_out.count) {
-            CRT_MARK("loop_begin bins");      // the optional bins are not part of the instruction model (tools/roofline.py): bracketed like a loop
-            const uint32_t ni = bin_append(a.bins_out, emit_next, ray_bin_key(a.bins_out, nx0, nx1));
-            if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
-            CRT_MARK("loop_end");
-        } else {
-            const uint32_t ni = wave_append(emit_next, count_next);
-            if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
-        }
         }   // samples
         if (FIRST && a.tile_cost && lane == 0u && cost_valid)
             atomicAdd(a.tile_cost + cost_tile, (uint32_t)__builtin_readcyclecounter() - cost_t0);     // a wave lives far less than 2^32 cycles
@@ -1461,7 +1497,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
-    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * (a.stack_entries + CRT_HIT_SLOTS) * 64u + lane;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
     CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_pool_chunk<false>(wid, a.count, 0u, it);
@@ -1478,6 +1514,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArg
             [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
                 const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
                 o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
+                return true;
             },
             [&](uint32_t e, const HitState& best, bool hit) {
                 hits[e] = make_float4(best.t, best.u, best.v, __int_as_float(hit ? best.tri : -1));
@@ -1499,7 +1536,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     const WaveId wid = wave_id();
     const uint32_t lane = wid.lane, wave = wid.wave;
-    uint2* stk = s_lds + (size_t)wid.lds_wave * a.stack_entries * 64u + lane;
+    uint2* stk = s_lds + (size_t)wid.lds_wave * (a.stack_entries + CRT_HIT_SLOTS) * 64u + lane;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
     CRT_CHUNK_LOOP(it) {
         const uint32_t v = static_chunk<false>(wid, a.count, 0u, it);
@@ -1662,7 +1699,7 @@ static inline uint32_t fit_waves(uint32_t waves, size_t lds_per_wave) {
     waves = waves == 1u ? 1u : waves == 2u ? 2u : 4u;
     return (size_t)waves * lds_per_wave > 64u * 1024u ? 1u : waves;
 }
-static inline size_t stack_bytes(uint32_t entries) { return (size_t)entries * 64 * sizeof(uint2); }
+static inline size_t stack_bytes(uint32_t entries) { return (size_t)(entries + CRT_HIT_SLOTS) * 64 * sizeof(uint2); }   // the lane's stack column + its hit record
 // `grid` counts 4-wave chunks; with single-wave workgroups each of them becomes 4 workgroups
 static inline dim3 grid_dim(uint32_t grid, uint32_t waves) { return dim3(grid * (4u / waves)); }
 static inline dim3 block_dim(uint32_t waves) { return dim3(waves * 64u); }
@@ -1791,7 +1828,7 @@ static void launch_segment_impl(const SegmentArgs& a, bool first, bool pretraced
     size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
     waves = fit_waves(waves, per_wave);
     compact = compact && inplace && !pretraced && !bvh2 && waves > 1u;      // shadow-ray compaction needs partner waves
-    if (compact) per_wave = std::max(per_wave, (size_t)4096);                // 64 B of ray record per lane alias the stacks
+    if (compact) per_wave = std::max(per_wave, stack_bytes(8u));             // 64 B of ray record per lane alias the stacks (k_segment's wave_stride)
     const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
     const size_t lds = waves * per_wave + (compact || share ? 16 : 0) + (share ? (size_t)waves * CRT_SHARE_BYTES : 0);
     const bool tex = a.textures != nullptr;
