@@ -451,7 +451,7 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
     if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
 #endif
-    if (const char* e = std::getenv("CRT_RAY_BINS")) s->ray_bins = (uint32_t)std::min(3, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CRT_RAY_BINS")) s->ray_bins = (uint32_t)std::min(5, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(3, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
@@ -1047,7 +1047,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
             s->spans.push_back(sp);
         }
     }
-    else if (!std::strcmp(name, "ray_bins")) s->ray_bins = (uint32_t)std::min(3, std::max(0, value));
+    else if (!std::strcmp(name, "ray_bins")) s->ray_bins = (uint32_t)std::min(5, std::max(0, value));
     else if (!std::strcmp(name, "debug_fail_batch_alloc")) {
         // one injected failure, on ONE device: 1 = this scene's own, k >= 2 = its (k - 1)-th peer (streams / crt_set_devices); 0 disarms all
         if (value >= 2 && (size_t)(value - 2) < s->peers.size()) s->peers[(size_t)(value - 2)]->debug_fail_batch_alloc = 1u;
@@ -1212,7 +1212,9 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             crt::RayBins& o = sa.bins_out;
             o.count = s->bin_count(b + 1); o.cap = s->bin_cap(s->bank, b + 1); o.off = s->bin_off(s->bank, b + 1);
             o.ovf_count = s->bin_ovf(b + 1); o.ovf_base = Qe;
-            o.per_lane = s->ray_bins == 2u ? 1u : s->ray_bins == 3u ? (b > 0 ? 1u : 0u) : 0u;
+            // option "ray_bins": 1 ballots, 2 per-ray atomics, 3 ballots for the first segment's emission and per-ray atomics after, 4 ranking
+            // through LDS, 5 ballots for the first segment's emission (a handful of keys per wave) and LDS ranking after
+            o.per_lane = s->ray_bins == 2u ? 1u : s->ray_bins == 3u ? (b > 0 ? 1u : 0u) : s->ray_bins == 4u ? 2u : s->ray_bins == 5u ? (b > 0 ? 2u : 0u) : 0u;
             for (int k = 0; k < 3; ++k) {
                 const float ext = s->bounds_hi[k] - s->bounds_lo[k];
                 o.origin[k] = s->bounds_lo[k];

@@ -766,10 +766,38 @@ __device__ __forceinline__ uint32_t ray_bin_key(const RayBins& b, float4 o, floa
 // Queue entry for this lane's ray (meaningless where !want).  The lanes of a wave that share a key are found with one ballot per
 // distinct key (a bounce off one 8 x 8 pixel patch spreads over a handful of cells and 4 - 8 octants), each such set takes its places
 // with ONE atomic (all sets' atomics issue together), and what does not fit its bin takes a place in the overflow region.
-__device__ __forceinline__ uint32_t bin_append(const RayBins& b, bool want, uint32_t key) {
+// `tab`: 768 words of wave-private LDS that nothing else uses right now (the wave's traversal stack: both walks are over when a
+// segment emits its rays), or null.
+__device__ __forceinline__ uint32_t bin_append(const RayBins& b, bool want, uint32_t key, uint32_t* tab = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t idx = 0;
-    if (b.per_lane) {
+    if (b.per_lane == 2u && tab != nullptr) {
+        // Ranking through LDS: a 256-slot wave-private table hashed by the key.  The first ray to reach a slot owns
+        // it and publishes its key; the rays that share that key then rank themselves with one ds_add_rtn each and take their places in
+        // the bin with ONE global atomic for all of them.  A ray whose key collides with another key's slot (a wave of bounce rays holds
+        // ~50 keys in 256 slots: a few rays per wave) takes its place with an atomic of its own, as per_lane = 1 does for every ray.
+        // ~45 instructions per emitting wave where the ballot loop below needs ~12 per distinct key (~600 on a wave of bounce rays).
+        uint32_t* const t_cnt = tab; uint32_t* const t_key = tab + 256; uint32_t* const t_base = tab + 512;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) t_cnt[lane + 64u * k] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t h = (key ^ (key >> 8)) & 255u;               // cell bits and octant bits folded together
+        const bool first = want && atomicAdd(&t_cnt[h], 1u) == 0u;   // ds_add_rtn_u32: who got here first owns the slot
+        if (first) t_key[h] = key;
+        __builtin_amdgcn_wave_barrier();
+        const bool same = want && t_key[h] == key;                    // this ray shares the owner's key
+        __builtin_amdgcn_wave_barrier();
+        if (first) t_cnt[h] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t rank = 0;
+        if (same) rank = atomicAdd(&t_cnt[h], 1u);                    // consecutive ranks among the rays of that key
+        __builtin_amdgcn_wave_barrier();
+        if (same && rank == 0u) t_base[h] = atomicAdd(b.count + key, t_cnt[h]);
+        __builtin_amdgcn_wave_barrier();
+        if (same) idx = t_base[h] + rank;
+        else if (want) idx = atomicAdd(b.count + key, 1u);            // a collided key: its own place
+        __builtin_amdgcn_wave_barrier();                              // the table is the traversal stack again after this
+    } else if (b.per_lane) {
         // a wave of bounce rays holds about as many keys as rays (its rays left one cell in one octant and landed all over the
         // scene): finding the few lanes that share one costs more than their atomics
         if (want) idx = atomicAdd(b.count + key, 1u);
@@ -1363,7 +1391,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         }
         if (a.bins_out.count) {
             CRT_MARK("loop_begin bins");      // the optional bins are not part of the instruction model (tools/roofline.py): bracketed like a loop
-            const uint32_t ni = bin_append(a.bins_out, emit_next, ray_bin_key(a.bins_out, nx0, nx1));
+            // the wave's own stack region is free between the walks: the LDS table of the ranked append (3 KB) lives there when it fits
+            uint32_t* const tab = wave_stride * 8u >= 3072u ? reinterpret_cast<uint32_t*>(s_lds + (size_t)wid.lds_wave * wave_stride) : nullptr;
+            const uint32_t ni = bin_append(a.bins_out, emit_next, ray_bin_key(a.bins_out, nx0, nx1), tab);
             if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
             CRT_MARK("loop_end");
         } else {

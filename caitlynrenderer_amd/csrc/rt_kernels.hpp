@@ -84,8 +84,10 @@ struct RayBins {
     const uint32_t* off;        // [CRT_RAY_BINS] first queue entry of each bin
     uint32_t* ovf_count;        // rays that found their bin full: entry ovf_base + k
     uint32_t ovf_base;
-    uint32_t per_lane;          // 1: every ray takes its place with its own atomic (launches whose waves hold ~64 different keys: bounce
-                                // segments); 0: the lanes of a wave that share a key take theirs with one (coherent first segment)
+    uint32_t per_lane;          // how the rays of a wave that share a key find each other.  0: one ballot per distinct key, one atomic per key
+                                // (coherent first segment: a handful of keys); 1: not at all, every ray takes its place with its own
+                                // atomic; 2: by ranking through a wave-private LDS table hashed by the key, one atomic per key (waves of
+                                // bounce rays: ~50 keys)
     float origin[3], scale[3];  // cell coordinate = clamp((p - origin) * scale, 0, 7)
 };
 struct BinScanArgs {             // k_bin_scan: one workgroup of 1024 threads between the emitting and the consuming launch

@@ -186,7 +186,9 @@ int crt_sync(crt_scene* s);
  *                         octant, 8^3 cell of the origin) whose places in the queue follow the previous frame's counts, so the next
  *                         segment's 64-ray batches hold rays that start together and head the same way (wave-level traversal steps
  *                         -10 % on the 1 M-triangle frame; the append costs more than that saves: frame time +3.6 %); 2 / 3 = variants
- *                         of the append (one atomic per ray)
+ *                         of the append (one atomic per ray); 4 = the rays of a wave that share a bin find each other by ranking through a
+ *                         wave-private LDS table (one ds_add_rtn per ray, one global atomic per bin); 5 = 1 for the first segment's
+ *                         emission (a handful of bins per wave) and 4 for the bounce segments'
  *     "wave_samples"      crt_render_frames, first segment: where the samples of a launch run.  0 = one after the other in the wave
  *                         that owns the 8x8 pixel batch; 1 = side by side on the 2 to 4 waves of one workgroup, added to the sum in
  *                         sample order through LDS; 3 = four samples of a 4x4 pixel quadrant in the lanes of one wave (lane = sample x 16

@@ -53,7 +53,7 @@ for case in range(n_cases):
         if EXPERIMENTS:          # variants of a `make EXPERIMENTS=1` library only
             opts.update(bounce_refill=int(rng.random() < 0.3), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])),
                         waves_per_workgroup=int(rng.choice([1, 1, 2, 4])), compact_shadow=int(rng.random() < 0.5))
-    opts["ray_bins"] = int(rng.choice([0, 0, 1, 1, 2, 3]))     # bounce rays in emission order or binned by (octant, origin cell)
+    opts["ray_bins"] = int(rng.choice([0, 0, 1, 1, 2, 3, 4, 4, 5]))     # bounce rays in emission order or binned by (octant, origin cell)
     opts["adaptive_tiles"] = int(rng.random() < 0.7)          # cost-sorted or centre-out tile order: the same pixels either way
     opts["wave_samples"] = int(rng.choice([0, 1, 2, 2, 3]))   # the samples of a launch in one wave, on the waves of a workgroup, or four in the lanes of a wave
     opts["wide_first"] = int(rng.choice([0, 1, 2]))           # the 5- or the 6-waves-per-SIMD build of the first-segment kernel
