@@ -452,7 +452,7 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
 #endif
     if (const char* e = std::getenv("CRT_RAY_BINS")) s->ray_bins = (uint32_t)std::min(5, std::max(0, std::atoi(e)));
-    if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(3, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(15, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
@@ -1023,7 +1023,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     }
     else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(3u, (uint32_t)value);
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
-    else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(3, std::max(0, value));
+    else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(15, std::max(0, value));
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "adaptive_tiles")) { s->adaptive_tiles = value ? 1u : 0u; if (value) s->tile_state = crt_scene::TILES_WANT; }
     else if (!std::strcmp(name, "accel")) {
@@ -1203,7 +1203,10 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         // default (3): no sharing in the first segment, closest-hit + shadow sharing in the bounce segments.  (Until the launch was
         // scheduled by tile cost, sharing also paid in the first segment — it shortened the long waves a launch ended on; with
         // every SIMD busy only the instruction count matters: 1 M triangles 0.2566 -> 0.2486 ms, 4K 3.45 -> 3.26 ms without it.)
-        sa.tri_share = s->tri_share == 3u ? (b == 0 ? 0u : 2u) : s->tri_share;
+        // values 0..3 as before (3 = 0 for the first segment, 2 after); + 4: the in-place shadow walk shares its triangle steps in the lean
+        // form (traverse_any_shared) in every segment; 8 = first segment only
+        sa.tri_share = (s->tri_share & 3u) == 3u ? (b == 0 ? 0u : 2u) : (s->tri_share & 3u);
+        if ((s->tri_share & 4u) || ((s->tri_share & 8u) && b == 0)) sa.tri_share |= 4u;
         if (s->info.n_tris8 > (1ull << 24)) sa.tri_share = 0u;     // a shared item is (triangle index | owner lane << 24)
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         const bool bins = uses_ray_bins(s);              // tables and the queues' overflow halves exist (prepare_batch)
@@ -1278,7 +1281,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         // (P * n_samples spread evenly over the 8 groups is fewer chunks than that when the units do not divide by 8.)
         uint32_t grid = s->trace_grid(P, sa.wide_first ? 6 : 5);
         if (b > 0 && deferred) grid *= n_samples;
-        const int wide_ran = crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && s->tri_share == 0u, s->count_visits, grid, s->waves_per_workgroup, s->stream);
+        const int wide_ran = crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && (s->tri_share & 3u) == 0u, s->count_visits, grid, s->waves_per_workgroup, s->stream);
         if (b == 0) s->last_launch_wide = wide_ran;
         if (sa.bins_out.count) {
             // fill counts -> the next launch's index space and ray count, and the next frame's capacities (the other parity)
@@ -1356,7 +1359,7 @@ static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
 // rays walked in place) — bounce queues and the shadow queue hold one entry per pixel
 static uint32_t batch_limit(const crt_scene* s) {
     const bool inplace = s->accel != 0u || s->inplace_shadow != 0u;
-    const bool compact = s->compact_shadow != 0u && s->tri_share == 0u && s->waves_per_workgroup > 1u;   // as launch_segment decides
+    const bool compact = s->compact_shadow != 0u && (s->tri_share & 3u) == 0u && s->waves_per_workgroup > 1u;   // as launch_segment decides
     if (!inplace || compact || s->count_visits) return 1u;            // counting frames run one by one
 #ifndef CRT_EXPERIMENTS
     if (s->accel != 0u) return 1u;                                     // the BVH2 frame mode (a comparison aid) has no batched build

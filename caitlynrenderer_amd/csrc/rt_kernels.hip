@@ -462,6 +462,112 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
     CRT_MARK("loop_end");
 }
 
+// Any-hit walk of one lock-step batch with SHARED triangle steps, lean form (round 4).  The NEE shadow rays of a wave are few (39 % of the
+// lanes on primary hits) and each meets its leaves at its own time, so the plain loop runs the 80-instruction Moller-Trumbore block with
+// 9 of 64 lanes enabled — the block with the most wave-level steps of the whole first segment.  Here a lane that
+// reaches a leaf group publishes up to three (triangle, owner lane) items to a 64-entry wave-private list; ALL 64 lanes then test one
+// item each with the OWNER's ray, fetched from the owner's registers by ds_bpermute (the ray is constant for the whole walk), and an
+// owner learns from one ballot whether any of its items hit.  Unlike traverse_pool's SHARE this needs no ray / result strips in LDS —
+// an occlusion test has no (t, u, v) to hand back and no order to respect — only the item list, which lives in the lane's hit-record
+// slots (CRT_HIT_SLOTS: unused during an any-hit walk).  A lane's own sequence of node fetches and triangle tests is unchanged (its items
+// are examined in their original order and it stops at its first hit), so occlusion and the per-ray counters keep the oracle's values.
+// `base` = the wave's stack region (lane 0's column); every lane of the wave must call this together.
+template <bool STATS>
+__device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
+                                                    uint32_t* overflow, bool has_ray, vec3 o, vec3 d, float tmax, uint32_t tri_min,
+                                                    uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2* const stk = base + lane;
+    uint32_t* const items = reinterpret_cast<uint32_t*>(base + stack_entries * 64);     // [64]: triangle index | owner lane << 24
+    const bool finite = __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z);
+    const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+    const bool negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
+    const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+    const vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+    bool busy = has_ray && finite, occluded = false;
+    uint2 cur = busy ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    int sp = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    CRT_MARK("loop_begin anyshare");
+    while (__ballot(busy) != 0ull) {
+        const bool has_tri = busy && tg.y != 0u;
+        const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
+        const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
+        const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+        const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the same vote as traverse_pool
+        if (node_phase) {
+            if (can_node) {
+                CRT_MARK("node_begin");
+                const uint32_t hits_imask = cur.y;
+                const int off = 31 - __builtin_clz(hits_imask);
+                const uint32_t nbase = cur.x;
+                cur.y &= ~(1u << off);
+                if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u); }
+                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+                const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                const uint4* np = node_rows(nodes, nidx);
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
+                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax);
+                cur.x = n1.x;
+                tg.x = n1.y;
+                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                tg.y = hitmask & 0x00ffffffu;
+                CRT_MARK("node_end");
+            }
+        } else {
+            CRT_MARK("share_begin");
+            const uint32_t pend = has_tri ? (uint32_t)__builtin_popcount(tg.y) : 0u;
+            const uint32_t k = pend > 3u ? 3u : pend;
+            const unsigned long long b0 = __ballot((k & 1u) != 0u), b1 = __ballot((k & 2u) != 0u);
+            const uint32_t off = (uint32_t)__builtin_popcountll(b0 & lt) + 2u * (uint32_t)__builtin_popcountll(b1 & lt);
+            const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1);
+            const uint32_t room = off < 64u ? 64u - off : 0u;
+            const uint32_t lim = k < room ? k : room;            // items of this lane tested in this step
+            uint32_t bits = tg.y;
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; ++j)
+                if (j < lim) {
+                    const int b = 31 - __builtin_clz(bits);
+                    bits &= ~(1u << b);
+                    items[off + j] = (tg.x + (uint32_t)b) | (lane << 24);
+                }
+            __builtin_amdgcn_wave_barrier();
+            if (STATS) count_wave_step(w_tris);
+            const uint32_t n_items = total < 64u ? total : 64u;
+            // every lane below n_items tests one item with its owner's ray (the lanes read each other's registers: all 64 take part in the shuffles)
+            const uint32_t item = lane < n_items ? items[lane] : (lane << 24);
+            const int src = (int)(item >> 24);
+            const vec3 ro = V3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+            const vec3 rd = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+            const float rt = __shfl(tmax, src);
+            bool hit = false;
+            if (lane < n_items) {
+                const float4* tp = tri_rows(tris, item & 0x00ffffffu);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                float u, v, t;
+                hit = mt_test(ta, tb, tc, ro, rd, u, v, t) && t < rt;
+            }
+            const unsigned long long hits = __ballot(hit);
+            if (lim != 0u) {
+                // my items sit at off .. off + lim - 1, in their original order: the first one that hit ends the walk
+                const uint32_t mine = (uint32_t)(hits >> off) & ((1u << lim) - 1u);
+                if (STATS) n_tris += mine ? (uint32_t)__builtin_ctz(mine) + 1u : lim;
+                if (mine) { occluded = true; busy = false; tg.y = 0u; }
+                else tg.y = bits;
+            }
+            __builtin_amdgcn_wave_barrier();                     // the list is rewritten by the next step
+            CRT_MARK("share_end");
+        }
+        if (busy && tg.y == 0u && !(cur.y & 0xff000000u)) {
+            if (sp == 0) busy = false;
+            else { --sp; cur = stk[sp * 64]; }
+        }
+    }
+    CRT_MARK("loop_end");
+    return occluded;
+}
+
 // ------------------------------------------------------------------ scheduling -------
 
 // XCD-aware work distribution shared by all traversal kernels.  By default the host launches one (single-wave)
@@ -986,12 +1092,15 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 
 // ------------------------------------------------------------------ path segment -----
 #ifndef CRT_SEG_OCC
-#define CRT_SEG_OCC 5        // waves per SIMD the bounce-segment kernels are compiled for (96 VGPRs); see the note above k_segment
+// Waves per SIMD the segment kernels are compiled for: 6 (80 VGPRs).  Until round 4 the bounce kernels needed 90-96 VGPRs and lost 20 % when
+// forced to 80 (spills); since the register diet (hit record in LDS, path state fetched after the walk, shadow walk after the bounce
+// emission) every hot kernel fits 80 without a spill, and the sixth wave is worth +3.7 % on four segments of the 1 M-triangle scene and
+// +6 % on the Cornell box; a seventh (72 VGPRs) +0.8 % / -1.8 % (profiles/r04_occupancy_ab.txt).
+#define CRT_SEG_OCC 6
 #endif
 #ifndef CRT_SEG_OCC_FIRST
-// The first-segment kernels (ray generation instead of a queue fetch and path state) can take 6 waves per SIMD at 80 VGPRs: same box,
-// three runs each, 5 / 6 / 7 / 8 waves: 1 M triangles 1080p 12,205 / 12,384 / 12,032 / 10,875 Mray/s, 4K 13,980 / 14,267 / 13,979 /
-// 12,759, Cornell 40,349 / 40,556 / 37,648 / 32,226.  The bounce kernels lose at 6 (spills: 1.77 -> 2.15 ms for 4 segments).
+// The batched first-segment kernel <FIRST, INPLACE, BATCH, WIDE> (the headline's launch): 6 as well; round 3, same box, three runs each,
+// 5 / 6 / 7 / 8 waves: 1 M triangles 1080p 12,205 / 12,384 / 12,032 / 10,875 Mray/s, 4K 13,980 / 14,267 / 13,979 / 12,759.
 #define CRT_SEG_OCC_FIRST 6
 #endif
 
@@ -1402,7 +1511,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (!BVH2 && SHARE && a.tri_share == 2u) {
+            if (!BVH2 && (a.tri_share & 4u) && a.tri_min != 0u) {
+                // shared triangle steps, lean form (traverse_any_shared): every lane of the wave takes part
+                const bool occluded = traverse_any_shared<STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
+                                                                 V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, nn_any, nt_any, wn_any, wt_any);
+                if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
+            } else if (!BVH2 && SHARE && (a.tri_share & 3u) == 2u) {
                 // one lock-step batch of the voting, triangle-sharing loop: every lane of the wave tests triangles, lanes without a shadow ray only that
                 bool occluded = false;
                 traverse_pool<true, STATS, true>(
@@ -1778,7 +1892,7 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 #define CRT_K(F, S, T, Y, B2, M, SH, BA, WI) k_segment<F, S, T, false, Y, B2, M, false, SH, BA, WI>
 static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, bool bvh2, bool mat, bool stats, uint32_t grid, hipStream_t stream, int& wide_ran) {
     const bool tex = a.textures != nullptr;
-    const bool share = !first && a.tri_share != 0u && a.tri_min != 0u && inplace && !bvh2;
+    const bool share = !first && (a.tri_share & 3u) != 0u && a.tri_min != 0u && inplace && !bvh2;
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
     const size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
     const dim3 g = grid_dim(grid, 1u), b = block_dim(1u);
@@ -1853,7 +1967,7 @@ int launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool in
 // first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
 // !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
 static void launch_segment_impl(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
-    const bool share = a.tri_share != 0u && a.tri_min != 0u && inplace && !pretraced && !bvh2 && !compact;
+    const bool share = (a.tri_share & 3u) != 0u && a.tri_min != 0u && inplace && !pretraced && !bvh2 && !compact;
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
     size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
     waves = fit_waves(waves, per_wave);

@@ -49,7 +49,7 @@ for case in range(n_cases):
     opts = {"streams": int(rng.choice([1, 1, 1, 2, 2, 3]))}      # the frame on one stream, or its tile shards side by side on two or three
     opts["accel"] = accel
     if accel == 0:
-        opts.update(inplace_shadow=int(rng.random() < 0.7), tri_min=int(rng.choice([0, 1, 2, 2, 3])), tri_share=int(rng.choice([0, 1, 2, 3, 3])))
+        opts.update(inplace_shadow=int(rng.random() < 0.7), tri_min=int(rng.choice([0, 1, 2, 2, 3])), tri_share=int(rng.choice([0, 1, 2, 3, 3, 4, 4, 7, 8, 11])))
         if EXPERIMENTS:          # variants of a `make EXPERIMENTS=1` library only
             opts.update(bounce_refill=int(rng.random() < 0.3), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])),
                         waves_per_workgroup=int(rng.choice([1, 1, 2, 4])), compact_shadow=int(rng.random() < 0.5))
@@ -76,7 +76,7 @@ for case in range(n_cases):
         tot = np.zeros(2, np.int64)
         last = np.zeros(2, np.int64)
         per_launch = 8 if (((accel != 0 and EXPERIMENTS) or (accel == 0 and opts.get("inplace_shadow", 1) == 1)) and (depth == 1 or not opts.get("bounce_refill", 0))
-                           and not (opts.get("compact_shadow", 1) and opts.get("tri_share", 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
+                           and not (opts.get("compact_shadow", 1) and (opts.get("tri_share", 3) & 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
         # the library's own split of a call into launches (crt_render_frames_async): up to per_launch frames each, and where four samples
         # can sit in the lanes of a wave (wave_samples >= 2, a tree of 64+ nodes, CWBVH) a launch of 5..7 frames goes as 4 + the rest
         fours = opts.get("wave_samples", 2) >= 2 and scene.bvh_info()["n_nodes8"] >= 64 and accel == 0
