@@ -180,9 +180,11 @@ struct crt_scene {
     uint32_t oversubscribe = 0;
     bool special_materials = false;          // some material is Mirror_type / Disney_type (albedo.w, Scene.h:111-132): k_segment<MAT>
     uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 2, or 4 = 256-thread workgroups
-    // triangle steps shared out to all lanes of the wave: 0 off, 1 closest-hit walk, 2 + in-place shadow rays, 3 (default) = 1 for
-    // the first segment (coherent shadow rays: the plain loop is faster, 0.291 vs 0.298 ms) and 2 for bounce segments (0.4526 vs 0.4556 ms)
-    uint32_t tri_share = 3;
+    // triangle steps shared out to all lanes of the wave (include/crt.h, option "tri_share").  Default 16: the closest-hit walks test their
+    // own triangles (the strips of the shared form cap a CU at 18 waves: 5,064 against 5,652 Mray/s on four segments at 6 waves per SIMD)
+    // and the bounce segments' in-place shadow walks share theirs in the lean form (5,742; the 8 M-triangle scene 3,617 -> 3,767)
+    uint32_t tri_share = 16;
+    uint32_t any_lanes = 1;                  // option "any_lanes": in-place shadow walks with 2 or 4 lanes per ray where at most half of a wave's lanes have one
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
@@ -452,7 +454,7 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
 #endif
     if (const char* e = std::getenv("CRT_RAY_BINS")) s->ray_bins = (uint32_t)std::min(5, std::max(0, std::atoi(e)));
-    if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(15, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(31, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
@@ -1023,7 +1025,8 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     }
     else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(3u, (uint32_t)value);
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
-    else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(15, std::max(0, value));
+    else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(31, std::max(0, value));
+    else if (!std::strcmp(name, "any_lanes")) s->any_lanes = value ? 1u : 0u;
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "adaptive_tiles")) { s->adaptive_tiles = value ? 1u : 0u; if (value) s->tile_state = crt_scene::TILES_WANT; }
     else if (!std::strcmp(name, "accel")) {
@@ -1203,11 +1206,13 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         // default (3): no sharing in the first segment, closest-hit + shadow sharing in the bounce segments.  (Until the launch was
         // scheduled by tile cost, sharing also paid in the first segment — it shortened the long waves a launch ended on; with
         // every SIMD busy only the instruction count matters: 1 M triangles 0.2566 -> 0.2486 ms, 4K 3.45 -> 3.26 ms without it.)
-        // values 0..3 as before (3 = 0 for the first segment, 2 after); + 4: the in-place shadow walk shares its triangle steps in the lean
-        // form (traverse_any_shared) in every segment; 8 = first segment only
+        // bits 0..1 as before (0 none, 1 closest-hit walk, 2 + shadow walk through the strips, 3 = 0 for the first segment and 2 after);
+        // the in-place shadow walk in the lean shared form (traverse_any_shared): + 4 every segment, + 8 the first only, + 16 the bounce
+        // segments only (the default: 16).  The first-segment kernels carry the lean form only in a CRT_EXPERIMENTS build.
         sa.tri_share = (s->tri_share & 3u) == 3u ? (b == 0 ? 0u : 2u) : (s->tri_share & 3u);
-        if ((s->tri_share & 4u) || ((s->tri_share & 8u) && b == 0)) sa.tri_share |= 4u;
+        if ((s->tri_share & 4u) || ((s->tri_share & 8u) && b == 0) || ((s->tri_share & 16u) && b > 0)) sa.tri_share |= 4u;
         if (s->info.n_tris8 > (1ull << 24)) sa.tri_share = 0u;     // a shared item is (triangle index | owner lane << 24)
+        sa.any_lanes = s->any_lanes;
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         const bool bins = uses_ray_bins(s);              // tables and the queues' overflow halves exist (prepare_batch)
         const uint32_t Qe = 8u * s->sub_capacity;        // entries of the bins' half of a queue = what the sub-queue form holds
@@ -1676,7 +1681,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
     r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
-    r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
+    r->any_lanes = src->any_lanes; r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
     r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }

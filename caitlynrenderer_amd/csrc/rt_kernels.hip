@@ -568,6 +568,151 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
     return occluded;
 }
 
+// Any-hit walk with SEVERAL LANES PER RAY (round 4).  The 8 child tests of a node are independent
+// (cwbvh.fs:376-446), and so are the up to three triangle tests of a leaf.  A wave whose shadow rays fill at most half of its lanes —
+// the usual case: 39 % of primary hits are lit, the any-hit node block ran at 33 % of the lanes and was the largest single cost of the
+// first segment — gives every ray K = 2 or 4 adjacent lanes (K = 4 when at most 16 lanes have a ray): the ray's operands are copied into
+// the group's lanes once (ds_bpermute from the owner), every lane walks the same nodes with the same stack (its own LDS column:
+// redundant, but lock-step by construction), and inside a node step lane `sub` of the group tests children [sub * 8 / K, (sub + 1) * 8 / K)
+// only; the group's hit masks are OR-ed with DPP moves.  A node step then costs ~116 (K = 2) or ~89 (K = 4) vector instructions instead
+// of 230, and a leaf's triangles are tested side by side.  The same tests on the same operands: occlusion and, counted once per group,
+// the per-ray visit counters keep the oracle's values (a leaf's triangles count up to the first one that hit, in their original order).
+template <int KL> __device__ __forceinline__ uint32_t group_or(uint32_t x) {
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);                 // quad_perm [1, 0, 3, 2]
+    if (KL >= 2) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2, 3, 0, 1]
+    return x;
+}
+// children [sub * PER, (sub + 1) * PER) of the node, PER = 8 >> KL: the arithmetic of node8_intersect on a part of the slots
+template <int KL>
+__device__ __forceinline__ uint32_t node8_intersect_part(const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, const uint4 n4, vec3 o, vec3 inv,
+                                                         bool negx, bool negy, bool negz, uint32_t oct4, float max_t, uint32_t sub) {
+    constexpr int PER = 8 >> KL;
+    const vec3 p = V3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
+    const uint32_t e_imask = n0.w;
+    const vec3 adj_inv = V3(__uint_as_float((e_imask & 0xffu) << 23) * inv.x, __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * inv.y,
+                            __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * inv.z);
+    const vec3 adj_o = (p - o) * inv;
+    const bool hi = (sub * (uint32_t)PER) >= 4u;                       // slots 4..7: the second word of every row pair
+    const uint32_t sh = ((sub * (uint32_t)PER) & 3u) * 8u;             // first byte of this lane's slots inside that word
+    const uint32_t meta4 = (hi ? n1.w : n1.z) >> sh;
+    const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+    const uint32_t inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
+    const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1F1F1F1Fu;
+    const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+    const uint32_t qlox = (hi ? n2.y : n2.x) >> sh, qhix = (hi ? n2.w : n2.z) >> sh;
+    const uint32_t qloy = (hi ? n3.y : n3.x) >> sh, qhiy = (hi ? n3.w : n3.z) >> sh;
+    const uint32_t qloz = (hi ? n4.y : n4.x) >> sh, qhiz = (hi ? n4.w : n4.z) >> sh;
+    const uint32_t xmin = negx ? qhix : qlox, xmax = negx ? qlox : qhix;
+    const uint32_t ymin = negy ? qhiy : qloy, ymax = negy ? qloy : qhiy;
+    const uint32_t zmin = negz ? qhiz : qloz, zmax = negz ? qloz : qhiz;
+    uint32_t hit_mask = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const float tminx = __builtin_fmaf(ubyte_f(xmin, j), adj_inv.x, adj_o.x);
+        const float tminy = __builtin_fmaf(ubyte_f(ymin, j), adj_inv.y, adj_o.y);
+        const float tminz = __builtin_fmaf(ubyte_f(zmin, j), adj_inv.z, adj_o.z);
+        const float tmaxx = __builtin_fmaf(ubyte_f(xmax, j), adj_inv.x, adj_o.x);
+        const float tmaxy = __builtin_fmaf(ubyte_f(ymax, j), adj_inv.y, adj_o.y);
+        const float tmaxz = __builtin_fmaf(ubyte_f(zmax, j), adj_inv.z, adj_o.z);
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(tminx, tminy), __builtin_fmaxf(tminz, 0.0f));
+        const float tmax = __builtin_fminf(__builtin_fminf(tmaxx, tmaxy), __builtin_fminf(tmaxz, max_t));
+        if (tmin <= tmax) {
+            const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
+            const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
+            hit_mask |= child_bits << bit_index;
+        }
+    }
+    return hit_mask;
+}
+
+// `base` = the wave's stack region (lane 0's column); m = ballot of the lanes that have a shadow ray (1 <= popcount <= 64 >> KL); every
+// lane of the wave calls this together.  Returns, in the OWNER's lane, whether its ray is occluded.
+template <int KL, bool STATS>
+__device__ __forceinline__ bool traverse_any_grouped(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
+                                                     uint32_t* overflow, unsigned long long m, vec3 o_own, vec3 d_own, float tmax_own,
+                                                     uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
+    constexpr uint32_t K = 1u << KL;
+    const uint32_t lane = threadIdx.x & 63u, g = lane >> KL, sub = lane & (K - 1u);
+    uint2* const stk = base + lane;
+    uint32_t* const owners = reinterpret_cast<uint32_t*>(base + stack_entries * 64);    // [64] in the hit-record slots: group -> owner lane
+    const bool own = (m >> lane) & 1ull;
+    const uint32_t rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)), n = (uint32_t)__builtin_popcountll(m);
+    if (own) owners[rank] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const bool active = g < n;
+    const int src = active ? (int)owners[g] : (int)lane;
+    const vec3 o = V3(__shfl(o_own.x, src), __shfl(o_own.y, src), __shfl(o_own.z, src));
+    const vec3 d = V3(__shfl(d_own.x, src), __shfl(d_own.y, src), __shfl(d_own.z, src));
+    const float tmax = __shfl(tmax_own, src);
+    __builtin_amdgcn_wave_barrier();                                  // the slots may be rewritten after this call
+    bool occluded = false;
+    if (active && __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z)) {     // uniform inside a group
+        const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+        const bool negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
+        const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+        const vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+        int sp = 0;
+        uint2 cur = make_uint2(0u, 0x80000000u);
+        CRT_MARK("loop_begin grouped");
+        for (;;) {
+            uint2 tg;
+            if (cur.y & 0xff000000u) {
+                const uint32_t hits_imask = cur.y;
+                const int off = 31 - __builtin_clz(hits_imask);
+                const uint32_t nbase = cur.x;
+                cur.y &= ~(1u << off);
+                if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else if (sub == 0u) atomicAdd(overflow, 1u); }
+                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+                const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                const uint4* np = node_rows(nodes, nidx);
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); }
+                const uint32_t hitmask = group_or<KL>(node8_intersect_part<KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax, sub));
+                cur.x = n1.x;
+                tg.x = n1.y;
+                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                tg.y = hitmask & 0x00ffffffu;
+            } else {
+                tg = cur;
+                cur = make_uint2(0u, 0u);
+            }
+            while (tg.y) {
+                // lane `sub` takes the sub-th pending triangle from the top (the order the plain loop tests them in)
+                uint32_t t = tg.y, rest = tg.y;
+#pragma unroll
+                for (uint32_t q = 0; q < K; ++q) {
+                    if (rest) rest &= ~(1u << (31 - __builtin_clz(rest)));
+                    if (q + 1u < K && q < sub && t) t &= ~(1u << (31 - __builtin_clz(t)));
+                }
+                const uint32_t pend = (uint32_t)__builtin_popcount(tg.y), tested = pend < K ? pend : K;
+                bool hit = false;
+                if (sub < tested) {
+                    const uint32_t ti = tg.x + (uint32_t)(31 - __builtin_clz(t));
+                    const float4* tp = tri_rows(tris, ti);
+                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    float u, v, tt;
+                    hit = mt_test(ta, tb, tc, o, d, u, v, tt) && tt < tmax;
+                }
+                if (STATS) count_wave_step(w_tris);
+                const uint32_t mine = (uint32_t)(__ballot(hit) >> (lane & ~(K - 1u))) & ((1u << K) - 1u);      // my group's hits, bit = sub
+                if (STATS && sub == 0u) n_tris += mine ? (uint32_t)__builtin_ctz(mine) + 1u : tested;
+                if (mine) { occluded = true; break; }
+                tg.y = rest;
+            }
+            if (occluded) break;
+            if (!(cur.y & 0xff000000u)) {
+                if (sp == 0) break;
+                --sp;
+                cur = stk[sp * 64];
+            }
+        }
+        CRT_MARK("loop_end");
+    }
+    // back to the owners: group r's verdict sits in lanes r * K .. r * K + K - 1
+    const bool got = __shfl((int)occluded, (int)(rank << KL)) != 0;
+    return own && got;
+}
+
 // ------------------------------------------------------------------ scheduling -------
 
 // XCD-aware work distribution shared by all traversal kernels.  By default the host launches one (single-wave)
@@ -1103,6 +1248,21 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // 5 / 6 / 7 / 8 waves: 1 M triangles 1080p 12,205 / 12,384 / 12,032 / 10,875 Mray/s, 4K 13,980 / 14,267 / 13,979 / 12,759.
 #define CRT_SEG_OCC_FIRST 6
 #endif
+#ifndef CRT_SEG_OCC_BATCH
+// The other batched first-segment builds (the sample loop's state on top of everything else; materials): 5 waves, 96 VGPRs.  They run where a
+// launch is only as long as its longest waves (a shard, a small frame: SegmentArgs::wide_first = 0), which finish sooner without scratch
+// traffic (1/8 of a 1080p frame, 4 samples side by side: 0.0453 ms per frame at 5 waves, 0.0503 at 6), and on Mirror / Disney scenes.
+#define CRT_SEG_OCC_BATCH 5
+#endif
+
+// The lean shared shadow walk (traverse_any_shared) is compiled into the bounce kernels; into the first-segment kernels only with
+// -DCRT_EXPERIMENTS: there it lost (primary hits' shadow rays are coherent: 13,567 against 13,927 Mray/s on the 1 M-triangle frame) and
+// its registers cost the 80-VGPR batched build its spill-free fit.
+#ifdef CRT_EXPERIMENTS
+#define CRT_ANYSHARE_IN(first) true
+#else
+#define CRT_ANYSHARE_IN(first) (!(first))
+#endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
 // shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
@@ -1136,7 +1296,7 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // BATCH (FIRST + INPLACE, a one-segment path): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.
 template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false, bool SHARE = false,
           bool BATCH = false, bool WIDE = false>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : BATCH ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
     // uniform: the workgroup's waves are the samples of one 64-pixel batch.  The 6-waves-per-SIMD build is never launched in that form
     // (launch_segment), and compiling the form out of it frees the registers its LDS result strip and wave index would hold
@@ -1511,7 +1671,16 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : C
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (!BVH2 && (a.tri_share & 4u) && a.tri_min != 0u) {
+            const unsigned long long pm = __ballot(pending);
+            const uint32_t n_pend = (uint32_t)__builtin_popcountll(pm);
+            if (!BVH2 && a.any_lanes != 0u && a.tri_min != 0u && n_pend != 0u && n_pend <= 32u) {
+                // at most half of the lanes have a shadow ray: 2 or 4 lanes per ray (traverse_any_grouped)
+                const vec3 so = V3(sh0.x, sh0.y, sh0.z), sd = V3(sh1.x, sh1.y, sh1.z);
+                const bool occluded = n_pend <= 16u
+                    ? traverse_any_grouped<2, STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pm, so, sd, sh0.w, nn_any, nt_any, wn_any, wt_any)
+                    : traverse_any_grouped<1, STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pm, so, sd, sh0.w, nn_any, nt_any, wn_any, wt_any);
+                if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
+            } else if (CRT_ANYSHARE_IN(FIRST) && !BVH2 && (a.tri_share & 4u) && a.tri_min != 0u) {
                 // shared triangle steps, lean form (traverse_any_shared): every lane of the wave takes part
                 const bool occluded = traverse_any_shared<STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
                                                                  V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, nn_any, nt_any, wn_any, wt_any);

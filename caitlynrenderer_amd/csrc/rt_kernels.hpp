@@ -116,6 +116,7 @@ struct SegmentArgs {
     FrameArgs f;
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
     uint32_t tri_min;          // vote ratio of traverse_pool; 0 = plain per-lane loop (tiny trees)
+    uint32_t any_lanes;        // 1: a wave whose in-place shadow rays fill at most half of its lanes walks them with 2 or 4 lanes per ray (traverse_any_grouped)
     uint32_t tri_share;        // 0: one triangle per waiting lane and step; 1: pending triangles shared out to all lanes (closest hit); 2: + in-place shadow rays
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart

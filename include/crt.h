@@ -178,9 +178,15 @@ int crt_sync(crt_scene* s);
  *     "inplace_shadow"    1 = NEE shadow rays walked inside the segment kernel (default), 0 = shadow queue + k_shadow
  *     "tri_min"           vote ratio of the closest-hit traversal loop (default 2); 0 = plain per-lane loop, which
  *                         trees under 64 nodes get anyway
- *     "tri_share"         triangle steps of the voting loop hand the waiting lanes' pending triangles (up to 3 each) to ALL lanes
- *                         of the wave through a wave-private LDS strip, in bounce segments (the coherent first segment is faster
- *                         without): 0 off, 1 closest-hit walk, 2 or 3 (default) also the in-place shadow rays
+ *     "tri_share"         triangle steps of the traversal loops hand the waiting lanes' pending triangles (up to 3 each) to ALL lanes
+ *                         of the wave.  Bits 0..1, through wave-private LDS strips (ray, result): 0 off, 1 the closest-hit walks of
+ *                         the bounce segments, 2 = 3 also their in-place shadow walks.  + 16 (the default: 16): the bounce segments'
+ *                         in-place shadow walks in the lean form — no strips, the owner's ray comes by ds_bpermute, one ballot says
+ *                         which items hit (1 M triangles, 4 segments: 5,652 -> 5,742 Mray/s; 8 M triangles 3,617 -> 3,767); + 4 / + 8:
+ *                         the same in every segment / the first only (CRT_EXPERIMENTS builds: coherent primary hits lose 2.6 % with it)
+ *     "any_lanes"         1 (default): a wave whose in-place shadow rays fill at most half of its lanes walks them with 2 lanes per ray
+ *                         (4 when at most 16 lanes have one): the 8 child tests of a node and the triangles of a leaf are split among
+ *                         the ray's lanes (cwbvh.fs:376-446: the child tests are independent); 0: one lane per ray as before
  *     "ray_bins"          bounce rays regrouped between segments (BASELINE configs[3], "sorting stress"): 0 (default) = per-group
  *                         sub-queues in emission order; 1 = the rays a segment emits are appended to 4096 bins keyed by (direction
  *                         octant, 8^3 cell of the origin) whose places in the queue follow the previous frame's counts, so the next

@@ -481,7 +481,7 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
             other.set_option(k, v)
         other.close()
     for options in ({"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
-                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"tri_share": 4}, {"tri_share": 11}, {"tri_share": 4, "tri_min": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
+                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"any_lanes": 0}, {"any_lanes": 0, "tri_share": 0}, {"tri_share": 4}, {"tri_share": 11}, {"tri_share": 4, "tri_min": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
                     {"tri_share": 0, "waves_per_workgroup": 2}, {"tri_share": 2, "tri_min": 1}, {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
                     {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
                     {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5}, {"ray_bins": 1}, {"ray_bins": 2}, {"ray_bins": 4}, {"ray_bins": 5, "tri_share": 1}, {"ray_bins": 3, "tri_share": 0}, {"ray_bins": 1, "inplace_shadow": 0},
@@ -513,9 +513,11 @@ def test_shared_triangle_steps_keep_sums_and_counters(cr, ob, scenes, disney_sce
         for rx, ry in rvs:
             _, cnt = orc.render_frame(rx, ry, ref, threads=8)
         steps = {}
-        for share in (0, 1, 2, 3, 4, 8, 7):          # + 4 / + 8: the in-place shadow walk shares its triangle steps in the lean form (every segment / first only)
+        for share in (0, 1, 2, 3, 4, 8, 7, 16, -1):  # + 4 / + 8 / + 16: the in-place shadow walk shares its triangle steps in the lean form (every segment / first / bounce only); -1: the defaults
             s = cr.Scene(d, W, H, depth)
-            s.set_option("tri_share", share)
+            if share >= 0:
+                s.set_option("tri_share", share)
+                s.set_option("any_lanes", 0)         # the sharing forms by themselves; the default (several lanes per ray where few have one) is case -1
             s.set_option("count_visits", 1)
             for rx, ry in rvs:
                 s.render_frame(rx, ry)
@@ -525,7 +527,7 @@ def test_shared_triangle_steps_keep_sums_and_counters(cr, ob, scenes, disney_sce
             assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32)), share
             steps[share] = (st["wave_steps_closest_tris"], st["wave_steps_any_tris"], st["tris_closest"], st["tris_any"])
             s.close()
-        assert steps[0][2:] == steps[1][2:] == steps[2][2:] == steps[3][2:] == steps[4][2:] == steps[8][2:] == steps[7][2:]
+        assert steps[0][2:] == steps[1][2:] == steps[2][2:] == steps[3][2:] == steps[4][2:] == steps[8][2:] == steps[7][2:] == steps[16][2:] == steps[-1][2:]
         assert steps[1][0] < steps[0][0] and steps[2][1] < steps[0][1]              # fewer wave-level triangle steps
         assert steps[4][1] < 0.7 * steps[0][1] and steps[8][1] < steps[0][1]             # the lean form: a third of the any-hit triangle steps
 
