@@ -84,6 +84,7 @@ SYMBOLS = {
     "crt_debug_time_graph": (_I, [_P, _U32, _P, _U32, C.POINTER(_F), C.POINTER(_F)]),
     "crt_debug_launch_form": (_I, [_P, C.POINTER(C.c_int32)]),
     "crt_debug_launch_info": (_I, [_P, C.POINTER(C.c_int32)]),
+    "crt_debug_step_hist": (_I, [_P, _P]),
     "crt_set_shard": (_I, [_P, _U32, _U32, _U32]),
     "crt_set_devices": (_I, [_P, C.POINTER(C.c_int32), _U32, _U32]),
     "crt_shard_tiles": (_I, [_U32] * 7 + [_P, _SZ, C.POINTER(_SZ)]),

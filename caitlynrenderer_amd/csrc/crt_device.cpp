@@ -1876,6 +1876,24 @@ int crt_debug_launch_form(crt_scene* s, int32_t* form) {
     return CRT_OK;
 }
 
+// Measurement aid: enabled lanes per node step of the counting kernels (option count_visits), closest-hit walks in hist[0..64], any-hit
+// walks in hist[65..129], accumulated since the previous call (which zeroes it).  Process-wide (one device symbol); null stops it.
+int crt_debug_step_hist(crt_scene* s, unsigned long long* hist) {
+    static unsigned long long* d_hist = nullptr;
+    if (!s) return fail(CRT_ERR_INVALID, "crt_debug_step_hist: null scene");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (!hist) { crt::set_step_hist(nullptr); return CRT_OK; }
+    if (!d_hist) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_hist), 130 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(d_hist, 0, 130 * sizeof(unsigned long long)));
+    }
+    HIPCHK(hipMemcpy(hist, d_hist, 130 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(d_hist, 0, 130 * sizeof(unsigned long long)));
+    crt::set_step_hist(d_hist);
+    return CRT_OK;
+}
+
 int crt_debug_launch_info(crt_scene* s, int32_t info[4]) {
     if (!s || !info) return fail(CRT_ERR_INVALID, "crt_debug_launch_info: null argument");
     info[0] = s->last_launch_form; info[1] = s->last_launch_wide; info[2] = s->last_launch_samples; info[3] = (int32_t)s->peers.size() + 1;

@@ -110,6 +110,17 @@ __device__ __forceinline__ void count_wave_step(uint32_t& c) {
     if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) ++c;
 }
 
+// Measurement aid (crt_debug_step_hist): how many lanes were enabled at each node step of the counting kernels, per walk kind — the
+// distribution behind the lane-utilisation figures (how much of the idle time is "fewer than half of the lanes still have a ray").
+__device__ unsigned long long* g_step_hist = nullptr;       // [2][65]: closest-hit walks, any-hit walks; null = off
+__device__ __forceinline__ void hist_node_step(bool any) {
+    unsigned long long* const h = g_step_hist;
+    if (h == nullptr) return;
+    const unsigned long long m = __ballot(true);
+    if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) atomicAdd(&h[(any ? 65 : 0) + __builtin_popcountll(m)], 1ull);
+}
+void set_step_hist(unsigned long long* d_hist) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist), &d_hist, sizeof d_hist); }
+
 struct HitState {
     float t, u, v;
     int tri;   // index into the CWBVH-ordered triangle array, -1 = none
@@ -190,7 +201,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
             const uint4* np = node_rows(nodes, base + rel);
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
+            if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
             const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
             cur.x = n1.x;
             tg.x = n1.y;
@@ -360,7 +371,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 const uint4* np = node_rows(nodes, nidx);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
                 cur.x = n1.x;
                 tg.x = n1.y;
@@ -507,7 +518,7 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
                 const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 const uint4* np = node_rows(nodes, nidx);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); }
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax);
                 cur.x = n1.x;
                 tg.x = n1.y;

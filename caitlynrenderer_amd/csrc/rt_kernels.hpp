@@ -196,6 +196,7 @@ void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pix
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 
+void set_step_hist(unsigned long long* d_hist);      // measurement aid: [2][65] node-step histogram of the counting kernels, null = off
 int warm_rt_kernels();      // crt_warmup: loads this unit's code object on the current device
 
 }  // namespace crt

@@ -187,6 +187,15 @@ class Scene:
         check(lib().crt_debug_launch_info(self._h, info))
         return {"form": info[0], "wide": bool(info[1]), "samples": info[2], "shards": info[3]}
 
+    def debug_step_hist(self, stop=False):
+        """crt_debug_step_hist: (closest[65], any[65]) node steps of the counting frames since the previous call by number of enabled lanes"""
+        if stop:
+            check(lib().crt_debug_step_hist(self._h, None))
+            return None
+        h = np.zeros(130, np.uint64)
+        check(lib().crt_debug_step_hist(self._h, _ptr(h)))
+        return h[:65].copy(), h[65:].copy()
+
     def set_shard(self, rank, world, tile=16):
         check(lib().crt_set_shard(self._h, int(rank), int(world), int(tile)))
 

@@ -266,6 +266,10 @@ int crt_debug_launch_form(crt_scene* s, int32_t* form);
  * info[1] = 1 when the first segment ran its 6-waves-per-SIMD build (option "wide_first"), info[2] = samples per pixel of the launch,
  * info[3] = tile shards rendering side by side (option "streams" / crt_set_devices) */
 int crt_debug_launch_info(crt_scene* s, int32_t info[4]);
+/* measurement aid: hist[130] receives, for the counting frames ("count_visits") rendered since the previous call, how many node steps ran
+ * with k of the wave's 64 lanes enabled — closest-hit walks in hist[k], any-hit walks in hist[65 + k] — and the collection (re)starts;
+ * hist = NULL stops it.  Process-wide; tools/lane_hist.py prints the distribution behind the lane-utilisation figures. */
+int crt_debug_step_hist(crt_scene* s, unsigned long long* hist);
 
 /* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is
  * cut into tile x tile squares dealt round-robin in Morton order to `world` ranks;
