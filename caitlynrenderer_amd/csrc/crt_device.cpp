@@ -184,7 +184,7 @@ struct crt_scene {
     // own triangles (the strips of the shared form cap a CU at 18 waves: 5,064 against 5,652 Mray/s on four segments at 6 waves per SIMD)
     // and the bounce segments' in-place shadow walks share theirs in the lean form (5,742; the 8 M-triangle scene 3,617 -> 3,767)
     uint32_t tri_share = 16;
-    uint32_t any_lanes = 1;                  // option "any_lanes": in-place shadow walks with 2 or 4 lanes per ray where at most half of a wave's lanes have one
+    uint32_t lanes_per_ray = 8;              // option "lanes_per_ray" (1, 2, 4, 8): how far a ray may spread over the lanes of its draining wave (rt_kernels.hip walk_batch)
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
@@ -1026,7 +1026,10 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(3u, (uint32_t)value);
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
     else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(31, std::max(0, value));
-    else if (!std::strcmp(name, "any_lanes")) s->any_lanes = value ? 1u : 0u;
+    else if (!std::strcmp(name, "lanes_per_ray")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(CRT_ERR_INVALID, "crt_set_option: lanes_per_ray is 1, 2, 4 or 8");
+        s->lanes_per_ray = (uint32_t)value;
+    }
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
     else if (!std::strcmp(name, "adaptive_tiles")) { s->adaptive_tiles = value ? 1u : 0u; if (value) s->tile_state = crt_scene::TILES_WANT; }
     else if (!std::strcmp(name, "accel")) {
@@ -1212,7 +1215,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sa.tri_share = (s->tri_share & 3u) == 3u ? (b == 0 ? 0u : 2u) : (s->tri_share & 3u);
         if ((s->tri_share & 4u) || ((s->tri_share & 8u) && b == 0) || ((s->tri_share & 16u) && b > 0)) sa.tri_share |= 4u;
         if (s->info.n_tris8 > (1ull << 24)) sa.tri_share = 0u;     // a shared item is (triangle index | owner lane << 24)
-        sa.any_lanes = s->any_lanes;
+        sa.lanes_log2 = s->lanes_per_ray >= 8u ? 3u : s->lanes_per_ray >= 4u ? 2u : s->lanes_per_ray >= 2u ? 1u : 0u;
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         const bool bins = uses_ray_bins(s);              // tables and the queues' overflow halves exist (prepare_batch)
         const uint32_t Qe = 8u * s->sub_capacity;        // entries of the bins' half of a queue = what the sub-queue form holds
@@ -1681,7 +1684,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
     r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
-    r->any_lanes = src->any_lanes; r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
+    r->lanes_per_ray = src->lanes_per_ray; r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
     r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }

@@ -579,18 +579,30 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
     return occluded;
 }
 
-// Any-hit walk with SEVERAL LANES PER RAY (round 4).  The 8 child tests of a node are independent
-// (cwbvh.fs:376-446), and so are the up to three triangle tests of a leaf.  A wave whose shadow rays fill at most half of its lanes —
-// the usual case: 39 % of primary hits are lit, the any-hit node block ran at 33 % of the lanes and was the largest single cost of the
-// first segment — gives every ray K = 2 or 4 adjacent lanes (K = 4 when at most 16 lanes have a ray): the ray's operands are copied into
-// the group's lanes once (ds_bpermute from the owner), every lane walks the same nodes with the same stack (its own LDS column:
-// redundant, but lock-step by construction), and inside a node step lane `sub` of the group tests children [sub * 8 / K, (sub + 1) * 8 / K)
-// only; the group's hit masks are OR-ed with DPP moves.  A node step then costs ~116 (K = 2) or ~89 (K = 4) vector instructions instead
-// of 230, and a leaf's triangles are tested side by side.  The same tests on the same operands: occlusion and, counted once per group,
-// the per-ray visit counters keep the oracle's values (a leaf's triangles count up to the first one that hit, in their original order).
+// ---- SEVERAL LANES PER RAY, as a wave drains (round 4) ----
+// A lock-step batch starts with one ray per lane and ends on its longest rays: on the 1 M-triangle scene 56 % of the closest-hit node
+// steps of the bounce segments run with at most 32 of the 64 lanes enabled, 37 % with at most 8 (any-hit: 68 % / 41 %;
+// profiles/r04_lane_hist.txt).  The 8 child tests of a node are independent (cwbvh.fs:376-446) and so are the triangle tests of a leaf,
+// so walk_batch gives the rays that are still alive MORE LANES: whenever at most half of the lanes are busy the rays are regrouped into
+// groups of K = 2, 4, then 8 adjacent lanes.  A regroup copies the ray's state from its old leader lane into the new group's lanes
+// (ds_bpermute: origin, direction, best hit, the two pending masks, stack depth, stack column); after that every lane of a group runs the
+// same control flow on the same data — lock-step by construction — except that inside a node step lane `sub` tests children
+// [sub * 8 / K, (sub + 1) * 8 / K) only (the group's masks are OR-ed with DPP moves: ~116 / 89 / 65 vector instructions per node step for
+// K = 2 / 4 / 8 instead of 230), and a leaf's pending triangles are tested side by side.  The traversal stack is LDS anyway: a group keeps
+// using its ray's ORIGINAL column (`col`), written by the group's first lane and read by all; the best hit's (u, v, id) live there too,
+// and a finished ray leaves (t, triangle) in its column, where its original lane picks them up after the loop.
+// Same nodes in the same order, same tests on the same operands; closest hits fold a leaf's candidates by the rule's own total order
+// (nearer t, then lower id — the sequential rule's result for any order of arrival), any-hit walks stop at a leaf's first hit in the
+// original order: hits, occlusion and per-ray counters keep the oracle's values.
+template <int KL> __device__ __forceinline__ uint32_t dpp_xor(uint32_t x, int step) {       // value of the lane `step` away inside the group (step = 1, 2, 4)
+    if (step == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm [1, 0, 3, 2]
+    if (step == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);                   // row_half_mirror: lane i <-> 7 - i of every 8
+}
 template <int KL> __device__ __forceinline__ uint32_t group_or(uint32_t x) {
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);                 // quad_perm [1, 0, 3, 2]
-    if (KL >= 2) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2, 3, 0, 1]
+    if (KL >= 1) x |= dpp_xor<KL>(x, 1);
+    if (KL >= 2) x |= dpp_xor<KL>(x, 2);
+    if (KL >= 3) x |= dpp_xor<KL>(x, 4);     // the quads are uniform by now: mirroring the 8 lanes pairs the two quads
     return x;
 }
 // children [sub * PER, (sub + 1) * PER) of the node, PER = 8 >> KL: the arithmetic of node8_intersect on a part of the slots
@@ -636,92 +648,198 @@ __device__ __forceinline__ uint32_t node8_intersect_part(const uint4 n0, const u
     return hit_mask;
 }
 
-// `base` = the wave's stack region (lane 0's column); m = ballot of the lanes that have a shadow ray (1 <= popcount <= 64 >> KL); every
-// lane of the wave calls this together.  Returns, in the OWNER's lane, whether its ray is occluded.
-template <int KL, bool STATS>
-__device__ __forceinline__ bool traverse_any_grouped(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
-                                                     uint32_t* overflow, unsigned long long m, vec3 o_own, vec3 d_own, float tmax_own,
-                                                     uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
+// One triangle step of a group of K = 1 << KL lanes (K >= 2): lane `sub` tests the sub-th pending triangle from the top of tg.y.
+// Returns true when the ray is done (any-hit: occluded).  Closest hits: the group's candidates are reduced to the one the sequential
+// rule would end with — the lexicographic minimum of (t, id) — and accepted against the best so far; its lane writes the hit record.
+template <int KL, bool ANY, bool STATS>
+__device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, vec3 o, vec3 d, uint2& tg, uint32_t sub, float& best_t, int& best_tri,
+                                               uint2* hit_uv, uint2* hit_it, uint32_t& n_tris) {
     constexpr uint32_t K = 1u << KL;
-    const uint32_t lane = threadIdx.x & 63u, g = lane >> KL, sub = lane & (K - 1u);
-    uint2* const stk = base + lane;
-    uint32_t* const owners = reinterpret_cast<uint32_t*>(base + stack_entries * 64);    // [64] in the hit-record slots: group -> owner lane
-    const bool own = (m >> lane) & 1ull;
-    const uint32_t rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)), n = (uint32_t)__builtin_popcountll(m);
-    if (own) owners[rank] = lane;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t t_sel = tg.y, rest = tg.y;
+#pragma unroll
+    for (uint32_t q = 0; q < K; ++q) {
+        if (rest) rest &= ~(1u << (31 - __builtin_clz(rest)));
+        if (q + 1u < K && q < sub && t_sel) t_sel &= ~(1u << (31 - __builtin_clz(t_sel)));
+    }
+    const uint32_t pend = (uint32_t)__builtin_popcount(tg.y), tested = pend < K ? pend : K;
+    bool hit = false;
+    float u = 0.f, v = 0.f, t = 0.f;
+    int id = 0x7fffffff;
+    uint32_t ti = 0;
+    if (sub < tested) {
+        ti = tg.x + (uint32_t)(31 - __builtin_clz(t_sel));
+        const float4* tp = tri_rows(tris, ti);
+        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        hit = mt_test(ta, tb, tc, o, d, u, v, t);
+        id = __float_as_int(ta.w);
+    }
+    tg.y = rest;
+    if (ANY) {
+        const uint32_t mine = (uint32_t)(__ballot(hit && t < best_t) >> (lane & ~(K - 1u))) & ((1u << K) - 1u);      // my group's hits, bit = sub
+        if (STATS && sub == 0u) n_tris += mine ? (uint32_t)__builtin_ctz(mine) + 1u : tested;
+        if (mine) { best_tri = (int)tg.x; tg.y = 0u; return true; }
+        return false;
+    }
+    if (STATS && sub == 0u) n_tris += tested;
+    // candidate of this lane: (t, id, triangle), or (+inf, max) when it has none
+    uint32_t ct = hit ? __float_as_uint(t) : 0x7f800000u, ci = hit ? (uint32_t)id : 0x7fffffffu, cx = ti;
+#pragma unroll
+    for (int step = 1; step < (int)K; step <<= 1) {
+        const uint32_t pt = dpp_xor<KL>(ct, step), pi = dpp_xor<KL>(ci, step), px = dpp_xor<KL>(cx, step);
+        const float a = __uint_as_float(ct), b = __uint_as_float(pt);
+        const bool other = b < a || (b == a && (int)pi < (int)ci);      // t >= 0 for every hit: plain float order; equal t -> lower id
+        ct = other ? pt : ct; ci = other ? pi : ci; cx = other ? px : cx;
+    }
+    const float wt = __uint_as_float(ct);
+    if (ct != 0x7f800000u) {
+        bool take = wt < best_t;
+        if (wt == best_t && best_tri >= 0) take = (int)ci < (int)hit_it->x;
+        if (take) {
+            best_t = wt; best_tri = (int)cx;
+            if (hit && ti == cx) { *hit_uv = make_uint2(__float_as_uint(u), __float_as_uint(v)); hit_it->x = ci; }      // the winner's own lane has (u, v)
+        }
+    }
+    return false;
+}
+
+// `base` = the wave's LDS region (lane 0's stack column); every lane of the wave calls this together.  On return `out` holds, in every
+// lane that had a ray, its closest hit (ANY: out.tri >= 0 means occluded).  max_kl: lanes per ray grow up to 1 << max_kl (0 = never).
+template <bool ANY, bool STATS, bool UNIFORM_O>
+__device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
+                                           bool has_ray, vec3 o_in, vec3 d, float tmax_in, uint32_t tri_min, uint32_t max_kl, HitState& out,
+                                           uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2* const slot_uv = base + stack_entries * 64;              // [col] (u, v) of the best hit
+    uint2* const slot_it = base + (stack_entries + 1) * 64;        // [col] (original id of the best hit, final triangle)
+    uint2* const slot_ts = base + (stack_entries + 2) * 64;        // [col] (final t, regroup scratch)
+    vec3 o_lane = o_in;
+    float best_t = tmax_in;
+    int best_tri = -1;
+    uint32_t col = lane, sub = 0u, kl = 0u;                        // kl is wave-uniform
+    vec3 oo = UNIFORM_O ? o_uniform : o_lane;
+    bool busy = has_ray && __builtin_isfinite(oo.x) && __builtin_isfinite(oo.y) && __builtin_isfinite(oo.z);
+    vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+    bool negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
+    uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+    vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+    uint2 cur = busy ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    int sp = 0;
+    slot_it[lane] = make_uint2(0u, 0xffffffffu);                   // "no hit" unless a group leaves something else here
+    slot_ts[lane] = make_uint2(__float_as_uint(tmax_in), 0u);
     __builtin_amdgcn_wave_barrier();
-    const bool active = g < n;
-    const int src = active ? (int)owners[g] : (int)lane;
-    const vec3 o = V3(__shfl(o_own.x, src), __shfl(o_own.y, src), __shfl(o_own.z, src));
-    const vec3 d = V3(__shfl(d_own.x, src), __shfl(d_own.y, src), __shfl(d_own.z, src));
-    const float tmax = __shfl(tmax_own, src);
-    __builtin_amdgcn_wave_barrier();                                  // the slots may be rewritten after this call
-    bool occluded = false;
-    if (active && __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z)) {     // uniform inside a group
-        const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
-        const bool negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
-        const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
-        const vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
-        int sp = 0;
-        uint2 cur = make_uint2(0u, 0x80000000u);
-        CRT_MARK("loop_begin grouped");
-        for (;;) {
-            uint2 tg;
-            if (cur.y & 0xff000000u) {
+    CRT_MARK("loop_begin lanes");
+    for (;;) {
+        const unsigned long long bm = __ballot(busy);
+        if (bm == 0ull) break;
+        const uint32_t n_busy = (uint32_t)__builtin_popcountll(bm);
+        if (kl < max_kl && n_busy <= 32u) {
+            // ---- regroup: the rays still alive get twice (or more) the lanes ----
+            CRT_MARK("regroup_begin");
+            const uint32_t n_rays = n_busy >> kl;
+            uint32_t nkl = kl + 1u;
+            while (nkl < max_kl && (n_rays << (nkl + 1u)) <= 64u) ++nkl;
+            const bool leader = busy && sub == 0u;
+            const unsigned long long lm = __ballot(leader);
+            if (leader) slot_ts[(uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))].y = lane;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t g = lane >> nkl;
+            const bool act = g < n_rays;
+            const int src = act ? (int)slot_ts[g].y : (int)lane;
+            if (!UNIFORM_O) o_lane = V3(__shfl(o_lane.x, src), __shfl(o_lane.y, src), __shfl(o_lane.z, src));
+            d = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+            best_t = __shfl(best_t, src); best_tri = __shfl(best_tri, src);
+            cur.x = (uint32_t)__shfl((int)cur.x, src); cur.y = (uint32_t)__shfl((int)cur.y, src);
+            tg.x = (uint32_t)__shfl((int)tg.x, src); tg.y = (uint32_t)__shfl((int)tg.y, src);
+            sp = __shfl(sp, src); col = (uint32_t)__shfl((int)col, src);
+            __builtin_amdgcn_wave_barrier();
+            busy = act; kl = nkl; sub = lane & ((1u << nkl) - 1u);
+            dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+            negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
+            oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+            inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+            CRT_MARK("regroup_end");
+            continue;
+        }
+        const vec3 o = UNIFORM_O ? o_uniform : o_lane;
+        uint2* const stk = base + col;
+        const bool has_tri = busy && tg.y != 0u;
+        const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
+        const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
+        const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+        const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the vote of traverse_pool (both sides count lanes, i.e. rays x K)
+        bool finished = false;
+        if (node_phase) {
+            if (can_node) {
+                CRT_MARK("node_begin");
                 const uint32_t hits_imask = cur.y;
                 const int off = 31 - __builtin_clz(hits_imask);
                 const uint32_t nbase = cur.x;
                 cur.y &= ~(1u << off);
-                if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else if (sub == 0u) atomicAdd(overflow, 1u); }
+                if (cur.y & 0xff000000u) {
+                    if (sp < stack_entries) { if (sub == 0u) stk[sp * 64] = cur; ++sp; } else if (sub == 0u) atomicAdd(overflow, 1u);
+                }
                 const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
                 const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 const uint4* np = node_rows(nodes, nidx);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); }
-                const uint32_t hitmask = group_or<KL>(node8_intersect_part<KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax, sub));
+                if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); if (kl == 0u) hist_node_step(ANY); }
+                uint32_t hitmask;
+                if (kl == 0u)      hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
+                else if (kl == 1u) hitmask = group_or<1>(node8_intersect_part<1>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+                else if (kl == 2u) hitmask = group_or<2>(node8_intersect_part<2>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+                else               hitmask = group_or<3>(node8_intersect_part<3>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
                 cur.x = n1.x;
                 tg.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
                 tg.y = hitmask & 0x00ffffffu;
-            } else {
-                tg = cur;
-                cur = make_uint2(0u, 0u);
+                CRT_MARK("node_end");
             }
-            while (tg.y) {
-                // lane `sub` takes the sub-th pending triangle from the top (the order the plain loop tests them in)
-                uint32_t t = tg.y, rest = tg.y;
-#pragma unroll
-                for (uint32_t q = 0; q < K; ++q) {
-                    if (rest) rest &= ~(1u << (31 - __builtin_clz(rest)));
-                    if (q + 1u < K && q < sub && t) t &= ~(1u << (31 - __builtin_clz(t)));
+        } else if (has_tri) {
+            CRT_MARK("tri_begin");
+            if (STATS) count_wave_step(w_tris);
+            if (kl == 0u) {
+                const int b = 31 - __builtin_clz(tg.y);
+                tg.y &= ~(1u << b);
+                const uint32_t ti = tg.x + (uint32_t)b;
+                const float4* tp = tri_rows(tris, ti);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                if (STATS) ++n_tris;
+                float u, v, t;
+                if (mt_test(ta, tb, tc, o, d, u, v, t)) {
+                    if (ANY) {
+                        if (t < best_t) { best_tri = (int)ti; finished = true; tg.y = 0u; }
+                    } else {
+                        const int id = __float_as_int(ta.w);
+                        bool take = t < best_t;
+                        if (t == best_t && best_tri >= 0) take = id < (int)slot_it[col].x;
+                        if (take) { best_t = t; best_tri = (int)ti; slot_uv[col] = make_uint2(__float_as_uint(u), __float_as_uint(v)); slot_it[col].x = (uint32_t)id; }
+                    }
                 }
-                const uint32_t pend = (uint32_t)__builtin_popcount(tg.y), tested = pend < K ? pend : K;
-                bool hit = false;
-                if (sub < tested) {
-                    const uint32_t ti = tg.x + (uint32_t)(31 - __builtin_clz(t));
-                    const float4* tp = tri_rows(tris, ti);
-                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                    float u, v, tt;
-                    hit = mt_test(ta, tb, tc, o, d, u, v, tt) && tt < tmax;
-                }
-                if (STATS) count_wave_step(w_tris);
-                const uint32_t mine = (uint32_t)(__ballot(hit) >> (lane & ~(K - 1u))) & ((1u << K) - 1u);      // my group's hits, bit = sub
-                if (STATS && sub == 0u) n_tris += mine ? (uint32_t)__builtin_ctz(mine) + 1u : tested;
-                if (mine) { occluded = true; break; }
-                tg.y = rest;
             }
-            if (occluded) break;
-            if (!(cur.y & 0xff000000u)) {
-                if (sp == 0) break;
-                --sp;
-                cur = stk[sp * 64];
-            }
+            else if (kl == 1u) finished = group_tri_step<1, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+            else if (kl == 2u) finished = group_tri_step<2, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+            else               finished = group_tri_step<3, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+            CRT_MARK("tri_end");
         }
-        CRT_MARK("loop_end");
+        // a ray with neither a triangle group nor inner hits left pops its stack, or is done
+        if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
+            if (sp == 0) finished = true;
+            else { --sp; cur = stk[sp * 64]; }
+        }
+        if (finished) {
+            if (sub == 0u) { slot_ts[col].x = __float_as_uint(best_t); slot_it[col].y = (uint32_t)best_tri; }
+            busy = false;
+        }
     }
-    // back to the owners: group r's verdict sits in lanes r * K .. r * K + K - 1
-    const bool got = __shfl((int)occluded, (int)(rank << KL)) != 0;
-    return own && got;
+    CRT_MARK("loop_end");
+    __builtin_amdgcn_wave_barrier();
+    out.t = __uint_as_float(slot_ts[lane].x); out.tri = (int)slot_it[lane].y; out.u = 0.f; out.v = 0.f; out.id = -1;
+    if (!ANY && out.tri >= 0) {
+        const uint2 uv = slot_uv[lane];
+        out.u = __uint_as_float(uv.x); out.v = __uint_as_float(uv.y); out.id = (int)slot_it[lane].x;
+    }
+    __builtin_amdgcn_wave_barrier();              // the slots are free again
 }
 
 // ------------------------------------------------------------------ scheduling -------
@@ -1463,6 +1581,11 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : B
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
+            if (!SHARE) {
+                // the default: lanes per ray grow as the batch drains (a.lanes_log2 = 0: never — then this is traverse_pool's lock-step loop)
+                walk_batch<false, STATS, FIRST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
+                                                nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]));
+            } else
             traverse_pool<false, STATS, SHARE, FIRST>(
                 a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
                 [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = o; rd = d; tmax = CRT_INF; return active; },
@@ -1682,15 +1805,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : B
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            const unsigned long long pm = __ballot(pending);
-            const uint32_t n_pend = (uint32_t)__builtin_popcountll(pm);
-            if (!BVH2 && a.any_lanes != 0u && a.tri_min != 0u && n_pend != 0u && n_pend <= 32u) {
-                // at most half of the lanes have a shadow ray: 2 or 4 lanes per ray (traverse_any_grouped)
-                const vec3 so = V3(sh0.x, sh0.y, sh0.z), sd = V3(sh1.x, sh1.y, sh1.z);
-                const bool occluded = n_pend <= 16u
-                    ? traverse_any_grouped<2, STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pm, so, sd, sh0.w, nn_any, nt_any, wn_any, wt_any)
-                    : traverse_any_grouped<1, STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pm, so, sd, sh0.w, nn_any, nt_any, wn_any, wt_any);
-                if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
+            if (!BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+                // lanes per ray grow as the wave's shadow rays drain (walk_batch)
+                HitState shh;
+                walk_batch<true, STATS, false>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
+                                               sh0.w, a.tri_min, a.lanes_log2, shh, nn_any, nt_any, wn_any, wt_any);
+                if (pending && shh.tri < 0) L = L + V3(sh2.x, sh2.y, sh2.z);
             } else if (CRT_ANYSHARE_IN(FIRST) && !BVH2 && (a.tri_share & 4u) && a.tri_min != 0u) {
                 // shared triangle steps, lean form (traverse_any_shared): every lane of the wave takes part
                 const bool occluded = traverse_any_shared<STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),

@@ -8,9 +8,10 @@ namespace crt {
 // Upper bound of traversal-stack entries per ray, kept in LDS (reference LOCAL_STACK_SIZE, cwbvh.fs:374).
 // crt_scene_create refuses a CWBVH deeper than this; the launch uses min(this, depth of the tree).
 #define CRT_STACK_ENTRIES 16
-// Two more entries behind every lane's stack column: the (u, v) and the original id of a closest-hit walk's best hit so far
-// (rt_kernels.hip traverse_pool) — written a few times per ray, read once: LDS instead of three VGPRs across the traversal loop.
-#define CRT_HIT_SLOTS 2
+// Three more entries behind every lane's stack column: (u, v) and the original id of a closest-hit walk's best hit so far — written a few
+// times per ray, read once: LDS instead of three VGPRs across the traversal loop (rt_kernels.hip traverse_pool) — and the (t, triangle) a
+// finished ray leaves for its original lane when its walk ended in other lanes (walk_batch).
+#define CRT_HIT_SLOTS 3
 // Rows of 16 bytes between two nodes / two triangle records of the DEVICE copies the traversal reads (the C ABI's crt_node8 is 5 rows,
 // a record 3).  5 / 3 = packed.  8 / 4 pads a node to 128 bytes and a record to 64, so that neither straddles a cache line: a scene
 // that misses the caches then fetches one line per node instead of 1.6 on average (profiles/r03_experiments.md, "line-aligned records").
@@ -116,7 +117,7 @@ struct SegmentArgs {
     FrameArgs f;
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
     uint32_t tri_min;          // vote ratio of traverse_pool; 0 = plain per-lane loop (tiny trees)
-    uint32_t any_lanes;        // 1: a wave whose in-place shadow rays fill at most half of its lanes walks them with 2 or 4 lanes per ray (traverse_any_grouped)
+    uint32_t lanes_log2;       // walk_batch: a ray may spread over up to 1 << lanes_log2 lanes as its wave drains (0: one lane per ray throughout)
     uint32_t tri_share;        // 0: one triangle per waiting lane and step; 1: pending triangles shared out to all lanes (closest hit); 2: + in-place shadow rays
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart

@@ -184,9 +184,12 @@ int crt_sync(crt_scene* s);
  *                         in-place shadow walks in the lean form — no strips, the owner's ray comes by ds_bpermute, one ballot says
  *                         which items hit (1 M triangles, 4 segments: 5,652 -> 5,742 Mray/s; 8 M triangles 3,617 -> 3,767); + 4 / + 8:
  *                         the same in every segment / the first only (CRT_EXPERIMENTS builds: coherent primary hits lose 2.6 % with it)
- *     "any_lanes"         1 (default): a wave whose in-place shadow rays fill at most half of its lanes walks them with 2 lanes per ray
- *                         (4 when at most 16 lanes have one): the 8 child tests of a node and the triangles of a leaf are split among
- *                         the ray's lanes (cwbvh.fs:376-446: the child tests are independent); 0: one lane per ray as before
+ *     "lanes_per_ray"     8 (default), 4, 2 or 1: a lock-step batch starts with one ray per lane and ends on its longest rays (1 M
+ *                         triangles, bounce segments: 56 % of the closest-hit node steps run with at most 32 of the 64 lanes enabled,
+ *                         37 % with at most 8).  Whenever at most half of a wave's lanes are busy, the rays still alive are regrouped
+ *                         into groups of 2, 4, then up to this many adjacent lanes: the 8 child tests of a node (independent,
+ *                         cwbvh.fs:376-446) and the pending triangles of a leaf are split among a ray's lanes.  1 = one lane per ray
+ *                         throughout.  Closest-hit and in-place shadow walks of the CWBVH frame kernels.
  *     "ray_bins"          bounce rays regrouped between segments (BASELINE configs[3], "sorting stress"): 0 (default) = per-group
  *                         sub-queues in emission order; 1 = the rays a segment emits are appended to 4096 bins keyed by (direction
  *                         octant, 8^3 cell of the origin) whose places in the queue follow the previous frame's counts, so the next

@@ -17,7 +17,7 @@ name, depth = sys.argv[1], int(sys.argv[2])
 import bench
 data, cam, label, _ = bench.build_workload(name)
 scene = cr.Scene(data, 1920, 1080, depth)
-scene.set_option("any_lanes", 0)
+scene.set_option("lanes_per_ray", 1)
 scene.set_option("count_visits", 1)
 rnd = cr.Rnd()
 scene.debug_step_hist()                       # start
