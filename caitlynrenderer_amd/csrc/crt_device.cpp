@@ -180,11 +180,11 @@ struct crt_scene {
     uint32_t oversubscribe = 0;
     bool special_materials = false;          // some material is Mirror_type / Disney_type (albedo.w, Scene.h:111-132): k_segment<MAT>
     uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 2, or 4 = 256-thread workgroups
-    // triangle steps shared out to all lanes of the wave (include/crt.h, option "tri_share").  Default 16: the closest-hit walks test their
-    // own triangles (the strips of the shared form cap a CU at 18 waves: 5,064 against 5,652 Mray/s on four segments at 6 waves per SIMD)
-    // and the bounce segments' in-place shadow walks share theirs in the lean form (5,742; the 8 M-triangle scene 3,617 -> 3,767)
-    uint32_t tri_share = 16;
-    uint32_t lanes_per_ray = 8;              // option "lanes_per_ray" (1, 2, 4, 8): how far a ray may spread over the lanes of its draining wave (rt_kernels.hip walk_batch)
+    // triangle steps shared out to all lanes of the wave (include/crt.h, option "tri_share").  Default 0: the strips of the shared closest-hit
+    // form cap a CU at 18 waves (5,064 against 5,652 Mray/s on four segments at 6 waves per SIMD), and the bounce segments' walks spread a
+    // ray over four lanes instead once their wave has drained (lanes_per_ray)
+    uint32_t tri_share = 0;
+    uint32_t lanes_per_ray = 4;              // option "lanes_per_ray" (1, 2, 4, 8): how far a ray may spread over the lanes of its draining wave (rt_kernels.hip walk_batch)
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
@@ -1027,7 +1027,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
     else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(31, std::max(0, value));
     else if (!std::strcmp(name, "lanes_per_ray")) {
-        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(CRT_ERR_INVALID, "crt_set_option: lanes_per_ray is 1, 2, 4 or 8");
+        if (value != 1 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: lanes_per_ray is 1 or 4");
         s->lanes_per_ray = (uint32_t)value;
     }
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;

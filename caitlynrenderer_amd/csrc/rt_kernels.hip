@@ -594,6 +594,9 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
 // Same nodes in the same order, same tests on the same operands; closest hits fold a leaf's candidates by the rule's own total order
 // (nearer t, then lower id — the sequential rule's result for any order of arrival), any-hit walks stop at a leaf's first hit in the
 // original order: hits, occlusion and per-ray counters keep the oracle's values.
+#ifndef CRT_GROUP_KL
+#define CRT_GROUP_KL 2       // lanes per ray after the regroup = 1 << this: 4, one DPP quad (see the table in profiles/r04_experiments.md)
+#endif
 template <int KL> __device__ __forceinline__ uint32_t dpp_xor(uint32_t x, int step) {       // value of the lane `step` away inside the group (step = 1, 2, 4)
     if (step == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm [1, 0, 3, 2]
     if (step == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]
@@ -733,13 +736,12 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
         const unsigned long long bm = __ballot(busy);
         if (bm == 0ull) break;
         const uint32_t n_busy = (uint32_t)__builtin_popcountll(bm);
-        if (kl < max_kl && n_busy <= 32u) {
-            // ---- regroup: the rays still alive get twice (or more) the lanes ----
+        if (kl == 0u && max_kl != 0u && n_busy <= (64u >> CRT_GROUP_KL)) {
+            // ---- regroup: at most a quarter of the lanes still have a ray: each ray gets a quad ----
             CRT_MARK("regroup_begin");
-            const uint32_t n_rays = n_busy >> kl;
-            uint32_t nkl = kl + 1u;
-            while (nkl < max_kl && (n_rays << (nkl + 1u)) <= 64u) ++nkl;
-            const bool leader = busy && sub == 0u;
+            const uint32_t n_rays = n_busy;
+            const uint32_t nkl = CRT_GROUP_KL;
+            const bool leader = busy;
             const unsigned long long lm = __ballot(leader);
             if (leader) slot_ts[(uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))].y = lane;
             __builtin_amdgcn_wave_barrier();
@@ -785,10 +787,8 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                 if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); if (kl == 0u) hist_node_step(ANY); }
                 uint32_t hitmask;
-                if (kl == 0u)      hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
-                else if (kl == 1u) hitmask = group_or<1>(node8_intersect_part<1>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
-                else if (kl == 2u) hitmask = group_or<2>(node8_intersect_part<2>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
-                else               hitmask = group_or<3>(node8_intersect_part<3>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+                if (kl == 0u) hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
+                else          hitmask = group_or<CRT_GROUP_KL>(node8_intersect_part<CRT_GROUP_KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
                 cur.x = n1.x;
                 tg.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -817,9 +817,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     }
                 }
             }
-            else if (kl == 1u) finished = group_tri_step<1, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
-            else if (kl == 2u) finished = group_tri_step<2, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
-            else               finished = group_tri_step<3, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+            else finished = group_tri_step<CRT_GROUP_KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
             CRT_MARK("tri_end");
         }
         // a ray with neither a triangle group nor inner hits left pops its stack, or is done
@@ -1384,13 +1382,21 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #define CRT_SEG_OCC_BATCH 5
 #endif
 
-// The lean shared shadow walk (traverse_any_shared) is compiled into the bounce kernels; into the first-segment kernels only with
-// -DCRT_EXPERIMENTS: there it lost (primary hits' shadow rays are coherent: 13,567 against 13,927 Mray/s on the 1 M-triangle frame) and
-// its registers cost the 80-VGPR batched build its spill-free fit.
+// The lean shared shadow walk (traverse_any_shared, option tri_share + 4 / 8 / 16) is compiled only with -DCRT_EXPERIMENTS: in the first
+// segment it lost (primary hits' shadow rays are coherent: 13,567 against 13,927 Mray/s on the 1 M-triangle frame), in the bounce segments
+// it was worth +1.6 % until walk_batch took over their shadow walks (profiles/r04_experiments.md).
 #ifdef CRT_EXPERIMENTS
 #define CRT_ANYSHARE_IN(first) true
 #else
-#define CRT_ANYSHARE_IN(first) (!(first))
+#define CRT_ANYSHARE_IN(first) false
+#endif
+// walk_batch (a ray spreads over several lanes as its wave drains) is compiled into the bounce kernels.  The first-segment kernels keep
+// traverse_pool + the plain shadow loop: coherent primary rays finish together (29 % of their node steps run with <= 32 lanes, carrying
+// 6 % of the visits), and the larger kernel cost them 8 % (12,167 against 13,927 Mray/s; profiles/r04_experiments.md).
+#ifndef CRT_LANES_FIRST
+#define CRT_LANES_IN(first) (!(first))
+#else
+#define CRT_LANES_IN(first) true
 #endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
@@ -1581,8 +1587,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : B
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
-            if (!SHARE) {
-                // the default: lanes per ray grow as the batch drains (a.lanes_log2 = 0: never — then this is traverse_pool's lock-step loop)
+            if (!SHARE && CRT_LANES_IN(FIRST)) {
+                // bounce rays: a ray spreads over four lanes once the batch has drained to a quarter (a.lanes_log2 = 0: never — then this is
+                // traverse_pool's lock-step loop)
                 walk_batch<false, STATS, FIRST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
                                                 nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]));
             } else
@@ -1805,7 +1812,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : B
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (!BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+            if (CRT_LANES_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
                 walk_batch<true, STATS, false>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),

@@ -179,17 +179,17 @@ int crt_sync(crt_scene* s);
  *     "tri_min"           vote ratio of the closest-hit traversal loop (default 2); 0 = plain per-lane loop, which
  *                         trees under 64 nodes get anyway
  *     "tri_share"         triangle steps of the traversal loops hand the waiting lanes' pending triangles (up to 3 each) to ALL lanes
- *                         of the wave.  Bits 0..1, through wave-private LDS strips (ray, result): 0 off, 1 the closest-hit walks of
- *                         the bounce segments, 2 = 3 also their in-place shadow walks.  + 16 (the default: 16): the bounce segments'
- *                         in-place shadow walks in the lean form — no strips, the owner's ray comes by ds_bpermute, one ballot says
- *                         which items hit (1 M triangles, 4 segments: 5,652 -> 5,742 Mray/s; 8 M triangles 3,617 -> 3,767); + 4 / + 8:
- *                         the same in every segment / the first only (CRT_EXPERIMENTS builds: coherent primary hits lose 2.6 % with it)
- *     "lanes_per_ray"     8 (default), 4, 2 or 1: a lock-step batch starts with one ray per lane and ends on its longest rays (1 M
- *                         triangles, bounce segments: 56 % of the closest-hit node steps run with at most 32 of the 64 lanes enabled,
- *                         37 % with at most 8).  Whenever at most half of a wave's lanes are busy, the rays still alive are regrouped
- *                         into groups of 2, 4, then up to this many adjacent lanes: the 8 child tests of a node (independent,
- *                         cwbvh.fs:376-446) and the pending triangles of a leaf are split among a ray's lanes.  1 = one lane per ray
- *                         throughout.  Closest-hit and in-place shadow walks of the CWBVH frame kernels.
+ *                         of the wave.  Bits 0..1, through wave-private LDS strips (ray, result): 0 off (default), 1 the closest-hit
+ *                         walks of the bounce segments, 2 = 3 also their in-place shadow walks (the strips cap a CU at 18 waves: -10 %
+ *                         at 6 waves per SIMD).  + 4 / + 8 / + 16 (CRT_EXPERIMENTS builds): the in-place shadow walks of every / the
+ *                         first / the bounce segments in a lean form — no strips, the owner's ray comes by ds_bpermute, one ballot
+ *                         says which items hit (bounce segments +1.6 %, superseded by "lanes_per_ray"; first segment -2.6 %)
+ *     "lanes_per_ray"     4 (default) or 1: a lock-step batch starts with one ray per lane and ends on its longest rays (1 M triangles,
+ *                         bounce segments: 45 % of the closest-hit node steps run with at most 16 of the 64 lanes enabled, 51 % of
+ *                         the any-hit ones).  In the bounce segments' closest-hit and in-place shadow walks, once at most a quarter
+ *                         of a wave's lanes are busy the rays still alive are regrouped into groups of 4 adjacent lanes (one DPP quad):
+ *                         the 8 child tests of a node (independent, cwbvh.fs:376-446) and the pending triangles of a leaf are split
+ *                         among a ray's lanes.  1 = one lane per ray throughout.
  *     "ray_bins"          bounce rays regrouped between segments (BASELINE configs[3], "sorting stress"): 0 (default) = per-group
  *                         sub-queues in emission order; 1 = the rays a segment emits are appended to 4096 bins keyed by (direction
  *                         octant, 8^3 cell of the origin) whose places in the queue follow the previous frame's counts, so the next

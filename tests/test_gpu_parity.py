@@ -481,7 +481,7 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
             other.set_option(k, v)
         other.close()
     for options in ({"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
-                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"lanes_per_ray": 1}, {"lanes_per_ray": 2, "tri_share": 0}, {"lanes_per_ray": 4, "tri_min": 1}, {"tri_share": 4}, {"tri_share": 11}, {"tri_share": 4, "tri_min": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
+                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"lanes_per_ray": 1}, {"lanes_per_ray": 1, "tri_share": 0}, {"lanes_per_ray": 4, "tri_min": 1}, {"tri_share": 4}, {"tri_share": 11}, {"tri_share": 4, "tri_min": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
                     {"tri_share": 0, "waves_per_workgroup": 2}, {"tri_share": 2, "tri_min": 1}, {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
                     {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
                     {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5}, {"ray_bins": 1}, {"ray_bins": 2}, {"ray_bins": 4}, {"ray_bins": 5, "tri_share": 1}, {"ray_bins": 3, "tri_share": 0}, {"ray_bins": 1, "inplace_shadow": 0},
@@ -529,9 +529,9 @@ def test_shared_triangle_steps_keep_sums_and_counters(cr, ob, scenes, disney_sce
             s.close()
         assert steps[0][2:] == steps[1][2:] == steps[2][2:] == steps[3][2:] == steps[4][2:] == steps[8][2:] == steps[7][2:] == steps[16][2:] == steps[-1][2:]
         assert steps[1][0] < steps[0][0] and steps[2][1] < steps[0][1]              # fewer wave-level triangle steps
-        assert steps[4][1] < 0.7 * steps[0][1] and steps[16][1] < 0.7 * steps[0][1]      # the lean form: far fewer any-hit triangle steps (bounce segments)
-        assert not EXPERIMENTS or steps[8][1] < steps[0][1]                               # the first-segment kernels carry it in an experiments build only
-        assert steps[-1][1] < steps[0][1]                                                 # several lanes per ray: a leaf's triangles side by side
+        if EXPERIMENTS:                                                                   # the lean shared shadow walk exists in an experiments build only
+            assert steps[4][1] < 0.7 * steps[0][1] and steps[16][1] < 0.7 * steps[0][1] and steps[8][1] < steps[0][1]
+        assert steps[-1][1] < steps[0][1]                                                 # four lanes per ray once the wave has drained: a leaf's triangles side by side
 
 
 @pytest.mark.parametrize("T", [16, 24])
