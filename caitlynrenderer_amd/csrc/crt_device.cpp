@@ -184,7 +184,7 @@ struct crt_scene {
     // form cap a CU at 18 waves (5,064 against 5,652 Mray/s on four segments at 6 waves per SIMD), and the bounce segments' walks spread a
     // ray over four lanes instead once their wave has drained (lanes_per_ray)
     uint32_t tri_share = 0;
-    uint32_t lanes_per_ray = 4;              // option "lanes_per_ray" (1, 2, 4, 8): how far a ray may spread over the lanes of its draining wave (rt_kernels.hip walk_batch)
+    uint32_t lanes_per_ray = 8;              // option "lanes_per_ray" (1, 2, 4, 8): how far a ray may spread over the lanes of its draining wave (rt_kernels.hip walk_batch)
     uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
@@ -1027,7 +1027,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
     else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(31, std::max(0, value));
     else if (!std::strcmp(name, "lanes_per_ray")) {
-        if (value != 1 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: lanes_per_ray is 1 or 4");
+        if (value != 1 && value != 8) return fail(CRT_ERR_INVALID, "crt_set_option: lanes_per_ray is 1 or 8");
         s->lanes_per_ray = (uint32_t)value;
     }
     else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;

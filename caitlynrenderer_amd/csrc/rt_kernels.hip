@@ -595,7 +595,8 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
 // (nearer t, then lower id — the sequential rule's result for any order of arrival), any-hit walks stop at a leaf's first hit in the
 // original order: hits, occlusion and per-ray counters keep the oracle's values.
 #ifndef CRT_GROUP_KL
-#define CRT_GROUP_KL 2       // lanes per ray after the regroup = 1 << this: 4, one DPP quad (see the table in profiles/r04_experiments.md)
+#define CRT_GROUP_KL 3       // lanes per ray after the regroup = 1 << this: 8 (one regroup, when at most 8 rays are left: 6,021 Mray/s on four segments of the
+                             // 1 M-triangle scene against 5,464 with quads at <= 16 and 5,438 with pairs at <= 32; profiles/r04_experiments.md)
 #endif
 template <int KL> __device__ __forceinline__ uint32_t dpp_xor(uint32_t x, int step) {       // value of the lane `step` away inside the group (step = 1, 2, 4)
     if (step == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm [1, 0, 3, 2]
@@ -737,7 +738,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
         if (bm == 0ull) break;
         const uint32_t n_busy = (uint32_t)__builtin_popcountll(bm);
         if (kl == 0u && max_kl != 0u && n_busy <= (64u >> CRT_GROUP_KL)) {
-            // ---- regroup: at most a quarter of the lanes still have a ray: each ray gets a quad ----
+            // ---- regroup: at most 64 >> CRT_GROUP_KL lanes still have a ray: each ray gets 1 << CRT_GROUP_KL lanes ----
             CRT_MARK("regroup_begin");
             const uint32_t n_rays = n_busy;
             const uint32_t nkl = CRT_GROUP_KL;

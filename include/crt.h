@@ -184,12 +184,12 @@ int crt_sync(crt_scene* s);
  *                         at 6 waves per SIMD).  + 4 / + 8 / + 16 (CRT_EXPERIMENTS builds): the in-place shadow walks of every / the
  *                         first / the bounce segments in a lean form — no strips, the owner's ray comes by ds_bpermute, one ballot
  *                         says which items hit (bounce segments +1.6 %, superseded by "lanes_per_ray"; first segment -2.6 %)
- *     "lanes_per_ray"     4 (default) or 1: a lock-step batch starts with one ray per lane and ends on its longest rays (1 M triangles,
- *                         bounce segments: 45 % of the closest-hit node steps run with at most 16 of the 64 lanes enabled, 51 % of
- *                         the any-hit ones).  In the bounce segments' closest-hit and in-place shadow walks, once at most a quarter
- *                         of a wave's lanes are busy the rays still alive are regrouped into groups of 4 adjacent lanes (one DPP quad):
- *                         the 8 child tests of a node (independent, cwbvh.fs:376-446) and the pending triangles of a leaf are split
- *                         among a ray's lanes.  1 = one lane per ray throughout.
+ *     "lanes_per_ray"     8 (default) or 1: a lock-step batch starts with one ray per lane and ends on its longest rays (1 M triangles,
+ *                         bounce segments: 37 % of the closest-hit node steps run with at most 8 of the 64 lanes enabled, 41 % of
+ *                         the any-hit ones).  In the bounce segments' closest-hit and in-place shadow walks, once at most 8 rays of a
+ *                         wave are still alive each of them is given 8 adjacent lanes: the 8 child tests of a node (independent,
+ *                         cwbvh.fs:376-446) run one per lane, the pending triangles of a leaf side by side (4 segments: 5,420 ->
+ *                         6,021 Mray/s; 8 M triangles 3,464 -> 3,909).  1 = one lane per ray throughout.
  *     "ray_bins"          bounce rays regrouped between segments (BASELINE configs[3], "sorting stress"): 0 (default) = per-group
  *                         sub-queues in emission order; 1 = the rays a segment emits are appended to 4096 bins keyed by (direction
  *                         octant, 8^3 cell of the origin) whose places in the queue follow the previous frame's counts, so the next

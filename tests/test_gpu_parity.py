@@ -481,7 +481,7 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
             other.set_option(k, v)
         other.close()
     for options in ({"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
-                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"lanes_per_ray": 1}, {"lanes_per_ray": 1, "tri_share": 0}, {"lanes_per_ray": 4, "tri_min": 1}, {"tri_share": 4}, {"tri_share": 11}, {"tri_share": 4, "tri_min": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
+                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"lanes_per_ray": 1}, {"lanes_per_ray": 1, "tri_share": 0}, {"lanes_per_ray": 8, "tri_min": 1}, {"tri_share": 4}, {"tri_share": 11}, {"tri_share": 4, "tri_min": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
                     {"tri_share": 0, "waves_per_workgroup": 2}, {"tri_share": 2, "tri_min": 1}, {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
                     {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
                     {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5}, {"ray_bins": 1}, {"ray_bins": 2}, {"ray_bins": 4}, {"ray_bins": 5, "tri_share": 1}, {"ray_bins": 3, "tri_share": 0}, {"ray_bins": 1, "inplace_shadow": 0},

@@ -49,7 +49,7 @@ for case in range(n_cases):
     opts = {"streams": int(rng.choice([1, 1, 1, 2, 2, 3]))}      # the frame on one stream, or its tile shards side by side on two or three
     opts["accel"] = accel
     if accel == 0:
-        opts.update(inplace_shadow=int(rng.random() < 0.7), tri_min=int(rng.choice([0, 1, 2, 2, 3])), tri_share=int(rng.choice([0, 1, 2, 3, 3, 4, 4, 7, 8, 11, 16, 16, 16])), lanes_per_ray=int(rng.choice([1, 4, 4])))
+        opts.update(inplace_shadow=int(rng.random() < 0.7), tri_min=int(rng.choice([0, 1, 2, 2, 3])), tri_share=int(rng.choice([0, 1, 2, 3, 3, 4, 4, 7, 8, 11, 16, 16, 16])), lanes_per_ray=int(rng.choice([1, 8, 8])))
         if EXPERIMENTS:          # variants of a `make EXPERIMENTS=1` library only
             opts.update(bounce_refill=int(rng.random() < 0.3), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])),
                         waves_per_workgroup=int(rng.choice([1, 1, 2, 4])), compact_shadow=int(rng.random() < 0.5))
