@@ -737,12 +737,17 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
         const unsigned long long bm = __ballot(busy);
         if (bm == 0ull) break;
         const uint32_t n_busy = (uint32_t)__builtin_popcountll(bm);
-        if (kl == 0u && max_kl != 0u && n_busy <= (64u >> CRT_GROUP_KL)) {
-            // ---- regroup: at most 64 >> CRT_GROUP_KL lanes still have a ray: each ray gets 1 << CRT_GROUP_KL lanes ----
+        const uint32_t n_rays = n_busy >> kl;
+#ifdef CRT_GROUP_MID
+        // two levels (measurement variant): quads once at most 16 rays are left, then 8 lanes per ray at 8
+        const uint32_t nkl = n_rays <= 8u ? 3u : n_rays <= 16u ? 2u : 0u;
+#else
+        const uint32_t nkl = n_rays <= (64u >> CRT_GROUP_KL) ? (uint32_t)CRT_GROUP_KL : 0u;
+#endif
+        if (max_kl != 0u && nkl > kl) {
+            // ---- regroup: the rays still alive are few enough for 1 << nkl lanes each ----
             CRT_MARK("regroup_begin");
-            const uint32_t n_rays = n_busy;
-            const uint32_t nkl = CRT_GROUP_KL;
-            const bool leader = busy;
+            const bool leader = busy && sub == 0u;
             const unsigned long long lm = __ballot(leader);
             if (leader) slot_ts[(uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))].y = lane;
             __builtin_amdgcn_wave_barrier();
@@ -789,7 +794,12 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                 if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); if (kl == 0u) hist_node_step(ANY); }
                 uint32_t hitmask;
                 if (kl == 0u) hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
+#ifdef CRT_GROUP_MID
+                else if (kl == 2u) hitmask = group_or<2>(node8_intersect_part<2>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+                else               hitmask = group_or<3>(node8_intersect_part<3>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+#else
                 else          hitmask = group_or<CRT_GROUP_KL>(node8_intersect_part<CRT_GROUP_KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+#endif
                 cur.x = n1.x;
                 tg.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -818,7 +828,12 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     }
                 }
             }
+#ifdef CRT_GROUP_MID
+            else if (kl == 2u) finished = group_tri_step<2, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+            else               finished = group_tri_step<3, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+#else
             else finished = group_tri_step<CRT_GROUP_KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+#endif
             CRT_MARK("tri_end");
         }
         // a ray with neither a triangle group nor inner hits left pops its stack, or is done
@@ -1399,6 +1414,11 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #else
 #define CRT_LANES_IN(first) true
 #endif
+#ifdef CRT_LANES_FIRST_ANY       // measurement variant: the first segment's shadow walk alone
+#define CRT_LANES_ANY_IN(first) true
+#else
+#define CRT_LANES_ANY_IN(first) CRT_LANES_IN(first)
+#endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
 // shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
@@ -1813,7 +1833,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : B
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (CRT_LANES_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+            if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
                 walk_batch<true, STATS, false>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),

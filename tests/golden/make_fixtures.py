@@ -8,7 +8,7 @@ Writes
                           file Models/cornell-box.obj (+ .mtl): translated vertices, normals,
                           triangles, materials, lights, vertex_min, camera after load.  DATA only.
   cornell_bvh.json        SBVH + CWBVH of that scene from the product's builders (the BVH2 part is
-                          pinned by SURVEY.md §8c known answers, see test_sbvh.py).
+                          pinned by SURVEY.md §8c known answers, see tests/test_host.py::test_sbvh_cornell_known_answers and ::test_sbvh_reproduces_the_survey_probes_with_spatial_splits).
   oracle_vectors.npz      seeded rays and the oracle's answers (ids, t/u/v bit patterns, visit
                           counters, frame sums) on Cornell and the n=8 tessellation; catches drift
                           of the oracle across compilers/machines.
