@@ -100,7 +100,10 @@ class Scene:
             d.n_textures, d.tex_height, d.tex_width = tex.shape[0], tex.shape[1], tex.shape[2]
         d.width, d.height, d.max_depth = self.width, self.height, self.max_depth
         d.build_flags = int(getattr(data, "build_flags", 0))
+        import time
+        t0 = time.perf_counter()
         check(lib().crt_scene_create(C.byref(d), C.byref(self._h)))
+        self.create_ms = (time.perf_counter() - t0) * 1e3        # wall time of crt_scene_create itself (the arrays were marshalled before)
         if data.camera is not None:
             self.update(data.camera)
 

@@ -2,7 +2,7 @@
 """Copies what tools/profile_round.sh left under gpurun_out/round_<tag>/ into profiles/ (tracked): bench lines, rocprofv3 kernel stats,
 the per-dispatch PMC CSVs, the derived summaries.   usage: tools/profile_collect.py r03"""
 import glob, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(ROOT, "gpurun_out", f"round_{tag}"), os.path.join(ROOT, "profiles")
 
@@ -21,7 +21,7 @@ def cp(src, name):
 
 
 for n in ("bench_default.json", "bench_one_process_virtual8.json", "bench_config5_world1.json", "lane_util.txt", "valu_issue_cycles.txt",
-          "shard_times_4k.txt", "roofline_frac.txt"):
+          "shard_times_4k.txt", "roofline_frac.txt", "lane_hist.txt", "build_probe.txt"):
     cp(os.path.join(O, n), n)
 for wl in ("headline", "mesh1m_d4", "cornell_d1"):
     cp(first(os.path.join(O, f"stats_{wl}", "**", "*kernel_stats.csv")), f"{wl}_kernel_stats.csv")
