@@ -1392,7 +1392,7 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #define CRT_SEG_OCC_FIRST 6
 #endif
 #ifndef CRT_SEG_OCC_BATCH
-// The other batched first-segment builds (the sample loop's state on top of everything else; materials): 5 waves, 96 VGPRs.  They run where a
+// The other batched first-segment builds (the sample loop's state on top of everything else; materials) and the counting kernels: 5 waves, 96 VGPRs.  They run where a
 // launch is only as long as its longest waves (a shard, a small frame: SegmentArgs::wide_first = 0), which finish sooner without scratch
 // traffic (1/8 of a 1080p frame, 4 samples side by side: 0.0453 ms per frame at 5 waves, 0.0503 at 6), and on Mirror / Disney scenes.
 #define CRT_SEG_OCC_BATCH 5
@@ -1413,6 +1413,12 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #define CRT_LANES_IN(first) (!(first))
 #else
 #define CRT_LANES_IN(first) true
+#endif
+#ifndef CRT_LANES_CLOSEST        // measurement variants: walk_batch for the closest-hit walks only / the shadow walks only
+#define CRT_LANES_CLOSEST 1
+#endif
+#ifndef CRT_LANES_ANY
+#define CRT_LANES_ANY 1
 #endif
 #ifdef CRT_LANES_FIRST_ANY       // measurement variant: the first segment's shadow walk alone
 #define CRT_LANES_ANY_IN(first) true
@@ -1452,7 +1458,7 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // BATCH (FIRST + INPLACE, a one-segment path): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.
 template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false, bool SHARE = false,
           bool BATCH = false, bool WIDE = false>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : BATCH ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
     // uniform: the workgroup's waves are the samples of one 64-pixel batch.  The 6-waves-per-SIMD build is never launched in that form
     // (launch_segment), and compiling the form out of it frees the registers its LDS result strip and wave index would hold
@@ -1608,7 +1614,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : B
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
-            if (!SHARE && CRT_LANES_IN(FIRST)) {
+            if (!SHARE && CRT_LANES_IN(FIRST) && CRT_LANES_CLOSEST) {
                 // bounce rays: a ray spreads over four lanes once the batch has drained to a quarter (a.lanes_log2 = 0: never — then this is
                 // traverse_pool's lock-step loop)
                 walk_batch<false, STATS, FIRST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
@@ -1833,7 +1839,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : B
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+            if (CRT_LANES_ANY_IN(FIRST) && CRT_LANES_ANY && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
                 walk_batch<true, STATS, false>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
