@@ -708,11 +708,15 @@ __device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, 
 }
 
 // `base` = the wave's LDS region (lane 0's stack column); every lane of the wave calls this together.  On return `out` holds, in every
-// lane that had a ray, its closest hit (ANY: out.tri >= 0 means occluded).  max_kl: lanes per ray grow up to 1 << max_kl (0 = never).
+// lane that had a ray, its closest hit (ANY: out.tri >= 0 means occluded).  max_kl = 0: one lane per ray throughout.
+// Two loops: phase 1 is the lock-step voting loop of traverse_pool, one ray per lane, and ends when at most 64 >> CRT_GROUP_KL rays are
+// left; those are regrouped and finished by phase 2, which knows nothing but groups.  (One loop that carried the group size as a variable
+// cost the one-lane phase 5 %: a guard on every stack write, a switch in every step.)
 template <bool ANY, bool STATS, bool UNIFORM_O>
 __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
                                            bool has_ray, vec3 o_in, vec3 d, float tmax_in, uint32_t tri_min, uint32_t max_kl, HitState& out,
                                            uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
+    constexpr uint32_t KL = CRT_GROUP_KL, K = 1u << KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const slot_uv = base + stack_entries * 64;              // [col] (u, v) of the best hit
     uint2* const slot_it = base + (stack_entries + 1) * 64;        // [col] (original id of the best hit, final triangle)
@@ -720,7 +724,6 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
     vec3 o_lane = o_in;
     float best_t = tmax_in;
     int best_tri = -1;
-    uint32_t col = lane, sub = 0u, kl = 0u;                        // kl is wave-uniform
     vec3 oo = UNIFORM_O ? o_uniform : o_lane;
     bool busy = has_ray && __builtin_isfinite(oo.x) && __builtin_isfinite(oo.y) && __builtin_isfinite(oo.z);
     vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
@@ -729,93 +732,50 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
     vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
     uint2 cur = busy ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
     int sp = 0;
-    slot_it[lane] = make_uint2(0u, 0xffffffffu);                   // "no hit" unless a group leaves something else here
-    slot_ts[lane] = make_uint2(__float_as_uint(tmax_in), 0u);
-    __builtin_amdgcn_wave_barrier();
-    CRT_MARK("loop_begin lanes");
-    for (;;) {
-        const unsigned long long bm = __ballot(busy);
-        if (bm == 0ull) break;
-        const uint32_t n_busy = (uint32_t)__builtin_popcountll(bm);
-        const uint32_t n_rays = n_busy >> kl;
-#ifdef CRT_GROUP_MID
-        // two levels (measurement variant): quads once at most 16 rays are left, then 8 lanes per ray at 8
-        const uint32_t nkl = n_rays <= 8u ? 3u : n_rays <= 16u ? 2u : 0u;
-#else
-        const uint32_t nkl = n_rays <= (64u >> CRT_GROUP_KL) ? (uint32_t)CRT_GROUP_KL : 0u;
-#endif
-        if (max_kl != 0u && nkl > kl) {
-            // ---- regroup: the rays still alive are few enough for 1 << nkl lanes each ----
-            CRT_MARK("regroup_begin");
-            const bool leader = busy && sub == 0u;
-            const unsigned long long lm = __ballot(leader);
-            if (leader) slot_ts[(uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))].y = lane;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t g = lane >> nkl;
-            const bool act = g < n_rays;
-            const int src = act ? (int)slot_ts[g].y : (int)lane;
-            if (!UNIFORM_O) o_lane = V3(__shfl(o_lane.x, src), __shfl(o_lane.y, src), __shfl(o_lane.z, src));
-            d = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
-            best_t = __shfl(best_t, src); best_tri = __shfl(best_tri, src);
-            cur.x = (uint32_t)__shfl((int)cur.x, src); cur.y = (uint32_t)__shfl((int)cur.y, src);
-            tg.x = (uint32_t)__shfl((int)tg.x, src); tg.y = (uint32_t)__shfl((int)tg.y, src);
-            sp = __shfl(sp, src); col = (uint32_t)__shfl((int)col, src);
-            __builtin_amdgcn_wave_barrier();
-            busy = act; kl = nkl; sub = lane & ((1u << nkl) - 1u);
-            dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
-            negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
-            oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
-            inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
-            CRT_MARK("regroup_end");
-            continue;
-        }
+    bool regroup = false;
+    {
+        // ---------------- phase 1: one ray per lane ----------------
+        uint2* const stk = base + lane;
         const vec3 o = UNIFORM_O ? o_uniform : o_lane;
-        uint2* const stk = base + col;
-        const bool has_tri = busy && tg.y != 0u;
-        const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
-        const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
-        const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
-        const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the vote of traverse_pool (both sides count lanes, i.e. rays x K)
-        bool finished = false;
-        if (node_phase) {
-            if (can_node) {
-                CRT_MARK("node_begin");
-                const uint32_t hits_imask = cur.y;
-                const int off = 31 - __builtin_clz(hits_imask);
-                const uint32_t nbase = cur.x;
-                cur.y &= ~(1u << off);
-                if (cur.y & 0xff000000u) {
-                    if (sp < stack_entries) { if (sub == 0u) stk[sp * 64] = cur; ++sp; } else if (sub == 0u) atomicAdd(overflow, 1u);
+        CRT_MARK("loop_begin lanes1");
+        for (;;) {
+            const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy));
+            if (n_busy == 0u) break;
+            if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
+            const bool has_tri = busy && tg.y != 0u;
+            const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
+            const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
+            const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+            const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the vote of traverse_pool
+            bool finished = false;
+            if (node_phase) {
+                if (can_node) {
+                    CRT_MARK("node_begin");
+                    const uint32_t hits_imask = cur.y;
+                    const int off = 31 - __builtin_clz(hits_imask);
+                    const uint32_t nbase = cur.x;
+                    cur.y &= ~(1u << off);
+                    if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u); }
+                    const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+                    const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                    const uint4* np = node_rows(nodes, nidx);
+                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                    if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
+                    const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
+                    cur.x = n1.x;
+                    tg.x = n1.y;
+                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                    tg.y = hitmask & 0x00ffffffu;
+                    CRT_MARK("node_end");
                 }
-                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
-                const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-                const uint4* np = node_rows(nodes, nidx);
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); if (kl == 0u) hist_node_step(ANY); }
-                uint32_t hitmask;
-                if (kl == 0u) hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
-#ifdef CRT_GROUP_MID
-                else if (kl == 2u) hitmask = group_or<2>(node8_intersect_part<2>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
-                else               hitmask = group_or<3>(node8_intersect_part<3>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
-#else
-                else          hitmask = group_or<CRT_GROUP_KL>(node8_intersect_part<CRT_GROUP_KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
-#endif
-                cur.x = n1.x;
-                tg.x = n1.y;
-                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
-                tg.y = hitmask & 0x00ffffffu;
-                CRT_MARK("node_end");
-            }
-        } else if (has_tri) {
-            CRT_MARK("tri_begin");
-            if (STATS) count_wave_step(w_tris);
-            if (kl == 0u) {
+            } else if (has_tri) {
+                CRT_MARK("tri_begin");
                 const int b = 31 - __builtin_clz(tg.y);
                 tg.y &= ~(1u << b);
                 const uint32_t ti = tg.x + (uint32_t)b;
                 const float4* tp = tri_rows(tris, ti);
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                if (STATS) ++n_tris;
+                if (STATS) { ++n_tris; count_wave_step(w_tris); }
                 float u, v, t;
                 if (mt_test(ta, tb, tc, o, d, u, v, t)) {
                     if (ANY) {
@@ -823,32 +783,99 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     } else {
                         const int id = __float_as_int(ta.w);
                         bool take = t < best_t;
-                        if (t == best_t && best_tri >= 0) take = id < (int)slot_it[col].x;
-                        if (take) { best_t = t; best_tri = (int)ti; slot_uv[col] = make_uint2(__float_as_uint(u), __float_as_uint(v)); slot_it[col].x = (uint32_t)id; }
+                        if (t == best_t && best_tri >= 0) take = id < (int)slot_it[lane].x;
+                        if (take) { best_t = t; best_tri = (int)ti; slot_uv[lane] = make_uint2(__float_as_uint(u), __float_as_uint(v)); slot_it[lane].x = (uint32_t)id; }
                     }
                 }
+                CRT_MARK("tri_end");
             }
-#ifdef CRT_GROUP_MID
-            else if (kl == 2u) finished = group_tri_step<2, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
-            else               finished = group_tri_step<3, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
-#else
-            else finished = group_tri_step<CRT_GROUP_KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
-#endif
-            CRT_MARK("tri_end");
+            if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
+                if (sp == 0) finished = true;
+                else { --sp; cur = stk[sp * 64]; }
+            }
+            if (finished) busy = false;              // its result stays in this lane's registers
         }
-        // a ray with neither a triangle group nor inner hits left pops its stack, or is done
-        if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
-            if (sp == 0) finished = true;
-            else { --sp; cur = stk[sp * 64]; }
-        }
-        if (finished) {
-            if (sub == 0u) { slot_ts[col].x = __float_as_uint(best_t); slot_it[col].y = (uint32_t)best_tri; }
-            busy = false;
-        }
+        CRT_MARK("loop_end");
     }
-    CRT_MARK("loop_end");
-    __builtin_amdgcn_wave_barrier();
-    out.t = __uint_as_float(slot_ts[lane].x); out.tri = (int)slot_it[lane].y; out.u = 0.f; out.v = 0.f; out.id = -1;
+    out.t = best_t; out.tri = best_tri;
+    const bool moved = regroup && busy;             // this lane's ray is finished by a group: its result comes back through the column's slots
+    if (regroup) {
+        // ---------------- regroup: each of the <= 64 / K rays still alive gets K adjacent lanes ----------------
+        CRT_MARK("loop_begin regroup");
+        const unsigned long long lm = __ballot(busy);
+        const uint32_t n_rays = (uint32_t)__builtin_popcountll(lm);
+        if (busy) slot_ts[(uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))].y = lane;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t g = lane >> KL, sub = lane & (K - 1u);
+        const bool act = g < n_rays;
+        const int src = act ? (int)slot_ts[g].y : (int)lane;
+        if (!UNIFORM_O) o_lane = V3(__shfl(o_lane.x, src), __shfl(o_lane.y, src), __shfl(o_lane.z, src));
+        d = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+        best_t = __shfl(best_t, src); best_tri = __shfl(best_tri, src);
+        cur.x = (uint32_t)__shfl((int)cur.x, src); cur.y = (uint32_t)__shfl((int)cur.y, src);
+        tg.x = (uint32_t)__shfl((int)tg.x, src); tg.y = (uint32_t)__shfl((int)tg.y, src);
+        sp = __shfl(sp, src);
+        const uint32_t col = (uint32_t)src;         // the ray's original lane: its stack column and hit-record slots
+        __builtin_amdgcn_wave_barrier();
+        busy = act;
+        dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+        negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
+        oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+        inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+        CRT_MARK("loop_end");
+        // ---------------- phase 2: K lanes per ray ----------------
+        uint2* const stk = base + col;
+        const vec3 o = UNIFORM_O ? o_uniform : o_lane;
+        CRT_MARK("loop_begin lanes2");
+        while (__ballot(busy) != 0ull) {
+            const bool has_tri = busy && tg.y != 0u;
+            const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
+            const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
+            const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+            const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // both sides count lanes, i.e. rays x K
+            bool finished = false;
+            if (node_phase) {
+                if (can_node) {
+                    CRT_MARK("node_begin");
+                    const uint32_t hits_imask = cur.y;
+                    const int off = 31 - __builtin_clz(hits_imask);
+                    const uint32_t nbase = cur.x;
+                    cur.y &= ~(1u << off);
+                    if (cur.y & 0xff000000u) {
+                        if (sp < stack_entries) { if (sub == 0u) stk[sp * 64] = cur; ++sp; } else if (sub == 0u) atomicAdd(overflow, 1u);
+                    }
+                    const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+                    const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                    const uint4* np = node_rows(nodes, nidx);
+                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                    if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); }
+                    const uint32_t hitmask = group_or<KL>(node8_intersect_part<KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+                    cur.x = n1.x;
+                    tg.x = n1.y;
+                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                    tg.y = hitmask & 0x00ffffffu;
+                    CRT_MARK("node_end");
+                }
+            } else if (has_tri) {
+                CRT_MARK("tri_begin");
+                if (STATS) count_wave_step(w_tris);
+                finished = group_tri_step<KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+                CRT_MARK("tri_end");
+            }
+            if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
+                if (sp == 0) finished = true;
+                else { --sp; cur = stk[sp * 64]; }
+            }
+            if (finished) {
+                if (sub == 0u) { slot_ts[col].x = __float_as_uint(best_t); slot_it[col].y = (uint32_t)best_tri; }
+                busy = false;
+            }
+        }
+        CRT_MARK("loop_end");
+        __builtin_amdgcn_wave_barrier();
+        if (moved) { out.t = __uint_as_float(slot_ts[lane].x); out.tri = (int)slot_it[lane].y; }
+    }
+    out.u = 0.f; out.v = 0.f; out.id = -1;
     if (!ANY && out.tri >= 0) {
         const uint2 uv = slot_uv[lane];
         out.u = __uint_as_float(uv.x); out.v = __uint_as_float(uv.y); out.id = (int)slot_it[lane].x;
