@@ -1447,8 +1447,10 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #ifndef CRT_LANES_ANY
 #define CRT_LANES_ANY 1
 #endif
-#ifdef CRT_LANES_FIRST_ANY       // measurement variant: the first segment's shadow walk alone
+#if defined(CRT_LANES_FIRST_ANY)       // measurement variants: the first segment's shadow walk alone / its closest-hit walk alone
 #define CRT_LANES_ANY_IN(first) true
+#elif defined(CRT_LANES_FIRST_NOANY)
+#define CRT_LANES_ANY_IN(first) (!(first))
 #else
 #define CRT_LANES_ANY_IN(first) CRT_LANES_IN(first)
 #endif
