@@ -1433,26 +1433,15 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #else
 #define CRT_ANYSHARE_IN(first) false
 #endif
-// walk_batch (a ray spreads over several lanes as its wave drains) is compiled into the bounce kernels.  The first-segment kernels keep
-// traverse_pool + the plain shadow loop: coherent primary rays finish together (29 % of their node steps run with <= 32 lanes, carrying
-// 6 % of the visits), and the larger kernel cost them 8 % (12,167 against 13,927 Mray/s; profiles/r04_experiments.md).
-#ifndef CRT_LANES_FIRST
-#define CRT_LANES_IN(first) (!(first))
-#else
-#define CRT_LANES_IN(first) true
+// walk_batch (the last rays of a draining wave get eight lanes each) walks the closest hits of every segment and the in-place shadow
+// rays of the bounce segments.  The first segment's shadow rays keep the plain per-lane loop: they are coherent, and the voting loop
+// costs them more than the tail gives back (1 M triangles, 1080p: closest only 14,131 Mray/s, both 13,730, shadow only 13,618, neither
+// 13,965; 4K 15,424 against 15,190; 8 M triangles 9,302 against 9,040 — profiles/r04_experiments.md).
+#ifndef CRT_LANES_CLOSEST_IN
+#define CRT_LANES_CLOSEST_IN(first) true
 #endif
-#ifndef CRT_LANES_CLOSEST        // measurement variants: walk_batch for the closest-hit walks only / the shadow walks only
-#define CRT_LANES_CLOSEST 1
-#endif
-#ifndef CRT_LANES_ANY
-#define CRT_LANES_ANY 1
-#endif
-#if defined(CRT_LANES_FIRST_ANY)       // measurement variants: the first segment's shadow walk alone / its closest-hit walk alone
-#define CRT_LANES_ANY_IN(first) true
-#elif defined(CRT_LANES_FIRST_NOANY)
+#ifndef CRT_LANES_ANY_IN
 #define CRT_LANES_ANY_IN(first) (!(first))
-#else
-#define CRT_LANES_ANY_IN(first) CRT_LANES_IN(first)
 #endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
@@ -1643,9 +1632,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
-            if (!SHARE && CRT_LANES_IN(FIRST) && CRT_LANES_CLOSEST) {
-                // bounce rays: a ray spreads over four lanes once the batch has drained to a quarter (a.lanes_log2 = 0: never — then this is
-                // traverse_pool's lock-step loop)
+            if (!SHARE && CRT_LANES_CLOSEST_IN(FIRST)) {
+                // the last rays of the batch get eight lanes each (a.lanes_log2 = 0: never — then this is traverse_pool's lock-step loop)
                 walk_batch<false, STATS, FIRST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
                                                 nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]));
             } else
@@ -1868,7 +1856,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (CRT_LANES_ANY_IN(FIRST) && CRT_LANES_ANY && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+            if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
                 walk_batch<true, STATS, false>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
