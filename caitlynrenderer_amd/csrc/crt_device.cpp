@@ -277,7 +277,12 @@ struct crt_scene {
     EventSpan* new_span(int kind) {
         if (timing == 0u || (timing == 1u && kind != 1)) return nullptr;
         if (n_spans >= (int)spans.size()) return nullptr;
-        EventSpan* s = &spans[n_spans++];
+        EventSpan* s = &spans[n_spans];
+        // the events of a span are created the first time it is used: a scene that never asks for timings creates none (272 event creations
+        // were a quarter of a millisecond of every crt_scene_create)
+        if (!s->a && hipEventCreate(&s->a) != hipSuccess) { s->a = nullptr; return nullptr; }
+        if (!s->b && hipEventCreate(&s->b) != hipSuccess) { s->b = nullptr; return nullptr; }
+        ++n_spans;
         s->kind = kind;
         return s;
     }
@@ -503,12 +508,7 @@ static int finish_scene_setup(crt_scene* s) {
     if ((rc = dev_alloc(&s->d_overflow, 1))) return rc;
     if (hipMemset(s->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) return fail(CRT_ERR_HIP, "hipMemset failed");
     if ((rc = dev_alloc(&s->d_counts, 2 * kCounters))) return rc;
-    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
-        return fail(CRT_ERR_NOMEM, "hipHostMalloc failed");
-    s->spans.resize(kMaxEvents);
-    for (EventSpan& sp : s->spans)
-        if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess)
-            return fail(CRT_ERR_HIP, "hipEventCreate failed");
+    s->spans.resize(kMaxEvents);                 // events themselves: created by new_span when a timing option first needs them
     return CRT_OK;
 }
 
@@ -1046,12 +1046,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         s->timing_accumulate = value != 0;
         s->n_spans = 0;
         const size_t want = value > 0 ? (size_t)std::min(value, 1 << 14) : 0;   // value = launches to make room for
-        while (s->spans.size() < want) {
-            EventSpan sp;
-            HIPCHK(hipEventCreate(&sp.a));
-            if (hipEventCreate(&sp.b) != hipSuccess) { hipEventDestroy(sp.a); return fail(CRT_ERR_HIP, "hipEventCreate"); }
-            s->spans.push_back(sp);
-        }
+        try { if (s->spans.size() < want) s->spans.resize(want); } catch (const std::exception&) { return fail(CRT_ERR_NOMEM, "crt_set_option: out of host memory (timing spans)"); }
     }
     else if (!std::strcmp(name, "ray_bins")) s->ray_bins = (uint32_t)std::min(5, std::max(0, value));
     else if (!std::strcmp(name, "debug_fail_batch_alloc")) {
@@ -1446,6 +1441,8 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
         HIPCHK(hipStreamSynchronize(s->stream));
         if (s->stats_from_frame) {
             // the queue counters stay valid until the next frame's memset: fetch them only when asked
+            if (!s->h_counts && hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), kCounters * sizeof(uint32_t)) != hipSuccess)
+                return fail(CRT_ERR_NOMEM, "hipHostMalloc failed");
             HIPCHK(hipMemcpy(s->h_counts, s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
             uint64_t closest = 0, any = 0;
             closest = (uint64_t)s->n_local_in_frame * s->samples_in_stats;   // segment 0: one primary ray per in-frame pixel and sample
