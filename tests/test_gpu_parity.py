@@ -157,7 +157,7 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
     rnd = cr.Rnd()
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(19)]                  # 19 = 8 + 8 + 3
     for depth, opts, shard in ((1, {}, None), (1, {"tri_share": 0}, None), (1, {"accel": 1}, None), (1, {"inplace_shadow": 0}, None),
-                               (2, {}, None), (1, {"waves_per_workgroup": 4}, (1, 3)), (4, {}, None), (3, {"tri_share": 1}, (0, 2)),
+                               (2, {}, None), (1, {"waves_per_workgroup": 4, "compact_shadow": 0}, (1, 3)), (4, {}, None), (3, {"tri_share": 1}, (0, 2)),
                                (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None),
                                (1, {"wave_samples": 0}, None), (3, {"wave_samples": 0}, (1, 2)), (1, {"wave_samples": 1, "accel": 1}, (2, 3)),
                                (4, {"wave_samples": 1, "tri_share": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2)),

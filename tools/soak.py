@@ -76,7 +76,7 @@ for case in range(n_cases):
         tot = np.zeros(2, np.int64)
         last = np.zeros(2, np.int64)
         per_launch = 8 if (((accel != 0 and EXPERIMENTS) or (accel == 0 and opts.get("inplace_shadow", 1) == 1)) and (depth == 1 or not opts.get("bounce_refill", 0))
-                           and not (opts.get("compact_shadow", 1) and (opts.get("tri_share", 3) & 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
+                           and not (opts.get("compact_shadow", 1) and (opts.get("tri_share", 0) & 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
         # the library's own split of a call into launches (crt_render_frames_async): up to per_launch frames each, and where four samples
         # can sit in the lanes of a wave (wave_samples >= 2, a tree of 64+ nodes, CWBVH) a launch of 5..7 frames goes as 4 + the rest
         fours = opts.get("wave_samples", 2) >= 2 and scene.bvh_info()["n_nodes8"] >= 64 and accel == 0
