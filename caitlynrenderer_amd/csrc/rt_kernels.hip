@@ -590,7 +590,7 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
 // [sub * 8 / K, (sub + 1) * 8 / K) only (the group's masks are OR-ed with DPP moves: ~116 / 89 / 65 vector instructions per node step for
 // K = 2 / 4 / 8 instead of 230), and a leaf's pending triangles are tested side by side.  The traversal stack is LDS anyway: a group keeps
 // using its ray's ORIGINAL column (`col`), written by the group's first lane and read by all; the best hit's (u, v, id) live there too,
-// and a finished ray leaves (t, triangle) in its column, where its original lane picks them up after the loop.
+// and a finished ray's (t, triangle) are fetched from its group's registers by its original lane after the loop.
 // Same nodes in the same order, same tests on the same operands; closest hits fold a leaf's candidates by the rule's own total order
 // (nearer t, then lower id — the sequential rule's result for any order of arrival), any-hit walks stop at a leaf's first hit in the
 // original order: hits, occlusion and per-ray counters keep the oracle's values.
@@ -719,8 +719,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
     constexpr uint32_t KL = CRT_GROUP_KL, K = 1u << KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const slot_uv = base + stack_entries * 64;              // [col] (u, v) of the best hit
-    uint2* const slot_it = base + (stack_entries + 1) * 64;        // [col] (original id of the best hit, final triangle)
-    uint2* const slot_ts = base + (stack_entries + 2) * 64;        // [col] (final t, regroup scratch)
+    uint2* const slot_it = base + (stack_entries + 1) * 64;        // [col] (original id of the best hit, regroup scratch)
     vec3 o_lane = o_in;
     float best_t = tmax_in;
     int best_tri = -1;
@@ -804,11 +803,12 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
         CRT_MARK("loop_begin regroup");
         const unsigned long long lm = __ballot(busy);
         const uint32_t n_rays = (uint32_t)__builtin_popcountll(lm);
-        if (busy) slot_ts[(uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))].y = lane;
+        const uint32_t my_group = (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull));      // of a lane whose ray moves: the group that takes it
+        if (busy) slot_it[my_group].y = lane;
         __builtin_amdgcn_wave_barrier();
         const uint32_t g = lane >> KL, sub = lane & (K - 1u);
         const bool act = g < n_rays;
-        const int src = act ? (int)slot_ts[g].y : (int)lane;
+        const int src = act ? (int)slot_it[g].y : (int)lane;
         if (!UNIFORM_O) o_lane = V3(__shfl(o_lane.x, src), __shfl(o_lane.y, src), __shfl(o_lane.z, src));
         d = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
         best_t = __shfl(best_t, src); best_tri = __shfl(best_tri, src);
@@ -866,14 +866,14 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                 if (sp == 0) finished = true;
                 else { --sp; cur = stk[sp * 64]; }
             }
-            if (finished) {
-                if (sub == 0u) { slot_ts[col].x = __float_as_uint(best_t); slot_it[col].y = (uint32_t)best_tri; }
-                busy = false;
-            }
+            if (finished) busy = false;              // the group's lanes keep the ray's result in their registers
         }
         CRT_MARK("loop_end");
-        __builtin_amdgcn_wave_barrier();
-        if (moved) { out.t = __uint_as_float(slot_ts[lane].x); out.tri = (int)slot_it[lane].y; }
+        // a ray that moved fetches its result from the first lane of its group
+        const float t_back = __shfl(best_t, (int)(my_group << KL));
+        const int tri_back = __shfl(best_tri, (int)(my_group << KL));
+        if (moved) { out.t = t_back; out.tri = tri_back; }
+        __builtin_amdgcn_wave_barrier();            // the hit records were written by other lanes
     }
     out.u = 0.f; out.v = 0.f; out.id = -1;
     if (!ANY && out.tri >= 0) {
