@@ -707,6 +707,104 @@ __device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, 
     return false;
 }
 
+// The group phase of walk_batch (and of the first segment's shadow walk): `busy` lanes hand their rays — at most 64 >> CRT_GROUP_KL of them —
+// to groups of K adjacent lanes, which finish them; on return out.t / out.tri of a lane whose ray moved hold its result (closest hits: the
+// (u, v, id) record is in the lane's own column slots as always).  Every lane of the wave calls this together.
+template <bool ANY, bool STATS, bool UNIFORM_O>
+__device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
+                                            bool busy, vec3 o_lane, vec3 d, float best_t, int best_tri, uint2 cur, uint2 tg, int sp, uint32_t tri_min,
+                                            HitState& out, uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform) {
+    constexpr uint32_t KL = CRT_GROUP_KL, K = 1u << KL;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2* const slot_uv = base + stack_entries * 64;
+    uint2* const slot_it = base + (stack_entries + 1) * 64;
+    vec3 dc; bool negx, negy, negz; uint32_t oct4; vec3 inv;
+    const bool moved = busy;                        // this lane's ray is finished by a group: its result comes back from the group's registers
+    {
+        // ---------------- regroup: each of the <= 64 / K rays still alive gets K adjacent lanes ----------------
+        CRT_MARK("loop_begin regroup");
+        const unsigned long long lm = __ballot(busy);
+        const uint32_t n_rays = (uint32_t)__builtin_popcountll(lm);
+        const uint32_t my_group = (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull));      // of a lane whose ray moves: the group that takes it
+        if (busy) slot_it[my_group].y = lane;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t g = lane >> KL, sub = lane & (K - 1u);
+        const bool act = g < n_rays;
+        const int src = act ? (int)slot_it[g].y : (int)lane;
+        if (!UNIFORM_O) o_lane = V3(__shfl(o_lane.x, src), __shfl(o_lane.y, src), __shfl(o_lane.z, src));
+        d = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+        best_t = __shfl(best_t, src); best_tri = __shfl(best_tri, src);
+        cur.x = (uint32_t)__shfl((int)cur.x, src); cur.y = (uint32_t)__shfl((int)cur.y, src);
+        tg.x = (uint32_t)__shfl((int)tg.x, src); tg.y = (uint32_t)__shfl((int)tg.y, src);
+        sp = __shfl(sp, src);
+        const uint32_t col = (uint32_t)src;         // the ray's original lane: its stack column and hit-record slots
+        __builtin_amdgcn_wave_barrier();
+        busy = act;
+        dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+        negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
+        oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+        inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+        CRT_MARK("loop_end");
+        // ---------------- phase 2: K lanes per ray ----------------
+        uint2* const stk = base + col;
+        const vec3 o = UNIFORM_O ? o_uniform : o_lane;
+        CRT_MARK("loop_begin lanes2");
+        while (__ballot(busy) != 0ull) {
+            const bool has_tri = busy && tg.y != 0u;
+            const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
+            const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
+            const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+            const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // both sides count lanes, i.e. rays x K
+            bool finished = false;
+            if (node_phase) {
+                if (can_node) {
+                    CRT_MARK("node_begin");
+                    const uint32_t hits_imask = cur.y;
+                    const int off = 31 - __builtin_clz(hits_imask);
+                    const uint32_t nbase = cur.x;
+                    cur.y &= ~(1u << off);
+                    if (cur.y & 0xff000000u) {
+                        if (sp < stack_entries) { if (sub == 0u) stk[sp * 64] = cur; ++sp; } else if (sub == 0u) atomicAdd(overflow, 1u);
+                    }
+                    const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+                    const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                    const uint4* np = node_rows(nodes, nidx);
+                    // a lane of the group fetches only the words its child's bytes sit in: 52 instead of 80 bytes per lane through the
+                    // texture-address path (+0.7 .. 1.1 % on the multi-segment frames; the eight lanes of a group ask for the same node)
+                    const uint32_t* nw = reinterpret_cast<const uint32_t*>(np) + (((sub * (uint32_t)(8 >> KL)) >= 4u) ? 1u : 0u);
+                    const uint4 n0 = np[0];
+                    const uint2 n1xy = *reinterpret_cast<const uint2*>(np + 1);
+                    const uint32_t mw = nw[6], w2l = nw[8], w2h = nw[10], w3l = nw[12], w3h = nw[14], w4l = nw[16], w4h = nw[18];
+                    const uint4 n1 = make_uint4(n1xy.x, n1xy.y, mw, mw), n2 = make_uint4(w2l, w2l, w2h, w2h), n3 = make_uint4(w3l, w3l, w3h, w3h), n4 = make_uint4(w4l, w4l, w4h, w4h);
+                    if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); }
+                    const uint32_t hitmask = group_or<KL>(node8_intersect_part<KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+                    cur.x = n1.x;
+                    tg.x = n1.y;
+                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                    tg.y = hitmask & 0x00ffffffu;
+                    CRT_MARK("node_end");
+                }
+            } else if (has_tri) {
+                CRT_MARK("tri_begin");
+                if (STATS) count_wave_step(w_tris);
+                finished = group_tri_step<KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
+                CRT_MARK("tri_end");
+            }
+            if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
+                if (sp == 0) finished = true;
+                else { --sp; cur = stk[sp * 64]; }
+            }
+            if (finished) busy = false;              // the group's lanes keep the ray's result in their registers
+        }
+        CRT_MARK("loop_end");
+        // a ray that moved fetches its result from the first lane of its group
+        const float t_back = __shfl(best_t, (int)(my_group << KL));
+        const int tri_back = __shfl(best_tri, (int)(my_group << KL));
+        if (moved) { out.t = t_back; out.tri = tri_back; }
+        __builtin_amdgcn_wave_barrier();            // the hit records were written by other lanes
+    }
+}
+
 // `base` = the wave's LDS region (lane 0's stack column); every lane of the wave calls this together.  On return `out` holds, in every
 // lane that had a ray, its closest hit (ANY: out.tri >= 0 means occluded).  max_kl = 0: one lane per ray throughout.
 // Two loops: phase 1 is the lock-step voting loop of traverse_pool, one ray per lane, and ends when at most 64 >> CRT_GROUP_KL rays are
@@ -716,7 +814,7 @@ template <bool ANY, bool STATS, bool UNIFORM_O>
 __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
                                            bool has_ray, vec3 o_in, vec3 d, float tmax_in, uint32_t tri_min, uint32_t max_kl, HitState& out,
                                            uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
-    constexpr uint32_t KL = CRT_GROUP_KL, K = 1u << KL;
+    constexpr uint32_t KL = CRT_GROUP_KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const slot_uv = base + stack_entries * 64;              // [col] (u, v) of the best hit
     uint2* const slot_it = base + (stack_entries + 1) * 64;        // [col] (original id of the best hit, regroup scratch)
@@ -797,100 +895,88 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
         CRT_MARK("loop_end");
     }
     out.t = best_t; out.tri = best_tri;
-    const bool moved = regroup && busy;             // this lane's ray is finished by a group: its result comes back through the column's slots
-    if (regroup) {
-        // ---------------- regroup: each of the <= 64 / K rays still alive gets K adjacent lanes ----------------
-        CRT_MARK("loop_begin regroup");
-        const unsigned long long lm = __ballot(busy);
-        const uint32_t n_rays = (uint32_t)__builtin_popcountll(lm);
-        const uint32_t my_group = (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull));      // of a lane whose ray moves: the group that takes it
-        if (busy) slot_it[my_group].y = lane;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t g = lane >> KL, sub = lane & (K - 1u);
-        const bool act = g < n_rays;
-        const int src = act ? (int)slot_it[g].y : (int)lane;
-        if (!UNIFORM_O) o_lane = V3(__shfl(o_lane.x, src), __shfl(o_lane.y, src), __shfl(o_lane.z, src));
-        d = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
-        best_t = __shfl(best_t, src); best_tri = __shfl(best_tri, src);
-        cur.x = (uint32_t)__shfl((int)cur.x, src); cur.y = (uint32_t)__shfl((int)cur.y, src);
-        tg.x = (uint32_t)__shfl((int)tg.x, src); tg.y = (uint32_t)__shfl((int)tg.y, src);
-        sp = __shfl(sp, src);
-        const uint32_t col = (uint32_t)src;         // the ray's original lane: its stack column and hit-record slots
-        __builtin_amdgcn_wave_barrier();
-        busy = act;
-        dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
-        negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
-        oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
-        inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
-        CRT_MARK("loop_end");
-        // ---------------- phase 2: K lanes per ray ----------------
-        uint2* const stk = base + col;
-        const vec3 o = UNIFORM_O ? o_uniform : o_lane;
-        CRT_MARK("loop_begin lanes2");
-        while (__ballot(busy) != 0ull) {
-            const bool has_tri = busy && tg.y != 0u;
-            const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
-            const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
-            const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
-            const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // both sides count lanes, i.e. rays x K
-            bool finished = false;
-            if (node_phase) {
-                if (can_node) {
-                    CRT_MARK("node_begin");
-                    const uint32_t hits_imask = cur.y;
-                    const int off = 31 - __builtin_clz(hits_imask);
-                    const uint32_t nbase = cur.x;
-                    cur.y &= ~(1u << off);
-                    if (cur.y & 0xff000000u) {
-                        if (sp < stack_entries) { if (sub == 0u) stk[sp * 64] = cur; ++sp; } else if (sub == 0u) atomicAdd(overflow, 1u);
-                    }
-                    const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
-                    const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-                    const uint4* np = node_rows(nodes, nidx);
-#ifdef CRT_GROUP_NARROW_LOADS
-                    // measurement variant: a lane of the group fetches only the words its child's bytes sit in (52 instead of 80 bytes per
-                    // lane through the texture-address path, 9 instead of 5 vector-memory instructions)
-                    const uint32_t* nw = reinterpret_cast<const uint32_t*>(np) + (((sub * (uint32_t)(8 >> KL)) >= 4u) ? 1u : 0u);
-                    const uint4 n0 = np[0];
-                    const uint2 n1xy = *reinterpret_cast<const uint2*>(np + 1);
-                    const uint32_t mw = nw[6], w2l = nw[8], w2h = nw[10], w3l = nw[12], w3h = nw[14], w4l = nw[16], w4h = nw[18];
-                    const uint4 n1 = make_uint4(n1xy.x, n1xy.y, mw, mw), n2 = make_uint4(w2l, w2l, w2h, w2h), n3 = make_uint4(w3l, w3l, w3h, w3h), n4 = make_uint4(w4l, w4l, w4h, w4h);
-#else
-                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-#endif
-                    if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); }
-                    const uint32_t hitmask = group_or<KL>(node8_intersect_part<KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
-                    cur.x = n1.x;
-                    tg.x = n1.y;
-                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
-                    tg.y = hitmask & 0x00ffffffu;
-                    CRT_MARK("node_end");
-                }
-            } else if (has_tri) {
-                CRT_MARK("tri_begin");
-                if (STATS) count_wave_step(w_tris);
-                finished = group_tri_step<KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
-                CRT_MARK("tri_end");
-            }
-            if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
-                if (sp == 0) finished = true;
-                else { --sp; cur = stk[sp * 64]; }
-            }
-            if (finished) busy = false;              // the group's lanes keep the ray's result in their registers
-        }
-        CRT_MARK("loop_end");
-        // a ray that moved fetches its result from the first lane of its group
-        const float t_back = __shfl(best_t, (int)(my_group << KL));
-        const int tri_back = __shfl(best_tri, (int)(my_group << KL));
-        if (moved) { out.t = t_back; out.tri = tri_back; }
-        __builtin_amdgcn_wave_barrier();            // the hit records were written by other lanes
-    }
+    if (regroup)
+        group_phase<ANY, STATS, UNIFORM_O>(nodes, tris, base, stack_entries, overflow, busy, o_lane, d, best_t, best_tri, cur, tg, sp, tri_min, out,
+                                           n_nodes, n_tris, w_nodes, w_tris, o_uniform);
     out.u = 0.f; out.v = 0.f; out.id = -1;
     if (!ANY && out.tri >= 0) {
         const uint2 uv = slot_uv[lane];
         out.u = __uint_as_float(uv.x); out.v = __uint_as_float(uv.y); out.id = (int)slot_it[lane].x;
     }
     __builtin_amdgcn_wave_barrier();              // the slots are free again
+}
+
+// Any-hit walk of one batch: the plain per-lane loop of traverse<true> (each lane tests its leaf's triangles right after the node that found
+// them — the fastest form for the coherent shadow rays of primary hits) until at most 64 >> CRT_GROUP_KL rays are left, then the group phase.
+// Every lane of the wave calls this together; returns whether this lane's ray is occluded.
+template <bool STATS>
+__device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
+                                                         uint32_t* overflow, bool has_ray, vec3 o, vec3 d, float tmax, uint32_t tri_min, uint32_t max_kl,
+                                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
+    constexpr uint32_t KL = CRT_GROUP_KL;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2* const stk = base + lane;
+    bool busy = has_ray && __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z);
+    const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+    const bool negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
+    const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+    const vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+    uint2 cur = busy ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    int sp = 0, hit_tri = -1;
+    bool regroup = false;
+    CRT_MARK("loop_begin plain");
+    for (;;) {
+        const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy));
+        if (n_busy == 0u) break;
+        if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
+        if (busy) {
+            if (cur.y & 0xff000000u) {
+                CRT_MARK("node_begin");
+                const uint32_t hits_imask = cur.y;
+                const int off = 31 - __builtin_clz(hits_imask);
+                const uint32_t nbase = cur.x;
+                cur.y &= ~(1u << off);
+                if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u); }
+                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+                const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                const uint4* np = node_rows(nodes, nbase + rel);
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true); }
+                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax);
+                cur.x = n1.x;
+                tg.x = n1.y;
+                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                tg.y = hitmask & 0x00ffffffu;
+                CRT_MARK("node_end");
+            } else {
+                tg = cur;
+                cur = make_uint2(0u, 0u);
+            }
+            while (tg.y) {
+                CRT_MARK("tri_begin");
+                const int b = 31 - __builtin_clz(tg.y);
+                tg.y &= ~(1u << b);
+                const uint32_t ti = tg.x + (uint32_t)b;
+                const float4* tp = tri_rows(tris, ti);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                if (STATS) { ++n_tris; count_wave_step(w_tris); }
+                float u, v, t;
+                if (mt_test(ta, tb, tc, o, d, u, v, t) && t < tmax) { hit_tri = (int)ti; busy = false; tg.y = 0u; }
+                CRT_MARK("tri_end");
+            }
+            if (busy && !(cur.y & 0xff000000u)) {
+                if (sp == 0) busy = false;
+                else { --sp; cur = stk[sp * 64]; }
+            }
+        }
+    }
+    CRT_MARK("loop_end");
+    HitState out;
+    out.t = tmax; out.tri = hit_tri;
+    if (regroup)
+        group_phase<true, STATS, false>(nodes, tris, base, stack_entries, overflow, busy, o, d, tmax, -1, cur, tg, sp, tri_min, out, n_nodes, n_tris, w_nodes, w_tris,
+                                        V3(0.f, 0.f, 0.f));
+    return out.tri >= 0;
 }
 
 // ------------------------------------------------------------------ scheduling -------
@@ -1453,6 +1539,9 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #ifndef CRT_LANES_ANY_IN
 #define CRT_LANES_ANY_IN(first) (!(first))
 #endif
+#ifndef CRT_FIRST_ANY_GROUPS      // the first segment's shadow walk: plain loop, then the group phase for the wave's last rays (traverse_any_then_groups)
+#define CRT_FIRST_ANY_GROUPS 0
+#endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
 // shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
@@ -1866,7 +1955,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+            if (CRT_FIRST_ANY_GROUPS && FIRST && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+                // the first segment's shadow rays: the plain loop, then groups for the last rays of the wave
+                const bool occluded = traverse_any_then_groups<STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
+                                                                      V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any);
+                if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
+            } else if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
                 walk_batch<true, STATS, false>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
