@@ -598,6 +598,14 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
 #define CRT_GROUP_KL 3       // lanes per ray after the regroup = 1 << this: 8 (one regroup, when at most 8 rays are left: 6,021 Mray/s on four segments of the
                              // 1 M-triangle scene against 5,464 with quads at <= 16 and 5,438 with pairs at <= 32; profiles/r04_experiments.md)
 #endif
+// Measurement variants CRT_GROUP_PREFETCH / CRT_P1_PREFETCH: bring a node's cache line(s) towards the CU without a destination register —
+// global_load_lds_dword writes the loaded word to LDS at M0 + lane * 4 (`lds_dummy`: 256 bytes of the wave's region nobody reads), so
+// there is no VGPR for the compiler to wait on and no wait is ever issued for it; loads return in order, so the counts the compiler
+// keeps for its own loads stay conservative.  Built with one more hit slot per lane (the dummy region).
+__device__ __forceinline__ void touch_node(const uint4* nodes, uint32_t idx, uint32_t lds_dummy) {
+    const uint32_t off = idx * (uint32_t)(CRT_NODE_ROWS * 16);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\tglobal_load_lds_dword %0, %1 offset:76" ::"v"(off), "s"(nodes), "s"(lds_dummy));
+}
 template <int KL> __device__ __forceinline__ uint32_t dpp_xor(uint32_t x, int step) {       // value of the lane `step` away inside the group (step = 1, 2, 4)
     if (step == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm [1, 0, 3, 2]
     if (step == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]
@@ -748,6 +756,9 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
         // ---------------- phase 2: K lanes per ray ----------------
         uint2* const stk = base + col;
         const vec3 o = UNIFORM_O ? o_uniform : o_lane;
+#ifdef CRT_GROUP_PREFETCH
+        const uint32_t touch_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(base + (stack_entries + CRT_HIT_SLOTS - 1) * 64));
+#endif
         CRT_MARK("loop_begin lanes2");
         while (__ballot(busy) != 0ull) {
             const bool has_tri = busy && tg.y != 0u;
@@ -771,13 +782,28 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
                     const uint4* np = node_rows(nodes, nidx);
                     // a lane of the group fetches only the words its child's bytes sit in: 52 instead of 80 bytes per lane through the
                     // texture-address path (+0.7 .. 1.1 % on the multi-segment frames; the eight lanes of a group ask for the same node)
+#ifdef CRT_GROUP_WIDE_LOADS            // measurement variant: the five full rows
+                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+#else
                     const uint32_t* nw = reinterpret_cast<const uint32_t*>(np) + (((sub * (uint32_t)(8 >> KL)) >= 4u) ? 1u : 0u);
                     const uint4 n0 = np[0];
                     const uint2 n1xy = *reinterpret_cast<const uint2*>(np + 1);
                     const uint32_t mw = nw[6], w2l = nw[8], w2h = nw[10], w3l = nw[12], w3h = nw[14], w4l = nw[16], w4h = nw[18];
                     const uint4 n1 = make_uint4(n1xy.x, n1xy.y, mw, mw), n2 = make_uint4(w2l, w2l, w2h, w2h), n3 = make_uint4(w3l, w3l, w3h, w3h), n4 = make_uint4(w4l, w4l, w4h, w4h);
+#endif
                     if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); }
                     const uint32_t hitmask = group_or<KL>(node8_intersect_part<KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
+#ifdef CRT_GROUP_PREFETCH
+                    // measurement variant: the group's eight lanes touch the inner children that were hit but are not visited next (they go to
+                    // the stack): lane `sub` owns bit 24 + sub of the mask
+                    if (KL == 3) {
+                        const uint32_t inner_hits = hitmask >> 24;
+                        if (((inner_hits >> sub) & 1u) && (inner_hits >> (sub + 1u)) != 0u) {
+                            const uint32_t pslot = sub ^ (oct4 & 7u);
+                            touch_node(nodes, n1.x + (uint32_t)__builtin_popcount((n0.w >> 24) & ((1u << pslot) - 1u)), touch_lds);
+                        }
+                    }
+#endif
                     cur.x = n1.x;
                     tg.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -834,6 +860,9 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
         // ---------------- phase 1: one ray per lane ----------------
         uint2* const stk = base + lane;
         const vec3 o = UNIFORM_O ? o_uniform : o_lane;
+#ifdef CRT_P1_PREFETCH
+        const uint32_t touch_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(base + (stack_entries + CRT_HIT_SLOTS - 1) * 64));
+#endif
         CRT_MARK("loop_begin lanes1");
         for (;;) {
             const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy));
@@ -859,6 +888,16 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                     if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
                     const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
+#ifdef CRT_P1_PREFETCH
+                    {   // measurement variant: touch the second-nearest inner child that was hit (the next one this lane pops)
+                        const uint32_t inner_hits = hitmask >> 24;
+                        if (inner_hits & (inner_hits - 1u)) {
+                            const uint32_t rest = inner_hits & ~(1u << (31 - __builtin_clz(inner_hits)));
+                            const uint32_t pslot = (uint32_t)(31 - __builtin_clz(rest)) ^ (oct4 & 7u);
+                            touch_node(nodes, n1.x + (uint32_t)__builtin_popcount((n0.w >> 24) & ((1u << pslot) - 1u)), touch_lds);
+                        }
+                    }
+#endif
                     cur.x = n1.x;
                     tg.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);

@@ -11,7 +11,9 @@ namespace crt {
 // Two more entries behind every lane's stack column: (u, v) and the original id of a closest-hit walk's best hit so far — written a few
 // times per ray, read once: LDS instead of three VGPRs across the traversal loop (rt_kernels.hip traverse_pool, walk_batch; the id's
 // neighbour word is walk_batch's regroup scratch).
+#ifndef CRT_HIT_SLOTS
 #define CRT_HIT_SLOTS 2
+#endif
 // Rows of 16 bytes between two nodes / two triangle records of the DEVICE copies the traversal reads (the C ABI's crt_node8 is 5 rows,
 // a record 3).  5 / 3 = packed.  8 / 4 pads a node to 128 bytes and a record to 64, so that neither straddles a cache line: a scene
 // that misses the caches then fetches one line per node instead of 1.6 on average (profiles/r03_experiments.md, "line-aligned records").

@@ -8,7 +8,7 @@ IFS=';' read -ra BUILDS <<< "$AB_BUILDS"
 IFS=';' read -ra RUNS <<< "$AB_RUNS"
 for B in "${BUILDS[@]}"; do
   BL=${B%%|*}; EX=${B#*|}
-  rm -f $R/caitlynrenderer_amd/csrc/rt_kernels.o
+  rm -f $R/caitlynrenderer_amd/csrc/rt_kernels.o $R/caitlynrenderer_amd/csrc/crt_device.o
   make -C $R/caitlynrenderer_amd/csrc -s EXTRA="$EX" > $OUT/build_$BL.log 2>&1 || { echo "build $BL failed"; tail -5 $OUT/build_$BL.log; continue; }
   for RUN in "${RUNS[@]}"; do
     RL=${RUN%%|*}; ARGS=${RUN#*|}
@@ -24,5 +24,5 @@ PY
   done
 done
 # leave the default build behind
-rm -f $R/caitlynrenderer_amd/csrc/rt_kernels.o
+rm -f $R/caitlynrenderer_amd/csrc/rt_kernels.o $R/caitlynrenderer_amd/csrc/crt_device.o
 make -C $R/caitlynrenderer_amd/csrc -s > /dev/null 2>&1
