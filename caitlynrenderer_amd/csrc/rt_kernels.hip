@@ -1317,6 +1317,11 @@ __device__ __forceinline__ uint32_t ray_bin_key(const RayBins& b, float4 o, floa
     const float cy = __builtin_fminf(__builtin_fmaxf((o.y - b.origin[1]) * b.scale[1], 0.0f), 7.0f);
     const float cz = __builtin_fminf(__builtin_fmaxf((o.z - b.origin[2]) * b.scale[2], 0.0f), 7.0f);
     const uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+#if defined(CRT_BIN_KEY_MODE) && CRT_BIN_KEY_MODE == 1      // measurement variants: the octant alone / octant + 2^3 cells
+    return oct << 9;
+#elif defined(CRT_BIN_KEY_MODE) && CRT_BIN_KEY_MODE == 2
+    return (oct << 9) | (((uint32_t)cz >> 2) << 6) | (((uint32_t)cy >> 2) << 3) | ((uint32_t)cx >> 2);
+#endif
     return (oct << 9) | ((uint32_t)cz << 6) | ((uint32_t)cy << 3) | (uint32_t)cx;      // octant-major: neighbouring bins share the octant
 }
 // Queue entry for this lane's ray (meaningless where !want).  The lanes of a wave that share a key are found with one ballot per
@@ -1569,17 +1574,18 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #define CRT_ANYSHARE_IN(first) false
 #endif
 // walk_batch (the last rays of a draining wave get eight lanes each) walks the closest hits of every segment and the in-place shadow
-// rays of the bounce segments.  The first segment's shadow rays keep the plain per-lane loop: they are coherent, and the voting loop
-// costs them more than the tail gives back (1 M triangles, 1080p: closest only 14,131 Mray/s, both 13,730, shadow only 13,618, neither
-// 13,965; 4K 15,424 against 15,190; 8 M triangles 9,302 against 9,040 — profiles/r04_experiments.md).
+// rays of the bounce segments.  The first segment's shadow rays are coherent and the voting loop costs them more than it gives (1 M
+// triangles, 1080p: closest only 14,131 Mray/s, both 13,730, shadow only 13,618, neither 13,965 — profiles/r04_experiments.md): they keep
+// the plain per-lane loop and only hand the wave's last eight rays to the group phase (traverse_any_then_groups, CRT_FIRST_ANY_GROUPS:
+// 14,156 -> 14,282 at 1080p, 15,378 -> 15,512 at 4K, 8 M triangles 9,180 -> 9,355).
 #ifndef CRT_LANES_CLOSEST_IN
 #define CRT_LANES_CLOSEST_IN(first) true
 #endif
 #ifndef CRT_LANES_ANY_IN
 #define CRT_LANES_ANY_IN(first) (!(first))
 #endif
-#ifndef CRT_FIRST_ANY_GROUPS      // the first segment's shadow walk: plain loop, then the group phase for the wave's last rays (traverse_any_then_groups)
-#define CRT_FIRST_ANY_GROUPS 0
+#ifndef CRT_FIRST_ANY_GROUPS
+#define CRT_FIRST_ANY_GROUPS 1
 #endif
 
 // One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
