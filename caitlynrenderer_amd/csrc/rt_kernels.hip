@@ -113,10 +113,17 @@ __device__ __forceinline__ void count_wave_step(uint32_t& c) {
 // Measurement aid (crt_debug_step_hist): how many lanes were enabled at each node step of the counting kernels, per walk kind — the
 // distribution behind the lane-utilisation figures (how much of the idle time is "fewer than half of the lanes still have a ray").
 __device__ unsigned long long* g_step_hist = nullptr;       // [2][65]: closest-hit walks, any-hit walks; null = off
-__device__ __forceinline__ void hist_node_step(bool any) {
+// -DCRT_HIST_UNIFORM=1 / 2 (measurement builds): only the steps whose enabled lanes all fetch the SAME node (2: and share the octant) are binned
+__device__ __forceinline__ void hist_node_step(bool any, uint32_t nidx = 0u, uint32_t oct = 0u) {
     unsigned long long* const h = g_step_hist;
     if (h == nullptr) return;
     const unsigned long long m = __ballot(true);
+#ifdef CRT_HIST_UNIFORM
+    {
+        const uint32_t key = CRT_HIST_UNIFORM == 2 ? (nidx << 3) | (oct & 7u) : nidx;
+        if (__ballot(key == (uint32_t)__builtin_amdgcn_readfirstlane((int)key)) != m) return;
+    }
+#endif
     if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) atomicAdd(&h[(any ? 65 : 0) + __builtin_popcountll(m)], 1ull);
 }
 void set_step_hist(unsigned long long* d_hist) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist), &d_hist, sizeof d_hist); }
@@ -201,7 +208,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
             const uint4* np = node_rows(nodes, base + rel);
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
+            if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, base + rel, oct4); }
             const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
             cur.x = n1.x;
             tg.x = n1.y;
@@ -371,7 +378,7 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                 const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 const uint4* np = node_rows(nodes, nidx);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, nidx, oct4); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
                 cur.x = n1.x;
                 tg.x = n1.y;
@@ -886,7 +893,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                     const uint4* np = node_rows(nodes, nidx);
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                    if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
+                    if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, nidx, oct4); }
                     const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
 #ifdef CRT_P1_PREFETCH
                     {   // measurement variant: touch the second-nearest inner child that was hit (the next one this lane pops)
@@ -980,7 +987,7 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 const uint4* np = node_rows(nodes, nbase + rel);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true); }
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true, nbase + rel, oct4); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax);
                 cur.x = n1.x;
                 tg.x = n1.y;
