@@ -170,10 +170,44 @@ __device__ __forceinline__ const uint4* node_rows(const uint4* nodes, uint32_t i
 __device__ __forceinline__ const float4* tri_rows(const float4* tris, uint32_t idx) { return tris + (size_t)idx * CRT_TRI_ROWS; }
 #endif
 
+// ---- UNIFORM NODE STEPS (round 4): the node through the scalar cache ----
+// The 64 primary rays of a wave leave a 4 x 4 pixel quadrant, so near the root they all ask for the SAME node and share the direction
+// octant: 45 % of the first segment's closest-hit node steps and 30 % of its shadow walks' (8 x 8 pixel waves; profiles/r04_experiments.md).
+// Such a step needs no vector load at all: one lane's index, five s_load_dwordx4 through the scalar data cache, and the node sits in 20
+// SGPRs.  Everything that depends on the node and the octant alone — the three exponents, `meta` (inner mask, bit index, child bits), the
+// near / far plane selects, child_bits << bit_index of all eight children — then runs on the scalar unit; what is left per lane is the
+// arithmetic of node8_intersect itself on the same operands (conversions read the bytes from SGPRs), so the hit mask keeps its bits.
+// uniform_node_key: what must agree across the enabled lanes (node index, octant).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool node_step_is_uniform(uint32_t nidx, uint32_t oct4, uint32_t& key0) {
+    const uint32_t key = (nidx << 3) | (oct4 & 7u);          // crt_scene_create keeps node offsets below 4 GiB: nidx < 2^26
+    key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    return __ballot(key != key0) == 0ull;
+}
+__device__ __forceinline__ void load_node_scalar(const uint4* nodes, uint32_t nidx0, uint4& n0, uint4& n1, uint4& n2, uint4& n3, uint4& n4) {
+    const char* p = reinterpret_cast<const char*>(nodes) + (size_t)nidx0 * (size_t)(CRT_NODE_ROWS * 16);
+    u32x4 a, b, c, d, e;
+    // inline assembly: the compiler would pick a vector load here (it cannot prove that none of the kernel's stores touches the node array)
+    asm volatile("s_load_dwordx4 %0, %5, 0x0\n\ts_load_dwordx4 %1, %5, 0x10\n\ts_load_dwordx4 %2, %5, 0x20\n\ts_load_dwordx4 %3, %5, 0x30\n\t"
+                 "s_load_dwordx4 %4, %5, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e) : "s"(p));
+    n0 = make_uint4(a.x, a.y, a.z, a.w); n1 = make_uint4(b.x, b.y, b.z, b.w); n2 = make_uint4(c.x, c.y, c.z, c.w);
+    n3 = make_uint4(d.x, d.y, d.z, d.w); n4 = make_uint4(e.x, e.y, e.z, e.w);
+}
+#ifndef CRT_UNIFORM_CLOSEST      // first-segment closest-hit walk (walk_batch phase 1)
+#define CRT_UNIFORM_CLOSEST 1
+#endif
+#ifndef CRT_UNIFORM_ANY          // first-segment shadow walk (traverse_any_then_groups)
+#define CRT_UNIFORM_ANY 1
+#endif
+#ifndef CRT_UNIFORM_PLAIN        // first-segment walks of the plain per-lane loop (scenes of a few nodes: tri_min 0)
+#define CRT_UNIFORM_PLAIN 1
+#endif
+
 // One ray through the CWBVH (cwbvh.fs:448-536 closest, :538-616 any).  `stk` is this lane's column
 // of the wave's LDS stack: stk[level * 64]; stack_entries (<= CRT_STACK_ENTRIES) is sized from the
 // CWBVH's depth at scene creation so shallow trees leave more LDS for occupancy.
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool UNI = false>
 __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o,
                                          vec3 d, float tmax_in, uint2* stk, int stack_entries, uint32_t* overflow, HitState& best,
                                          uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
@@ -206,14 +240,28 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             }
             const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
             const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+            if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, base + rel, oct4); }
+            uint32_t key0 = 0u;
+            if (UNI && node_step_is_uniform(base + rel, oct4, key0)) {
+                CRT_MARK("uninode_begin");
+                uint4 n0, n1, n2, n3, n4;
+                load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
+                const uint32_t oct0 = key0 & 7u;
+                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, max_t);
+                cur.x = n1.x;
+                tg.x = n1.y;
+                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                tg.y = hitmask & 0x00ffffffu;
+                CRT_MARK("uninode_end");
+            } else {
             const uint4* np = node_rows(nodes, base + rel);
             const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, base + rel, oct4); }
             const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, max_t);
             cur.x = n1.x;
             tg.x = n1.y;
             cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
             tg.y = hitmask & 0x00ffffffu;
+            }
             CRT_MARK("node_end");
         } else {
             tg = cur;
@@ -843,7 +891,7 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
 // Two loops: phase 1 is the lock-step voting loop of traverse_pool, one ray per lane, and ends when at most 64 >> CRT_GROUP_KL rays are
 // left; those are regrouped and finished by phase 2, which knows nothing but groups.  (One loop that carried the group size as a variable
 // cost the one-lane phase 5 %: a guard on every stack write, a switch in every step.)
-template <bool ANY, bool STATS, bool UNIFORM_O>
+template <bool ANY, bool STATS, bool UNIFORM_O, bool UNI = false>
 __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
                                            bool has_ray, vec3 o_in, vec3 d, float tmax_in, uint32_t tri_min, uint32_t max_kl, HitState& out,
                                            uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
@@ -891,9 +939,23 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u); }
                     const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
                     const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                    if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, nidx, oct4); }
+                    uint32_t key0 = 0u;
+                    if (UNI && node_step_is_uniform(nidx, oct4, key0)) {
+                        // every enabled lane asks for this node and shares the octant: the node comes through the scalar cache
+                        CRT_MARK("uninode_begin");
+                        uint4 n0, n1, n2, n3, n4;
+                        load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
+                        const uint32_t oct0 = key0 & 7u;
+                        const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, best_t);
+                        cur.x = n1.x;
+                        tg.x = n1.y;
+                        cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                        tg.y = hitmask & 0x00ffffffu;
+                        CRT_MARK("uninode_end");
+                    } else {
                     const uint4* np = node_rows(nodes, nidx);
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                    if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, nidx, oct4); }
                     const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
 #ifdef CRT_P1_PREFETCH
                     {   // measurement variant: touch the second-nearest inner child that was hit (the next one this lane pops)
@@ -909,6 +971,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     tg.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
                     tg.y = hitmask & 0x00ffffffu;
+                    }
                     CRT_MARK("node_end");
                 }
             } else if (has_tri) {
@@ -985,14 +1048,28 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u); }
                 const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
                 const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true, nbase + rel, oct4); }
+                uint32_t key0 = 0u;
+                if (CRT_UNIFORM_ANY && node_step_is_uniform(nbase + rel, oct4, key0)) {
+                    CRT_MARK("uninode_begin");
+                    uint4 n0, n1, n2, n3, n4;
+                    load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
+                    const uint32_t oct0 = key0 & 7u;
+                    const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, tmax);
+                    cur.x = n1.x;
+                    tg.x = n1.y;
+                    cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                    tg.y = hitmask & 0x00ffffffu;
+                    CRT_MARK("uninode_end");
+                } else {
                 const uint4* np = node_rows(nodes, nbase + rel);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true, nbase + rel, oct4); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax);
                 cur.x = n1.x;
                 tg.x = n1.y;
                 cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
                 tg.y = hitmask & 0x00ffffffu;
+                }
                 CRT_MARK("node_end");
             } else {
                 tg = cur;
@@ -1778,14 +1855,14 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
         } else if (BVH2) {
             if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, a.overflow, hit, nn, nt);
         } else if (a.tri_min == 0u) {
-            if (active) traverse<false, STATS>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt);
+            if (active) traverse<false, STATS, FIRST && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
             if (!SHARE && CRT_LANES_CLOSEST_IN(FIRST)) {
                 // the last rays of the batch get eight lanes each (a.lanes_log2 = 0: never — then this is traverse_pool's lock-step loop)
-                walk_batch<false, STATS, FIRST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
+                walk_batch<false, STATS, FIRST, FIRST && CRT_UNIFORM_CLOSEST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
                                                 nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]));
             } else
             traverse_pool<false, STATS, SHARE, FIRST>(
@@ -2037,7 +2114,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
                 const vec3 so = V3(sh0.x, sh0.y, sh0.z), sd = V3(sh1.x, sh1.y, sh1.z);
                 const bool occluded = BVH2
                     ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, so, sd, sh0.w, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
-                    : traverse<true, STATS>(a.nodes, a.tris, so, sd, sh0.w, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any);
+                    : traverse<true, STATS, FIRST && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, so, sd, sh0.w, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any);
                 if (!occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
             }
             if (pending && emit_next) a.pb.L[pix] = make_float4(L.x, L.y, L.z, pend_pdf);     // the path goes on: its radiance so far waits in the path state
