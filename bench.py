@@ -540,7 +540,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             traffic = int(traffic * samples_per_launch / max(1, pmc.get("samples_per_launch", 1)))
         counters = {"primary_rays": int(n_primary), "closest_rays": int(cs["closest_rays"]), "any_rays": int(cs["any_rays"]),
                     "closest_hits": int(cs["closest_hits"]), "nodes_closest": int(cs["nodes_closest"]), "tris_closest": int(cs["tris_closest"]),
-                    "nodes_any": int(cs["nodes_any"]), "tris_any": int(cs["tris_any"])}
+                    "nodes_any": int(cs["nodes_any"]), "tris_any": int(cs["tris_any"]),
+                    "nodes_closest_uniform": int(cs.get("nodes_closest_uniform", 0)), "nodes_any_uniform": int(cs.get("nodes_any_uniform", 0))}
         roofline = valu_roofline(counters, t_launch, launches, samples_per_launch, args.accel, pmc)
         if one_proc and len(set(one_proc)) < len(one_proc):
             # virtual devices share one GPU: a launch's duration there says nothing about the kernel (the number this mode prints is not a

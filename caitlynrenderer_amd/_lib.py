@@ -53,7 +53,8 @@ class crt_frame_stats(C.Structure):
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("tris_any", C.c_uint64),
                 ("stack_overflows", C.c_uint32),
                 ("wave_steps_closest_nodes", C.c_uint64), ("wave_steps_closest_tris", C.c_uint64),
-                ("wave_steps_any_nodes", C.c_uint64), ("wave_steps_any_tris", C.c_uint64), ("closest_hits", C.c_uint64)]
+                ("wave_steps_any_nodes", C.c_uint64), ("wave_steps_any_tris", C.c_uint64), ("closest_hits", C.c_uint64),
+                ("nodes_closest_uniform", C.c_uint64), ("nodes_any_uniform", C.c_uint64)]
 
 
 class crt_bvh_info(C.Structure):

@@ -150,7 +150,7 @@ struct crt_scene {
     bool have_camera = false;
     uint32_t jitter = 1;
     bool count_visits = false;
-    unsigned long long* d_visit_totals = nullptr;   // [0..3] lane visits: closest nodes/tris, any nodes/tris; [4..7] wave-level steps of the same blocks; [8] closest-hit rays that hit
+    unsigned long long* d_visit_totals = nullptr;   // [0..3] lane visits: closest nodes/tris, any nodes/tris; [4..7] wave-level steps of the same blocks; [8] closest-hit rays that hit; [10], [11] closest / any-hit node visits of uniform node steps
     unsigned long long* h_visit_totals = nullptr;   // pinned
 
     // scratch for crt_trace (host rays)
@@ -438,6 +438,7 @@ int collect_stats(crt_scene* s) {
         st.wave_steps_closest_nodes = s->h_visit_totals[4]; st.wave_steps_closest_tris = s->h_visit_totals[5];
         st.wave_steps_any_nodes = s->h_visit_totals[6]; st.wave_steps_any_tris = s->h_visit_totals[7];
         st.closest_hits = s->h_visit_totals[8];
+        st.nodes_closest_uniform = s->h_visit_totals[10]; st.nodes_any_uniform = s->h_visit_totals[11];
     }
     s->stats = st;
     s->stats_pending = false;
@@ -1468,6 +1469,7 @@ int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out) {
         out->wave_steps_closest_nodes += ps.wave_steps_closest_nodes; out->wave_steps_closest_tris += ps.wave_steps_closest_tris;
         out->wave_steps_any_nodes += ps.wave_steps_any_nodes; out->wave_steps_any_tris += ps.wave_steps_any_tris;
         out->closest_hits += ps.closest_hits; out->stack_overflows += ps.stack_overflows;
+        out->nodes_closest_uniform += ps.nodes_closest_uniform; out->nodes_any_uniform += ps.nodes_any_uniform;
         out->ms_total = std::max(out->ms_total, ps.ms_total); out->ms_trace_closest = std::max(out->ms_trace_closest, ps.ms_trace_closest);
         out->ms_trace_any = std::max(out->ms_trace_any, ps.ms_trace_any); out->ms_shade = std::max(out->ms_shade, ps.ms_shade);
     }

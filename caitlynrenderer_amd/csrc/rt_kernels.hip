@@ -200,8 +200,8 @@ __device__ __forceinline__ void load_node_scalar(const uint4* nodes, uint32_t ni
 #ifndef CRT_UNIFORM_ANY          // first-segment shadow walk (traverse_any_then_groups)
 #define CRT_UNIFORM_ANY 1
 #endif
-#ifndef CRT_UNIFORM_PLAIN        // first-segment walks of the plain per-lane loop (scenes of a few nodes: tri_min 0)
-#define CRT_UNIFORM_PLAIN 1
+#ifndef CRT_UNIFORM_PLAIN        // first-segment walks of the plain per-lane loop (scenes of a few nodes: tri_min 0); measured on the Cornell box, 4 samples
+#define CRT_UNIFORM_PLAIN 0      // per launch: 43.7 Gray/s without any uniform code, 43.0 with the code present, 41.9 with the steps running
 #endif
 
 // One ray through the CWBVH (cwbvh.fs:448-536 closest, :538-616 any).  `stk` is this lane's column
@@ -210,7 +210,7 @@ __device__ __forceinline__ void load_node_scalar(const uint4* nodes, uint32_t ni
 template <bool ANY, bool STATS, bool UNI = false>
 __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const float4* __restrict__ tris, vec3 o,
                                          vec3 d, float tmax_in, uint2* stk, int stack_entries, uint32_t* overflow, HitState& best,
-                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
+                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, uint32_t* n_uni = nullptr) {
     best.t = tmax_in; best.u = 0.f; best.v = 0.f; best.tri = -1; best.id = -1;
     // a non-finite origin makes every slab NaN (all children pass): such a ray can hit nothing
     if (!(__builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z))) return false;
@@ -244,6 +244,7 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
             uint32_t key0 = 0u;
             if (UNI && node_step_is_uniform(base + rel, oct4, key0)) {
                 CRT_MARK("uninode_begin");
+                if (STATS && n_uni) ++*n_uni;
                 uint4 n0, n1, n2, n3, n4;
                 load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
                 const uint32_t oct0 = key0 & 7u;
@@ -894,7 +895,8 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
 template <bool ANY, bool STATS, bool UNIFORM_O, bool UNI = false>
 __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
                                            bool has_ray, vec3 o_in, vec3 d, float tmax_in, uint32_t tri_min, uint32_t max_kl, HitState& out,
-                                           uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
+                                           uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f),
+                                           uint32_t* n_uni = nullptr) {
     constexpr uint32_t KL = CRT_GROUP_KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const slot_uv = base + stack_entries * 64;              // [col] (u, v) of the best hit
@@ -944,6 +946,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     if (UNI && node_step_is_uniform(nidx, oct4, key0)) {
                         // every enabled lane asks for this node and shares the octant: the node comes through the scalar cache
                         CRT_MARK("uninode_begin");
+                if (STATS && n_uni) ++*n_uni;
                         uint4 n0, n1, n2, n3, n4;
                         load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
                         const uint32_t oct0 = key0 & 7u;
@@ -1018,10 +1021,10 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
 // Any-hit walk of one batch: the plain per-lane loop of traverse<true> (each lane tests its leaf's triangles right after the node that found
 // them — the fastest form for the coherent shadow rays of primary hits) until at most 64 >> CRT_GROUP_KL rays are left, then the group phase.
 // Every lane of the wave calls this together; returns whether this lane's ray is occluded.
-template <bool STATS>
+template <bool STATS, bool UNI = false>
 __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
                                                          uint32_t* overflow, bool has_ray, vec3 o, vec3 d, float tmax, uint32_t tri_min, uint32_t max_kl,
-                                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
+                                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, uint32_t* n_uni = nullptr) {
     constexpr uint32_t KL = CRT_GROUP_KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const stk = base + lane;
@@ -1050,8 +1053,9 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 const uint32_t rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true, nbase + rel, oct4); }
                 uint32_t key0 = 0u;
-                if (CRT_UNIFORM_ANY && node_step_is_uniform(nbase + rel, oct4, key0)) {
+                if (UNI && node_step_is_uniform(nbase + rel, oct4, key0)) {
                     CRT_MARK("uninode_begin");
+                if (STATS && n_uni) ++*n_uni;
                     uint4 n0, n1, n2, n3, n4;
                     load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
                     const uint32_t oct0 = key0 & 7u;
@@ -1706,6 +1710,12 @@ template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool B
           bool BATCH = false, bool WIDE = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
+    // Uniform node steps are compiled into the batched first-segment kernels (crt_render_frames: the samples-in-lanes waves leave a 4 x 4
+    // pixel quadrant) and into the counting kernels (so that the statistics can say how many visits were uniform).  In the single-sample
+    // kernel their code alone costs more than the steps return (32-triangle Cornell box 52.5 -> 50.3 Gray/s with the code merely present,
+    // 1 M triangles at one sample per launch 13,037 -> 12,822 Mray/s with it running: 8 x 8-pixel waves agree less, and the 20 scalar
+    // registers of the node push loop state out of the SGPR file).
+    constexpr bool UNI_K = FIRST && (BATCH || STATS);
     // uniform: the workgroup's waves are the samples of one 64-pixel batch.  The 6-waves-per-SIMD build is never launched in that form
     // (launch_segment), and compiling the form out of it frees the registers its LDS result strip and wave index would hold
     const bool wave_samples = BATCH && !WIDE && a.wave_samples == 1u;
@@ -1730,6 +1740,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
     uint32_t nn = 0, nt = 0, nn_any = 0, nt_any = 0;
     uint32_t wn = 0, wt = 0, wn_any = 0, wt_any = 0;     // wave-level step counts of the same blocks (counting kernels)
     uint32_t n_hits = 0;                                 // closest-hit rays that hit something, i.e. lanes that ran the shading code
+    uint32_t nu = 0, nu_any = 0;                         // node visits that went through the scalar cache (uniform node steps)
     // Queue counters are double-banked by frame parity: the first kernel of a frame clears the bank the next
     // frame will append to (last touched by the previous frame, which stream order has retired).
     if (FIRST && a.zero_counts && blockIdx.x == 0)   // 64 or 256 threads, either works
@@ -1855,15 +1866,15 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
         } else if (BVH2) {
             if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, a.overflow, hit, nn, nt);
         } else if (a.tri_min == 0u) {
-            if (active) traverse<false, STATS, FIRST && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt);
+            if (active) traverse<false, STATS, UNI_K && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt, &nu);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
             if (!SHARE && CRT_LANES_CLOSEST_IN(FIRST)) {
                 // the last rays of the batch get eight lanes each (a.lanes_log2 = 0: never — then this is traverse_pool's lock-step loop)
-                walk_batch<false, STATS, FIRST, FIRST && CRT_UNIFORM_CLOSEST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
-                                                nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]));
+                walk_batch<false, STATS, FIRST, UNI_K && !!CRT_UNIFORM_CLOSEST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
+                                                nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]), &nu);
             } else
             traverse_pool<false, STATS, SHARE, FIRST>(
                 a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
@@ -2086,8 +2097,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
             if (CRT_FIRST_ANY_GROUPS && FIRST && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // the first segment's shadow rays: the plain loop, then groups for the last rays of the wave
-                const bool occluded = traverse_any_then_groups<STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
-                                                                      V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any);
+                const bool occluded = traverse_any_then_groups<STATS, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
+                                                                      V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any, &nu_any);
                 if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
             } else if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
@@ -2114,7 +2125,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
                 const vec3 so = V3(sh0.x, sh0.y, sh0.z), sd = V3(sh1.x, sh1.y, sh1.z);
                 const bool occluded = BVH2
                     ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, so, sd, sh0.w, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
-                    : traverse<true, STATS, FIRST && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, so, sd, sh0.w, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any);
+                    : traverse<true, STATS, UNI_K && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, so, sd, sh0.w, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any, &nu_any);
                 if (!occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
             }
             if (pending && emit_next) a.pb.L[pix] = make_float4(L.x, L.y, L.z, pend_pdf);     // the path goes on: its radiance so far waits in the path state
@@ -2214,6 +2225,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
     if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any, wn_any, wt_any);
     if (STATS) flush_visit_totals(a.visit_totals + 8, n_hits, 0u);
+    if (STATS) flush_visit_totals(a.visit_totals + 10, nu, nu_any);
     (void)stk; (void)stk2;
 }
 

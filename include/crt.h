@@ -335,6 +335,10 @@ typedef struct crt_frame_stats {
     /* with "count_visits": closest-hit rays of the frame that hit something, i.e. the lanes that ran the shading code
      * (path_trace.fs:872-1018); bench.py's instruction model charges the shading instructions to these only */
     uint64_t closest_hits;
+    /* with "count_visits": the part of nodes_closest / nodes_any that was visited in UNIFORM node steps — every enabled lane of the
+     * wave asked for the same node and shared the direction octant, so the node came through the scalar cache and its decode ran on
+     * the scalar unit (first-segment walks; rt_kernels.hip "uniform node steps") */
+    uint64_t nodes_closest_uniform, nodes_any_uniform;
 } crt_frame_stats;
 int crt_get_frame_stats(crt_scene* s, crt_frame_stats* out);
 /* structural facts about the device-resident CWBVH */

@@ -906,6 +906,10 @@ def test_million_triangle_mesh_full_frame(cr, ob, mesh1m):
         st = scene.frame_stats()
         assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["stack_overflows"] == 0
         assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
+        # uniform node steps (first-segment walks: the node through the scalar cache when every enabled lane asks for the same one):
+        # a part of the same visits — the totals above already equal the oracle's — and a large one on primary rays (every ray
+        # starts at the root, and the waves whose rays do not share the octant are the few that straddle the image centre)
+        assert 0.9 * W * H < st["nodes_closest_uniform"] < st["nodes_closest"] and 0 < st["nodes_any_uniform"] < st["nodes_any"]
         out = scene.read_sum()
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
     # the same frame through the shadow queue + k_shadow pipeline (inplace_shadow = 0): same sum, and its queue feeds the

@@ -120,6 +120,15 @@ def parse_asm(path):
                 e["regions"].append(("loop", tag, n))
                 for j in range(b, i):
                     in_loop[j] = True
+        # uniform node steps (the node through the scalar cache): the text between its two markers — both volatile, with the volatile
+        # s_load block right behind the first — is the variant's own arithmetic; it sits INSIDE a node region and is counted apart
+        uni = []
+        for i, s in enumerate(lines):
+            if re.match(r"^; CRT_MARK uninode_begin", s):
+                for q in range(i, len(lines)):
+                    if re.match(r"^; CRT_MARK uninode_end", lines[q]):
+                        uni.append((i, q, sum(1 for t in lines[i:q] if is_instr(t) and t.split()[0].startswith("v_"))))
+                        break
         for i, s in enumerate(lines):
             m = re.match(r"^; CRT_MARK (node|tri|share|shade)_begin", s)
             if m:
@@ -129,6 +138,11 @@ def parse_asm(path):
                         # the shading block contains the in-place shadow walk: its loops are counted as loops, not as shading
                         n = sum(1 for q in range(j, label_at[mb.group(1)]) if is_instr(lines[q]) and lines[q].split()[0].startswith("v_")
                                 and not (m.group(1) == "shade" and in_loop[q]))
+                        if m.group(1) == "node":
+                            for (ub, ue, un) in uni:
+                                if j <= ub and ue <= label_at[mb.group(1)]:
+                                    n -= un
+                                    e["regions"].append(("uninode", "", un))
                         e["regions"].append((m.group(1), "", n))
                         break
             if not is_instr(s):
@@ -192,6 +206,7 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
         d = {"kernel": label_of(name), "valu_total": e["valu_total"], "valu_outside_loops": e["valu_outside_loops"],
              "salu_total": e["salu_total"], "vmem_total": e["vmem_total"], "lds_total": e["lds_total"],
              "node_steps": [r[2] for r in regs if r[0] == "node"], "tri_steps": [r[2] for r in regs if r[0] == "tri"],
+             "uniform_node_steps": [r[2] for r in regs if r[0] == "uninode"],
              "shared_tri_steps": [r[2] for r in regs if r[0] == "share"], "loops": [(r[1], r[2]) for r in loops],
              "shade": [r[2] for r in regs if r[0] == "shade"]}
         counts["kernels"][key] = d
@@ -202,6 +217,9 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
         # shadow walk is within a few instructions of it); the shell of a ray = everything outside the traversal loops
         counts["I_node"] = f["node_steps"][0]
         counts["I_tri"] = f["tri_steps"][0]
+        # a uniform node step (every enabled lane fetches the same node: scalar loads, scalar decode): what such a visit executes instead
+        if f.get("uniform_node_steps"):
+            counts["I_node_uniform"] = f["uniform_node_steps"][0]
         # a ray's shell: what every ray runs (ray generation or queue fetch, loop set-up, queue emission) and what only a ray that
         # hit something runs (shading, NEE set-up, bounce sampling)
         counts["I_shade"] = f["shade"][0] if f["shade"] else 0
@@ -211,7 +229,7 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
         counts["I_ray_bounce"] = b["valu_outside_loops"] - counts["I_shade_bounce"]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(counts, open(os.path.join(ROOT, "profiles", "isa_counts.json"), "w"), indent=1)
-    print(json.dumps({x: counts.get(x) for x in ("I_node", "I_tri", "I_ray_first", "I_shade", "I_ray_bounce", "I_shade_bounce")}))
+    print(json.dumps({x: counts.get(x) for x in ("I_node", "I_node_uniform", "I_tri", "I_ray_first", "I_shade", "I_ray_bounce", "I_shade_bounce")}))
     if os.path.exists(remarks):
         r = parse_remarks(remarks)
         path = os.path.join(ROOT, "profiles", f"{tag}_kernel_resources.txt")
@@ -227,7 +245,11 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
 def traversal_wave_instr(cs, isa, depth=1, samples=1):
     """Traversal wave-instructions of ONE launch (node visits and triangle tests only, 64-lane equivalents): the frame's total over its
     `depth` segment launches / depth, x samples per launch.  cs: totals of one counting frame."""
-    lane_instr = (cs["nodes_closest"] + cs["nodes_any"]) * isa["I_node"] + (cs["tris_closest"] + cs["tris_any"]) * isa["I_tri"]
+    # node visits of uniform node steps (the node through the scalar cache, its decode on the scalar unit) execute I_node_uniform
+    # vector instructions, the others I_node: executed counts, so that the figure cannot exceed what the counters saw
+    n_uni = cs.get("nodes_closest_uniform", 0) + cs.get("nodes_any_uniform", 0)
+    n_nodes = cs["nodes_closest"] + cs["nodes_any"]
+    lane_instr = (n_nodes - n_uni) * isa["I_node"] + n_uni * isa.get("I_node_uniform", isa["I_node"]) + (cs["tris_closest"] + cs["tris_any"]) * isa["I_tri"]
     return lane_instr / 64.0 / max(1, depth) * samples
 
 
