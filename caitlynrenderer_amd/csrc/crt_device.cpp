@@ -74,6 +74,7 @@ struct crt_scene {
 
     // scene (replicated on every rank)
     uint4* d_nodes = nullptr;
+    float4* d_planes = nullptr;          // the nodes' child planes as floats, 12 rows per node (uniform node steps; built by finish_scene_setup on every device)
     float4* d_tris = nullptr;
     int4* d_triangles = nullptr;
     float* d_normals = nullptr;
@@ -238,7 +239,7 @@ struct crt_scene {
         if (stream) hipStreamSynchronize(stream);
         if (shares_scene)                    // borrowed from the primary, which frees them
             for (const auto& b : scene_bufs) *reinterpret_cast<void**>(reinterpret_cast<char*>(this) + b.first) = nullptr;
-        void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
+        void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_planes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal, d_bins};
         for (void* p : ptrs) if (p) hipFree(p);
@@ -505,6 +506,12 @@ static int finish_scene_setup(crt_scene* s) {
         if ((rc = pad_rows(s, &s->d_nodes, 5u, (uint32_t)CRT_NODE_ROWS, (size_t)s->info.n_nodes8))) return rc;
         if ((rc = pad_rows(s, &s->d_tris, 3u, (uint32_t)CRT_TRI_ROWS, (size_t)s->info.n_tris8))) return rc;
         s->rows_padded = true;
+    }
+    if (s->d_nodes && s->info.n_nodes8 && !s->d_planes) {      // a replica got its copy (or the primary's own array) with the other scene buffers
+        if ((rc = dev_alloc(&s->d_planes, (size_t)s->info.n_nodes8 * 12))) return rc;
+        note_buf(s, &s->d_planes, (size_t)s->info.n_nodes8 * 12 * sizeof(float4));
+        crt::launch_expand_planes(s->d_nodes, (uint32_t)CRT_NODE_ROWS, s->d_planes, s->info.n_nodes8, s->stream);
+        if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail(CRT_ERR_HIP, "crt_scene_create: plane expansion failed");
     }
     if ((rc = dev_alloc(&s->d_overflow, 1))) return rc;
     if (hipMemset(s->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) return fail(CRT_ERR_HIP, "hipMemset failed");
@@ -1190,7 +1197,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
 
     for (uint32_t b = 0; b < s->max_depth; ++b) {
         crt::SegmentArgs sa{};
-        sa.nodes = s->d_nodes; sa.tris = s->d_tris; sa.triangles = s->d_triangles; sa.normals = s->d_normals;
+        sa.nodes = s->d_nodes; sa.planes = s->d_planes; sa.tris = s->d_tris; sa.triangles = s->d_triangles; sa.normals = s->d_normals;
         sa.materials = s->d_materials; sa.lights = s->d_lights; sa.n_lights = (int32_t)s->n_lights;
         sa.stack_entries = s->stack_entries;
         sa.texcoords = s->d_texcoords; sa.textures = s->d_textures;

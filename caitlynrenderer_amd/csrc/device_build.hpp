@@ -61,6 +61,8 @@ void launch_validate_triangles(const crt_triangle* d_tris, uint32_t n, uint32_t 
                                uint32_t n_texcoords, const float* d_materials /* 16 floats each */, int have_tex, uint32_t* d_flag, hipStream_t stream);
 // items of rows_in 16-byte rows -> items of rows_out rows (padding zeroed): the line-aligned device copies of nodes and records
 void launch_restride(const void* d_src, uint32_t rows_in, void* d_dst, uint32_t rows_out, uint64_t n_items, hipStream_t stream);
+// 12 float4 rows per node: the child planes as floats (uniform node steps; layout in scene_build.hip k_expand_planes)
+void launch_expand_planes(const void* d_nodes, uint32_t node_rows, void* d_planes, uint64_t n_nodes, hipStream_t stream);
 // d_slot_tris[slot] = d_in[tri_order[slot]] (the triangle array in BVH2 leaf order, as sbvh.h:130-139 leaves it) and the
 // slot-ordered intersection records (v0 | original id) (e1 | slot) (e2 | material) of the BVH2 walk (may be null).
 void launch_gather_slots(const crt_triangle* d_in, const uint32_t* d_tri_order, const float* d_verts, uint32_t n_slots, crt_triangle* d_slot_tris,

@@ -194,6 +194,81 @@ __device__ __forceinline__ void load_node_scalar(const uint4* nodes, uint32_t ni
     n0 = make_uint4(a.x, a.y, a.z, a.w); n1 = make_uint4(b.x, b.y, b.z, b.w); n2 = make_uint4(c.x, c.y, c.z, c.w);
     n3 = make_uint4(d.x, d.y, d.z, d.w); n4 = make_uint4(e.x, e.y, e.z, e.w);
 }
+// The uniform step without the 48 byte-to-float conversions: the scene keeps every node's child planes as floats as well (12 rows of
+// float4 per node, SegmentArgs::planes; (float)byte is exact), the step fetches the rows it needs through the scalar cache — near / far
+// row of each axis picked by ADDRESS from the shared octant — and each fma reads its plane straight from an SGPR.  Same operands, same
+// fma: the hit mask keeps its bits.  Two halves of four children (24 SGPRs of planes at a time).
+#ifndef CRT_UNIFORM_PLANES
+#define CRT_UNIFORM_PLANES 1
+#endif
+#ifndef CRT_PLANES_ONE_WAIT
+#define CRT_PLANES_ONE_WAIT 1      // all fourteen rows of a uniform step requested at once, one wait (0: head, first half, second half — three waits, 24 SGPRs of planes at a time)
+#endif
+__device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1, const uint4* nodes, const float4* planes, uint32_t nidx0, vec3 o, vec3 inv,
+                                                           uint32_t oct0, float max_t) {
+    // byte offsets of the near / far rows inside a half: axis * 32 + side * 16, side = hi planes when the direction is negative (oct bit clear)
+    const uint32_t sx = (oct0 & 4u) ? 0u : 16u, sy = (oct0 & 2u) ? 0u : 16u, sz = (oct0 & 1u) ? 0u : 16u;
+    const char* base = reinterpret_cast<const char*>(planes) + (size_t)nidx0 * 192u;
+    const char* np = reinterpret_cast<const char*>(nodes) + (size_t)nidx0 * (size_t)(CRT_NODE_ROWS * 16);
+    u32x4 row[2][6];
+    u32x4 a, b;
+#if CRT_PLANES_ONE_WAIT
+    asm volatile("s_load_dwordx4 %0, %14, 0x0\n\ts_load_dwordx4 %1, %14, 0x10\n\t"
+                 "s_load_dwordx4 %2, %15, %16\n\ts_load_dwordx4 %3, %15, %17\n\ts_load_dwordx4 %4, %15, %18\n\ts_load_dwordx4 %5, %15, %19\n\t"
+                 "s_load_dwordx4 %6, %15, %20\n\ts_load_dwordx4 %7, %15, %21\n\t"
+                 "s_load_dwordx4 %8, %22, %16\n\ts_load_dwordx4 %9, %22, %17\n\ts_load_dwordx4 %10, %22, %18\n\ts_load_dwordx4 %11, %22, %19\n\t"
+                 "s_load_dwordx4 %12, %22, %20\n\ts_load_dwordx4 %13, %22, %21\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(row[0][0]), "=&s"(row[0][1]), "=&s"(row[0][2]), "=&s"(row[0][3]), "=&s"(row[0][4]), "=&s"(row[0][5]),
+                   "=&s"(row[1][0]), "=&s"(row[1][1]), "=&s"(row[1][2]), "=&s"(row[1][3]), "=&s"(row[1][4]), "=&s"(row[1][5])
+                 : "s"(np), "s"(base), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz), "s"(base + 96));
+#else
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(np));
+#endif
+    n0 = make_uint4(a.x, a.y, a.z, a.w); n1 = make_uint4(b.x, b.y, b.z, b.w);
+    const vec3 p = V3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
+    const uint32_t e_imask = n0.w;
+    const vec3 adj_inv = V3(__uint_as_float((e_imask & 0xffu) << 23) * inv.x, __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * inv.y,
+                            __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * inv.z);
+    const vec3 adj_o = (p - o) * inv;
+    const uint32_t oct4 = oct0 * 0x01010101u;
+    uint32_t hit_mask = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#if !CRT_PLANES_ONE_WAIT
+        const char* bh = base + h * 96;
+        asm volatile("s_load_dwordx4 %0, %6, %7\n\ts_load_dwordx4 %1, %6, %8\n\ts_load_dwordx4 %2, %6, %9\n\ts_load_dwordx4 %3, %6, %10\n\t"
+                     "s_load_dwordx4 %4, %6, %11\n\ts_load_dwordx4 %5, %6, %12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(row[h][0]), "=&s"(row[h][1]), "=&s"(row[h][2]), "=&s"(row[h][3]), "=&s"(row[h][4]), "=&s"(row[h][5])
+                     : "s"(bh), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz));
+#endif
+        const u32x4 xn = row[h][0], xf = row[h][1], yn = row[h][2], yf = row[h][3], zn = row[h][4], zf = row[h][5];
+        const uint32_t meta4 = h == 0 ? n1.z : n1.w;
+        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
+        const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1F1F1F1Fu;
+        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float tminx = __builtin_fmaf(__uint_as_float(xn[j]), adj_inv.x, adj_o.x);
+            const float tminy = __builtin_fmaf(__uint_as_float(yn[j]), adj_inv.y, adj_o.y);
+            const float tminz = __builtin_fmaf(__uint_as_float(zn[j]), adj_inv.z, adj_o.z);
+            const float tmaxx = __builtin_fmaf(__uint_as_float(xf[j]), adj_inv.x, adj_o.x);
+            const float tmaxy = __builtin_fmaf(__uint_as_float(yf[j]), adj_inv.y, adj_o.y);
+            const float tmaxz = __builtin_fmaf(__uint_as_float(zf[j]), adj_inv.z, adj_o.z);
+            const float tmin = __builtin_fmaxf(__builtin_fmaxf(tminx, tminy), __builtin_fmaxf(tminz, 0.0f));
+            const float tmax = __builtin_fminf(__builtin_fminf(tmaxx, tmaxy), __builtin_fminf(tmaxz, max_t));
+            if (tmin <= tmax) {
+                const uint32_t child_bits = (child_bits4 >> (8 * j)) & 0xffu;
+                const uint32_t bit_index = (bit_index4 >> (8 * j)) & 0xffu;
+                hit_mask |= child_bits << bit_index;
+            }
+        }
+    }
+    return hit_mask;
+}
+#ifndef CRT_P1_NO_BUSY
+#define CRT_P1_NO_BUSY 1
+#endif
 #ifndef CRT_UNIFORM_CLOSEST      // first-segment closest-hit walk (walk_batch phase 1)
 #define CRT_UNIFORM_CLOSEST 1
 #endif
@@ -816,11 +891,21 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
         const uint32_t touch_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(base + (stack_entries + CRT_HIT_SLOTS - 1) * 64));
 #endif
         CRT_MARK("loop_begin lanes2");
+#if CRT_P1_NO_BUSY
+        if (!busy) { cur.y = 0u; tg.y = 0u; sp = 0; }       // lanes outside the groups: nothing pending (see walk_batch: no flag is carried through the loop)
+        for (;;) {
+            const bool has_tri = tg.y != 0u;
+            const bool can_node = !has_tri && (cur.y & 0xff000000u);
+            const unsigned long long m_tri = __ballot(has_tri), m_node = __ballot((cur.y & 0xff000000u) != 0u) & ~m_tri;
+            if ((m_tri | m_node) == 0ull) break;
+            const uint32_t n_tri = (uint32_t)__builtin_popcountll(m_tri), n_node = (uint32_t)__builtin_popcountll(m_node);
+#else
         while (__ballot(busy) != 0ull) {
             const bool has_tri = busy && tg.y != 0u;
             const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
             const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
             const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+#endif
             const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // both sides count lanes, i.e. rays x K
             bool finished = false;
             if (node_phase) {
@@ -872,11 +957,16 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
                 finished = group_tri_step<KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
                 CRT_MARK("tri_end");
             }
+#if CRT_P1_NO_BUSY
+            if (!finished && tg.y == 0u && !(cur.y & 0xff000000u) && sp != 0) { --sp; cur = stk[sp * 64]; }
+            if (ANY && finished) { cur.y = 0u; sp = 0; }    // the group's lanes keep the ray's result in their registers
+#else
             if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
                 if (sp == 0) finished = true;
                 else { --sp; cur = stk[sp * 64]; }
             }
             if (finished) busy = false;              // the group's lanes keep the ray's result in their registers
+#endif
         }
         CRT_MARK("loop_end");
         // a ray that moved fetches its result from the first lane of its group
@@ -896,7 +986,7 @@ template <bool ANY, bool STATS, bool UNIFORM_O, bool UNI = false>
 __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
                                            bool has_ray, vec3 o_in, vec3 d, float tmax_in, uint32_t tri_min, uint32_t max_kl, HitState& out,
                                            uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f),
-                                           uint32_t* n_uni = nullptr) {
+                                           uint32_t* n_uni = nullptr, const float4* planes = nullptr) {
     constexpr uint32_t KL = CRT_GROUP_KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const slot_uv = base + stack_entries * 64;              // [col] (u, v) of the best hit
@@ -922,6 +1012,18 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
 #endif
         CRT_MARK("loop_begin lanes1");
         for (;;) {
+#if CRT_P1_NO_BUSY
+            // No flag is carried from one iteration to the next: a lane has a ray exactly while it has a triangle group or inner hits
+            // pending (what is left of a finished ray is cleared below), so the three counts come from the two registers the step tests
+            // anyway.  (A loop-carried bool costs a v_cndmask + v_cmp pair at every ballot: the compiler materialises the lane mask.)
+            const bool has_tri = tg.y != 0u;
+            const bool can_node = !has_tri && (cur.y & 0xff000000u);
+            const unsigned long long m_tri = __ballot(has_tri), m_node = __ballot((cur.y & 0xff000000u) != 0u) & ~m_tri;
+            const uint32_t n_tri = (uint32_t)__builtin_popcountll(m_tri), n_node = (uint32_t)__builtin_popcountll(m_node);
+            const uint32_t n_busy = n_tri + n_node;
+            if (n_busy == 0u) break;
+            if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
+#else
             const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy));
             if (n_busy == 0u) break;
             if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
@@ -929,6 +1031,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
             const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
             const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
             const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+#endif
             const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the vote of traverse_pool
             bool finished = false;
             if (node_phase) {
@@ -947,10 +1050,16 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                         // every enabled lane asks for this node and shares the octant: the node comes through the scalar cache
                         CRT_MARK("uninode_begin");
                 if (STATS && n_uni) ++*n_uni;
-                        uint4 n0, n1, n2, n3, n4;
-                        load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
+                        uint4 n0, n1;
                         const uint32_t oct0 = key0 & 7u;
-                        const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, best_t);
+                        uint32_t hitmask;
+                        if (CRT_UNIFORM_PLANES) {            // the host builds the float planes for every scene (finish_scene_setup)
+                            hitmask = node8_intersect_planes(n0, n1, nodes, planes, key0 >> 3, o, inv, oct0, best_t);
+                        } else {
+                            uint4 n2, n3, n4;
+                            load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
+                            hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, best_t);
+                        }
                         cur.x = n1.x;
                         tg.x = n1.y;
                         cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -998,12 +1107,20 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                 }
                 CRT_MARK("tri_end");
             }
+#if CRT_P1_NO_BUSY
+            // a lane with nothing pending pops its stack; one without a ray has an empty stack and nothing happens to it
+            if (!finished && tg.y == 0u && !(cur.y & 0xff000000u) && sp != 0) { --sp; cur = stk[sp * 64]; }
+            if (ANY && finished) { cur.y = 0u; sp = 0; }      // an occluded ray leaves inner hits and stack entries behind (its result stays in this lane's registers)
+        }
+        busy = tg.y != 0u || (cur.y & 0xff000000u);
+#else
             if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
                 if (sp == 0) finished = true;
                 else { --sp; cur = stk[sp * 64]; }
             }
             if (finished) busy = false;              // its result stays in this lane's registers
         }
+#endif
         CRT_MARK("loop_end");
     }
     out.t = best_t; out.tri = best_tri;
@@ -1024,7 +1141,8 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
 template <bool STATS, bool UNI = false>
 __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
                                                          uint32_t* overflow, bool has_ray, vec3 o, vec3 d, float tmax, uint32_t tri_min, uint32_t max_kl,
-                                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, uint32_t* n_uni = nullptr) {
+                                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, uint32_t* n_uni = nullptr,
+                                                         const float4* planes = nullptr) {
     constexpr uint32_t KL = CRT_GROUP_KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const stk = base + lane;
@@ -1056,10 +1174,16 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 if (UNI && node_step_is_uniform(nbase + rel, oct4, key0)) {
                     CRT_MARK("uninode_begin");
                 if (STATS && n_uni) ++*n_uni;
-                    uint4 n0, n1, n2, n3, n4;
-                    load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
+                    uint4 n0, n1;
                     const uint32_t oct0 = key0 & 7u;
-                    const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, tmax);
+                    uint32_t hitmask;
+                    if (CRT_UNIFORM_PLANES) {            // the host builds the float planes for every scene (finish_scene_setup)
+                        hitmask = node8_intersect_planes(n0, n1, nodes, planes, key0 >> 3, o, inv, oct0, tmax);
+                    } else {
+                        uint4 n2, n3, n4;
+                        load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
+                        hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, tmax);
+                    }
                     cur.x = n1.x;
                     tg.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -1874,7 +1998,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
             if (!SHARE && CRT_LANES_CLOSEST_IN(FIRST)) {
                 // the last rays of the batch get eight lanes each (a.lanes_log2 = 0: never — then this is traverse_pool's lock-step loop)
                 walk_batch<false, STATS, FIRST, UNI_K && !!CRT_UNIFORM_CLOSEST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
-                                                nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]), &nu);
+                                                nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]), &nu, a.planes);
             } else
             traverse_pool<false, STATS, SHARE, FIRST>(
                 a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
@@ -2098,7 +2222,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
             if (CRT_FIRST_ANY_GROUPS && FIRST && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // the first segment's shadow rays: the plain loop, then groups for the last rays of the wave
                 const bool occluded = traverse_any_then_groups<STATS, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
-                                                                      V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any, &nu_any);
+                                                                      V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any, &nu_any, a.planes);
                 if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
             } else if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)

@@ -106,6 +106,7 @@ struct BinScanArgs {             // k_bin_scan: one workgroup of 1024 threads be
 
 struct SegmentArgs {
     const uint4* nodes;
+    const float4* planes;      // 12 rows per node: its child planes as floats (uniform node steps)
     const float4* tris;
     const int4* triangles;     // 3 x int4 per BVH2-ordered triangle (v, vn, vt)
     const float* normals;

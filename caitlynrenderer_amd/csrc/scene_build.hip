@@ -67,6 +67,19 @@ __global__ void k_restride(const uint4* __restrict__ src, uint32_t rows_in, uint
     dst[t] = r < rows_in ? src[i * rows_in + r] : make_uint4(0u, 0u, 0u, 0u);
 }
 
+// The child planes of every node as floats, for the uniform node steps of the traversal (rt_kernels.hip): 12 rows of float4 per node,
+// row = half * 6 + axis * 2 + side (side 0 = lo planes, 1 = hi planes), the four children 4 * half .. 4 * half + 3 of that row.
+// (float)byte is exact, so the traversal's fma sees the operand v_cvt_f32_ubyte would have produced.
+__global__ void k_expand_planes(const uint4* __restrict__ nodes, uint32_t node_rows, float4* __restrict__ planes, uint64_t n_nodes) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_nodes * 12u) return;
+    const uint64_t i = t / 12u;
+    const uint32_t r = (uint32_t)(t - i * 12u), half = r / 6u, axis = (r % 6u) >> 1, side = r & 1u;
+    const uint4 row = nodes[i * node_rows + 2u + axis];       // (lo[0..3], lo[4..7], hi[0..3], hi[4..7])
+    const uint32_t w = side ? (half ? row.w : row.z) : (half ? row.y : row.x);
+    planes[t] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+}
+
 inline dim3 grid_for(uint32_t n) { return dim3((n + 255u) / 256u ? (n + 255u) / 256u : 1u); }
 
 }  // namespace
@@ -80,6 +93,11 @@ void launch_restride(const void* d_src, uint32_t rows_in, void* d_dst, uint32_t 
     const uint64_t threads = n_items * rows_out;
     hipLaunchKernelGGL(k_restride, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, stream, static_cast<const uint4*>(d_src), rows_in,
                        static_cast<uint4*>(d_dst), rows_out, n_items);
+}
+void launch_expand_planes(const void* d_nodes, uint32_t node_rows, void* d_planes, uint64_t n_nodes, hipStream_t stream) {
+    const uint64_t threads = n_nodes * 12u;
+    hipLaunchKernelGGL(k_expand_planes, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, stream, static_cast<const uint4*>(d_nodes), node_rows,
+                       static_cast<float4*>(d_planes), n_nodes);
 }
 void launch_gather_slots(const crt_triangle* d_in, const uint32_t* d_tri_order, const float* d_verts, uint32_t n_slots, crt_triangle* d_slot_tris,
                          float4* d_recs2, hipStream_t stream) {
