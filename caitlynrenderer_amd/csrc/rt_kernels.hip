@@ -202,7 +202,8 @@ __device__ __forceinline__ void load_node_scalar(const uint4* nodes, uint32_t ni
 #define CRT_UNIFORM_PLANES 1
 #endif
 #ifndef CRT_PLANES_ONE_WAIT
-#define CRT_PLANES_ONE_WAIT 1      // all fourteen rows of a uniform step requested at once, one wait (0: head, first half, second half — three waits, 24 SGPRs of planes at a time)
+#define CRT_PLANES_ONE_WAIT 0      // 1: all fourteen rows of a uniform step requested at once, one wait — 56 SGPRs, and the loop's own scalars are spilled around the step (15,125 -> 14,666
+                                   // Mray/s on the headline); 0: head, first half, second half: three waits, 24 SGPRs of planes at a time
 #endif
 __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1, const uint4* nodes, const float4* planes, uint32_t nidx0, vec3 o, vec3 inv,
                                                            uint32_t oct0, float max_t) {
@@ -1156,11 +1157,19 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
     bool regroup = false;
     CRT_MARK("loop_begin plain");
     for (;;) {
+#if CRT_P1_NO_BUSY
+        // no flag carried through the loop (see walk_batch): a lane has a ray exactly while inner hits are pending — a leaf's triangles are
+        // tested in the iteration that found them, and what an occluded ray leaves behind is cleared
+        const bool busy_now = (cur.y & 0xff000000u) != 0u;
+        const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy_now));
+#else
+        const bool busy_now = busy;
         const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy));
+#endif
         if (n_busy == 0u) break;
         if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
-        if (busy) {
-            if (cur.y & 0xff000000u) {
+        if (busy_now) {
+            if (CRT_P1_NO_BUSY || (cur.y & 0xff000000u)) {
                 CRT_MARK("node_begin");
                 const uint32_t hits_imask = cur.y;
                 const int off = 31 - __builtin_clz(hits_imask);
@@ -1212,15 +1221,26 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 if (STATS) { ++n_tris; count_wave_step(w_tris); }
                 float u, v, t;
+#if CRT_P1_NO_BUSY
+                if (mt_test(ta, tb, tc, o, d, u, v, t) && t < tmax) { hit_tri = (int)ti; tg.y = 0u; cur.y = 0u; sp = 0; }
+#else
                 if (mt_test(ta, tb, tc, o, d, u, v, t) && t < tmax) { hit_tri = (int)ti; busy = false; tg.y = 0u; }
+#endif
                 CRT_MARK("tri_end");
             }
+#if CRT_P1_NO_BUSY
+            if (!(cur.y & 0xff000000u) && sp != 0) { --sp; cur = stk[sp * 64]; }
+#else
             if (busy && !(cur.y & 0xff000000u)) {
                 if (sp == 0) busy = false;
                 else { --sp; cur = stk[sp * 64]; }
             }
+#endif
         }
     }
+#if CRT_P1_NO_BUSY
+    busy = (cur.y & 0xff000000u) != 0u;
+#endif
     CRT_MARK("loop_end");
     HitState out;
     out.t = tmax; out.tri = hit_tri;
