@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     const char* np = reinterpret_cast<const char*>(nodes) + (size_t)nidx0 * (size_t)(CRT_NODE_ROWS * 16);
     u32x4 row[2][6];
     u32x4 a, b;
-#if CRT_PLANES_ONE_WAIT
+#if CRT_PLANES_ONE_WAIT == 1
     asm volatile("s_load_dwordx4 %0, %14, 0x0\n\ts_load_dwordx4 %1, %14, 0x10\n\t"
                  "s_load_dwordx4 %2, %15, %16\n\ts_load_dwordx4 %3, %15, %17\n\ts_load_dwordx4 %4, %15, %18\n\ts_load_dwordx4 %5, %15, %19\n\t"
                  "s_load_dwordx4 %6, %15, %20\n\ts_load_dwordx4 %7, %15, %21\n\t"
@@ -222,6 +222,12 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
                  : "=&s"(a), "=&s"(b), "=&s"(row[0][0]), "=&s"(row[0][1]), "=&s"(row[0][2]), "=&s"(row[0][3]), "=&s"(row[0][4]), "=&s"(row[0][5]),
                    "=&s"(row[1][0]), "=&s"(row[1][1]), "=&s"(row[1][2]), "=&s"(row[1][3]), "=&s"(row[1][4]), "=&s"(row[1][5])
                  : "s"(np), "s"(base), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz), "s"(base + 96));
+#elif CRT_PLANES_ONE_WAIT == 2      // head and first half together, then the second half: two waits
+    asm volatile("s_load_dwordx4 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x10\n\t"
+                 "s_load_dwordx4 %2, %9, %10\n\ts_load_dwordx4 %3, %9, %11\n\ts_load_dwordx4 %4, %9, %12\n\ts_load_dwordx4 %5, %9, %13\n\t"
+                 "s_load_dwordx4 %6, %9, %14\n\ts_load_dwordx4 %7, %9, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(row[0][0]), "=&s"(row[0][1]), "=&s"(row[0][2]), "=&s"(row[0][3]), "=&s"(row[0][4]), "=&s"(row[0][5])
+                 : "s"(np), "s"(base), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz));
 #else
     asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(np));
 #endif
@@ -235,12 +241,14 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     uint32_t hit_mask = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#if !CRT_PLANES_ONE_WAIT
+#if CRT_PLANES_ONE_WAIT == 0 || CRT_PLANES_ONE_WAIT == 2
+        if (CRT_PLANES_ONE_WAIT == 0 || h == 1) {
         const char* bh = base + h * 96;
         asm volatile("s_load_dwordx4 %0, %6, %7\n\ts_load_dwordx4 %1, %6, %8\n\ts_load_dwordx4 %2, %6, %9\n\ts_load_dwordx4 %3, %6, %10\n\t"
                      "s_load_dwordx4 %4, %6, %11\n\ts_load_dwordx4 %5, %6, %12\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(row[h][0]), "=&s"(row[h][1]), "=&s"(row[h][2]), "=&s"(row[h][3]), "=&s"(row[h][4]), "=&s"(row[h][5])
                      : "s"(bh), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz));
+        }
 #endif
         const u32x4 xn = row[h][0], xf = row[h][1], yn = row[h][2], yf = row[h][3], zn = row[h][4], zf = row[h][5];
         const uint32_t meta4 = h == 0 ? n1.z : n1.w;
@@ -1813,8 +1821,11 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #ifndef CRT_LANES_CLOSEST_IN
 #define CRT_LANES_CLOSEST_IN(first) true
 #endif
+#ifndef CRT_FIRST_ANY_VOTING     // measurement variant (with CRT_FIRST_ANY_GROUPS=0): the first segment's shadow rays through walk_batch's voting loop
+#define CRT_FIRST_ANY_VOTING 0
+#endif
 #ifndef CRT_LANES_ANY_IN
-#define CRT_LANES_ANY_IN(first) (!(first))
+#define CRT_LANES_ANY_IN(first) (!(first) || CRT_FIRST_ANY_VOTING)
 #endif
 #ifndef CRT_FIRST_ANY_GROUPS
 #define CRT_FIRST_ANY_GROUPS 1
@@ -2247,8 +2258,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
             } else if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
-                walk_batch<true, STATS, false>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
-                                               sh0.w, a.tri_min, a.lanes_log2, shh, nn_any, nt_any, wn_any, wt_any);
+                walk_batch<true, STATS, false, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
+                                               sh0.w, a.tri_min, a.lanes_log2, shh, nn_any, nt_any, wn_any, wt_any, V3(0.f, 0.f, 0.f), &nu_any, a.planes);
                 if (pending && shh.tri < 0) L = L + V3(sh2.x, sh2.y, sh2.z);
             } else if (CRT_ANYSHARE_IN(FIRST) && !BVH2 && (a.tri_share & 4u) && a.tri_min != 0u) {
                 // shared triangle steps, lean form (traverse_any_shared): every lane of the wave takes part
