@@ -278,6 +278,9 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
 #ifndef CRT_P1_NO_BUSY
 #define CRT_P1_NO_BUSY 1
 #endif
+#ifndef CRT_GROUP_TRI_WINDOW
+#define CRT_GROUP_TRI_WINDOW 1
+#endif
 #ifndef CRT_UNIFORM_CLOSEST      // first-segment closest-hit walk (walk_batch phase 1)
 #define CRT_UNIFORM_CLOSEST 1
 #endif
@@ -808,6 +811,37 @@ __device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, 
                                                uint2* hit_uv, uint2* hit_it, uint32_t& n_tris) {
     constexpr uint32_t K = 1u << KL;
     const uint32_t lane = threadIdx.x & 63u;
+#if CRT_GROUP_TRI_WINDOW
+    // The group takes the K bit POSITIONS from the highest pending triangle down — lane `sub` the position top - sub, if a triangle is pending
+    // there — instead of the K highest pending triangles: finding "the sub-th set bit" cost ~60 instructions per step (and seven lane masks
+    // the compiler kept in spilled SGPRs), the window ten.  The pending bits of a node are runs of 1 - 3 (a leaf's triangles) in the order of
+    // its leaves, so a window of eight positions usually holds them all; the tests, their operands and their order (descending position) stay.
+    const uint32_t pending = tg.y;                                            // != 0: the caller's has_tri
+    const uint32_t top = 31u - (uint32_t)__builtin_clz(pending);
+    const uint32_t lo = top >= K - 1u ? top - (K - 1u) : 0u;                  // the window is [lo, top]
+    const uint32_t rest = pending & ~(0xffffffffu << lo);
+    const uint32_t tested = (uint32_t)__builtin_popcount(pending >> lo);
+    const bool mine_set = sub <= top && ((pending >> (top - sub)) & 1u) != 0u;
+    bool hit = false;
+    float u = 0.f, v = 0.f, t = 0.f;
+    int id = 0x7fffffff;
+    uint32_t ti = 0;
+    if (mine_set) {
+        ti = tg.x + (top - sub);
+        const float4* tp = tri_rows(tris, ti);
+        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        hit = mt_test(ta, tb, tc, o, d, u, v, t);
+        id = __float_as_int(ta.w);
+    }
+    tg.y = rest;
+    if (ANY) {
+        const uint32_t mine = (uint32_t)(__ballot(hit && t < best_t) >> (lane & ~(K - 1u))) & ((1u << K) - 1u);      // my group's hits, bit = sub
+        // tests up to the first hit in the original order: the pending triangles at and above its position
+        if (STATS && sub == 0u) n_tris += mine ? (uint32_t)__builtin_popcount(pending >> (top - (uint32_t)__builtin_ctz(mine))) : tested;
+        if (mine) { best_tri = (int)tg.x; tg.y = 0u; return true; }
+        return false;
+    }
+#else
     uint32_t t_sel = tg.y, rest = tg.y;
 #pragma unroll
     for (uint32_t q = 0; q < K; ++q) {
@@ -833,6 +867,7 @@ __device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, 
         if (mine) { best_tri = (int)tg.x; tg.y = 0u; return true; }
         return false;
     }
+#endif
     if (STATS && sub == 0u) n_tris += tested;
     // candidate of this lane: (t, id, triangle), or (+inf, max) when it has none
     uint32_t ct = hit ? __float_as_uint(t) : 0x7f800000u, ci = hit ? (uint32_t)id : 0x7fffffffu, cx = ti;
