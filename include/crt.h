@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 4   /* 4: crt_warmup, crt_shard_tiles, crt_debug_launch_info, crt_debug_step_hist; options lanes_per_ray, ray_bins 4 / 5, tri_share bits;
+#define CRT_ABI_VERSION 5   /* 5: crt_frame_stats.nodes_closest_uniform / nodes_any_uniform (the struct grew);
+                              * 4: crt_warmup, crt_shard_tiles, crt_debug_launch_info, crt_debug_step_hist; options lanes_per_ray, ray_bins 4 / 5, tri_share bits;
                               * 3: crt_frame_stats.closest_hits, crt_set_devices (one process, several GPUs), crt_has_experiments;
                               * 2: crt_frame_stats.stack_overflows + wave_steps_*, crt_scene_desc.build_flags, crt_bvh_info build times */
 

@@ -210,7 +210,8 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
              "shared_tri_steps": [r[2] for r in regs if r[0] == "share"], "loops": [(r[1], r[2]) for r in loops],
              "shade": [r[2] for r in regs if r[0] == "shade"]}
         counts["kernels"][key] = d
-    f = counts["kernels"].get("first_single") or counts["kernels"].get("first")
+    # the batched first-segment kernel is the one the bench times (and the one that carries the uniform node steps)
+    f = counts["kernels"].get("first") or counts["kernels"].get("first_single")
     b = counts["kernels"].get("bounce_plain") or counts["kernels"].get("bounce")
     if f:
         # one node visit / one triangle test: the closest-hit voting loop of the first-segment kernel (the plain loop of the in-place
