@@ -656,7 +656,7 @@ def valu_roofline(c, t_launch, launches, samples_per_launch, accel="cwbvh", pmc=
          "achieved": None, "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Gwave-instr/s", "frac": None}
     if _ISA.get("I_node") and accel == "cwbvh" and t_launch > 0:
         got = roofline_module().roofline_block(c, _ISA, t_launch * 1e3, launches, samples_per_launch, pmc)
-        r.update({k: got[k] for k in ("achieved", "frac", "attainable", "traversal_wave_instr_per_launch", "shell_static_wave_instr_per_launch",
+        r.update({k: got[k] for k in ("achieved", "frac", "frac_at_general_step", "attainable", "traversal_wave_instr_per_launch", "shell_static_wave_instr_per_launch",
                                       "issue_busy", "lane_util", "counter_frac", "non_traversal_share") if k in got})
     return r
 

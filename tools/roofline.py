@@ -276,7 +276,12 @@ def counter_figures(pmc, samples_per_launch):
 def roofline_block(cs, isa, launch_ms, depth, samples, pmc=None):
     w = traversal_wave_instr(cs, isa, depth, samples)
     achieved = w / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    # the same visits priced at the GENERAL node step (what the walk would execute without the uniform steps): the uniform steps lower
+    # the executed instructions per visit, so `frac` (executed) falls while the rays per second rise; this figure moves with the speed
+    cs_general = dict(cs, nodes_closest_uniform=0, nodes_any_uniform=0)
+    w_general = traversal_wave_instr(cs_general, isa, depth, samples)
     r = {"achieved": round(achieved, 1), "peak": PEAK_GINSTR, "frac": round(achieved / PEAK_GINSTR, 4),
+         "frac_at_general_step": round(w_general / (launch_ms * 1e-3) / 1e9 / PEAK_GINSTR, 4) if launch_ms > 0 else 0.0,
          "attainable": round(ATTAINABLE_GINSTR, 1), "frac_of_attainable": round(achieved / ATTAINABLE_GINSTR, 4),
          "traversal_wave_instr_per_launch": int(w), "shell_static_wave_instr_per_launch": int(shell_static_wave_instr(cs, isa, depth, samples))}
     c = counter_figures(pmc, samples)
