@@ -287,8 +287,11 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
 #ifndef CRT_UNIFORM_ANY          // first-segment shadow walk (traverse_any_then_groups)
 #define CRT_UNIFORM_ANY 1
 #endif
-#ifndef CRT_UNIFORM_PLAIN        // first-segment walks of the plain per-lane loop (scenes of a few nodes: tri_min 0); measured on the Cornell box, 4 samples
-#define CRT_UNIFORM_PLAIN 0      // per launch: 43.7 Gray/s without any uniform code, 43.0 with the code present, 41.9 with the steps running
+#ifndef CRT_UNIFORM_SINGLE       // also in the single-sample first-segment kernel (crt_render_frame): 1 M triangles at one sample per launch 14,012 -> 14,516 Mray/s,
+#define CRT_UNIFORM_SINGLE 1     // 4K 16,212 -> 16,971 (on the byte-plane / flag-carrying loops of the round's first half it lost 1.6 % there)
+#endif
+#ifndef CRT_UNIFORM_PLAIN        // first-segment walks of the plain per-lane loop (scenes of a few nodes: tri_min 0; a launch with lanes_per_ray 1): with the float planes
+#define CRT_UNIFORM_PLAIN 1      // and the lean loops Cornell 53.2 -> 53.4 Gray/s, 4K at one sample per launch 16,971 -> 17,125 (it lost 4 % on the Cornell box before)
 #endif
 
 // One ray through the CWBVH (cwbvh.fs:448-536 closest, :538-616 any).  `stk` is this lane's column
@@ -427,7 +430,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
                                               vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t next = pool_begin;                     // wave-uniform
+#if !CRT_P1_NO_BUSY
     bool busy = false;
+#endif
     uint32_t idx = 0;
     vec3 o_lane = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
     bool negx = false, negy = false, negz = false;
@@ -450,6 +455,11 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
     };
     CRT_MARK("loop_begin voting");
     for (;;) {
+#if CRT_P1_NO_BUSY
+        // no flag carried through the loop (see walk_batch): a lane has a ray exactly while it has a triangle group or inner hits pending; a
+        // ray that is loaded without either (non-finite origin, empty slot) is finished by the end of the same iteration
+        bool busy = tg.y != 0u || (cur.y & 0xff000000u) != 0u;
+#endif
         const unsigned long long idle = next < pool_end ? __ballot(!busy) : 0ull;     // a drained pool skips the refill logic
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
         if (next < pool_end && (n_idle >= refill_min || n_idle == 64u)) {
@@ -611,6 +621,9 @@ __device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, c
             }
             done(idx, best, best_tri >= 0);
             busy = false;
+#if CRT_P1_NO_BUSY
+            cur.y = 0u; sp = 0;                     // what an occluded ray leaves behind
+#endif
         }
     }
     CRT_MARK("loop_end");
@@ -1900,12 +1913,10 @@ template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool B
           bool BATCH = false, bool WIDE = false>
 __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
-    // Uniform node steps are compiled into the batched first-segment kernels (crt_render_frames: the samples-in-lanes waves leave a 4 x 4
-    // pixel quadrant) and into the counting kernels (so that the statistics can say how many visits were uniform).  In the single-sample
-    // kernel their code alone costs more than the steps return (32-triangle Cornell box 52.5 -> 50.3 Gray/s with the code merely present,
-    // 1 M triangles at one sample per launch 13,037 -> 12,822 Mray/s with it running: 8 x 8-pixel waves agree less, and the 20 scalar
-    // registers of the node push loop state out of the SGPR file).
-    constexpr bool UNI_K = FIRST && (BATCH || STATS);
+    // Uniform node steps are compiled into every first-segment kernel.  (In the single-sample kernel they lost while the uniform step still
+    // converted bytes and the loops carried their flags — 8 x 8-pixel waves agree less than the 4 x 4-pixel waves of a batched launch, and the
+    // node's SGPRs pushed loop state out of the scalar register file; with the float planes and the lean loops they win there too.)
+    constexpr bool UNI_K = FIRST && (BATCH || STATS || CRT_UNIFORM_SINGLE);
     // uniform: the workgroup's waves are the samples of one 64-pixel batch.  The 6-waves-per-SIMD build is never launched in that form
     // (launch_segment), and compiling the form out of it frees the registers its LDS result strip and wave index would hold
     const bool wave_samples = BATCH && !WIDE && a.wave_samples == 1u;
