@@ -1794,7 +1794,7 @@ __device__ __forceinline__ void disney_eval(const Disney& m, vec3 n, vec3 wo, ve
     const vec3 hs = wi + wo;
     const float hh = dot(hs, hs);
     if (!(hh > 0.0f)) return;
-    const vec3 h = hs * __fdiv_rn(1.0f, sqrt_ieee(hh));
+    const vec3 h = hs * rcp_ieee(sqrt_ieee(hh));
     const float nh = dot(n, h), lh = dot(wi, h);
     if (!(nh > 0.0f && lh > 0.0f)) return;
     const float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(lh);
@@ -2599,7 +2599,7 @@ __global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linea
         const float c0 = linear[3 * (size_t)i] * inv_count, c1 = linear[3 * (size_t)i + 1] * inv_count,
                     c2 = linear[3 * (size_t)i + 2] * inv_count;
         const float lum = 0.3f * c0 + 0.6f * c1 + 0.1f * c2;
-        const float k = __fdiv_rn(1.0f, 1.0f + __fdiv_rn(lum, 2.0f));
+        const float k = rcp_ieee(1.0f + __fdiv_rn(lum, 2.0f));
         const float cc[3] = {c0, c1, c2};
         uchar4 out;
         uint8_t* o8 = reinterpret_cast<uint8_t*>(&out);
