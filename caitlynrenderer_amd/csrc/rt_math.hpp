@@ -19,18 +19,31 @@ __device__ __forceinline__ float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y *
 __device__ __forceinline__ vec3 cross(vec3 a, vec3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+#ifndef CRT_FAST_RCP
+#define CRT_FAST_RCP 1
+#endif
 // IEEE correctly rounded square root.  NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS the HIP
 // headers map that to __ocml_native_sqrt_f32 (bare v_sqrt_f32, 1 ulp).  sqrtf lowers to llvm.sqrt.f32,
 // which hipcc expands to v_sqrt_f32 + fma refinement under its default
 // -fhip-fp32-correctly-rounded-divide-sqrt.
-__device__ __forceinline__ float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+// For 2^-100 <= x <= 2^100 the reciprocal square root (1 ulp) and one Newton step in fma arithmetic give the same bits in five
+// instructions (every such float checked: tools/ubench/sqrt_exhaustive.hip, candidate A: 0 differences); zero, denormals, infinities,
+// negative numbers and NaN take sqrtf.
+__device__ __forceinline__ float sqrt_ieee(float x) {
+#if CRT_FAST_RCP
+    if (__builtin_expect(x >= 0x1p-100f && x <= 0x1p100f, 1)) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        const float s = x * y, h = 0.5f * y;
+        const float r = __builtin_fmaf(-s, s, x);
+        return __builtin_fmaf(r, h, s);
+    }
+#endif
+    return __builtin_sqrtf(x);
+}
 // 1 / x, IEEE correctly rounded.  hipcc expands the division into v_div_scale x 2, v_rcp, five fma, v_div_fmas, v_div_fixup (~43 issue cycles:
 // a sixth of a Moller-Trumbore test).  For 2^-100 <= |x| <= 2^100 the hardware reciprocal (1 ulp) and ONE Newton step in fma arithmetic
 // give the same bits — checked on all 2^32 inputs, tools/ubench/rcp_exhaustive.hip: 0 differences — in 2 compares + 3 instructions; anything
 // outside that range (denormal results, infinities, NaN) takes the division.
-#ifndef CRT_FAST_RCP
-#define CRT_FAST_RCP 1
-#endif
 __device__ __forceinline__ float rcp_ieee(float x) {
 #if CRT_FAST_RCP
     const float ax = __builtin_fabsf(x);
