@@ -278,6 +278,9 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
 #ifndef CRT_P1_NO_BUSY
 #define CRT_P1_NO_BUSY 1
 #endif
+#ifndef CRT_GROUP_LDS_STAGE
+#define CRT_GROUP_LDS_STAGE 0
+#endif
 #ifndef CRT_GROUP_TRI_WINDOW
 #define CRT_GROUP_TRI_WINDOW 1
 #endif
@@ -947,6 +950,10 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
 #ifdef CRT_GROUP_PREFETCH
         const uint32_t touch_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(base + (stack_entries + CRT_HIT_SLOTS - 1) * 64));
 #endif
+#if CRT_GROUP_LDS_STAGE      // built with CRT_HIT_SLOTS 4: the last two rows of the wave's LDS region (1 KB) are the staging area, 128 bytes per group
+        uint2* const stage = base + (stack_entries + CRT_HIT_SLOTS - 2) * 64;
+        const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(stage));
+#endif
         CRT_MARK("loop_begin lanes2");
 #if CRT_P1_NO_BUSY
         if (!busy) { cur.y = 0u; tg.y = 0u; sp = 0; }       // lanes outside the groups: nothing pending (see walk_batch: no flag is carried through the loop)
@@ -982,6 +989,22 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
                     // texture-address path (+0.7 .. 1.1 % on the multi-segment frames; the eight lanes of a group ask for the same node)
 #ifdef CRT_GROUP_WIDE_LOADS            // measurement variant: the five full rows
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+#elif CRT_GROUP_LDS_STAGE
+                    // the group's node staged through LDS: lanes sub 0..4 fetch one 16-byte row each straight into LDS (global_load_lds_dwordx4: the
+                    // row lands at M0 + lane * 16, i.e. the node of group g at stage + 128 g), then every lane reads the words it needs from there —
+                    // one vector-memory instruction and 80 bytes per group through the texture-address path instead of nine and 52 bytes per lane
+                    if (sub < 5u) {
+                        const uint32_t goff = nidx * (uint32_t)(CRT_NODE_ROWS * 16) + sub * 16u;
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(goff), "s"(nodes), "s"(stage_lds) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage) + (lane >> 3) * 32u;
+                    const uint32_t hi_w = ((sub * (uint32_t)(8 >> KL)) >= 4u) ? 1u : 0u;
+                    const uint4 n0 = *reinterpret_cast<const uint4*>(sw);
+                    const uint2 n1xy = *reinterpret_cast<const uint2*>(sw + 4);
+                    const uint32_t mw = sw[6u + hi_w], w2l = sw[8u + hi_w], w2h = sw[10u + hi_w], w3l = sw[12u + hi_w], w3h = sw[14u + hi_w], w4l = sw[16u + hi_w], w4h = sw[18u + hi_w];
+                    const uint4 n1 = make_uint4(n1xy.x, n1xy.y, mw, mw), n2 = make_uint4(w2l, w2l, w2h, w2h), n3 = make_uint4(w3l, w3l, w3h, w3h), n4 = make_uint4(w4l, w4l, w4h, w4h);
+                    asm volatile("" ::: "memory");      // the reads above are done before the next step's rows arrive
 #else
                     const uint32_t* nw = reinterpret_cast<const uint32_t*>(np) + (((sub * (uint32_t)(8 >> KL)) >= 4u) ? 1u : 0u);
                     const uint4 n0 = np[0];
