@@ -1952,3 +1952,23 @@ def test_bench_one_process_several_devices(tmp_path):
     assert d["n_gpus"] == 4 and d["config"]["devices"] == [0, 0, 0, 0] and d["config"]["parallelism"] == "tiles/4"
     assert "inside the C ABI" in d["config"]["gather"] and d["gather_ms"] > 0 and d["value"] > 500
     assert d["roofline"]["counters"]["primary_rays"] == 3840 * 2160
+
+
+def test_short_reciprocal_and_square_root_are_exact_on_every_float(tmp_path):
+    """rt_math.hpp computes 1 / x as v_rcp_f32 + one Newton step and sqrt(x) as v_rsq_f32 + one Newton step for 2^-100 <= |x| <= 2^100 and says
+    the bits are those of the IEEE division / sqrtf the floating-point contract asks for.  A float has 2^32 values: the two
+    checkers under tools/ubench run every one of them through both forms on the GPU (candidate A of each file is the shipped sequence)."""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    for name in ("rcp_exhaustive", "sqrt_exhaustive"):
+        exe = str(tmp_path / name)
+        subprocess.run([hipcc, "-O3", "-ffp-contract=off", "--offload-arch=gfx950", "-o", exe, os.path.join(ROOT, "tools", "ubench", name + ".hip")],
+                       check=True, capture_output=True, timeout=300)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
+        m = re.search(r"candidate A differs on (\d+)", out)
+        assert m and int(m.group(1)) == 0, out
