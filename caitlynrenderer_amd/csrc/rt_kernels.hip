@@ -278,6 +278,9 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
 #ifndef CRT_P1_NO_BUSY
 #define CRT_P1_NO_BUSY 1
 #endif
+#ifndef CRT_SUM_ONCE
+#define CRT_SUM_ONCE 1
+#endif
 #ifndef CRT_GROUP_LDS_STAGE
 #define CRT_GROUP_LDS_STAGE 0
 #endif
@@ -2367,12 +2370,33 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
             // after the other would add, zero radiance skipped as everywhere
             const bool mine = finished && !pending;
             const float mx = mine ? L.x : 0.f, my = mine ? L.y : 0.f, mz = mine ? L.z : 0.f;
+#if !CRT_SUM_ONCE
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
                 const int src = (int)((lane & 15u) + 16u * k);
                 const float rx = __shfl(mx, src), ry = __shfl(my, src), rz = __shfl(mz, src);
                 if (lane < 16u && e < n && (rx != 0.f || ry != 0.f || rz != 0.f)) add_to_sum(a.sum, e, V3(rx, ry, rz));
             }
+#else
+            // one read-modify-write of the pixel's sum for the four samples: s = L_k + s in sample order, in registers — the additions
+            // add_to_sum would do one frame after the other, without three of the four loads, stores and address computations
+            float rx[4], ry[4], rz[4];
+            bool any_nz = false;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const int src = (int)((lane & 15u) + 16u * k);
+                rx[k] = __shfl(mx, src); ry[k] = __shfl(my, src); rz[k] = __shfl(mz, src);
+                any_nz = any_nz || rx[k] != 0.f || ry[k] != 0.f || rz[k] != 0.f;
+            }
+            if (lane < 16u && e < n && any_nz) {
+                float* const sp3 = a.sum + 3 * (size_t)e;
+                float s0 = sp3[0], s1 = sp3[1], s2 = sp3[2];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k)
+                    if (rx[k] != 0.f || ry[k] != 0.f || rz[k] != 0.f) { s0 = rx[k] + s0; s1 = ry[k] + s1; s2 = rz[k] + s2; }
+                sp3[0] = s0; sp3[1] = s1; sp3[2] = s2;
+            }
+#endif
         }
         if (wave_samples && !a.l_final) {
             // the waves' samples of this batch, added in sample order by wave 0 (what the frames one after the other would add)
