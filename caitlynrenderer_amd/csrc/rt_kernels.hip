@@ -278,6 +278,12 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
 #ifndef CRT_P1_NO_BUSY
 #define CRT_P1_NO_BUSY 1
 #endif
+#ifndef CRT_ONE_MAT_OCC6        // the one-pass builds with materials / textures compiled for 6 waves per SIMD as well (they need 83 VGPRs at 5)
+#define CRT_ONE_MAT_OCC6 1
+#endif
+#ifndef CRT_ONE_PASS_KERNEL
+#define CRT_ONE_PASS_KERNEL 1
+#endif
 #ifndef CRT_SUM_ONCE
 #define CRT_SUM_ONCE 1
 #endif
@@ -1936,8 +1942,8 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 // == 2 also walks the in-place shadow rays that way.
 // BATCH (FIRST + INPLACE, a one-segment path): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.
 template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false, bool SHARE = false,
-          bool BATCH = false, bool WIDE = false>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
+          bool BATCH = false, bool WIDE = false, bool ONE = false>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT_OCC6)) ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
     // Uniform node steps are compiled into every first-segment kernel.  (In the single-sample kernel they lost while the uniform step still
     // converted bytes and the loops carried their flags — 8 x 8-pixel waves agree less than the 4 x 4-pixel waves of a batched launch, and the
@@ -1945,10 +1951,13 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
     constexpr bool UNI_K = FIRST && (BATCH || STATS || CRT_UNIFORM_SINGLE);
     // uniform: the workgroup's waves are the samples of one 64-pixel batch.  The 6-waves-per-SIMD build is never launched in that form
     // (launch_segment), and compiling the form out of it frees the registers its LDS result strip and wave index would hold
-    const bool wave_samples = BATCH && !WIDE && a.wave_samples == 1u;
+    const bool wave_samples = BATCH && !WIDE && !ONE && a.wave_samples == 1u;
     // uniform: a wave is one 4 x 4 pixel quadrant of a batch x 4 samples (lane = sample * 16 + pixel): the 64 rays of a wave leave a
     // quarter of the area, i.e. agree on their nodes like the rays of a frame of twice the resolution
-    const bool lane_samples = BATCH && a.wave_samples == 2u;
+    // ONE (with WIDE): the launch is four samples in the lanes form — one pass, known at compile time: around a sample loop whose trip count
+    // is a run-time value the compiler hoists every constant and uniform condition of the body into SGPRs that then live across both walks
+    // (and are spilled into VGPR lanes: 73 v_writelane + 86 v_readlane in the headline kernel before this)
+    const bool lane_samples = ONE || (BATCH && a.wave_samples == 2u);
     const WaveId wid = wave_id(wave_samples, lane_samples);
     const uint32_t lane = wid.lane, wave = wid.wave;
     // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
@@ -2025,7 +2034,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, (WIDE ? CRT_SEG_OCC_FIRST : (
         // tails (1 M triangles, 4 samples: 0.299 -> 0.276 ms per frame; Cornell 0.080 -> 0.064).  A separate instantiation:
         // the loop-carried state costs the single-sample kernel 50 bytes of scratch per lane otherwise.
         const uint32_t ws_waves = blockDim.x >> 6;           // wave_samples: wave w renders samples w, w + W, w + 2 W, ...
-        const uint32_t n_smp = BATCH ? (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : lane_samples ? a.n_samples >> 2 : a.n_samples) : 1u;
+        const uint32_t n_smp = ONE ? 1u : BATCH ? (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : lane_samples ? a.n_samples >> 2 : a.n_samples) : 1u;
         const uint32_t e_of_chunk = e;
         for (uint32_t smp_it = 0; smp_it < n_smp; ++smp_it) {
         // BATCH: the pixel index goes through an empty asm statement at the top of every sample, so that what is derived from it
@@ -2755,8 +2764,12 @@ static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, 
         // in the lanes of four single-wave workgroups per batch (one 4 x 4 pixel quadrant x 4 samples each): 16 * grid workgroups
         const dim3 gg = side_by_side ? dim3(grid * 4u) : in_lanes ? dim3(grid * 16u) : g, bb = side_by_side ? dim3(ws * 64u) : b;
         const size_t ll = side_by_side ? lds4 : lds;
-        if (feat == 2)      launch(CRT_K(true, false, true, true, false, true, false, true, false), gg, bb, ll, stream, v);
+        const bool one_pass = in_lanes && a.n_samples == 4u && CRT_ONE_PASS_KERNEL;      // four samples in the lanes of a wave: the builds without a sample loop
+        if (feat == 2 && one_pass)      launch(k_segment<true, false, true, false, true, false, true, false, false, true, false, true>, gg, bb, ll, stream, v);
+        else if (feat == 1 && one_pass) launch(k_segment<true, false, false, false, true, false, true, false, false, true, false, true>, gg, bb, ll, stream, v);
+        else if (feat == 2) launch(CRT_K(true, false, true, true, false, true, false, true, false), gg, bb, ll, stream, v);
         else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, true, false), gg, bb, ll, stream, v);
+        else if (v.wide_first && in_lanes && a.n_samples == 4u && CRT_ONE_PASS_KERNEL) { wide_ran = 1; launch(k_segment<true, false, false, false, true, false, false, false, false, true, true, true>, gg, bb, ll, stream, v); }
         else if (v.wide_first && !side_by_side) { wide_ran = 1; launch(CRT_K(true, false, false, true, false, false, false, true, true), gg, bb, ll, stream, v); }
         else                launch(CRT_K(true, false, false, true, false, false, false, true, false), gg, bb, ll, stream, v);
         return;

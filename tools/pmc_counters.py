@@ -16,7 +16,7 @@ def short(name):
     if not m:
         return n
     flags = [x.strip() == "true" for x in m.group(1).split(",")]
-    names = ["FIRST", "STATS", "TEX", "PRETRACED", "INPLACE", "BVH2", "MAT", "COMPACT", "SHARE", "BATCH", "WIDE"]
+    names = ["FIRST", "STATS", "TEX", "PRETRACED", "INPLACE", "BVH2", "MAT", "COMPACT", "SHARE", "BATCH", "WIDE", "ONE"]
     return "k_segment<" + ",".join(n for n, f in zip(names, flags) if f) + ">"
 
 
