@@ -2101,7 +2101,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
             }
         } else if (BVH2) {
             if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, a.overflow, hit, nn, nt);
-        } else if (a.tri_min == 0u) {
+        } else if (!ONE && a.tri_min == 0u) {      // (a one-pass build is launched with the voting loop and the group phase on: launch_segment)
             if (active) traverse<false, STATS, UNI_K && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt, &nu);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
@@ -2331,7 +2331,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
         }
         if (INPLACE && !COMPACT) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (CRT_FIRST_ANY_GROUPS && FIRST && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+            if (CRT_FIRST_ANY_GROUPS && FIRST && !BVH2 && (ONE || (a.lanes_log2 != 0u && a.tri_min != 0u))) {
                 // the first segment's shadow rays: the plain loop, then groups for the last rays of the wave
                 const bool occluded = traverse_any_then_groups<STATS, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
                                                                       V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any, &nu_any, a.planes);
@@ -2764,12 +2764,12 @@ static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, 
         // in the lanes of four single-wave workgroups per batch (one 4 x 4 pixel quadrant x 4 samples each): 16 * grid workgroups
         const dim3 gg = side_by_side ? dim3(grid * 4u) : in_lanes ? dim3(grid * 16u) : g, bb = side_by_side ? dim3(ws * 64u) : b;
         const size_t ll = side_by_side ? lds4 : lds;
-        const bool one_pass = in_lanes && a.n_samples == 4u && CRT_ONE_PASS_KERNEL;      // four samples in the lanes of a wave: the builds without a sample loop
+        const bool one_pass = in_lanes && a.n_samples == 4u && a.tri_min != 0u && a.lanes_log2 != 0u && CRT_ONE_PASS_KERNEL;      // four samples in the lanes of a wave: the builds without a sample loop
         if (feat == 2 && one_pass)      launch(k_segment<true, false, true, false, true, false, true, false, false, true, false, true>, gg, bb, ll, stream, v);
         else if (feat == 1 && one_pass) launch(k_segment<true, false, false, false, true, false, true, false, false, true, false, true>, gg, bb, ll, stream, v);
         else if (feat == 2) launch(CRT_K(true, false, true, true, false, true, false, true, false), gg, bb, ll, stream, v);
         else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, true, false), gg, bb, ll, stream, v);
-        else if (v.wide_first && in_lanes && a.n_samples == 4u && CRT_ONE_PASS_KERNEL) { wide_ran = 1; launch(k_segment<true, false, false, false, true, false, false, false, false, true, true, true>, gg, bb, ll, stream, v); }
+        else if (v.wide_first && one_pass) { wide_ran = 1; launch(k_segment<true, false, false, false, true, false, false, false, false, true, true, true>, gg, bb, ll, stream, v); }
         else if (v.wide_first && !side_by_side) { wide_ran = 1; launch(CRT_K(true, false, false, true, false, false, false, true, true), gg, bb, ll, stream, v); }
         else                launch(CRT_K(true, false, false, true, false, false, false, true, false), gg, bb, ll, stream, v);
         return;

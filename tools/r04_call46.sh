@@ -1,0 +1,11 @@
+#!/bin/bash
+# one-pass builds without the alternative walks (71 VGPRs: 7 waves per SIMD fit): parity, A/B against the previous form
+set -o pipefail
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
+OUT=$R/gpurun_out/r4au; mkdir -p $OUT
+cd $R
+timeout -k 10 900 python -m pytest tests -q -m gpu > $OUT/pytest.log 2>&1; RC=$?; echo "pytest rc $RC"; tail -4 $OUT/pytest.log
+[ $RC -ne 0 ] && exit $RC
+export AB_BUILDS="dflt|;general|-DCRT_ONE_PASS_KERNEL=0"
+export AB_RUNS="d1|--workload mesh1m --depth 1 --spp 4;k4|--workload mesh1m --depth 1 --spp 4 --resolution 3840x2160;d2|--workload mesh1m --depth 2 --spp 4;d4|--workload mesh1m --depth 4 --spp 4;d4_disney|--workload mesh1m --depth 4 --spp 4 --materials disney;hbm_d1|--workload mesh520 --device-built sah --depth 1 --spp 4 --steps 10;hbm_d4|--workload mesh520 --device-built sah --depth 4 --spp 4 --steps 10;d1_l1|--workload mesh1m --depth 1 --spp 4 --option lanes_per_ray=1"
+bash tools/ab.sh $OUT
