@@ -281,6 +281,9 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
 #ifndef CRT_ONE_MAT_OCC6        // the one-pass builds with materials / textures compiled for 6 waves per SIMD as well (they need 83 VGPRs at 5)
 #define CRT_ONE_MAT_OCC6 1
 #endif
+#ifndef CRT_LEAN_BOUNCE
+#define CRT_LEAN_BOUNCE 0
+#endif
 #ifndef CRT_ONE_PASS_KERNEL
 #define CRT_ONE_PASS_KERNEL 1
 #endif
@@ -1957,7 +1960,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
     // ONE (with WIDE): the launch is four samples in the lanes form — one pass, known at compile time: around a sample loop whose trip count
     // is a run-time value the compiler hoists every constant and uniform condition of the body into SGPRs that then live across both walks
     // (and are spilled into VGPR lanes: 73 v_writelane + 86 v_readlane in the headline kernel before this)
-    const bool lane_samples = ONE || (BATCH && a.wave_samples == 2u);
+    const bool lane_samples = (ONE && FIRST) || (BATCH && a.wave_samples == 2u);
     const WaveId wid = wave_id(wave_samples, lane_samples);
     const uint32_t lane = wid.lane, wave = wid.wave;
     // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
@@ -2034,7 +2037,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
         // tails (1 M triangles, 4 samples: 0.299 -> 0.276 ms per frame; Cornell 0.080 -> 0.064).  A separate instantiation:
         // the loop-carried state costs the single-sample kernel 50 bytes of scratch per lane otherwise.
         const uint32_t ws_waves = blockDim.x >> 6;           // wave_samples: wave w renders samples w, w + W, w + 2 W, ...
-        const uint32_t n_smp = ONE ? 1u : BATCH ? (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : lane_samples ? a.n_samples >> 2 : a.n_samples) : 1u;
+        const uint32_t n_smp = (ONE || !BATCH) ? 1u : (wave_samples ? (a.n_samples + ws_waves - 1u) / ws_waves : lane_samples ? a.n_samples >> 2 : a.n_samples);
         const uint32_t e_of_chunk = e;
         for (uint32_t smp_it = 0; smp_it < n_smp; ++smp_it) {
         // BATCH: the pixel index goes through an empty asm statement at the top of every sample, so that what is derived from it
@@ -2336,7 +2339,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                 const bool occluded = traverse_any_then_groups<STATS, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
                                                                       V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any, &nu_any, a.planes);
                 if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
-            } else if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && a.lanes_log2 != 0u && a.tri_min != 0u) {
+            } else if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && (ONE || (a.lanes_log2 != 0u && a.tri_min != 0u))) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
                 walk_batch<true, STATS, false, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
@@ -2804,6 +2807,12 @@ static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, 
         if (feat == 2)      launch(CRT_K(false, false, true, true, false, true, true, false, false), g, b, lds, stream, a);
         else if (feat == 1) launch(CRT_K(false, false, false, true, false, true, true, false, false), g, b, lds, stream, a);
         else                launch(CRT_K(false, false, false, true, false, false, true, false, false), g, b, lds, stream, a);
+#if CRT_LEAN_BOUNCE      // measurement variant: bounce kernels that carry only the walks a default launch runs — the same 79 VGPRs, no faster (7,192 against 7,208 Mray/s on four segments)
+    } else if (a.tri_min != 0u && a.lanes_log2 != 0u && CRT_ONE_PASS_KERNEL) {
+        if (feat == 2)      launch(k_segment<false, false, true, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
+        else if (feat == 1) launch(k_segment<false, false, false, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
+        else                launch(k_segment<false, false, false, false, true, false, false, false, false, false, false, true>, g, b, lds, stream, a);
+#endif
     } else {
         if (feat == 2)      launch(CRT_K(false, false, true, true, false, true, false, false, false), g, b, lds, stream, a);
         else if (feat == 1) launch(CRT_K(false, false, false, true, false, true, false, false, false), g, b, lds, stream, a);
