@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -280,6 +281,9 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
 #endif
 #ifndef CRT_ONE_MAT_OCC6        // the one-pass builds with materials / textures compiled for 6 waves per SIMD as well (they need 83 VGPRs at 5)
 #define CRT_ONE_MAT_OCC6 1
+#endif
+#ifndef CRT_LEAN_SINGLE
+#define CRT_LEAN_SINGLE 0
 #endif
 #ifndef CRT_LEAN_BOUNCE
 #define CRT_LEAN_BOUNCE 0
@@ -1960,7 +1964,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
     // ONE (with WIDE): the launch is four samples in the lanes form — one pass, known at compile time: around a sample loop whose trip count
     // is a run-time value the compiler hoists every constant and uniform condition of the body into SGPRs that then live across both walks
     // (and are spilled into VGPR lanes: 73 v_writelane + 86 v_readlane in the headline kernel before this)
-    const bool lane_samples = (ONE && FIRST) || (BATCH && a.wave_samples == 2u);
+    const bool lane_samples = BATCH && (ONE || a.wave_samples == 2u);
     const WaveId wid = wave_id(wave_samples, lane_samples);
     const uint32_t lane = wid.lane, wave = wid.wave;
     // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
@@ -2682,6 +2686,10 @@ static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 template <typename K, typename A>
 static inline void launch(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t stream, const A& a) {
+    // measurement aid: CRT_LDS_PAD=<bytes> adds unused dynamic LDS to every launch (LDS is handed out in 1,280-byte units: a way to take waves
+    // off a CU without touching the kernel)
+    static const size_t pad = [] { const char* e = getenv("CRT_LDS_PAD"); return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)0; }();
+    lds += pad;
     if (g_ev_start || g_ev_stop) {
         hipExtLaunchKernelGGL(kernel, g, b, (uint32_t)lds, stream, g_ev_start, g_ev_stop, 0, a);
         g_ev_start = g_ev_stop = nullptr;
@@ -2798,6 +2806,15 @@ static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, 
         return;
     }
     if (first) {
+        // one sample per launch (crt_render_frame): the builds with only the walks a default launch runs, where the launch is one
+#if CRT_LEAN_SINGLE      // measurement variant: 72 VGPRs (7 waves per SIMD) and SLOWER — 1 M triangles 13,452 against 14,719 Mray/s, 4K 15,748 against 17,186
+        if (a.tri_min != 0u && a.lanes_log2 != 0u && CRT_ONE_PASS_KERNEL) {
+            if (feat == 2)      launch(k_segment<true, false, true, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
+            else if (feat == 1) launch(k_segment<true, false, false, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
+            else                launch(k_segment<true, false, false, false, true, false, false, false, false, false, false, true>, g, b, lds, stream, a);
+            return;
+        }
+#endif
         if (feat == 2)      launch(CRT_K(true, false, true, true, false, true, false, false, false), g, b, lds, stream, a);
         else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, false, false), g, b, lds, stream, a);
         else                launch(CRT_K(true, false, false, true, false, false, false, false, false), g, b, lds, stream, a);
