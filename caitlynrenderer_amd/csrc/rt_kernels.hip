@@ -276,6 +276,15 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     }
     return hit_mask;
 }
+// ---- build switches of round 4 (A/B builds: make EXTRA="-D<switch>=<value>", tools/ab.sh; what each one measured: profiles/r04_experiments.md) ----
+// CRT_P1_NO_BUSY 1        the traversal loops carry no per-lane flag from one iteration to the next (section 12)
+// CRT_ONE_PASS_KERNEL 1   builds of the batched first-segment kernels for four samples in the lanes of a wave: no sample loop, default walks only (18)
+// CRT_ONE_MAT_OCC6 1      ... the material / texture ones compiled for 6 waves per SIMD as well
+// CRT_LEAN_SINGLE 0, CRT_LEAN_BOUNCE 0   the same idea for the single-sample and the bounce kernels: slower / no gain
+// CRT_SUM_ONCE 1          one read-modify-write of the sum for the four samples of a pixel
+// CRT_GROUP_TRI_WINDOW 1  group phase: lanes take bit positions below the highest pending triangle (13)
+// CRT_GROUP_LDS_STAGE 0   group phase: the node staged through LDS by global_load_lds_dwordx4 (15; needs CRT_HIT_SLOTS 4)
+// CRT_UNIFORM_CLOSEST / _ANY / _SINGLE / _PLAIN 1, CRT_UNIFORM_PLANES 1, CRT_PLANES_ONE_WAIT 0   uniform node steps (11)
 #ifndef CRT_P1_NO_BUSY
 #define CRT_P1_NO_BUSY 1
 #endif
