@@ -112,11 +112,19 @@ struct crt_scene {
     float* d_linear = nullptr;
     uint8_t* d_rgba = nullptr;
     float4* d_rays[2] = {nullptr, nullptr};   // path-ray queues, only for max_depth > 1
-    float4* d_shadow = nullptr;               // 3 x float4 per shadow ray: ray, ray, pending contribution C
-    float4* d_qhits = nullptr;                // closest hits of the path-ray queue (max_depth > 1, refill tracing)
-    // segments >= 1: 0 = fused lock-step k_segment (default: with the shadow rays walked in place it beats the pools,
-    // 1.87 vs 2.09 ms for 4 segments at 1 M triangles); 1 = closest hits through lane-refill pools (k_closest_queue) + shade-only pass
+    // DEFERRED NEE shadow rays (option "inplace_shadow" 0 / 2, rt_kernels.hip k_segment<!INPLACE>): the frame's NEE queue — one region per
+    // deferring segment, 8 sub-queues each, 2 x float4 per ray: (o, tmax) (d, contribution slot) — and the contribution slots, one per
+    // (deferring segment, path): (C | T e, visibility word)
+    float4* d_nee = nullptr;
+    float4* d_contrib = nullptr;
+    uint32_t defer_cap = 0, defer_regions = 0, defer_sub_capacity = 0;   // what the two were sized for
+    uint32_t lfinal_cap = 0;                  // samples d_lfinal is sized for
+    float4* d_qhits = nullptr;                // closest hits of the path-ray queue (max_depth > 1, option bounce_refill)
+    // segments >= 1: 0 = fused lock-step k_segment (default); 1 = closest hits through lane-refill pools (k_closest_queue) + shade-only pass
     uint32_t bounce_refill = 0;
+    uint32_t refill_pool = 256;               // rays per wave of k_closest_queue (64 with refill_min 65: lock-step batches)
+    uint32_t shadow_pool = 64;                // rays per wave of k_shadow_deferred
+    uint32_t shadow_refill_min = 65;          // idle lanes that trigger a refill there (65: never — one lock-step batch per 64 rays of the pool)
     // crt_render_frames, how the samples of a launch sit on the hardware (include/crt.h, option "wave_samples"): 0 = one after the other in
     // each wave; 1 = side by side on the waves of a workgroup; 2 (default) = four samples of a 4 x 4 pixel quadrant in the lanes of a wave
     // where the launch allows it (a multiple of 4 samples, a tree of >= 64 nodes, CWBVH), otherwise 1 when the launch is bound by its longest
@@ -125,7 +133,7 @@ struct crt_scene {
     uint32_t wide_first = 2;            // first-segment kernels built for 6 waves per SIMD: 0 never, 1 always, 2 by the same measure
     float tile_cost_spread = 0.f;       // 99th percentile of the measured tile costs over their mean; 0 = nothing measured yet
     int last_launch_form = 0;           // crt_debug_launch_form
-    int last_launch_wide = 0, last_launch_samples = 1;      // crt_debug_launch_info
+    int last_launch_wide = 0, last_launch_samples = 1, last_launch_one_pass = 0;      // crt_debug_launch_info
     bool use_wave_samples() const { return wave_samples == 2u ? bound_by_longest_waves() : wave_samples == 1u; }
     bool bound_by_longest_waves() const {
         // One wave renders the n samples of its 64 pixels one after the other: the launch cannot end before the most expensive
@@ -165,9 +173,12 @@ struct crt_scene {
     bool stats_from_frame = false;
     bool stats_counted = false;
     uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
-    uint32_t inplace_shadow = 1;             // NEE shadow rays walked inside k_segment (0: shadow queue + k_shadow)
+    // NEE shadow rays: 1 = walked inside k_segment, every segment (default); 0 = every segment's deferred to ONE any-hit launch behind the
+    // last segment (k_shadow_deferred) with the contributions folded per path in segment order (k_fold_paths); 2 = first segment in place,
+    // bounce segments deferred
+    uint32_t inplace_shadow = 1;
     uint32_t accel = 0;                      // frames: 0 CWBVH; 1 BVH2 walked as the shipped shader does (first visited wins); 2 BVH2, lowest id wins
-    uint32_t refill_min = 8;                // traverse_pool: idle lanes that trigger a refill
+    uint32_t refill_min = 8;                // walk_pool (crt_trace, k_closest_queue): idle lanes that trigger a refill
     // crt_trace: rays per wave (its refill pool): 64, 128 or 256.  64 = one lock-step batch per single-wave workgroup: four times the
     // workgroups for the dispatcher to balance, which is what a launch of a few million rays needs (tools/refill_probe.py, 1 M
     // triangles: 2.07 M primary rays 0.153 ms against 0.346 with 256-ray pools, whose 8,100 waves all start at once and end with the
@@ -181,12 +192,7 @@ struct crt_scene {
     uint32_t oversubscribe = 0;
     bool special_materials = false;          // some material is Mirror_type / Disney_type (albedo.w, Scene.h:111-132): k_segment<MAT>
     uint32_t waves_per_workgroup = 1;        // 1 = every wave its own workgroup (default), 2, or 4 = 256-thread workgroups
-    // triangle steps shared out to all lanes of the wave (include/crt.h, option "tri_share").  Default 0: the strips of the shared closest-hit
-    // form cap a CU at 18 waves (5,064 against 5,652 Mray/s on four segments at 6 waves per SIMD), and the bounce segments' walks spread a
-    // ray over four lanes instead once their wave has drained (lanes_per_ray)
-    uint32_t tri_share = 0;
     uint32_t lanes_per_ray = 8;              // option "lanes_per_ray" (1, 2, 4, 8): how far a ray may spread over the lanes of its draining wave (rt_kernels.hip walk_batch)
-    uint32_t compact_shadow = 1;             // with >= 2 waves per workgroup: gather the in-place shadow rays into full waves first
     uint32_t* d_overflow = nullptr;          // dropped stack pushes since scene creation (stays 0 for every accepted tree)
     float4* d_lfinal = nullptr;              // batched frames on multi-segment paths: per (sample, pixel) final radiance (SegmentArgs::l_final)
     // bounce rays regrouped by (direction octant, origin cell) between segments (rt_kernels.hpp RayBins).  Tables per segment a ray
@@ -240,7 +246,7 @@ struct crt_scene {
         if (shares_scene)                    // borrowed from the primary, which frees them
             for (const auto& b : scene_bufs) *reinterpret_cast<void**>(reinterpret_cast<char*>(this) + b.first) = nullptr;
         void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_planes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
-                        d_rays[0], d_rays[1], d_shadow, d_qhits, pb.L, pb.T, pb.seed, d_counts,
+                        d_rays[0], d_rays[1], d_nee, d_contrib, d_qhits, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal, d_bins};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_tile_cost) hipHostFree(h_tile_cost);
@@ -337,10 +343,11 @@ int build_shard(crt_scene* s) {
 
 void free_frame_buffers(crt_scene* s) {
     void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_tile_order, (void**)&s->d_tile_cost, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
-                     (void**)&s->d_rays[1], (void**)&s->d_shadow, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed,
+                     (void**)&s->d_rays[1], (void**)&s->d_nee, (void**)&s->d_contrib, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed,
                      (void**)&s->d_lfinal};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     s->batch_cap = 1;
+    s->defer_cap = s->defer_regions = s->defer_sub_capacity = s->lfinal_cap = 0;
     // the bins' capacities and offsets describe the queues that were just freed: back to "everything overflows"
     if (s->d_bins) (void)hipMemset(s->d_bins, 0, crt_scene::bins_words() * sizeof(uint32_t));
     if (s->h_tile_cost) { (void)hipHostFree(s->h_tile_cost); s->h_tile_cost = nullptr; }
@@ -379,7 +386,7 @@ int alloc_frame_buffers(crt_scene* s) {
     // a workgroup group handles every 8th unit of 4096 pixels/rays, so it can emit at most this many rays per segment
     s->sub_capacity = (uint32_t)(((P + 4095) / 4096 + 7) / 8 * 4096);
     const size_t Q = 8 * (size_t)s->sub_capacity;
-    // the shadow queue (inplace_shadow = 0) and the hit buffer of the bounce pools (bounce_refill = 1) are allocated
+    // the deferred shadow rays' buffers (inplace_shadow 0 / 2) and the hit buffer of the bounce pools (bounce_refill = 1) are allocated
     // by the first frame that needs them
     if (s->max_depth > 1) {                      // path state and ray queues exist only for multi-segment paths
         if ((rc = dev_alloc(&s->d_rays[0], 2 * Q))) return rc;
@@ -453,19 +460,7 @@ static int init_scene_common(crt_scene* s, const crt_scene_desc* d) {
     if (hipGetDevice(&s->device) != hipSuccess) return (fail(CRT_ERR_HIP, "hipGetDevice failed"));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
-#ifdef CRT_EXPERIMENTS
-    if (const char* e = std::getenv("CRT_TRACE_OCC")) s->trace_occupancy = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("CRT_BOUNCE_REFILL")) s->bounce_refill = std::atoi(e) ? 1u : 0u;
-    if (const char* e = std::getenv("CRT_OVERSUB")) s->oversubscribe = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("CRT_WAVES_PER_WG")) { const int v = std::atoi(e); s->waves_per_workgroup = v == 1 ? 1u : v == 2 ? 2u : 4u; }
-    if (const char* e = std::getenv("CRT_COMPACT_SHADOW")) s->compact_shadow = std::atoi(e) ? 1u : 0u;
-#endif
-    if (const char* e = std::getenv("CRT_RAY_BINS")) s->ray_bins = (uint32_t)std::min(5, std::max(0, std::atoi(e)));
-    if (const char* e = std::getenv("CRT_TRI_SHARE")) s->tri_share = (uint32_t)std::min(31, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("CRT_TIMING")) s->timing = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("CRT_INPLACE")) s->inplace_shadow = (uint32_t)std::atoi(e);
-    if (const char* e = std::getenv("CRT_TRI_MIN")) s->tri_min = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
-    if (const char* e = std::getenv("CRT_REFILL_MIN")) s->refill_min = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return (fail(CRT_ERR_HIP, "hipStreamCreate failed"));
     s->width = d->width; s->height = d->height; s->max_depth = d->max_depth; s->n_lights = (uint32_t)d->n_lights;
     if (d->n_vertices) {
@@ -999,20 +994,23 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     if (!s || !name) return fail(CRT_ERR_INVALID, "crt_set_option: null argument");
     if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
     else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
+    else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
+    else if (!std::strcmp(name, "refill_pool") || !std::strcmp(name, "shadow_pool")) {
+        if (value != 64 && value != 128 && value != 256 && value != 512) return fail(CRT_ERR_INVALID, std::string("crt_set_option: ") + name + " is 64, 128, 256 or 512");
+        (name[0] == 'r' ? s->refill_pool : s->shadow_pool) = (uint32_t)value;
+    }
+    else if (!std::strcmp(name, "shadow_refill_min")) s->shadow_refill_min = (uint32_t)std::min(65, std::max(1, value));
 #ifdef CRT_EXPERIMENTS
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
-    else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
     else if (!std::strcmp(name, "waves_per_workgroup")) {
         if (value != 1 && value != 2 && value != 4) return fail(CRT_ERR_INVALID, "crt_set_option: waves_per_workgroup is 1, 2 or 4");
         s->waves_per_workgroup = (uint32_t)value;
     }
-    else if (!std::strcmp(name, "compact_shadow")) s->compact_shadow = value ? 1u : 0u;
 #else
-    // variants that lost every measurement live in the CRT_EXPERIMENTS build only (make EXPERIMENTS=1); their default values are accepted
-    else if (!std::strcmp(name, "trace_occupancy") || !std::strcmp(name, "bounce_refill") || !std::strcmp(name, "oversubscribe") ||
-             !std::strcmp(name, "waves_per_workgroup") || !std::strcmp(name, "compact_shadow")) {
-        const bool is_default = !std::strcmp(name, "waves_per_workgroup") ? value == 1 : !std::strcmp(name, "bounce_refill") || !std::strcmp(name, "oversubscribe") ? value == 0 : true;
+    // persistent grids and multi-wave workgroups live in the CRT_EXPERIMENTS build only (make EXPERIMENTS=1); their default values are accepted
+    else if (!std::strcmp(name, "trace_occupancy") || !std::strcmp(name, "oversubscribe") || !std::strcmp(name, "waves_per_workgroup")) {
+        const bool is_default = !std::strcmp(name, "waves_per_workgroup") ? value == 1 : !std::strcmp(name, "oversubscribe") ? value == 0 : true;
         if (!is_default) return fail(CRT_ERR_INVALID, std::string("crt_set_option: ") + name + " is an experimental variant: this library was built without CRT_EXPERIMENTS");
     }
 #endif
@@ -1036,12 +1034,14 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     }
     else if (!std::strcmp(name, "wave_samples")) s->wave_samples = value < 0 ? 0u : std::min<uint32_t>(3u, (uint32_t)value);
     else if (!std::strcmp(name, "wide_first")) s->wide_first = value < 0 ? 0u : std::min<uint32_t>(2u, (uint32_t)value);
-    else if (!std::strcmp(name, "tri_share")) s->tri_share = (uint32_t)std::min(31, std::max(0, value));
     else if (!std::strcmp(name, "lanes_per_ray")) {
         if (value != 1 && value != 8) return fail(CRT_ERR_INVALID, "crt_set_option: lanes_per_ray is 1 or 8");
         s->lanes_per_ray = (uint32_t)value;
     }
-    else if (!std::strcmp(name, "inplace_shadow")) s->inplace_shadow = value ? 1u : 0u;
+    else if (!std::strcmp(name, "inplace_shadow")) {
+        if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: inplace_shadow is 1 (in place), 0 (every segment's shadow rays deferred) or 2 (bounce segments' deferred)");
+        s->inplace_shadow = (uint32_t)value;
+    }
     else if (!std::strcmp(name, "adaptive_tiles")) { s->adaptive_tiles = value ? 1u : 0u; if (value) s->tile_state = crt_scene::TILES_WANT; }
     else if (!std::strcmp(name, "accel")) {
         if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: accel is 0 (CWBVH), 1 (BVH2, reference order) or 2 (BVH2, lowest-id ties)");
@@ -1068,7 +1068,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         return CRT_OK;
     }
     else if (!std::strcmp(name, "tri_min")) s->tri_min = (uint32_t)std::min(64, std::max(0, value));   // 0: plain per-lane closest-hit loop (what trees of a few nodes get)
-    else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(64, std::max(1, value));
+    else if (!std::strcmp(name, "refill_min")) s->refill_min = (uint32_t)std::min(65, std::max(1, value));   // 65: never while a lane is busy (lock-step batches)
     else if (!std::strcmp(name, "trace_pool")) {
         if (value != 64 && value != 128 && value != 256) return fail(CRT_ERR_INVALID, "crt_set_option: trace_pool is 64, 128 or 256");
         s->trace_pool = (uint32_t)value;
@@ -1094,6 +1094,38 @@ static bool uses_ray_bins(const crt_scene* s) {
     // bounce rays binned between the segments (option "ray_bins"): big trees, CWBVH walks, the lock-step segment kernels
     return s->ray_bins != 0u && s->max_depth > 1u && s->info.n_nodes8 >= 64 && s->accel == 0u && !s->bounce_refill;
 }
+// Segments [first, max_depth) defer their NEE shadow rays (option "inplace_shadow"); first = max_depth: none does.  BVH2 frames walk in place.
+static uint32_t first_deferred_segment(const crt_scene* s) {
+    if (s->accel != 0u || s->inplace_shadow == 1u) return s->max_depth;
+    return s->inplace_shadow == 0u ? 0u : std::min(1u, s->max_depth);
+}
+// d_lfinal for the samples the path buffers are sized for (frames that fold: several samples of multi-segment paths, deferred shadow rays)
+static int ensure_lfinal(crt_scene* s) {
+    if (s->d_lfinal && s->lfinal_cap >= s->batch_cap) return CRT_OK;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->d_lfinal) { (void)hipFree(s->d_lfinal); s->d_lfinal = nullptr; }
+    const size_t n = (size_t)s->n_local_pixels * s->batch_cap;
+    int rc = dev_alloc(&s->d_lfinal, n);
+    if (rc) return rc;
+    HIPCHK(hipMemset(s->d_lfinal, 0, n * sizeof(float4)));      // pixels outside the frame are never written: they stay zero
+    s->lfinal_cap = s->batch_cap;
+    return CRT_OK;
+}
+// The NEE queue and the contribution slots of the deferring segments, for the samples per launch the path buffers are sized for
+static int ensure_defer_buffers(crt_scene* s) {
+    const uint32_t regions = s->max_depth - first_deferred_segment(s);
+    if (regions == 0u) return CRT_OK;
+    if (s->d_nee && s->defer_cap == s->batch_cap && s->defer_regions >= regions && s->defer_sub_capacity == s->sub_capacity) return CRT_OK;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (void** p : {(void**)&s->d_nee, (void**)&s->d_contrib}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    s->defer_cap = s->defer_regions = 0;
+    const uint64_t slots = (uint64_t)regions * s->n_local_pixels * s->batch_cap;
+    if (slots >= (1ull << 32)) return fail(CRT_ERR_LIMIT, "deferred shadow rays: more than 2^32 contribution slots (segments x pixels x samples per launch); use inplace_shadow 1");
+    int rc;
+    if ((rc = dev_alloc(&s->d_nee, 2 * 8 * (size_t)s->sub_capacity * regions)) || (rc = dev_alloc(&s->d_contrib, (size_t)slots))) return rc;
+    s->defer_cap = s->batch_cap; s->defer_regions = regions; s->defer_sub_capacity = s->sub_capacity;
+    return CRT_OK;
+}
 // Everything a batch of n_samples needs ALLOCATED on this device, and nothing enqueued: a scene on several devices or streams prepares
 // all of them before the first launch of any, so that an allocation failing on one leaves no device with half a batch in its sums.
 static int prepare_batch(crt_scene* s, uint32_t n_samples) {
@@ -1101,15 +1133,15 @@ static int prepare_batch(crt_scene* s, uint32_t n_samples) {
     int rc = ensure_frame(s);
     if (rc) return rc;
     if (s->n_local_pixels == 0) return CRT_OK;
-    const bool deferred = n_samples > 1u && s->max_depth > 1u;       // finished paths leave their radiance in d_lfinal
-    if (deferred && (rc = ensure_batch_buffers(s, n_samples))) return rc;   // grows to the largest batch ever asked for
+    const bool batched_paths = n_samples > 1u && s->max_depth > 1u;       // finished paths leave their radiance in d_lfinal
+    if (batched_paths && (rc = ensure_batch_buffers(s, n_samples))) return rc;   // grows to the largest batch ever asked for
+    if (first_deferred_segment(s) < s->max_depth && ((rc = ensure_lfinal(s)) || (rc = ensure_defer_buffers(s)))) return rc;
     if (s->count_visits && !s->d_visit_totals) {
         if ((rc = dev_alloc(&s->d_visit_totals, 16))) return rc;
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_visit_totals), 16 * sizeof(unsigned long long)));
     }
-    // the shadow queue (inplace_shadow = 0) and the hit buffer of the bounce pools (bounce_refill = 1): allocated by the first frame that needs them
+    // the hit buffer of the bounce pools (bounce_refill = 1): allocated by the first frame that needs it
     const size_t Q = 8 * (size_t)s->sub_capacity;
-    if (!s->inplace_shadow && s->accel == 0u && !s->d_shadow && (rc = dev_alloc(&s->d_shadow, 3 * Q))) return rc;
     if (s->bounce_refill && s->max_depth > 1 && !s->d_qhits && (rc = dev_alloc(&s->d_qhits, Q))) return rc;
     if (uses_ray_bins(s)) {
         if (!s->d_bins) {
@@ -1138,7 +1170,11 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
     if (rc) return rc;
     if (s->n_local_pixels == 0) return CRT_OK;
     const uint32_t P = s->n_local_pixels;
-    const bool deferred = n_samples > 1u && s->max_depth > 1u;
+    const bool batched_paths = n_samples > 1u && s->max_depth > 1u;
+    const uint32_t first_deferred = first_deferred_segment(s);         // segments from here on leave their shadow rays to k_shadow_deferred
+    const bool any_deferred = first_deferred < s->max_depth;
+    const bool folds = batched_paths || any_deferred;                   // finished paths leave their radiance in d_lfinal, k_fold_paths adds it to the sum
+    const size_t n_paths = (size_t)P * n_samples;
     const float rx = rxs[0], ry = rys[0];
     const crt::FrameArgs f = frame_args(s, rx, ry);
     if (!s->timing_accumulate) s->n_spans = 0;
@@ -1210,17 +1246,8 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         const bool bvh2 = s->accel != 0u;
         // trees of a few nodes: plain per-lane closest-hit loop (tri_min = 0) and no bounce pools
         const bool small_tree = s->info.n_nodes8 < 64;
-        const bool inplace = bvh2 || s->inplace_shadow != 0u;   // shadow rays walked inside k_segment: no queue, no k_shadow launch
+        const bool inplace = b < first_deferred;            // shadow rays walked inside k_segment (else: left to k_shadow_deferred)
         sa.tri_min = small_tree ? 0u : s->tri_min;
-        // default (3): no sharing in the first segment, closest-hit + shadow sharing in the bounce segments.  (Until the launch was
-        // scheduled by tile cost, sharing also paid in the first segment — it shortened the long waves a launch ended on; with
-        // every SIMD busy only the instruction count matters: 1 M triangles 0.2566 -> 0.2486 ms, 4K 3.45 -> 3.26 ms without it.)
-        // bits 0..1 as before (0 none, 1 closest-hit walk, 2 + shadow walk through the strips, 3 = 0 for the first segment and 2 after);
-        // the in-place shadow walk in the lean shared form (traverse_any_shared): + 4 every segment, + 8 the first only, + 16 the bounce
-        // segments only (the default: 16).  The first-segment kernels carry the lean form only in a CRT_EXPERIMENTS build.
-        sa.tri_share = (s->tri_share & 3u) == 3u ? (b == 0 ? 0u : 2u) : (s->tri_share & 3u);
-        if ((s->tri_share & 4u) || ((s->tri_share & 8u) && b == 0) || ((s->tri_share & 16u) && b > 0)) sa.tri_share |= 4u;
-        if (s->info.n_tris8 > (1ull << 24)) sa.tri_share = 0u;     // a shared item is (triangle index | owner lane << 24)
         sa.lanes_log2 = s->lanes_per_ray >= 8u ? 3u : s->lanes_per_ray >= 4u ? 2u : s->lanes_per_ray >= 2u ? 1u : 0u;
         sa.nodes2 = s->d_bvh2; sa.tris2 = s->d_tris2; sa.stack_entries2 = s->bvh2_stack; sa.tie = s->accel == 2u ? 1u : 0u;
         const bool bins = uses_ray_bins(s);              // tables and the queues' overflow halves exist (prepare_batch)
@@ -1241,13 +1268,20 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         if (bins && b > 0) { sa.bin_start = s->bin_start(b); sa.bin_off_in = s->bin_off(s->bank, b); sa.ovf_base_in = Qe; }
         sa.rays_in = s->d_rays[b & 1]; sa.count_in = cnt + counter_index(b, 0, 0);
         sa.rays_next = s->d_rays[(b + 1) & 1]; sa.count_next = cnt + counter_index(b + 1, 0, 0);
-        sa.shadow = s->d_shadow; sa.count_shadow = cnt + counter_index(b, 1, 0);
+        sa.count_shadow = cnt + counter_index(b, 1, 0);
+        if (!inplace) {
+            const uint32_t r = b - first_deferred;           // this segment's region of the NEE queue and of the slot array
+            sa.shadow = s->d_nee + 2 * (size_t)r * 8u * s->sub_capacity;
+            sa.contrib = s->d_contrib + (size_t)r * n_paths;
+            sa.slot_first = (uint32_t)((size_t)r * n_paths);
+            sa.slot_bit = 1u << (8u + b);
+        }
         sa.pb = s->pb; sa.sum = s->d_sum;
         sa.last_segment = (b + 1 == s->max_depth) ? 1u : 0u;
         sa.visit_totals = s->d_visit_totals;
         sa.overflow = s->d_overflow;
         if (b == 0) { sa.zero_counts = s->d_counts + (size_t)(s->bank ^ 1u) * kCounters; sa.n_zero = kCounters; }
-        sa.l_final = deferred ? s->d_lfinal : nullptr;
+        sa.l_final = folds ? s->d_lfinal : nullptr;
         sa.tile_cost = (b == 0 && measure_tiles) ? s->d_tile_cost : nullptr;
         sa.n_samples = b == 0 ? n_samples : 1u;
         // how the samples of a batched launch sit on the hardware (option "wave_samples"): 2 = four samples of a 4 x 4 pixel quadrant in
@@ -1272,31 +1306,26 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         if (b == 0) { s->last_launch_form = (int)sa.wave_samples; s->last_launch_samples = (int)n_samples; }
         for (uint32_t k = 0; k < 8u; ++k) sa.rv_s[k] = k < n_samples ? rxs[k] * rys[k] : 0.f;
         EventSpan* sp = s->new_span(1);
-#ifdef CRT_EXPERIMENTS
-        const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u && !s->special_materials;
-#else
-        const bool pretraced = false;
-#endif
-#ifdef CRT_EXPERIMENTS
+        // option bounce_refill: the closest hits of a bounce segment through lane-refill pools (k_closest_queue), then a shade-only pass
+        const bool pretraced = b > 0 && s->bounce_refill && !small_tree && !bvh2 && s->tri_min != 0u && !bins;
         if (pretraced) {
             crt::QueueTraceArgs qa{};
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
             qa.stack_entries = s->stack_entries; qa.sub_capacity = s->sub_capacity; qa.refill_min = s->refill_min; qa.tri_min = s->tri_min;
+            qa.pool = s->refill_pool; qa.lanes_log2 = sa.lanes_log2;
             qa.visit_totals = s->d_visit_totals; qa.overflow = s->d_overflow;
             if (sp) crt::set_launch_events(sp->a, nullptr);                 // span = both launches of the segment
-            crt::launch_closest_queue(qa, s->count_visits, s->trace_grid(P, 8, 1024), s->waves_per_workgroup, s->stream);
+            crt::launch_closest_queue(qa, s->count_visits, (s->sub_capacity + qa.pool - 1u) / qa.pool, s->stream);
             sa.hits_in = s->d_qhits;
             if (sp) crt::set_launch_events(nullptr, sp->b);
-        } else
-#endif
-        if (sp) crt::set_launch_events(sp->a, sp->b);
+        } else if (sp) crt::set_launch_events(sp->a, sp->b);
         // A workgroup renders ONE chunk (CRT_CHUNK_LOOP), so the grid has to cover every chunk a sub-queue can hold: a group's
         // sub-queue gets the rays of that group's units of 4096 pixels — ceil(units / 8) of them — times the samples of the launch.
         // (P * n_samples spread evenly over the 8 groups is fewer chunks than that when the units do not divide by 8.)
         uint32_t grid = s->trace_grid(P, sa.wide_first ? 6 : 5);
-        if (b > 0 && deferred) grid *= n_samples;
-        const int wide_ran = crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->compact_shadow != 0u && (s->tri_share & 3u) == 0u, s->count_visits, grid, s->waves_per_workgroup, s->stream);
-        if (b == 0) s->last_launch_wide = wide_ran;
+        if (b > 0 && batched_paths) grid *= n_samples;
+        const int build = crt::launch_segment(sa, b == 0, pretraced, inplace, bvh2, s->special_materials, s->count_visits, grid, s->waves_per_workgroup, s->stream);
+        if (b == 0) { s->last_launch_wide = build & 1; s->last_launch_one_pass = (build >> 1) & 1; }
         if (sa.bins_out.count) {
             // fill counts -> the next launch's index space and ray count, and the next frame's capacities (the other parity)
             crt::BinScanArgs ba{};
@@ -1307,17 +1336,23 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             crt::launch_bin_scan(ba, s->stream);
         }
 
-        if (inplace) continue;                       // shadow rays were traced inside k_segment
+    }
+    if (any_deferred) {
+        // ONE any-hit launch for the shadow rays of every deferring segment: full waves from the first step
         crt::ShadowArgs sh{};
-        sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_shadow; sh.count = cnt + counter_index(b, 1, 0);
-        sh.L = s->pb.L; sh.sum = s->d_sum; sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity; sh.refill_min = s->refill_min; sh.tri_min = 0;
+        sh.nodes = s->d_nodes; sh.tris = s->d_tris; sh.shadow = s->d_nee; sh.contrib = s->d_contrib;
+        sh.count = cnt + counter_index(first_deferred, 1, 0); sh.count_stride = counter_index(1, 1, 0) - counter_index(0, 1, 0);
+        sh.stack_entries = s->stack_entries; sh.sub_capacity = s->sub_capacity;
+        sh.pool = s->shadow_pool; sh.refill_min = s->shadow_refill_min; sh.tri_min = s->tri_min ? s->tri_min : 1u;
+        sh.lanes_log2 = s->lanes_per_ray >= 8u ? 3u : 0u;
+        sh.pools_per_region = (s->sub_capacity + sh.pool - 1u) / sh.pool;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sh.overflow = s->d_overflow;
-        sp = s->new_span(2);
+        EventSpan* sp = s->new_span(2);
         if (sp) crt::set_launch_events(sp->a, sp->b);
-        crt::launch_shadow(sh, s->count_visits, s->trace_grid(P, 8), s->waves_per_workgroup, s->stream);
+        crt::launch_shadow_deferred(sh, s->count_visits, s->max_depth - first_deferred, s->stream);
     }
-    if (deferred) crt::launch_accumulate_samples(s->d_sum, s->d_lfinal, P, n_samples, s->stream);
+    if (folds) crt::launch_fold_paths(s->d_sum, s->d_lfinal, any_deferred ? s->d_contrib : nullptr, P, n_samples, first_deferred, s->stream);
     if (s->count_visits)
         HIPCHK(hipMemcpyAsync(s->h_visit_totals, s->d_visit_totals, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     if (measure_tiles) {
@@ -1339,9 +1374,10 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
 static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
     if (s->batch_cap >= cap) return CRT_OK;
     HIPCHK(hipStreamSynchronize(s->stream));
-    // The lazily allocated shadow queue and hit buffer follow the per-group capacity: dropped now (null pointers the next frame
-    // re-allocates at the size then in force), whatever happens below.
-    for (void** p : {(void**)&s->d_shadow, (void**)&s->d_qhits}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    // The lazily allocated hit buffer and the deferred shadow rays' buffers follow the per-group capacity: dropped now (null pointers the
+    // next frame re-allocates at the size then in force), whatever happens below.
+    for (void** p : {(void**)&s->d_nee, (void**)&s->d_contrib, (void**)&s->d_qhits}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    s->defer_cap = s->defer_regions = 0;
     // Everything else is allocated at the new size FIRST and swapped in only when all of it exists: a failed growth (~250 B per
     // pixel and sample: 16 GB for a 4K frame at 8 samples) leaves the scene exactly as it was, able to render frame by frame.
     const size_t P = s->n_local_pixels;
@@ -1364,6 +1400,7 @@ static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
     s->d_rays[0] = rays0; s->d_rays[1] = rays1; s->pb.L = L; s->pb.T = T; s->pb.seed = seed; s->d_lfinal = lfinal;
     s->sub_capacity = sub_capacity;
     s->batch_cap = cap;
+    s->lfinal_cap = cap;
     s->rays_doubled = false;
     if (s->d_bins) HIPCHK(hipMemset(s->d_bins, 0, crt_scene::bins_words() * sizeof(uint32_t)));     // new queues: the bins start empty-handed again
     return CRT_OK;
@@ -1372,16 +1409,12 @@ static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
 // how many samples one launch may render: more than one only when nothing travels between launches (one path segment, shadow
 // rays walked in place) — bounce queues and the shadow queue hold one entry per pixel
 static uint32_t batch_limit(const crt_scene* s) {
-    const bool inplace = s->accel != 0u || s->inplace_shadow != 0u;
-    const bool compact = s->compact_shadow != 0u && (s->tri_share & 3u) == 0u && s->waves_per_workgroup > 1u;   // as launch_segment decides
-    if (!inplace || compact || s->count_visits) return 1u;            // counting frames run one by one
-#ifndef CRT_EXPERIMENTS
+    // the batched builds of the first segment walk its shadow rays in place; counting frames run one by one
+    if (first_deferred_segment(s) == 0u || s->count_visits) return 1u;
     if (s->accel != 0u) return 1u;                                     // the BVH2 frame mode (a comparison aid) has no batched build
-#endif
     if (s->max_depth == 1u) return 8u;
     // several segments: every sample keeps its own path state and queue entries (ensure_batch_buffers) and the samples' radiance is
-    // added in frame order by k_accumulate_samples; the bounce pools' hit buffer is not part of that
-    if (s->bounce_refill) return 1u;
+    // added in frame order by k_fold_paths
     // path ids are sample * n_local_pixels + pixel and must stay below 2^31 (bit 31 tags queue entries)
     const uint64_t fit = s->n_local_pixels ? 0x7fffffffull / s->n_local_pixels : 8ull;
     return (uint32_t)std::min<uint64_t>(8ull, std::max<uint64_t>(1ull, fit));         // 1 M triangles, 4 segments: 1.78 / 1.61 / 1.50 / 1.45 ms per frame at 1 / 2 / 4 / 8 frames per launch
@@ -1693,7 +1726,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
     r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
-    r->lanes_per_ray = src->lanes_per_ray; r->tri_share = src->tri_share; r->compact_shadow = src->compact_shadow; r->bounce_refill = src->bounce_refill;
+    r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
     r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }
@@ -1908,7 +1941,7 @@ int crt_debug_step_hist(crt_scene* s, unsigned long long* hist) {
 
 int crt_debug_launch_info(crt_scene* s, int32_t info[4]) {
     if (!s || !info) return fail(CRT_ERR_INVALID, "crt_debug_launch_info: null argument");
-    info[0] = s->last_launch_form; info[1] = s->last_launch_wide; info[2] = s->last_launch_samples; info[3] = (int32_t)s->peers.size() + 1;
+    info[0] = s->last_launch_form; info[1] = s->last_launch_wide | (s->last_launch_one_pass << 1); info[2] = s->last_launch_samples; info[3] = (int32_t)s->peers.size() + 1;
     return CRT_OK;
 }
 
@@ -1972,9 +2005,11 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
     std::vector<uint32_t> counts(kCounters);
     HIPCHK(hipMemcpy(counts.data(), s->counts(), kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (which != 2 && s->d_bins && s->ray_bins) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: the path-ray queue is binned (option ray_bins 0 gives the sub-queue form this reads)");
-    const float4* src = which == 2 ? s->d_shadow : s->d_rays[segment & 1];
-    if (!src) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: that queue does not exist (shadow queue: only with inplace_shadow = 0; path queues: max_depth > 1)");
-    const size_t entry = which == 2 ? 3 * sizeof(float4) : sizeof(crt_ray);
+    const uint32_t first_def = first_deferred_segment(s);
+    const float4* src = which == 2 ? ((s->d_nee && segment >= first_def && segment - first_def < s->defer_regions) ? s->d_nee + 2 * (size_t)(segment - first_def) * 8u * s->sub_capacity : nullptr)
+                                   : s->d_rays[segment & 1];
+    if (!src) return fail(CRT_ERR_INVALID, "crt_debug_read_queue: that queue does not exist (shadow rays: only of segments that defer them, inplace_shadow 0 / 2; path queues: max_depth > 1)");
+    const size_t entry = sizeof(crt_ray);        // a deferred shadow ray is (o, tmax) (d, contribution slot)
     size_t total = 0;
     for (uint32_t g = 0; g < 8; ++g) total += counts[counter_index(segment, which == 2 ? 1 : 0, g)];
     *n_out = total;
@@ -1986,7 +2021,6 @@ int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst
             n = std::min(n, cap - done);
             if (!n) continue;
             const char* from = reinterpret_cast<const char*>(src) + (size_t)g * s->sub_capacity * entry;
-            // shadow entries are 64 B (ray, ray, C, L): copy the leading crt_ray of each
             HIPCHK(hipMemcpy2D(dst + done, sizeof(crt_ray), from, entry, sizeof(crt_ray), n, hipMemcpyDeviceToHost));
             done += n;
         }

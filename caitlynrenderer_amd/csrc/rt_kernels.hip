@@ -114,17 +114,10 @@ __device__ __forceinline__ void count_wave_step(uint32_t& c) {
 // Measurement aid (crt_debug_step_hist): how many lanes were enabled at each node step of the counting kernels, per walk kind — the
 // distribution behind the lane-utilisation figures (how much of the idle time is "fewer than half of the lanes still have a ray").
 __device__ unsigned long long* g_step_hist = nullptr;       // [2][65]: closest-hit walks, any-hit walks; null = off
-// -DCRT_HIST_UNIFORM=1 / 2 (measurement builds): only the steps whose enabled lanes all fetch the SAME node (2: and share the octant) are binned
 __device__ __forceinline__ void hist_node_step(bool any, uint32_t nidx = 0u, uint32_t oct = 0u) {
     unsigned long long* const h = g_step_hist;
     if (h == nullptr) return;
     const unsigned long long m = __ballot(true);
-#ifdef CRT_HIST_UNIFORM
-    {
-        const uint32_t key = CRT_HIST_UNIFORM == 2 ? (nidx << 3) | (oct & 7u) : nidx;
-        if (__ballot(key == (uint32_t)__builtin_amdgcn_readfirstlane((int)key)) != m) return;
-    }
-#endif
     if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) atomicAdd(&h[(any ? 65 : 0) + __builtin_popcountll(m)], 1ull);
 }
 void set_step_hist(unsigned long long* d_hist) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist), &d_hist, sizeof d_hist); }
@@ -159,17 +152,12 @@ __device__ __forceinline__ bool mt_test(const float4 a, const float4 b, const fl
 // Row address of a node / triangle record as uniform base + a 32-bit byte offset: the load then takes the base from an SGPR pair and the
 // offset from one VGPR (global_load ... v_off, s[base]) instead of a 64-bit v_mad_u64_u32 per visit — an instruction that costs 8.9
 // issue cycles against 4.4 for the 32-bit multiply (profiles/r03_valu_issue_cycles.txt).  crt_scene_create refuses arrays beyond 4 GiB.
-#ifndef CRT_ADDR64
 __device__ __forceinline__ const uint4* node_rows(const uint4* nodes, uint32_t idx) {
     return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + (size_t)(idx * (uint32_t)(CRT_NODE_ROWS * 16)));
 }
 __device__ __forceinline__ const float4* tri_rows(const float4* tris, uint32_t idx) {
     return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + (size_t)(idx * (uint32_t)(CRT_TRI_ROWS * 16)));
 }
-#else
-__device__ __forceinline__ const uint4* node_rows(const uint4* nodes, uint32_t idx) { return nodes + (size_t)idx * CRT_NODE_ROWS; }
-__device__ __forceinline__ const float4* tri_rows(const float4* tris, uint32_t idx) { return tris + (size_t)idx * CRT_TRI_ROWS; }
-#endif
 
 // ---- UNIFORM NODE STEPS (round 4): the node through the scalar cache ----
 // The 64 primary rays of a wave leave a 4 x 4 pixel quadrant, so near the root they all ask for the SAME node and share the direction
@@ -183,7 +171,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool node_step_is_uniform(uint32_t nidx, uint32_t oct4, uint32_t& key0) {
     const uint32_t key = (nidx << 3) | (oct4 & 7u);          // crt_scene_create keeps node offsets below 4 GiB: nidx < 2^26
     key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-    return __ballot(key != key0) == 0ull;
+    // "no lane disagrees" must not hold vacuously: scalar loads ignore EXEC, so a block reached with no lane enabled would read the node of a
+    // stale key (the compiler skips such blocks today; nothing guarantees it)
+    return __ballot(true) != 0ull && __ballot(key != key0) == 0ull;
 }
 __device__ __forceinline__ void load_node_scalar(const uint4* nodes, uint32_t nidx0, uint4& n0, uint4& n1, uint4& n2, uint4& n3, uint4& n4) {
     const char* p = reinterpret_cast<const char*>(nodes) + (size_t)nidx0 * (size_t)(CRT_NODE_ROWS * 16);
@@ -199,13 +189,6 @@ __device__ __forceinline__ void load_node_scalar(const uint4* nodes, uint32_t ni
 // float4 per node, SegmentArgs::planes; (float)byte is exact), the step fetches the rows it needs through the scalar cache — near / far
 // row of each axis picked by ADDRESS from the shared octant — and each fma reads its plane straight from an SGPR.  Same operands, same
 // fma: the hit mask keeps its bits.  Two halves of four children (24 SGPRs of planes at a time).
-#ifndef CRT_UNIFORM_PLANES
-#define CRT_UNIFORM_PLANES 1
-#endif
-#ifndef CRT_PLANES_ONE_WAIT
-#define CRT_PLANES_ONE_WAIT 0      // 1: all fourteen rows of a uniform step requested at once, one wait — 56 SGPRs, and the loop's own scalars are spilled around the step (15,125 -> 14,666
-                                   // Mray/s on the headline); 0: head, first half, second half: three waits, 24 SGPRs of planes at a time
-#endif
 __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1, const uint4* nodes, const float4* planes, uint32_t nidx0, vec3 o, vec3 inv,
                                                            uint32_t oct0, float max_t) {
     // byte offsets of the near / far rows inside a half: axis * 32 + side * 16, side = hi planes when the direction is negative (oct bit clear)
@@ -214,24 +197,7 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     const char* np = reinterpret_cast<const char*>(nodes) + (size_t)nidx0 * (size_t)(CRT_NODE_ROWS * 16);
     u32x4 row[2][6];
     u32x4 a, b;
-#if CRT_PLANES_ONE_WAIT == 1
-    asm volatile("s_load_dwordx4 %0, %14, 0x0\n\ts_load_dwordx4 %1, %14, 0x10\n\t"
-                 "s_load_dwordx4 %2, %15, %16\n\ts_load_dwordx4 %3, %15, %17\n\ts_load_dwordx4 %4, %15, %18\n\ts_load_dwordx4 %5, %15, %19\n\t"
-                 "s_load_dwordx4 %6, %15, %20\n\ts_load_dwordx4 %7, %15, %21\n\t"
-                 "s_load_dwordx4 %8, %22, %16\n\ts_load_dwordx4 %9, %22, %17\n\ts_load_dwordx4 %10, %22, %18\n\ts_load_dwordx4 %11, %22, %19\n\t"
-                 "s_load_dwordx4 %12, %22, %20\n\ts_load_dwordx4 %13, %22, %21\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(a), "=&s"(b), "=&s"(row[0][0]), "=&s"(row[0][1]), "=&s"(row[0][2]), "=&s"(row[0][3]), "=&s"(row[0][4]), "=&s"(row[0][5]),
-                   "=&s"(row[1][0]), "=&s"(row[1][1]), "=&s"(row[1][2]), "=&s"(row[1][3]), "=&s"(row[1][4]), "=&s"(row[1][5])
-                 : "s"(np), "s"(base), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz), "s"(base + 96));
-#elif CRT_PLANES_ONE_WAIT == 2      // head and first half together, then the second half: two waits
-    asm volatile("s_load_dwordx4 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x10\n\t"
-                 "s_load_dwordx4 %2, %9, %10\n\ts_load_dwordx4 %3, %9, %11\n\ts_load_dwordx4 %4, %9, %12\n\ts_load_dwordx4 %5, %9, %13\n\t"
-                 "s_load_dwordx4 %6, %9, %14\n\ts_load_dwordx4 %7, %9, %15\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(a), "=&s"(b), "=&s"(row[0][0]), "=&s"(row[0][1]), "=&s"(row[0][2]), "=&s"(row[0][3]), "=&s"(row[0][4]), "=&s"(row[0][5])
-                 : "s"(np), "s"(base), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz));
-#else
     asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(np));
-#endif
     n0 = make_uint4(a.x, a.y, a.z, a.w); n1 = make_uint4(b.x, b.y, b.z, b.w);
     const vec3 p = V3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z));
     const uint32_t e_imask = n0.w;
@@ -242,15 +208,13 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     uint32_t hit_mask = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#if CRT_PLANES_ONE_WAIT == 0 || CRT_PLANES_ONE_WAIT == 2
-        if (CRT_PLANES_ONE_WAIT == 0 || h == 1) {
+        {
         const char* bh = base + h * 96;
         asm volatile("s_load_dwordx4 %0, %6, %7\n\ts_load_dwordx4 %1, %6, %8\n\ts_load_dwordx4 %2, %6, %9\n\ts_load_dwordx4 %3, %6, %10\n\t"
                      "s_load_dwordx4 %4, %6, %11\n\ts_load_dwordx4 %5, %6, %12\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(row[h][0]), "=&s"(row[h][1]), "=&s"(row[h][2]), "=&s"(row[h][3]), "=&s"(row[h][4]), "=&s"(row[h][5])
                      : "s"(bh), "s"(sx), "s"(16u - sx), "s"(32u + sy), "s"(48u - sy), "s"(64u + sz), "s"(80u - sz));
         }
-#endif
         const u32x4 xn = row[h][0], xf = row[h][1], yn = row[h][2], yf = row[h][3], zn = row[h][4], zf = row[h][5];
         const uint32_t meta4 = h == 0 ? n1.z : n1.w;
         const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
@@ -276,51 +240,16 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     }
     return hit_mask;
 }
-// ---- build switches of round 4 (A/B builds: make EXTRA="-D<switch>=<value>", tools/ab.sh; what each one measured: profiles/r04_experiments.md) ----
-// CRT_P1_NO_BUSY 1        the traversal loops carry no per-lane flag from one iteration to the next (section 12)
-// CRT_ONE_PASS_KERNEL 1   builds of the batched first-segment kernels for four samples in the lanes of a wave: no sample loop, default walks only (18)
-// CRT_ONE_MAT_OCC6 1      ... the material / texture ones compiled for 6 waves per SIMD as well
-// CRT_LEAN_SINGLE 0, CRT_LEAN_BOUNCE 0   the same idea for the single-sample and the bounce kernels: slower / no gain
-// CRT_SUM_ONCE 1          one read-modify-write of the sum for the four samples of a pixel
-// CRT_GROUP_TRI_WINDOW 1  group phase: lanes take bit positions below the highest pending triangle (13)
-// CRT_GROUP_LDS_STAGE 0   group phase: the node staged through LDS by global_load_lds_dwordx4 (15; needs CRT_HIT_SLOTS 4)
-// CRT_UNIFORM_CLOSEST / _ANY / _SINGLE / _PLAIN 1, CRT_UNIFORM_PLANES 1, CRT_PLANES_ONE_WAIT 0   uniform node steps (11)
-#ifndef CRT_P1_NO_BUSY
-#define CRT_P1_NO_BUSY 1
-#endif
-#ifndef CRT_ONE_MAT_OCC6        // the one-pass builds with materials / textures compiled for 6 waves per SIMD as well (they need 83 VGPRs at 5)
-#define CRT_ONE_MAT_OCC6 1
-#endif
-#ifndef CRT_LEAN_SINGLE
-#define CRT_LEAN_SINGLE 0
-#endif
-#ifndef CRT_LEAN_BOUNCE
-#define CRT_LEAN_BOUNCE 0
-#endif
-#ifndef CRT_ONE_PASS_KERNEL
-#define CRT_ONE_PASS_KERNEL 1
-#endif
-#ifndef CRT_SUM_ONCE
-#define CRT_SUM_ONCE 1
-#endif
-#ifndef CRT_GROUP_LDS_STAGE
-#define CRT_GROUP_LDS_STAGE 0
-#endif
-#ifndef CRT_GROUP_TRI_WINDOW
-#define CRT_GROUP_TRI_WINDOW 1
-#endif
-#ifndef CRT_UNIFORM_CLOSEST      // first-segment closest-hit walk (walk_batch phase 1)
-#define CRT_UNIFORM_CLOSEST 1
-#endif
-#ifndef CRT_UNIFORM_ANY          // first-segment shadow walk (traverse_any_then_groups)
-#define CRT_UNIFORM_ANY 1
-#endif
-#ifndef CRT_UNIFORM_SINGLE       // also in the single-sample first-segment kernel (crt_render_frame): 1 M triangles at one sample per launch 14,012 -> 14,516 Mray/s,
-#define CRT_UNIFORM_SINGLE 1     // 4K 16,212 -> 16,971 (on the byte-plane / flag-carrying loops of the round's first half it lost 1.6 % there)
-#endif
-#ifndef CRT_UNIFORM_PLAIN        // first-segment walks of the plain per-lane loop (scenes of a few nodes: tri_min 0; a launch with lanes_per_ray 1): with the float planes
-#define CRT_UNIFORM_PLAIN 1      // and the lean loops Cornell 53.2 -> 53.4 Gray/s, 4K at one sample per launch 16,971 -> 17,125 (it lost 4 % on the Cornell box before)
-#endif
+// Build switches that remain (make EXTRA="-D<name>=<value>"; tools/variant.sh builds a variant library beside the product one):
+//   CRT_SEG_OCC, CRT_SEG_OCC_FIRST, CRT_SEG_OCC_BATCH   waves per SIMD the segment kernels are compiled for (6 / 6 / 5)
+//   CRT_HIT_SLOTS, CRT_NODE_ROWS, CRT_TRI_ROWS           LDS hit-record slots per lane; device row strides (rt_kernels.hpp)
+//   CRT_ISA_MARKS                                        `make asm`: marker comments tools/roofline.py counts between
+//   CRT_EXPERIMENTS                                      persistent grids and 2- / 4-wave workgroups (make EXPERIMENTS=1)
+// Every variant that lost its measurement twice (flag-carrying loops, node touches, LDS-staged group nodes, one-wait plane loads, shared
+// triangle steps, shadow-ray compaction across waves, the lean single / bounce builds ...) is in the git history and in
+// profiles/r04_experiments.md, not here.
+constexpr uint32_t GROUP_KL = 3;     // lanes per ray after the regroup = 1 << this: 8 (one regroup, when at most 8 rays are left: 6,021 Mray/s on four
+                                     // segments of the 1 M-triangle scene against 5,464 with quads at <= 16 and 5,438 with pairs at <= 32)
 
 // One ray through the CWBVH (cwbvh.fs:448-536 closest, :538-616 any).  `stk` is this lane's column
 // of the wave's LDS stack: stk[level * 64]; stack_entries (<= CRT_STACK_ENTRIES) is sized from the
@@ -419,350 +348,6 @@ __device__ __forceinline__ bool traverse(const uint4* __restrict__ nodes, const 
     return best.tri >= 0;
 }
 
-// Wave-level traversal of a POOL of rays with lane refill (persistent threads in the sense of Aila & Laine):
-// a lane whose ray has finished immediately takes the next ray of the wave's pool instead of idling until
-// the slowest ray of its 64-ray batch is done.  Incoherent rays (bounces, shadow rays) ran at 21 % VALU lane
-// utilisation in lock-step batches; per-ray work and its order are unchanged, so hits and visit counters stay
-// bit-identical to the oracle.
-//   load(idx, o, d, tmax)  fetches ray idx of the pool;  done(idx, best, occluded)  consumes its result.
-// The pool is [pool_begin, pool_end); refill happens when at least `refill_min` lanes are idle (or none is busy).
-//
-// SHARE: triangle steps hand the pending triangles of the waiting lanes to ALL lanes of the wave.  In the plain loop a
-// triangle step tests one triangle per waiting lane, so a lane with three pending triangles costs the wave three steps,
-// run with the 9-20 lanes that happen to wait (lane utilisation of the triangle blocks: 30 % / 15 % at one segment,
-// 20 % / 7 % at four, half of all wave-level steps).  Here every waiting lane publishes up to three
-// (lane, triangle) items through a wave-private LDS strip (offsets from two ballots: counts are 0..3), lane r of the wave
-// tests item r with the OWNER's ray (origin and direction live in the same strip, written when the ray was loaded), and the
-// owner folds its items' results in their original order — the same tests with the same operands, by another lane, and the
-// same acceptance rule in the same order: hits and per-ray counters stay bit-identical.
-struct TriShare {
-    float4* ray;        // [2][64]: origin, direction of each lane's current ray
-    uint32_t* items;    // [64]: triangle index | owner lane << 24
-    float4* res;        // [64]: t, u, v, original id (int bits; -1 = no hit)
-};
-#define CRT_SHARE_BYTES (2 * 64 * 16 + 64 * 4 + 64 * 16)      // per wave
-
-// Registers.  What a closest-hit walk carries besides the ray is (t, u, v, triangle, original id) of the best hit so far, yet u, v and
-// the id are written a handful of times per ray (when a nearer hit is accepted) and read once at the end — the id also when two hits tie
-// on t, which is rare.  They live in two extra entries of the lane's LDS stack column (CRT_HIT_SLOTS: stk[stack_entries * 64] =
-// (u, v), stk[(stack_entries + 1) * 64].x = id) instead of three VGPRs across a 600-instruction loop; same values, same comparisons.
-// UNIFORM_O: every ray of the pool starts at the same point (primary rays: the camera position, a kernel argument): the origin then
-// stays in scalar registers (`o_uniform`, never assigned under a lane mask) instead of three more VGPRs; load() still says, per lane,
-// whether it has a ray at all.
-//   bool load(idx, o, d, tmax)  fetches ray idx of the pool (false: no ray in this slot);  done(idx, best, occluded)  consumes its result.
-template <bool ANY, bool STATS, bool SHARE = false, bool UNIFORM_O = false, typename Load, typename Done>
-__device__ __forceinline__ void traverse_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* stk,
-                                              int stack_entries, uint32_t* overflow, uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min,
-                                              uint32_t tri_min, Load load, Done done, uint32_t& n_nodes, uint32_t& n_tris,
-                                              uint32_t& w_nodes, uint32_t& w_tris, TriShare share = TriShare{nullptr, nullptr, nullptr},
-                                              vec3 o_uniform = V3(0.f, 0.f, 0.f)) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t next = pool_begin;                     // wave-uniform
-#if !CRT_P1_NO_BUSY
-    bool busy = false;
-#endif
-    uint32_t idx = 0;
-    vec3 o_lane = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
-    bool negx = false, negy = false, negz = false;
-    uint32_t oct4 = 0;
-    float best_t = 0.f;                             // closest hit so far (closest-hit walks: also the far clip of every box and triangle test)
-    int best_tri = -1;
-    uint2* const hit_uv = stk + stack_entries * 64;             // CRT_HIT_SLOTS
-    uint2* const hit_id = stk + (stack_entries + 1) * 64;
-    int sp = 0;
-    uint2 cur = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
-    // nearer wins; equal t -> lower original id; the stored id is fetched only when t ties
-    auto accept = [&](float t, float u, float v, int id, int ti) {
-        bool take = t < best_t;
-        if (t == best_t && best_tri >= 0) take = id < (int)hit_id->x;
-        if (take) {
-            best_t = t; best_tri = ti;
-            *hit_uv = make_uint2(__float_as_uint(u), __float_as_uint(v));
-            hit_id->x = (uint32_t)id;
-        }
-    };
-    CRT_MARK("loop_begin voting");
-    for (;;) {
-#if CRT_P1_NO_BUSY
-        // no flag carried through the loop (see walk_batch): a lane has a ray exactly while it has a triangle group or inner hits pending; a
-        // ray that is loaded without either (non-finite origin, empty slot) is finished by the end of the same iteration
-        bool busy = tg.y != 0u || (cur.y & 0xff000000u) != 0u;
-#endif
-        const unsigned long long idle = next < pool_end ? __ballot(!busy) : 0ull;     // a drained pool skips the refill logic
-        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (next < pool_end && (n_idle >= refill_min || n_idle == 64u)) {
-            const uint32_t mine = next + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-            if (!busy && mine < pool_end) {
-                idx = mine;
-                float tmax_in;
-                const bool has_ray = load(idx, o_lane, d, tmax_in);
-                best_t = tmax_in; best_tri = -1;
-                sp = 0;
-                busy = true;
-                // same prologue as traverse(): non-finite origin -> immediate miss; clamp zero direction components
-                const vec3 oo = UNIFORM_O ? o_uniform : o_lane;
-                const bool finite = __builtin_isfinite(oo.x) && __builtin_isfinite(oo.y) && __builtin_isfinite(oo.z);
-                const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
-                negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
-                oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
-                inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
-                cur = (finite && has_ray) ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
-                tg = make_uint2(0u, 0u);
-                if (SHARE) {                        // whoever tests this ray's triangles reads its operands from here
-                    share.ray[lane] = make_float4(oo.x, oo.y, oo.z, 0.f);
-                    share.ray[64u + lane] = make_float4(d.x, d.y, d.z, 0.f);
-                }
-            }
-            next = next + n_idle < pool_end ? next + n_idle : pool_end;
-        }
-        if (__ballot(busy) == 0ull) break;          // pool drained and every lane finished
-        const vec3 o = UNIFORM_O ? o_uniform : o_lane;
-
-        // ---- one step per iteration: either a node step (lanes in state N: inner hits pending, no triangle
-        // group pending) or a triangle step (lanes in state T: a triangle group pending).  The wave votes: triangle
-        // tests are postponed while node-ready lanes outnumber waiting lanes tri_min : 1 (tri_min is a ratio), so the
-        // 90-instruction Moller-Trumbore block and the 200-instruction node block each run with more lanes enabled.  A lane's own sequence of node
-        // fetches and triangle tests is unchanged (it cannot fetch a node while its triangle group is pending),
-        // so hits and visit counters stay bit-identical to the oracle.
-        // (A wave-level dedup of the node loads — one leader lane per distinct node, followers fed by ds_bpermute —
-        // was measured and dropped: 0.469 vs 0.394 ms on coherent primary rays, 0.509 vs 0.434 ms on bounce rays;
-        // the kernel is bound by VALU issue, not by the texture-address unit.)
-        const bool has_tri = busy && tg.y != 0u;
-        const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
-        const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
-        const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
-        // node step only while the lanes that can fetch a node outnumber the lanes waiting for a triangle test by
-        // vote_ratio : 1 (measured at 1 M triangles, ratio 1 / 2: 0.293 / 0.283 ms against 0.311 ms for a fixed
-        // threshold of 8 waiting lanes and 0.397 ms for the un-voted loop)
-        const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;
-        bool finished = false;
-        if (node_phase) {
-            if (can_node) {
-                CRT_MARK("node_begin");
-                const uint32_t hits_imask = cur.y;
-                const int off = 31 - __builtin_clz(hits_imask);
-                const uint32_t base = cur.x;
-                cur.y &= ~(1u << off);
-                if (cur.y & 0xff000000u) {
-                    // crt_scene_create sizes the stack from the validated depth of the tree, so a push always fits; if a
-                // caller-supplied tree ever got past the validator the dropped push is counted, not silent
-                if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u);
-                }
-                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
-                const uint32_t nidx = base + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-                const uint4* np = node_rows(nodes, nidx);
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, nidx, oct4); }
-                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
-                cur.x = n1.x;
-                tg.x = n1.y;
-                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
-                tg.y = hitmask & 0x00ffffffu;
-                CRT_MARK("node_end");
-            }
-        } else if (SHARE) {
-            // ---- shared triangle step (the whole wave takes part, waiting or not) ----
-            CRT_MARK("share_begin");
-            const unsigned long long act = __ballot(true), lt = (1ull << lane) - 1ull;
-            const uint32_t n_cons = (uint32_t)__builtin_popcountll(act), rank = (uint32_t)__builtin_popcountll(act & lt);
-            const uint32_t pend = has_tri ? (uint32_t)__builtin_popcount(tg.y) : 0u;
-            const uint32_t k = pend > 3u ? 3u : pend;
-            const unsigned long long b0 = __ballot((k & 1u) != 0u), b1 = __ballot((k & 2u) != 0u);
-            const uint32_t off = (uint32_t)__builtin_popcountll(b0 & lt) + 2u * (uint32_t)__builtin_popcountll(b1 & lt);
-            const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1);
-            if (total != 0u) {
-                const uint32_t room = off < n_cons ? n_cons - off : 0u;
-                const uint32_t lim = k < room ? k : room;        // items this lane gets tested in this step
-                uint32_t bits = tg.y;
-#pragma unroll
-                for (uint32_t j = 0; j < 3u; ++j)
-                    if (j < lim) {
-                        const int b = 31 - __builtin_clz(bits);
-                        bits &= ~(1u << b);
-                        share.items[off + j] = (tg.x + (uint32_t)b) | (lane << 24);
-                    }
-                __builtin_amdgcn_wave_barrier();
-                if (STATS) count_wave_step(w_tris);
-                const uint32_t n_items = total < n_cons ? total : n_cons;
-                if (rank < n_items) {
-                    const uint32_t item = share.items[rank];
-                    const uint32_t src = item >> 24, ti = item & 0x00ffffffu;
-                    const float4 ro = share.ray[src], rd = share.ray[64u + src];
-                    const float4* tp = tri_rows(tris, ti);
-                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                    float u, v, t;
-                    const bool hit = mt_test(ta, tb, tc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), u, v, t);
-                    share.res[rank] = make_float4(t, u, v, hit ? ta.w : __int_as_float(-1));
-                }
-                __builtin_amdgcn_wave_barrier();
-                uint32_t mine = tg.y;
-#pragma unroll
-                for (uint32_t j = 0; j < 3u; ++j)
-                    if (j < lim && !finished) {
-                        const int b = 31 - __builtin_clz(mine);
-                        mine &= ~(1u << b);
-                        const float4 r = share.res[off + j];
-                        if (STATS) ++n_tris;
-                        const int id = __float_as_int(r.w);
-                        if (id >= 0) {
-                            const uint32_t ti = tg.x + (uint32_t)b;
-                            if (ANY) {
-                                if (r.x < best_t) { best_tri = (int)ti; finished = true; }
-                            } else {
-                                accept(r.x, r.y, r.z, id, (int)ti);
-                            }
-                        }
-                    }
-                tg.y = finished ? 0u : bits;
-                __builtin_amdgcn_wave_barrier();                 // results are consumed before the next step's items overwrite the strip
-            }
-            CRT_MARK("share_end");
-        } else if (has_tri) {
-            CRT_MARK("tri_begin");
-            const int b = 31 - __builtin_clz(tg.y);
-            tg.y &= ~(1u << b);
-            const uint32_t ti = tg.x + (uint32_t)b;
-            const float4* tp = tri_rows(tris, ti);
-            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            if (STATS) { ++n_tris; count_wave_step(w_tris); }
-            float u, v, t;
-            if (mt_test(ta, tb, tc, o, d, u, v, t)) {
-                if (ANY) {
-                    if (t < best_t) { best_tri = (int)ti; finished = true; tg.y = 0u; }
-                } else {
-                    accept(t, u, v, __float_as_int(ta.w), (int)ti);
-                }
-            }
-            CRT_MARK("tri_end");
-        }
-        // a lane with neither a triangle group nor inner hits left pops its stack, or is done
-        if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
-            if (sp == 0) finished = true;
-            else { --sp; cur = stk[sp * 64]; }
-        }
-        if (finished) {
-            HitState best;
-            best.t = best_t; best.tri = best_tri; best.u = 0.f; best.v = 0.f; best.id = -1;
-            if (!ANY && best_tri >= 0) {
-                const uint2 uv = *hit_uv;
-                best.u = __uint_as_float(uv.x); best.v = __uint_as_float(uv.y); best.id = (int)hit_id->x;
-            }
-            done(idx, best, best_tri >= 0);
-            busy = false;
-#if CRT_P1_NO_BUSY
-            cur.y = 0u; sp = 0;                     // what an occluded ray leaves behind
-#endif
-        }
-    }
-    CRT_MARK("loop_end");
-}
-
-// Any-hit walk of one lock-step batch with SHARED triangle steps, lean form (round 4).  The NEE shadow rays of a wave are few (39 % of the
-// lanes on primary hits) and each meets its leaves at its own time, so the plain loop runs the 80-instruction Moller-Trumbore block with
-// 9 of 64 lanes enabled — the block with the most wave-level steps of the whole first segment.  Here a lane that
-// reaches a leaf group publishes up to three (triangle, owner lane) items to a 64-entry wave-private list; ALL 64 lanes then test one
-// item each with the OWNER's ray, fetched from the owner's registers by ds_bpermute (the ray is constant for the whole walk), and an
-// owner learns from one ballot whether any of its items hit.  Unlike traverse_pool's SHARE this needs no ray / result strips in LDS —
-// an occlusion test has no (t, u, v) to hand back and no order to respect — only the item list, which lives in the lane's hit-record
-// slots (CRT_HIT_SLOTS: unused during an any-hit walk).  A lane's own sequence of node fetches and triangle tests is unchanged (its items
-// are examined in their original order and it stops at its first hit), so occlusion and the per-ray counters keep the oracle's values.
-// `base` = the wave's stack region (lane 0's column); every lane of the wave must call this together.
-template <bool STATS>
-__device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
-                                                    uint32_t* overflow, bool has_ray, vec3 o, vec3 d, float tmax, uint32_t tri_min,
-                                                    uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint2* const stk = base + lane;
-    uint32_t* const items = reinterpret_cast<uint32_t*>(base + stack_entries * 64);     // [64]: triangle index | owner lane << 24
-    const bool finite = __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z);
-    const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
-    const bool negx = dc.x < 0.0f, negy = dc.y < 0.0f, negz = dc.z < 0.0f;
-    const uint32_t oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
-    const vec3 inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
-    bool busy = has_ray && finite, occluded = false;
-    uint2 cur = busy ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
-    int sp = 0;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    CRT_MARK("loop_begin anyshare");
-    while (__ballot(busy) != 0ull) {
-        const bool has_tri = busy && tg.y != 0u;
-        const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
-        const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
-        const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
-        const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the same vote as traverse_pool
-        if (node_phase) {
-            if (can_node) {
-                CRT_MARK("node_begin");
-                const uint32_t hits_imask = cur.y;
-                const int off = 31 - __builtin_clz(hits_imask);
-                const uint32_t nbase = cur.x;
-                cur.y &= ~(1u << off);
-                if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u); }
-                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
-                const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-                const uint4* np = node_rows(nodes, nidx);
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(true); }
-                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, tmax);
-                cur.x = n1.x;
-                tg.x = n1.y;
-                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
-                tg.y = hitmask & 0x00ffffffu;
-                CRT_MARK("node_end");
-            }
-        } else {
-            CRT_MARK("share_begin");
-            const uint32_t pend = has_tri ? (uint32_t)__builtin_popcount(tg.y) : 0u;
-            const uint32_t k = pend > 3u ? 3u : pend;
-            const unsigned long long b0 = __ballot((k & 1u) != 0u), b1 = __ballot((k & 2u) != 0u);
-            const uint32_t off = (uint32_t)__builtin_popcountll(b0 & lt) + 2u * (uint32_t)__builtin_popcountll(b1 & lt);
-            const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1);
-            const uint32_t room = off < 64u ? 64u - off : 0u;
-            const uint32_t lim = k < room ? k : room;            // items of this lane tested in this step
-            uint32_t bits = tg.y;
-#pragma unroll
-            for (uint32_t j = 0; j < 3u; ++j)
-                if (j < lim) {
-                    const int b = 31 - __builtin_clz(bits);
-                    bits &= ~(1u << b);
-                    items[off + j] = (tg.x + (uint32_t)b) | (lane << 24);
-                }
-            __builtin_amdgcn_wave_barrier();
-            if (STATS) count_wave_step(w_tris);
-            const uint32_t n_items = total < 64u ? total : 64u;
-            // every lane below n_items tests one item with its owner's ray (the lanes read each other's registers: all 64 take part in the shuffles)
-            const uint32_t item = lane < n_items ? items[lane] : (lane << 24);
-            const int src = (int)(item >> 24);
-            const vec3 ro = V3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
-            const vec3 rd = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
-            const float rt = __shfl(tmax, src);
-            bool hit = false;
-            if (lane < n_items) {
-                const float4* tp = tri_rows(tris, item & 0x00ffffffu);
-                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                float u, v, t;
-                hit = mt_test(ta, tb, tc, ro, rd, u, v, t) && t < rt;
-            }
-            const unsigned long long hits = __ballot(hit);
-            if (lim != 0u) {
-                // my items sit at off .. off + lim - 1, in their original order: the first one that hit ends the walk
-                const uint32_t mine = (uint32_t)(hits >> off) & ((1u << lim) - 1u);
-                if (STATS) n_tris += mine ? (uint32_t)__builtin_ctz(mine) + 1u : lim;
-                if (mine) { occluded = true; busy = false; tg.y = 0u; }
-                else tg.y = bits;
-            }
-            __builtin_amdgcn_wave_barrier();                     // the list is rewritten by the next step
-            CRT_MARK("share_end");
-        }
-        if (busy && tg.y == 0u && !(cur.y & 0xff000000u)) {
-            if (sp == 0) busy = false;
-            else { --sp; cur = stk[sp * 64]; }
-        }
-    }
-    CRT_MARK("loop_end");
-    return occluded;
-}
-
 // ---- SEVERAL LANES PER RAY, as a wave drains (round 4) ----
 // A lock-step batch starts with one ray per lane and ends on its longest rays: on the 1 M-triangle scene 56 % of the closest-hit node
 // steps of the bounce segments run with at most 32 of the 64 lanes enabled, 37 % with at most 8 (any-hit: 68 % / 41 %;
@@ -778,18 +363,6 @@ __device__ __forceinline__ bool traverse_any_shared(const uint4* __restrict__ no
 // Same nodes in the same order, same tests on the same operands; closest hits fold a leaf's candidates by the rule's own total order
 // (nearer t, then lower id — the sequential rule's result for any order of arrival), any-hit walks stop at a leaf's first hit in the
 // original order: hits, occlusion and per-ray counters keep the oracle's values.
-#ifndef CRT_GROUP_KL
-#define CRT_GROUP_KL 3       // lanes per ray after the regroup = 1 << this: 8 (one regroup, when at most 8 rays are left: 6,021 Mray/s on four segments of the
-                             // 1 M-triangle scene against 5,464 with quads at <= 16 and 5,438 with pairs at <= 32; profiles/r04_experiments.md)
-#endif
-// Measurement variants CRT_GROUP_PREFETCH / CRT_P1_PREFETCH: bring a node's cache line(s) towards the CU without a destination register —
-// global_load_lds_dword writes the loaded word to LDS at M0 + lane * 4 (`lds_dummy`: 256 bytes of the wave's region nobody reads), so
-// there is no VGPR for the compiler to wait on and no wait is ever issued for it; loads return in order, so the counts the compiler
-// keeps for its own loads stay conservative.  Built with one more hit slot per lane (the dummy region).
-__device__ __forceinline__ void touch_node(const uint4* nodes, uint32_t idx, uint32_t lds_dummy) {
-    const uint32_t off = idx * (uint32_t)(CRT_NODE_ROWS * 16);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\tglobal_load_lds_dword %0, %1 offset:76" ::"v"(off), "s"(nodes), "s"(lds_dummy));
-}
 template <int KL> __device__ __forceinline__ uint32_t dpp_xor(uint32_t x, int step) {       // value of the lane `step` away inside the group (step = 1, 2, 4)
     if (step == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm [1, 0, 3, 2]
     if (step == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);     // quad_perm [2, 3, 0, 1]
@@ -852,7 +425,6 @@ __device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, 
                                                uint2* hit_uv, uint2* hit_it, uint32_t& n_tris) {
     constexpr uint32_t K = 1u << KL;
     const uint32_t lane = threadIdx.x & 63u;
-#if CRT_GROUP_TRI_WINDOW
     // The group takes the K bit POSITIONS from the highest pending triangle down — lane `sub` the position top - sub, if a triangle is pending
     // there — instead of the K highest pending triangles: finding "the sub-th set bit" cost ~60 instructions per step (and seven lane masks
     // the compiler kept in spilled SGPRs), the window ten.  The pending bits of a node are runs of 1 - 3 (a leaf's triangles) in the order of
@@ -882,33 +454,6 @@ __device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, 
         if (mine) { best_tri = (int)tg.x; tg.y = 0u; return true; }
         return false;
     }
-#else
-    uint32_t t_sel = tg.y, rest = tg.y;
-#pragma unroll
-    for (uint32_t q = 0; q < K; ++q) {
-        if (rest) rest &= ~(1u << (31 - __builtin_clz(rest)));
-        if (q + 1u < K && q < sub && t_sel) t_sel &= ~(1u << (31 - __builtin_clz(t_sel)));
-    }
-    const uint32_t pend = (uint32_t)__builtin_popcount(tg.y), tested = pend < K ? pend : K;
-    bool hit = false;
-    float u = 0.f, v = 0.f, t = 0.f;
-    int id = 0x7fffffff;
-    uint32_t ti = 0;
-    if (sub < tested) {
-        ti = tg.x + (uint32_t)(31 - __builtin_clz(t_sel));
-        const float4* tp = tri_rows(tris, ti);
-        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-        hit = mt_test(ta, tb, tc, o, d, u, v, t);
-        id = __float_as_int(ta.w);
-    }
-    tg.y = rest;
-    if (ANY) {
-        const uint32_t mine = (uint32_t)(__ballot(hit && t < best_t) >> (lane & ~(K - 1u))) & ((1u << K) - 1u);      // my group's hits, bit = sub
-        if (STATS && sub == 0u) n_tris += mine ? (uint32_t)__builtin_ctz(mine) + 1u : tested;
-        if (mine) { best_tri = (int)tg.x; tg.y = 0u; return true; }
-        return false;
-    }
-#endif
     if (STATS && sub == 0u) n_tris += tested;
     // candidate of this lane: (t, id, triangle), or (+inf, max) when it has none
     uint32_t ct = hit ? __float_as_uint(t) : 0x7f800000u, ci = hit ? (uint32_t)id : 0x7fffffffu, cx = ti;
@@ -931,14 +476,14 @@ __device__ __forceinline__ bool group_tri_step(const float4* __restrict__ tris, 
     return false;
 }
 
-// The group phase of walk_batch (and of the first segment's shadow walk): `busy` lanes hand their rays — at most 64 >> CRT_GROUP_KL of them —
+// The group phase of walk_batch (and of the first segment's shadow walk): `busy` lanes hand their rays — at most 64 >> GROUP_KL of them —
 // to groups of K adjacent lanes, which finish them; on return out.t / out.tri of a lane whose ray moved hold its result (closest hits: the
 // (u, v, id) record is in the lane's own column slots as always).  Every lane of the wave calls this together.
 template <bool ANY, bool STATS, bool UNIFORM_O>
 __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
                                             bool busy, vec3 o_lane, vec3 d, float best_t, int best_tri, uint2 cur, uint2 tg, int sp, uint32_t tri_min,
                                             HitState& out, uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform) {
-    constexpr uint32_t KL = CRT_GROUP_KL, K = 1u << KL;
+    constexpr uint32_t KL = GROUP_KL, K = 1u << KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const slot_uv = base + stack_entries * 64;
     uint2* const slot_it = base + (stack_entries + 1) * 64;
@@ -972,15 +517,7 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
         // ---------------- phase 2: K lanes per ray ----------------
         uint2* const stk = base + col;
         const vec3 o = UNIFORM_O ? o_uniform : o_lane;
-#ifdef CRT_GROUP_PREFETCH
-        const uint32_t touch_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(base + (stack_entries + CRT_HIT_SLOTS - 1) * 64));
-#endif
-#if CRT_GROUP_LDS_STAGE      // built with CRT_HIT_SLOTS 4: the last two rows of the wave's LDS region (1 KB) are the staging area, 128 bytes per group
-        uint2* const stage = base + (stack_entries + CRT_HIT_SLOTS - 2) * 64;
-        const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(stage));
-#endif
         CRT_MARK("loop_begin lanes2");
-#if CRT_P1_NO_BUSY
         if (!busy) { cur.y = 0u; tg.y = 0u; sp = 0; }       // lanes outside the groups: nothing pending (see walk_batch: no flag is carried through the loop)
         for (;;) {
             const bool has_tri = tg.y != 0u;
@@ -988,13 +525,6 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
             const unsigned long long m_tri = __ballot(has_tri), m_node = __ballot((cur.y & 0xff000000u) != 0u) & ~m_tri;
             if ((m_tri | m_node) == 0ull) break;
             const uint32_t n_tri = (uint32_t)__builtin_popcountll(m_tri), n_node = (uint32_t)__builtin_popcountll(m_node);
-#else
-        while (__ballot(busy) != 0ull) {
-            const bool has_tri = busy && tg.y != 0u;
-            const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
-            const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
-            const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
-#endif
             const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // both sides count lanes, i.e. rays x K
             bool finished = false;
             if (node_phase) {
@@ -1012,44 +542,13 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
                     const uint4* np = node_rows(nodes, nidx);
                     // a lane of the group fetches only the words its child's bytes sit in: 52 instead of 80 bytes per lane through the
                     // texture-address path (+0.7 .. 1.1 % on the multi-segment frames; the eight lanes of a group ask for the same node)
-#ifdef CRT_GROUP_WIDE_LOADS            // measurement variant: the five full rows
-                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-#elif CRT_GROUP_LDS_STAGE
-                    // the group's node staged through LDS: lanes sub 0..4 fetch one 16-byte row each straight into LDS (global_load_lds_dwordx4: the
-                    // row lands at M0 + lane * 16, i.e. the node of group g at stage + 128 g), then every lane reads the words it needs from there —
-                    // one vector-memory instruction and 80 bytes per group through the texture-address path instead of nine and 52 bytes per lane
-                    if (sub < 5u) {
-                        const uint32_t goff = nidx * (uint32_t)(CRT_NODE_ROWS * 16) + sub * 16u;
-                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(goff), "s"(nodes), "s"(stage_lds) : "memory");
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage) + (lane >> 3) * 32u;
-                    const uint32_t hi_w = ((sub * (uint32_t)(8 >> KL)) >= 4u) ? 1u : 0u;
-                    const uint4 n0 = *reinterpret_cast<const uint4*>(sw);
-                    const uint2 n1xy = *reinterpret_cast<const uint2*>(sw + 4);
-                    const uint32_t mw = sw[6u + hi_w], w2l = sw[8u + hi_w], w2h = sw[10u + hi_w], w3l = sw[12u + hi_w], w3h = sw[14u + hi_w], w4l = sw[16u + hi_w], w4h = sw[18u + hi_w];
-                    const uint4 n1 = make_uint4(n1xy.x, n1xy.y, mw, mw), n2 = make_uint4(w2l, w2l, w2h, w2h), n3 = make_uint4(w3l, w3l, w3h, w3h), n4 = make_uint4(w4l, w4l, w4h, w4h);
-                    asm volatile("" ::: "memory");      // the reads above are done before the next step's rows arrive
-#else
                     const uint32_t* nw = reinterpret_cast<const uint32_t*>(np) + (((sub * (uint32_t)(8 >> KL)) >= 4u) ? 1u : 0u);
                     const uint4 n0 = np[0];
                     const uint2 n1xy = *reinterpret_cast<const uint2*>(np + 1);
                     const uint32_t mw = nw[6], w2l = nw[8], w2h = nw[10], w3l = nw[12], w3h = nw[14], w4l = nw[16], w4h = nw[18];
                     const uint4 n1 = make_uint4(n1xy.x, n1xy.y, mw, mw), n2 = make_uint4(w2l, w2l, w2h, w2h), n3 = make_uint4(w3l, w3l, w3h, w3h), n4 = make_uint4(w4l, w4l, w4h, w4h);
-#endif
                     if (STATS) { if (sub == 0u) ++n_nodes; count_wave_step(w_nodes); }
                     const uint32_t hitmask = group_or<KL>(node8_intersect_part<KL>(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t, sub));
-#ifdef CRT_GROUP_PREFETCH
-                    // measurement variant: the group's eight lanes touch the inner children that were hit but are not visited next (they go to
-                    // the stack): lane `sub` owns bit 24 + sub of the mask
-                    if (KL == 3) {
-                        const uint32_t inner_hits = hitmask >> 24;
-                        if (((inner_hits >> sub) & 1u) && (inner_hits >> (sub + 1u)) != 0u) {
-                            const uint32_t pslot = sub ^ (oct4 & 7u);
-                            touch_node(nodes, n1.x + (uint32_t)__builtin_popcount((n0.w >> 24) & ((1u << pslot) - 1u)), touch_lds);
-                        }
-                    }
-#endif
                     cur.x = n1.x;
                     tg.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -1062,16 +561,8 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
                 finished = group_tri_step<KL, ANY, STATS>(tris, o, d, tg, sub, best_t, best_tri, slot_uv + col, slot_it + col, n_tris);
                 CRT_MARK("tri_end");
             }
-#if CRT_P1_NO_BUSY
             if (!finished && tg.y == 0u && !(cur.y & 0xff000000u) && sp != 0) { --sp; cur = stk[sp * 64]; }
             if (ANY && finished) { cur.y = 0u; sp = 0; }    // the group's lanes keep the ray's result in their registers
-#else
-            if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
-                if (sp == 0) finished = true;
-                else { --sp; cur = stk[sp * 64]; }
-            }
-            if (finished) busy = false;              // the group's lanes keep the ray's result in their registers
-#endif
         }
         CRT_MARK("loop_end");
         // a ray that moved fetches its result from the first lane of its group
@@ -1084,7 +575,7 @@ __device__ __forceinline__ void group_phase(const uint4* __restrict__ nodes, con
 
 // `base` = the wave's LDS region (lane 0's stack column); every lane of the wave calls this together.  On return `out` holds, in every
 // lane that had a ray, its closest hit (ANY: out.tri >= 0 means occluded).  max_kl = 0: one lane per ray throughout.
-// Two loops: phase 1 is the lock-step voting loop of traverse_pool, one ray per lane, and ends when at most 64 >> CRT_GROUP_KL rays are
+// Two loops: phase 1 is the lock-step voting loop (walk_pool's, without the refill), one ray per lane, and ends when at most 64 >> GROUP_KL rays are
 // left; those are regrouped and finished by phase 2, which knows nothing but groups.  (One loop that carried the group size as a variable
 // cost the one-lane phase 5 %: a guard on every stack write, a switch in every step.)
 template <bool ANY, bool STATS, bool UNIFORM_O, bool UNI = false>
@@ -1092,7 +583,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                                            bool has_ray, vec3 o_in, vec3 d, float tmax_in, uint32_t tri_min, uint32_t max_kl, HitState& out,
                                            uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, vec3 o_uniform = V3(0.f, 0.f, 0.f),
                                            uint32_t* n_uni = nullptr, const float4* planes = nullptr) {
-    constexpr uint32_t KL = CRT_GROUP_KL;
+    constexpr uint32_t KL = GROUP_KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const slot_uv = base + stack_entries * 64;              // [col] (u, v) of the best hit
     uint2* const slot_it = base + (stack_entries + 1) * 64;        // [col] (original id of the best hit, regroup scratch)
@@ -1112,12 +603,8 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
         // ---------------- phase 1: one ray per lane ----------------
         uint2* const stk = base + lane;
         const vec3 o = UNIFORM_O ? o_uniform : o_lane;
-#ifdef CRT_P1_PREFETCH
-        const uint32_t touch_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(base + (stack_entries + CRT_HIT_SLOTS - 1) * 64));
-#endif
         CRT_MARK("loop_begin lanes1");
         for (;;) {
-#if CRT_P1_NO_BUSY
             // No flag is carried from one iteration to the next: a lane has a ray exactly while it has a triangle group or inner hits
             // pending (what is left of a finished ray is cleared below), so the three counts come from the two registers the step tests
             // anyway.  (A loop-carried bool costs a v_cndmask + v_cmp pair at every ballot: the compiler materialises the lane mask.)
@@ -1128,16 +615,7 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
             const uint32_t n_busy = n_tri + n_node;
             if (n_busy == 0u) break;
             if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
-#else
-            const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy));
-            if (n_busy == 0u) break;
-            if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
-            const bool has_tri = busy && tg.y != 0u;
-            const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
-            const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
-            const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
-#endif
-            const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the vote of traverse_pool
+            const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;      // the vote of walk_pool
             bool finished = false;
             if (node_phase) {
                 if (can_node) {
@@ -1157,14 +635,8 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                 if (STATS && n_uni) ++*n_uni;
                         uint4 n0, n1;
                         const uint32_t oct0 = key0 & 7u;
-                        uint32_t hitmask;
-                        if (CRT_UNIFORM_PLANES) {            // the host builds the float planes for every scene (finish_scene_setup)
-                            hitmask = node8_intersect_planes(n0, n1, nodes, planes, key0 >> 3, o, inv, oct0, best_t);
-                        } else {
-                            uint4 n2, n3, n4;
-                            load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
-                            hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, best_t);
-                        }
+                        // (the host builds the float planes for every scene: finish_scene_setup)
+                        const uint32_t hitmask = node8_intersect_planes(n0, n1, nodes, planes, key0 >> 3, o, inv, oct0, best_t);
                         cur.x = n1.x;
                         tg.x = n1.y;
                         cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -1174,16 +646,6 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                     const uint4* np = node_rows(nodes, nidx);
                     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                     const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
-#ifdef CRT_P1_PREFETCH
-                    {   // measurement variant: touch the second-nearest inner child that was hit (the next one this lane pops)
-                        const uint32_t inner_hits = hitmask >> 24;
-                        if (inner_hits & (inner_hits - 1u)) {
-                            const uint32_t rest = inner_hits & ~(1u << (31 - __builtin_clz(inner_hits)));
-                            const uint32_t pslot = (uint32_t)(31 - __builtin_clz(rest)) ^ (oct4 & 7u);
-                            touch_node(nodes, n1.x + (uint32_t)__builtin_popcount((n0.w >> 24) & ((1u << pslot) - 1u)), touch_lds);
-                        }
-                    }
-#endif
                     cur.x = n1.x;
                     tg.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -1212,20 +674,11 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
                 }
                 CRT_MARK("tri_end");
             }
-#if CRT_P1_NO_BUSY
             // a lane with nothing pending pops its stack; one without a ray has an empty stack and nothing happens to it
             if (!finished && tg.y == 0u && !(cur.y & 0xff000000u) && sp != 0) { --sp; cur = stk[sp * 64]; }
             if (ANY && finished) { cur.y = 0u; sp = 0; }      // an occluded ray leaves inner hits and stack entries behind (its result stays in this lane's registers)
         }
         busy = tg.y != 0u || (cur.y & 0xff000000u);
-#else
-            if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
-                if (sp == 0) finished = true;
-                else { --sp; cur = stk[sp * 64]; }
-            }
-            if (finished) busy = false;              // its result stays in this lane's registers
-        }
-#endif
         CRT_MARK("loop_end");
     }
     out.t = best_t; out.tri = best_tri;
@@ -1240,15 +693,164 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
     __builtin_amdgcn_wave_barrier();              // the slots are free again
 }
 
+// Wave-level traversal of a POOL of rays with lane refill (persistent threads in the sense of Aila & Laine): a lane whose ray has finished
+// takes the next ray of the wave's pool instead of idling until the slowest ray of its 64-ray batch is done, and when the pool has run dry
+// the wave's last eight rays get eight lanes each (group_phase, max_kl != 0).  Per-ray work and its order are unchanged, so hits and visit
+// counters stay bit-identical to the oracle.  The pool is [pool_begin, pool_end); refill happens when at least `refill_min` lanes are idle
+// (or none is busy); refill_min = 65 makes it one lock-step batch per 64 rays of the pool.
+//   bool load(idx, o, d, tmax)  fetches ray idx of the pool (false: no ray in this slot);  done(idx, best, hit)  consumes its result.
+// The best hit's (u, v) and original id live in the lane's hit slots (rt_kernels.hpp CRT_HIT_SLOTS), as in walk_batch.  `base` = the wave's
+// LDS region (lane 0's stack column); every lane of the wave calls this together.  Per-RAY counters (k_trace's stats) need max_kl = 0: a
+// regrouped ray's visits are counted by its group's first lane.
+template <bool ANY, bool STATS, typename Load, typename Done>
+__device__ __forceinline__ void walk_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
+                                          uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min, uint32_t tri_min, uint32_t max_kl, Load load, Done done,
+                                          uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2* const stk = base + lane;
+    uint32_t next = pool_begin;                     // wave-uniform
+    uint32_t idx = 0;
+    vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
+    bool negx = false, negy = false, negz = false;
+    uint32_t oct4 = 0;
+    float best_t = 0.f;                             // closest hit so far (closest-hit walks: also the far clip of every box and triangle test)
+    int best_tri = -1;
+    uint2* const hit_uv = stk + stack_entries * 64;             // CRT_HIT_SLOTS
+    uint2* const hit_id = stk + (stack_entries + 1) * 64;
+    int sp = 0;
+    uint2 cur = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    bool regroup = false;
+    auto finish = [&](float t, int tri) {
+        HitState best;
+        best.t = t; best.tri = tri; best.u = 0.f; best.v = 0.f; best.id = -1;
+        if (!ANY && tri >= 0) {
+            const uint2 uv = *hit_uv;
+            best.u = __uint_as_float(uv.x); best.v = __uint_as_float(uv.y); best.id = (int)hit_id->x;
+        }
+        done(idx, best, tri >= 0);
+    };
+    CRT_MARK("loop_begin pool");
+    for (;;) {
+        // no flag carried through the loop (see walk_batch): a lane has a ray exactly while it has a triangle group or inner hits pending; a
+        // ray that is loaded without either (non-finite origin, empty slot) is finished by the end of the same iteration
+        bool busy = tg.y != 0u || (cur.y & 0xff000000u) != 0u;
+        if (next < pool_end) {
+            const unsigned long long idle = __ballot(!busy);
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+            if (n_idle >= refill_min || n_idle == 64u) {
+                const uint32_t mine = next + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+                if (!busy && mine < pool_end) {
+                    idx = mine;
+                    float tmax_in;
+                    const bool has_ray = load(idx, o, d, tmax_in);
+                    best_t = tmax_in; best_tri = -1;
+                    sp = 0;
+                    busy = true;
+                    // same prologue as traverse(): non-finite origin -> immediate miss; clamp zero direction components
+                    const bool finite = __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z);
+                    const vec3 dc = V3(clamp_dir(d.x), clamp_dir(d.y), clamp_dir(d.z));
+                    negx = dc.x < 0.0f; negy = dc.y < 0.0f; negz = dc.z < 0.0f;
+                    oct4 = (negx ? 0u : 0x04040404u) | (negy ? 0u : 0x02020202u) | (negz ? 0u : 0x01010101u);
+                    inv = V3(rcp_ieee(dc.x), rcp_ieee(dc.y), rcp_ieee(dc.z));
+                    cur = (finite && has_ray) ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
+                    tg = make_uint2(0u, 0u);
+                }
+                next = next + n_idle < pool_end ? next + n_idle : pool_end;
+            }
+        }
+        const unsigned long long m_busy = __ballot(busy);
+        if (m_busy == 0ull) break;                  // pool drained and every lane finished
+        // the pool has run dry and at most eight rays are left: they get eight lanes each (a just-loaded ray with nothing pending is
+        // finished by this iteration first: the group phase wants rays that have something pending)
+        if (max_kl != 0u && next >= pool_end && (uint32_t)__builtin_popcountll(m_busy) <= (64u >> GROUP_KL) &&
+            __ballot(busy && tg.y == 0u && !(cur.y & 0xff000000u)) == 0ull) { regroup = true; break; }
+
+        // ---- one step per iteration: either a node step (lanes with inner hits pending and no triangle group pending) or a triangle step
+        // (lanes with a triangle group pending).  The wave votes: triangle tests are postponed while node-ready lanes outnumber waiting
+        // lanes tri_min : 1, so that the Moller-Trumbore block and the node block each run with more lanes enabled.  A lane's own sequence
+        // of node fetches and triangle tests is unchanged (it cannot fetch a node while its triangle group is pending).
+        // (A wave-level dedup of the node loads — one leader lane per distinct node, followers fed by ds_bpermute — was measured and
+        // dropped: 0.469 vs 0.394 ms on coherent primary rays, 0.509 vs 0.434 ms on bounce rays: the bound is VALU issue.)
+        const bool has_tri = busy && tg.y != 0u;
+        const bool can_node = busy && !has_tri && (cur.y & 0xff000000u);
+        const uint32_t n_tri = (uint32_t)__builtin_popcountll(__ballot(has_tri));
+        const uint32_t n_node = (uint32_t)__builtin_popcountll(__ballot(can_node));
+        const bool node_phase = n_node != 0u && n_node >= tri_min * n_tri;
+        bool finished = false;
+        if (node_phase) {
+            if (can_node) {
+                CRT_MARK("node_begin");
+                const uint32_t hits_imask = cur.y;
+                const int off = 31 - __builtin_clz(hits_imask);
+                const uint32_t nbase = cur.x;
+                cur.y &= ~(1u << off);
+                // crt_scene_create sizes the stack from the validated depth of the tree, so a push always fits; if a caller-supplied tree
+                // ever got past the validator the dropped push is counted, not silent
+                if (cur.y & 0xff000000u) { if (sp < stack_entries) { stk[sp * 64] = cur; ++sp; } else atomicAdd(overflow, 1u); }
+                const uint32_t slot = (uint32_t)(off - 24) ^ (oct4 & 0xffu);
+                const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+                const uint4* np = node_rows(nodes, nidx);
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
+                const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
+                cur.x = n1.x;
+                tg.x = n1.y;
+                cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
+                tg.y = hitmask & 0x00ffffffu;
+                CRT_MARK("node_end");
+            }
+        } else if (has_tri) {
+            CRT_MARK("tri_begin");
+            const int b = 31 - __builtin_clz(tg.y);
+            tg.y &= ~(1u << b);
+            const uint32_t ti = tg.x + (uint32_t)b;
+            const float4* tp = tri_rows(tris, ti);
+            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            if (STATS) { ++n_tris; count_wave_step(w_tris); }
+            float u, v, t;
+            if (mt_test(ta, tb, tc, o, d, u, v, t)) {
+                if (ANY) {
+                    if (t < best_t) { best_tri = (int)ti; finished = true; tg.y = 0u; }
+                } else {
+                    // nearer wins; equal t -> lower original id; the stored id is fetched only when t ties
+                    const int id = __float_as_int(ta.w);
+                    bool take = t < best_t;
+                    if (t == best_t && best_tri >= 0) take = id < (int)hit_id->x;
+                    if (take) { best_t = t; best_tri = (int)ti; *hit_uv = make_uint2(__float_as_uint(u), __float_as_uint(v)); hit_id->x = (uint32_t)id; }
+                }
+            }
+            CRT_MARK("tri_end");
+        }
+        // a lane with neither a triangle group nor inner hits left pops its stack, or is done
+        if (busy && !finished && tg.y == 0u && !(cur.y & 0xff000000u)) {
+            if (sp == 0) finished = true;
+            else { --sp; cur = stk[sp * 64]; }
+        }
+        if (finished) {
+            finish(best_t, best_tri);
+            cur.y = 0u; sp = 0;                     // what an occluded ray leaves behind
+        }
+    }
+    CRT_MARK("loop_end");
+    if (regroup) {
+        const bool moved = tg.y != 0u || (cur.y & 0xff000000u) != 0u;
+        HitState out;
+        out.t = best_t; out.tri = best_tri;
+        group_phase<ANY, STATS, false>(nodes, tris, base, stack_entries, overflow, moved, o, d, best_t, best_tri, cur, tg, sp, tri_min, out, n_nodes, n_tris, w_nodes, w_tris,
+                                       V3(0.f, 0.f, 0.f));
+        if (moved) finish(out.t, out.tri);
+    }
+}
+
 // Any-hit walk of one batch: the plain per-lane loop of traverse<true> (each lane tests its leaf's triangles right after the node that found
-// them — the fastest form for the coherent shadow rays of primary hits) until at most 64 >> CRT_GROUP_KL rays are left, then the group phase.
+// them — the fastest form for the coherent shadow rays of primary hits) until at most 64 >> GROUP_KL rays are left, then the group phase.
 // Every lane of the wave calls this together; returns whether this lane's ray is occluded.
 template <bool STATS, bool UNI = false>
 __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries,
                                                          uint32_t* overflow, bool has_ray, vec3 o, vec3 d, float tmax, uint32_t tri_min, uint32_t max_kl,
                                                          uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris, uint32_t* n_uni = nullptr,
                                                          const float4* planes = nullptr) {
-    constexpr uint32_t KL = CRT_GROUP_KL;
+    constexpr uint32_t KL = GROUP_KL;
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const stk = base + lane;
     bool busy = has_ray && __builtin_isfinite(o.x) && __builtin_isfinite(o.y) && __builtin_isfinite(o.z);
@@ -1261,19 +863,14 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
     bool regroup = false;
     CRT_MARK("loop_begin plain");
     for (;;) {
-#if CRT_P1_NO_BUSY
         // no flag carried through the loop (see walk_batch): a lane has a ray exactly while inner hits are pending — a leaf's triangles are
         // tested in the iteration that found them, and what an occluded ray leaves behind is cleared
         const bool busy_now = (cur.y & 0xff000000u) != 0u;
         const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy_now));
-#else
-        const bool busy_now = busy;
-        const uint32_t n_busy = (uint32_t)__builtin_popcountll(__ballot(busy));
-#endif
         if (n_busy == 0u) break;
         if (max_kl != 0u && n_busy <= (64u >> KL)) { regroup = true; break; }
         if (busy_now) {
-            if (CRT_P1_NO_BUSY || (cur.y & 0xff000000u)) {
+            {
                 CRT_MARK("node_begin");
                 const uint32_t hits_imask = cur.y;
                 const int off = 31 - __builtin_clz(hits_imask);
@@ -1289,14 +886,7 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 if (STATS && n_uni) ++*n_uni;
                     uint4 n0, n1;
                     const uint32_t oct0 = key0 & 7u;
-                    uint32_t hitmask;
-                    if (CRT_UNIFORM_PLANES) {            // the host builds the float planes for every scene (finish_scene_setup)
-                        hitmask = node8_intersect_planes(n0, n1, nodes, planes, key0 >> 3, o, inv, oct0, tmax);
-                    } else {
-                        uint4 n2, n3, n4;
-                        load_node_scalar(nodes, key0 >> 3, n0, n1, n2, n3, n4);
-                        hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, (oct0 & 4u) == 0u, (oct0 & 2u) == 0u, (oct0 & 1u) == 0u, oct0 * 0x01010101u, tmax);
-                    }
+                    const uint32_t hitmask = node8_intersect_planes(n0, n1, nodes, planes, key0 >> 3, o, inv, oct0, tmax);
                     cur.x = n1.x;
                     tg.x = n1.y;
                     cur.y = (hitmask & 0xff000000u) | (n0.w >> 24);
@@ -1312,9 +902,6 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 tg.y = hitmask & 0x00ffffffu;
                 }
                 CRT_MARK("node_end");
-            } else {
-                tg = cur;
-                cur = make_uint2(0u, 0u);
             }
             while (tg.y) {
                 CRT_MARK("tri_begin");
@@ -1325,26 +912,13 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 if (STATS) { ++n_tris; count_wave_step(w_tris); }
                 float u, v, t;
-#if CRT_P1_NO_BUSY
                 if (mt_test(ta, tb, tc, o, d, u, v, t) && t < tmax) { hit_tri = (int)ti; tg.y = 0u; cur.y = 0u; sp = 0; }
-#else
-                if (mt_test(ta, tb, tc, o, d, u, v, t) && t < tmax) { hit_tri = (int)ti; busy = false; tg.y = 0u; }
-#endif
                 CRT_MARK("tri_end");
             }
-#if CRT_P1_NO_BUSY
             if (!(cur.y & 0xff000000u) && sp != 0) { --sp; cur = stk[sp * 64]; }
-#else
-            if (busy && !(cur.y & 0xff000000u)) {
-                if (sp == 0) busy = false;
-                else { --sp; cur = stk[sp * 64]; }
-            }
-#endif
         }
     }
-#if CRT_P1_NO_BUSY
     busy = (cur.y & 0xff000000u) != 0u;
-#endif
     CRT_MARK("loop_end");
     HitState out;
     out.t = tmax; out.tri = hit_tri;
@@ -1517,7 +1091,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
                     a.stats[i] = ((dt > 65535u ? 65535u : dt) << 16) | (dn > 65535u ? 65535u : dn);
                 }
             };
-        traverse_pool<ANY, STATS>(a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, load, done, nn, nt, wn_unused, wt_unused);
+        walk_pool<ANY, STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, 0u, load, done, nn, nt, wn_unused, wt_unused);
         nn_total += nn; nt_total += nt;
     }
     (void)nn_total; (void)nt_total; (void)lane;
@@ -1653,11 +1227,6 @@ __device__ __forceinline__ uint32_t ray_bin_key(const RayBins& b, float4 o, floa
     const float cy = __builtin_fminf(__builtin_fmaxf((o.y - b.origin[1]) * b.scale[1], 0.0f), 7.0f);
     const float cz = __builtin_fminf(__builtin_fmaxf((o.z - b.origin[2]) * b.scale[2], 0.0f), 7.0f);
     const uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-#if defined(CRT_BIN_KEY_MODE) && CRT_BIN_KEY_MODE == 1      // measurement variants: the octant alone / octant + 2^3 cells
-    return oct << 9;
-#elif defined(CRT_BIN_KEY_MODE) && CRT_BIN_KEY_MODE == 2
-    return (oct << 9) | (((uint32_t)cz >> 2) << 6) | (((uint32_t)cy >> 2) << 3) | ((uint32_t)cx >> 2);
-#endif
     return (oct << 9) | ((uint32_t)cz << 6) | ((uint32_t)cy << 3) | (uint32_t)cx;      // octant-major: neighbouring bins share the octant
 }
 // Queue entry for this lane's ray (meaningless where !want).  The lanes of a wave that share a key are found with one ballot per
@@ -1901,70 +1470,37 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 #define CRT_SEG_OCC_BATCH 5
 #endif
 
-// The lean shared shadow walk (traverse_any_shared, option tri_share + 4 / 8 / 16) is compiled only with -DCRT_EXPERIMENTS: in the first
-// segment it lost (primary hits' shadow rays are coherent: 13,567 against 13,927 Mray/s on the 1 M-triangle frame), in the bounce segments
-// it was worth +1.6 % until walk_batch took over their shadow walks (profiles/r04_experiments.md).
-#ifdef CRT_EXPERIMENTS
-#define CRT_ANYSHARE_IN(first) true
-#else
-#define CRT_ANYSHARE_IN(first) false
-#endif
-// walk_batch (the last rays of a draining wave get eight lanes each) walks the closest hits of every segment and the in-place shadow
+// One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit -> shading (path_trace.fs:872-1018) ->
+// emission of the next path ray with wave-ballot compaction -> the NEE shadow ray.  Nothing but the output queues (and, for paths that go
+// on, 40 B of path state) touches HBM; a path that ends here adds its radiance to the sum buffer directly (or leaves it in l_final).
+// TEX compiles the textured-albedo branch in (its double-precision pow costs registers the untextured path should not pay for); MAT the
+// mirror / Disney branches.  Every hot build fits 80 VGPRs = 6 waves per SIMD (CRT_SEG_OCC*).
+// Walks: walk_batch (the last rays of a draining wave get eight lanes each) walks the closest hits of every segment and the in-place shadow
 // rays of the bounce segments.  The first segment's shadow rays are coherent and the voting loop costs them more than it gives (1 M
 // triangles, 1080p: closest only 14,131 Mray/s, both 13,730, shadow only 13,618, neither 13,965 — profiles/r04_experiments.md): they keep
-// the plain per-lane loop and only hand the wave's last eight rays to the group phase (traverse_any_then_groups, CRT_FIRST_ANY_GROUPS:
-// 14,156 -> 14,282 at 1080p, 15,378 -> 15,512 at 4K, 8 M triangles 9,180 -> 9,355).
-#ifndef CRT_LANES_CLOSEST_IN
-#define CRT_LANES_CLOSEST_IN(first) true
-#endif
-#ifndef CRT_FIRST_ANY_VOTING     // measurement variant (with CRT_FIRST_ANY_GROUPS=0): the first segment's shadow rays through walk_batch's voting loop
-#define CRT_FIRST_ANY_VOTING 0
-#endif
-#ifndef CRT_LANES_ANY_IN
-#define CRT_LANES_ANY_IN(first) (!(first) || CRT_FIRST_ANY_VOTING)
-#endif
-#ifndef CRT_FIRST_ANY_GROUPS
-#define CRT_FIRST_ANY_GROUPS 1
-#endif
-
-// One path segment per lane, fused: [ray generation (FIRST) | queue fetch] -> CWBVH closest hit ->
-// shading (path_trace.fs:872-1018) -> emission of the NEE shadow ray and of the next path ray with
-// wave-ballot compaction.  Nothing but the two output queues (and, for paths that go on, 40 B of path
-// state) touches HBM; a path that ends here adds its radiance to the sum buffer directly.
-// TEX compiles the textured-albedo branch in (its double-precision pow costs registers the untextured path
-// should not pay for).  96-VGPR budget = 5 waves per SIMD for the bounce segments; the first segment runs at 80 VGPRs = 6 waves
-// (CRT_SEG_OCC_FIRST above: since the launch is scheduled by tile cost and every SIMD issues all the time, the sixth wave pays
-// for its scratch traffic; under round 1's schedule 80 was no faster, 0.225 vs 0.226 ms) and 64 is slower everywhere.
-// PRETRACED: the closest hit of each queue entry was found by k_closest_queue (incoherent bounce rays are
-// traced with lane refill, which cannot be fused with lock-step shading); the kernel then only shades.
-// INPLACE: the NEE shadow ray is walked right here (path_trace.fs:968, where the shader has it) instead of going
-// through the shadow queue and k_shadow.  The walk runs with only the lanes that have a shadow ray (39 % on average),
-// yet it is the faster arrangement at every scene size measured: the rays start where the closest-hit walk of the same
-// lanes just ended, so their first nodes and triangles are still in L1, and 48 B per ray of queue traffic, a launch
-// and a second kernel's tail disappear (1 M triangles: 0.214 + 0.158 ms as two kernels, 0.292 ms fused; Cornell
-// 0.104 -> 0.087 ms).  The queue + k_shadow path remains selectable (option "inplace_shadow" 0).  Hoisting the walk
-// out of the shading branches so that it could use the voting loop was measured too: 0.310 / 0.304 / 0.302 ms at
-// ratios 1 / 2 / 3 against 0.297 ms for the plain loop in that arrangement and 0.293 ms as written here.
-// a.tri_min == 0 (trees of a few nodes, e.g. the 32-triangle Cornell box: 0.0755 vs 0.0816 ms) selects the plain
-// per-lane closest-hit loop instead of the voting loop.
-// BVH2 (INPLACE's structure): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks
-// (path_trace.fs:511-819, traverse_bvh2) on the FlatNode array — the live path of the reference as a frame renderer.
-// COMPACT (with INPLACE, workgroups of 2 or 4 waves): the NEE shadow rays of the workgroup's waves — 39 % of the lanes on
-// average, so a wave walking only its own runs the ~200-instruction node step with most lanes masked off — are first
-// gathered through LDS (ballot + prefix over the waves) into full waves: wave w of the workgroup walks rays [64 w, 64 w + 64)
-// of the compacted list and finishes those paths itself (L + C into the sum buffer or the path state), a wave left without
-// rays retires at once.  Each ray is walked exactly as before, by another lane: sums and counters stay bit-identical.
-// SHARE: the closest-hit walk hands pending triangles to all lanes of the wave (traverse_pool<..., SHARE>); a.tri_share
-// == 2 also walks the in-place shadow rays that way.
-// BATCH (FIRST + INPLACE, a one-segment path): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.
-template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool COMPACT = false, bool SHARE = false,
-          bool BATCH = false, bool WIDE = false, bool ONE = false>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT_OCC6)) ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
-    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]; COMPACT: the ray records alias them between the walks
+// the plain per-lane loop and only hand the wave's last eight rays to the group phase (traverse_any_then_groups).  a.tri_min == 0 (trees of
+// a few nodes, e.g. the 32-triangle Cornell box: 0.0755 vs 0.0816 ms) or a.lanes_log2 == 0 selects the plain per-lane loops.
+// PRETRACED (option bounce_refill): the closest hit of each queue entry was found by k_closest_queue (lane refill over pools of rays, which
+// cannot be fused with lock-step shading); the kernel then only shades.
+// INPLACE: the NEE shadow ray is walked right here (path_trace.fs:968, where the shader has it) — after the bounce ray has been sampled and
+// queued, so that nothing but L, C and the path's index sits in registers through the walk.  The rays start where the closest-hit walk of
+// the same lanes just ended, so their first nodes and triangles are still in L1, and no queue traffic, launch or second kernel's tail is paid
+// (first segment, 1 M triangles: 0.214 + 0.158 ms as two kernels, 0.292 ms fused).
+// !INPLACE (DEFERRED shadow rays, round 5): the ray goes to the frame's NEE queue with the index of a CONTRIBUTION SLOT (segment, path) that
+// holds C, and k_shadow_deferred walks the shadow rays of all such segments in one full-occupancy launch after the last segment, clearing
+// the slots of occluded rays.  The segment no longer carries L: what it adds to the path's radiance — C, or the emitter's T * e (:894-928) —
+// sits in its slot, the path state keeps the mask of slots written, and k_fold_paths adds a path's slots in segment order afterwards: the
+// additions the in-place form does, in the same order on the same operands.
+// BVH2 (in place only): the closest-hit and the shadow walk are the shipped shader's own BVH2 walks (path_trace.fs:511-819, traverse_bvh2)
+// on the FlatNode array — the live path of the reference as a frame renderer.
+// BATCH (FIRST + INPLACE): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.  WIDE / ONE: see below.
+template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool BATCH = false, bool WIDE = false, bool ONE = false>
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
+    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     // Uniform node steps are compiled into every first-segment kernel.  (In the single-sample kernel they lost while the uniform step still
     // converted bytes and the loops carried their flags — 8 x 8-pixel waves agree less than the 4 x 4-pixel waves of a batched launch, and the
     // node's SGPRs pushed loop state out of the scalar register file; with the float planes and the lean loops they win there too.)
-    constexpr bool UNI_K = FIRST && (BATCH || STATS || CRT_UNIFORM_SINGLE);
+    constexpr bool UNI_K = FIRST;
     // uniform: the workgroup's waves are the samples of one 64-pixel batch.  The 6-waves-per-SIMD build is never launched in that form
     // (launch_segment), and compiling the form out of it frees the registers its LDS result strip and wave index would hold
     const bool wave_samples = BATCH && !WIDE && !ONE && a.wave_samples == 1u;
@@ -1976,17 +1512,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
     const bool lane_samples = BATCH && (ONE || a.wave_samples == 2u);
     const WaveId wid = wave_id(wave_samples, lane_samples);
     const uint32_t lane = wid.lane, wave = wid.wave;
-    // per-wave LDS region in uint2 units; COMPACT needs 64 B per lane for the records
-    const uint32_t wave_stride = ((COMPACT && a.stack_entries < 8u ? 8u : a.stack_entries) + CRT_HIT_SLOTS) * 64u;
+    const uint32_t wave_stride = (a.stack_entries + CRT_HIT_SLOTS) * 64u;     // per-wave LDS region in uint2 units
     uint2* stk = s_lds + (size_t)wid.lds_wave * wave_stride + lane;
     int* stk2 = reinterpret_cast<int*>(s_lds) + (size_t)wid.lds_wave * a.stack_entries2 * 64u + lane;   // BVH2 mode
-    TriShare share{nullptr, nullptr, nullptr};
-    if (SHARE) {                                         // wave-private strip behind the stacks (and COMPACT's wave counters)
-        char* base = reinterpret_cast<char*>(s_lds + (size_t)(blockDim.x >> 6) * wave_stride) + 16 + (size_t)wid.lds_wave * CRT_SHARE_BYTES;
-        share.ray = reinterpret_cast<float4*>(base);
-        share.res = reinterpret_cast<float4*>(base + 2 * 64 * 16);
-        share.items = reinterpret_cast<uint32_t*>(base + 3 * 64 * 16);
-    }
     const float4* const recs = BVH2 ? a.tris2 : a.tris;   // intersection records the hit index refers to
     const FrameArgs& f = a.f;
     uint32_t nn = 0, nt = 0, nn_any = 0, nt_any = 0;
@@ -2013,7 +1541,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
         const uint32_t g = v >> 28;                         // owner group of this chunk: its sub-queues get the output
         uint32_t* const count_shadow = a.count_shadow + g * CRT_COUNTER_STRIDE;
         uint32_t* const count_next = a.count_next + g * CRT_COUNTER_STRIDE;
-        float4* const shadow_q = a.shadow + 3 * (size_t)g * a.sub_capacity;
+        float4* const shadow_q = a.shadow + 2 * (size_t)g * a.sub_capacity;      // !INPLACE: this segment's region of the NEE queue
         float4* const next_q = a.rays_next + 2 * (size_t)g * a.sub_capacity;
         uint32_t e, n;
         uint32_t cost_tile = 0;
@@ -2069,6 +1597,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
         vec3 L = V3(0.f, 0.f, 0.f), T = V3(1.f, 1.f, 1.f);
         float prev_pdf = 1.0f, sx = 0.f, sy = 0.f;
         bool is_specular = true, true_area = false;
+        uint32_t slot_mask = 0u;                            // !INPLACE: contribution slots this path has written (bits 8..)
         if (FIRST) {                                        // path_trace.fs:1026-1047
             uint32_t px = 0, py = 0;
             pix = BATCH ? smp * f.n_local_pixels + e : e;     // the path's id: its pixel, or (sample, pixel) when a launch renders several samples
@@ -2118,21 +1647,14 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
         } else if (BVH2) {
             if (active) traverse_bvh2<false, STATS>(a.nodes2, a.tris2, o, d, CRT_INF, a.tie, stk2, (int)a.stack_entries2, a.overflow, hit, nn, nt);
         } else if (!ONE && a.tri_min == 0u) {      // (a one-pass build is launched with the voting loop and the group phase on: launch_segment)
-            if (active) traverse<false, STATS, UNI_K && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt, &nu);
+            if (active) traverse<false, STATS, UNI_K>(a.nodes, a.tris, o, d, CRT_INF, stk, (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt, &nu);
         } else {
             // lock-step batch (one ray per lane, no refill) through the voting traversal loop: lanes that have no
             // ray say so and finish immediately with no visits (1 M triangles: 0.397 -> 0.310 ms)
             // (primary rays all start at the camera: the origin of the first segment's walk stays in scalar registers, UNIFORM_O)
-            if (!SHARE && CRT_LANES_CLOSEST_IN(FIRST)) {
-                // the last rays of the batch get eight lanes each (a.lanes_log2 = 0: never — then this is traverse_pool's lock-step loop)
-                walk_batch<false, STATS, FIRST, UNI_K && !!CRT_UNIFORM_CLOSEST>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
-                                                nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]), &nu, a.planes);
-            } else
-            traverse_pool<false, STATS, SHARE, FIRST>(
-                a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
-                [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = o; rd = d; tmax = CRT_INF; return active; },
-                [&](uint32_t, const HitState& best, bool) { hit = best; },
-                nn, nt, wn, wt, share, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]));
+            // the last rays of the batch get eight lanes each (a.lanes_log2 = 0: never — then this is the lock-step voting loop alone)
+            walk_batch<false, STATS, FIRST, UNI_K>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, active, o, d, CRT_INF, a.tri_min, a.lanes_log2, hit,
+                                                   nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]), &nu, a.planes);
         }
 
         if (!FIRST && active) {
@@ -2145,14 +1667,22 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                 rv = a.rv_s[0];
                 for (uint32_t k = 1; k < 8u; ++k) rv = smp_of == k ? a.rv_s[k] : rv;
             }
-            const float4 Lp = a.pb.L[pix], Tp = a.pb.T[pix];
+            const float4 Tp = a.pb.T[pix];
             const float2 sd = a.pb.seed[pix];
-            L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w;
+            if (INPLACE) { const float4 Lp = a.pb.L[pix]; L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w; }
+            else prev_pdf = a.pb.L[pix].w;                 // a deferred segment adds nothing to L itself: the radiance so far is fetched when the path ends
             T = V3(Tp.x, Tp.y, Tp.z);
             is_specular = (__float_as_uint(Tp.w) & 1u) != 0u;
             true_area = (__float_as_uint(Tp.w) & 2u) != 0u;
+            slot_mask = __float_as_uint(Tp.w) & 0xffffff00u;
             sx = sd.x; sy = sd.y;
         }
+        // !INPLACE: what this segment adds to the path's radiance goes to its contribution slot instead of into L (k_fold_paths adds the slots in
+        // segment order afterwards); slot_mask = the slots written so far, bit 8 + segment, kept in the path state's flag word
+        auto contribute = [&](vec3 c) {
+            if (INPLACE) L = L + c;
+            else { a.contrib[pix] = make_float4(c.x, c.y, c.z, 1.0f); slot_mask |= a.slot_bit; }
+        };
         bool emit_shadow = false, emit_next = false, finished = active, pending = false;
         float pend_pdf = 0.f;
         float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0, nx0 = sh0, nx1 = sh0;
@@ -2181,7 +1711,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
             if (cos_incident > 0) n = -n;
             if (m_emission.w != -1.0f) {                                          // path_trace.fs:894-928
                 const vec3 em = V3(m_emission.x, m_emission.y, m_emission.z);
-                if (is_specular) L = L + T * em;
+                if (is_specular) contribute(T * em);
                 else {
                     vec3 ld = d * t;
                     const float len = length(ld);
@@ -2194,7 +1724,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                     if (MAT && true_area) pdf_light = 2.0f * pdf_light;           // the previous vertex was a Disney one (below)
                     const float tt = prev_pdf * prev_pdf;                         // power_heuristic :214-218
                     const float w = __fdiv_rn(tt, pdf_light * pdf_light + tt);
-                    L = L + (T * em) * w;
+                    contribute((T * em) * w);
                 }
             } else {
                 const vec3 hit_point = (o + d * t) + n * 0.0002f;                 // path_trace.fs:930
@@ -2222,8 +1752,8 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                     T = T * albedo;
                     if (!a.last_segment) {
                         const vec3 rdir = d - ns * (2.0f * dn);
-                        a.pb.L[pix] = make_float4(L.x, L.y, L.z, prev_pdf);
-                        a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(1u));
+                        if (INPLACE || FIRST) a.pb.L[pix] = make_float4(L.x, L.y, L.z, prev_pdf);      // (a deferred bounce segment leaves (L, pdf) as they are)
+                        a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(1u | slot_mask));
                         a.pb.seed[pix] = make_float2(sx, sy);
                         emit_next = true;
                         finished = false;
@@ -2253,7 +1783,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                             ldir = ldir * ilen;
                             const float cos_mtl = dot(ldir, original_n);
                             const float cos_light = dot(ldir, V3(Lt[9], Lt[10], Lt[11]));
-                            bool lit = cos_mtl > 0.0f && cos_light < 0.0f;            // :968 (the occlusion test follows: in place, or in k_shadow with inplace_shadow = 0)
+                            bool lit = cos_mtl > 0.0f && cos_light < 0.0f;            // :968 (the occlusion test follows: in place, or deferred to k_shadow_deferred)
                             if (disney) lit = lit && dot(ns, ldir) > 0.0f;            // the lobe is zero below the shading horizon: no ray
                             if (lit) {
                                 const vec3 le = V3(Lt[12], Lt[13], Lt[14]);
@@ -2274,19 +1804,20 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                                 }
                                 c = V3(__fdiv_rn(c.x, pdf_light), __fdiv_rn(c.y, pdf_light), __fdiv_rn(c.z, pdf_light));
                                 if (INPLACE) {
-                                    // the occlusion test of path_trace.fs:968 is walked in this kernel (what k_shadow does with a queue entry) —
-                                    // below, after the bounce ray has been sampled and queued: nothing but L, C and the path's index
-                                    // then sits in registers through the walk's loop (the shader walks it right here; the order of two
-                                    // independent computations is all that changes)
+                                    // the occlusion test of path_trace.fs:968 is walked in this kernel — below, after the bounce ray has
+                                    // been sampled and queued: nothing but L, C and the path's index then sits in registers through the
+                                    // walk's loop (the shader walks it right here; the order of two independent computations is all that changes)
                                     const unsigned long long m = __ballot(true);
                                     if ((int)lane == __builtin_ctzll(m)) atomicAdd(count_shadow, (uint32_t)__builtin_popcountll(m));   // ray count only
                                     pending = true;
+                                    sh2 = make_float4(c.x, c.y, c.z, 0.f);
                                 } else {
+                                    // deferred: C waits in this segment's slot of the path, the ray goes to the NEE queue (below)
                                     emit_shadow = true;
+                                    contribute(c);
                                 }
                                 sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
-                                sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(pix));
-                                sh2 = make_float4(c.x, c.y, c.z, 0.f);
+                                sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(INPLACE ? pix : a.slot_first + pix));
                             }
                         }
                     }
@@ -2317,19 +1848,15 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                         }
                         if (go_on) {
                             if (INPLACE && pending) pend_pdf = bsdf_pdf;              // whoever walks the shadow ray writes L (+ C) and this pdf
-                            else a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
-                            a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(disney ? 2u : 0u));   // bit 0 is_specular, bit 1 true_area
+                            else if (INPLACE || FIRST) a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
+                            else reinterpret_cast<float*>(a.pb.L + pix)[3] = bsdf_pdf;      // deferred bounce segment: the radiance so far stays where it is
+                            a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float((disney ? 2u : 0u) | slot_mask));   // bit 0 is_specular, bit 1 true_area, bits 8.. slots written
                             a.pb.seed[pix] = make_float2(sx, sy);
                             emit_next = true;
                             finished = false;
                             nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
                             nx1 = make_float4(sdir.x, sdir.y, sdir.z, __uint_as_float(pix));
                         }
-                    }
-                    if (emit_shadow && !emit_next) {
-                        // the path ends with this segment and its shadow ray is still in the queue: k_shadow finishes it
-                        finished = false;
-                        sh1.w = __uint_as_float(pix | 0x80000000u);
                     }
                 }
             }
@@ -2345,48 +1872,47 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
             const uint32_t ni = wave_append(emit_next, count_next);
             if (emit_next) { next_q[2 * (size_t)ni] = nx0; next_q[2 * (size_t)ni + 1] = nx1; }
         }
-        if (INPLACE && !COMPACT) {
+        if (INPLACE) {
             // ---- the NEE shadow rays of this wave, walked now that the next segment's ray is out of the registers ----
-            if (CRT_FIRST_ANY_GROUPS && FIRST && !BVH2 && (ONE || (a.lanes_log2 != 0u && a.tri_min != 0u))) {
+            const bool lanes_walks = !BVH2 && (ONE || (a.lanes_log2 != 0u && a.tri_min != 0u));
+            if (FIRST && lanes_walks) {
                 // the first segment's shadow rays: the plain loop, then groups for the last rays of the wave
-                const bool occluded = traverse_any_then_groups<STATS, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
+                const bool occluded = traverse_any_then_groups<STATS, UNI_K>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
                                                                       V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, a.lanes_log2, nn_any, nt_any, wn_any, wt_any, &nu_any, a.planes);
                 if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
-            } else if (CRT_LANES_ANY_IN(FIRST) && !BVH2 && (ONE || (a.lanes_log2 != 0u && a.tri_min != 0u))) {
+            } else if (lanes_walks) {
                 // lanes per ray grow as the wave's shadow rays drain (walk_batch)
                 HitState shh;
-                walk_batch<true, STATS, false, UNI_K && !!CRT_UNIFORM_ANY>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
+                walk_batch<true, STATS, false, UNI_K>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z), V3(sh1.x, sh1.y, sh1.z),
                                                sh0.w, a.tri_min, a.lanes_log2, shh, nn_any, nt_any, wn_any, wt_any, V3(0.f, 0.f, 0.f), &nu_any, a.planes);
                 if (pending && shh.tri < 0) L = L + V3(sh2.x, sh2.y, sh2.z);
-            } else if (CRT_ANYSHARE_IN(FIRST) && !BVH2 && (a.tri_share & 4u) && a.tri_min != 0u) {
-                // shared triangle steps, lean form (traverse_any_shared): every lane of the wave takes part
-                const bool occluded = traverse_any_shared<STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, pending, V3(sh0.x, sh0.y, sh0.z),
-                                                                 V3(sh1.x, sh1.y, sh1.z), sh0.w, a.tri_min, nn_any, nt_any, wn_any, wt_any);
-                if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
-            } else if (!BVH2 && SHARE && (a.tri_share & 3u) == 2u) {
-                // one lock-step batch of the voting, triangle-sharing loop: every lane of the wave tests triangles, lanes without a shadow ray only that
-                bool occluded = false;
-                traverse_pool<true, STATS, true>(
-                    a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, 0u, 64u, 65u, a.tri_min,
-                    [&](uint32_t, vec3& ro, vec3& rd, float& tmax) { ro = V3(sh0.x, sh0.y, sh0.z); rd = V3(sh1.x, sh1.y, sh1.z); tmax = sh0.w; return pending; },
-                    [&](uint32_t, const HitState&, bool h) { occluded = h; },
-                    nn_any, nt_any, wn_any, wt_any, share);
-                if (pending && !occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
             } else if (pending) {
                 HitState sh;
                 const vec3 so = V3(sh0.x, sh0.y, sh0.z), sd = V3(sh1.x, sh1.y, sh1.z);
                 const bool occluded = BVH2
                     ? traverse_bvh2<true, STATS>(a.nodes2, a.tris2, so, sd, sh0.w, a.tie, stk2, (int)a.stack_entries2, a.overflow, sh, nn_any, nt_any)
-                    : traverse<true, STATS, UNI_K && !!CRT_UNIFORM_PLAIN>(a.nodes, a.tris, so, sd, sh0.w, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any, &nu_any);
+                    : traverse<true, STATS, UNI_K>(a.nodes, a.tris, so, sd, sh0.w, stk, (int)a.stack_entries, a.overflow, sh, nn_any, nt_any, wn_any, wt_any, &nu_any);
                 if (!occluded) L = L + V3(sh2.x, sh2.y, sh2.z);
             }
             if (pending && emit_next) a.pb.L[pix] = make_float4(L.x, L.y, L.z, pend_pdf);     // the path goes on: its radiance so far waits in the path state
             pending = false;                                                                   // a path that ended here adds L below
+        } else {
+            // ---- deferred: the shadow ray waits in this segment's region of the NEE queue for k_shadow_deferred ----
+            const uint32_t si = wave_append(emit_shadow, count_shadow);
+            if (emit_shadow) { shadow_q[2 * (size_t)si] = sh0; shadow_q[2 * (size_t)si + 1] = sh1; }
+            // a path that ends in a deferred segment leaves the radiance it had gathered before (in-place segments: the path state's L) and
+            // the mask of its slots; k_fold_paths adds the slots in segment order
+            if (finished) {
+                vec3 Lp = V3(0.f, 0.f, 0.f);
+                if (!FIRST) { const float4 l = a.pb.L[pix]; Lp = V3(l.x, l.y, l.z); }
+                a.l_final[pix] = make_float4(Lp.x, Lp.y, Lp.z, __uint_as_float(0x80000000u | (slot_mask >> 8)));
+            }
+            finished = false;
         }
         // a path that ends here with nothing pending adds its radiance to the running sum now
         if (finished && !pending) {
             // several samples per launch on a path of several segments: the samples of a pixel finish in different launches, so each
-            // leaves its radiance at its own place and k_accumulate_samples adds them in the order the frames would have come
+            // leaves its radiance at its own place and k_fold_paths adds them in the order the frames would have come
             if (a.l_final) a.l_final[pix] = make_float4(L.x, L.y, L.z, 0.f);
             else if (!wave_samples && !lane_samples && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, (FIRST && BATCH) ? e : pix, L);
         }
@@ -2395,14 +1921,6 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
             // after the other would add, zero radiance skipped as everywhere
             const bool mine = finished && !pending;
             const float mx = mine ? L.x : 0.f, my = mine ? L.y : 0.f, mz = mine ? L.z : 0.f;
-#if !CRT_SUM_ONCE
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                const int src = (int)((lane & 15u) + 16u * k);
-                const float rx = __shfl(mx, src), ry = __shfl(my, src), rz = __shfl(mz, src);
-                if (lane < 16u && e < n && (rx != 0.f || ry != 0.f || rz != 0.f)) add_to_sum(a.sum, e, V3(rx, ry, rz));
-            }
-#else
             // one read-modify-write of the pixel's sum for the four samples: s = L_k + s in sample order, in registers — the additions
             // add_to_sum would do one frame after the other, without three of the four loads, stores and address computations
             float rx[4], ry[4], rz[4];
@@ -2421,7 +1939,6 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
                     if (rx[k] != 0.f || ry[k] != 0.f || rz[k] != 0.f) { s0 = rx[k] + s0; s1 = ry[k] + s1; s2 = rz[k] + s2; }
                 sp3[0] = s0; sp3[1] = s1; sp3[2] = s2;
             }
-#endif
         }
         if (wave_samples && !a.l_final) {
             // the waves' samples of this batch, added in sample order by wave 0 (what the frames one after the other would add)
@@ -2439,147 +1956,71 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || (ONE && CRT_ONE_MAT
             }
             __syncthreads();                                       // persistent grids: the next pass reuses the strip
         }
-        if (COMPACT) {
-            // ---- gather the workgroup's shadow rays into full waves (LDS), walk them, finish their paths ----
-            const uint32_t W = blockDim.x >> 6;
-            uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_lds + (size_t)W * wave_stride);
-            float4* const s_rec = reinterpret_cast<float4*>(s_lds);                  // [4][W * 64], aliases the stacks
-            const unsigned long long pm = __ballot(pending);
-            if (lane == 0u) s_cnt[wid.lds_wave] = (uint32_t)__builtin_popcountll(pm);
-            __syncthreads();                                                          // every wave is done with its stack
-            uint32_t base = 0u, total = 0u;
-            for (uint32_t w = 0; w < W; ++w) {
-                const uint32_t cw = s_cnt[w];
-                base += w < wid.lds_wave ? cw : 0u;
-                total += cw;
-            }
-            const uint32_t cap = W * 64u;
-            if (pending) {
-                const uint32_t slot = base + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                s_rec[slot] = sh0;
-                s_rec[cap + slot] = make_float4(sh1.x, sh1.y, sh1.z, __uint_as_float(pix | (emit_next ? 0u : 0x80000000u)));
-                s_rec[2u * cap + slot] = make_float4(sh2.x, sh2.y, sh2.z, pend_pdf);
-                s_rec[3u * cap + slot] = make_float4(L.x, L.y, L.z, 0.f);
-            }
-            __syncthreads();
-            const uint32_t r = wid.lds_wave * 64u + lane;
-            const bool have = r < total;
-            float4 r0 = sh0, r1 = sh0, r2 = sh0, r3 = sh0;
-            if (have) { r0 = s_rec[r]; r1 = s_rec[cap + r]; r2 = s_rec[2u * cap + r]; r3 = s_rec[3u * cap + r]; }
-            __syncthreads();                                                          // records are in registers: the stacks may be written again
-            if (have) {
-                HitState shh;
-                const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
-                                                            (int)a.stack_entries, a.overflow, shh, nn_any, nt_any, wn_any, wt_any);
-                vec3 L2 = V3(r3.x, r3.y, r3.z);
-                if (!occluded) L2 = L2 + V3(r2.x, r2.y, r2.z);
-                const uint32_t tag = __float_as_uint(r1.w), spix = tag & 0x7fffffffu;
-                if (tag & 0x80000000u) {                                              // the path ended with this segment
-                    if (L2.x != 0.f || L2.y != 0.f || L2.z != 0.f) add_to_sum(a.sum, spix, L2);
-                } else {
-                    a.pb.L[spix] = make_float4(L2.x, L2.y, L2.z, r2.w);
-                }
-            }
-            __syncthreads();                                                          // persistent grids: the next pass reuses the region
-        }
-        if (!INPLACE) {
-            const uint32_t si = wave_append(emit_shadow, count_shadow);
-            if (emit_shadow) {
-                float4* q = shadow_q + 3 * (size_t)si;
-                q[0] = sh0; q[1] = sh1; q[2] = sh2;
-                // the radiance gathered so far waits in the path state (a 1-segment path has gathered none)
-                if (!emit_next && a.pb.L) a.pb.L[pix] = make_float4(L.x, L.y, L.z, 0.f);
-            }
-        }
         }   // samples
         if (FIRST && a.tile_cost && lane == 0u && cost_valid)
             atomicAdd(a.tile_cost + cost_tile, (uint32_t)__builtin_readcyclecounter() - cost_t0);     // a wave lives far less than 2^32 cycles
     }
     if (STATS && !PRETRACED) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
-    if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any, wn_any, wt_any);
+    if (STATS && INPLACE) flush_visit_totals(a.visit_totals + 2, nn_any, nt_any, wn_any, wt_any);     // deferred shadow rays: k_shadow_deferred counts them
     if (STATS) flush_visit_totals(a.visit_totals + 8, n_hits, 0u);
     if (STATS) flush_visit_totals(a.visit_totals + 10, nu, nu_any);
     (void)stk; (void)stk2;
 }
 
-#ifdef CRT_EXPERIMENTS
-// Closest hit for a device-written path-ray queue (segments >= 1): per-wave 256-ray pools with lane refill
-// (traverse_pool); hits go to a buffer parallel to the queue and k_segment<PRETRACED> shades them.
+// Closest hit for a device-written path-ray queue (segments >= 1; option bounce_refill): per-wave pools of a.pool rays with lane refill
+// (walk_pool: a finished lane takes the pool's next ray, the pool's last eight rays get eight lanes each); hits go to a buffer parallel to
+// the queue and k_segment<PRETRACED> shades them.  One single-wave workgroup per pool.
 template <bool STATS>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_closest_queue(QueueTraceArgs a) {
-    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
-    const WaveId wid = wave_id();
-    const uint32_t lane = wid.lane, wave = wid.wave;
-    uint2* stk = s_lds + (size_t)wid.lds_wave * (a.stack_entries + CRT_HIT_SLOTS) * 64u + lane;
+__global__ void __launch_bounds__(64, CRT_SEG_OCC) k_closest_queue(QueueTraceArgs a) {
+    extern __shared__ uint2 s_lds[];     // this wave's traversal stack [level][lane] + hit slots
+    const uint32_t g = blockIdx.x & 7u, c = blockIdx.x >> 3;
+    const uint32_t n = a.count[g * CRT_COUNTER_STRIDE];
+    const uint32_t first = c * a.pool;
+    if (first >= n) return;
+    const uint32_t last = first + a.pool < n ? first + a.pool : n;
+    const float4* const rays = a.rays + 2 * (size_t)g * a.sub_capacity;
+    float4* const hits = a.hits + (size_t)g * a.sub_capacity;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
-    CRT_CHUNK_LOOP(it) {
-        const uint32_t v = static_pool_chunk<false>(wid, a.count, 0u, it);
-        if (v == CRT_NO_WORK) break;
-        const uint32_t g = v >> 28;
-        const uint32_t n = a.count[g * CRT_COUNTER_STRIDE];
-        const uint32_t first = (v & 0x0fffffffu) * 1024u + wave * 256u;
-        if (first >= n) continue;
-        const uint32_t last = first + 256u < n ? first + 256u : n;
-        const float4* const rays = a.rays + 2 * (size_t)g * a.sub_capacity;
-        float4* const hits = a.hits + (size_t)g * a.sub_capacity;
-        traverse_pool<false, STATS>(
-            a.nodes, a.tris, stk, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min,
-            [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
-                const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
-                o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
-                return true;
-            },
-            [&](uint32_t e, const HitState& best, bool hit) {
-                hits[e] = make_float4(best.t, best.u, best.v, __int_as_float(hit ? best.tri : -1));
-            },
-            nn, nt, wn, wt);
-    }
-    (void)lane;
+    walk_pool<false, STATS>(
+        a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, a.lanes_log2,
+        [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
+            const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
+            o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
+            return true;
+        },
+        [&](uint32_t e, const HitState& best, bool hit) { hits[e] = make_float4(best.t, best.u, best.v, __int_as_float(hit ? best.tri : -1)); },
+        nn, nt, wn, wt);
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
 }
-#endif  // CRT_EXPERIMENTS
 
-// NEE occlusion test (path_trace.fs:968) fused with its resolve: an unoccluded ray adds its pending
-// contribution C to the path's radiance; if the path ended with this segment the total goes straight
-// into the sum buffer, otherwise into the path state the next segment reads.  Lock-step 64-ray batches:
-// any-hit rays are short and neighbouring pixels aim at the same light, so lane refill costs more than
-// it recovers here (measured 0.235 vs 0.180 ms at 1 M triangles).
+// The deferred NEE occlusion tests (path_trace.fs:968) of a frame, all segments in ONE launch: region r of the queue holds the shadow rays
+// segment r (of those that defer) emitted, 8 sub-queues each; every single-wave workgroup takes a pool of a.pool rays of one sub-queue
+// (a.pool = 64 and refill_min = 65: one lock-step batch) and walks them with walk_pool — full waves from the first step, the last eight rays
+// of a pool on eight lanes each.  An OCCLUDED ray clears the visibility word of its contribution slot (queue entry: (o, tmax) (d, slot));
+// k_fold_paths then adds what is left, in segment order.  Same rays, same walks as the in-place form: occlusion and visit totals keep the
+// oracle's values.
 template <bool STATS>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_shadow(ShadowArgs a) {
-    extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
-    const WaveId wid = wave_id();
-    const uint32_t lane = wid.lane, wave = wid.wave;
-    uint2* stk = s_lds + (size_t)wid.lds_wave * (a.stack_entries + CRT_HIT_SLOTS) * 64u + lane;
+__global__ void __launch_bounds__(64, CRT_SEG_OCC) k_shadow_deferred(ShadowArgs a) {
+    extern __shared__ uint2 s_lds[];
+    const uint32_t g = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t r = q / a.pools_per_region, c = q - r * a.pools_per_region;     // region (segment), pool within the group's sub-queue
+    const uint32_t n = a.count[(size_t)r * a.count_stride + g * CRT_COUNTER_STRIDE];
+    const uint32_t first = c * a.pool;
+    if (first >= n) return;
+    const uint32_t last = first + a.pool < n ? first + a.pool : n;
+    const float4* const rays = a.shadow + 2 * ((size_t)r * 8u + g) * a.sub_capacity;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
-    CRT_CHUNK_LOOP(it) {
-        const uint32_t v = static_chunk<false>(wid, a.count, 0u, it);
-        if (v == CRT_NO_WORK) break;
-        const uint32_t g = v >> 28;
-        const uint32_t e = ((v & 0x0fffffffu) * 4u + wave) * 64u + lane;
-        if (e >= a.count[g * CRT_COUNTER_STRIDE]) continue;
-        const float4* q = a.shadow + 3 * ((size_t)g * a.sub_capacity + e);
-        const float4 r0 = q[0], r1 = q[1];
-        HitState hit;
-        // plain per-lane loop: neither lane refill (0.235 ms) nor the voting loop (0.193 ms at ratio 2) beat it
-        // (0.180 ms) on these short, fairly coherent rays; re-measured with single-wave workgroups: voting at
-        // ratio 1/2/3 0.164/0.163/0.164 vs 0.154 ms (and it costs 93 instead of 64 VGPRs)
-        const bool occluded = traverse<true, STATS>(a.nodes, a.tris, V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), r0.w, stk,
-                                                    (int)a.stack_entries, a.overflow, hit, nn, nt, wn, wt);
-        const uint32_t tag = __float_as_uint(r1.w);
-        const uint32_t pix = tag & 0x7fffffffu;
-        if (tag & 0x80000000u) {                             // the path ended with this segment
-            const float4 c = q[2];
-            vec3 L = V3(0.f, 0.f, 0.f);
-            if (a.L) { const float4 l = a.L[pix]; L = V3(l.x, l.y, l.z); }
-            if (!occluded) L = L + V3(c.x, c.y, c.z);
-            if (L.x != 0.f || L.y != 0.f || L.z != 0.f) add_to_sum(a.sum, pix, L);
-        } else if (!occluded) {
-            const float4 c = q[2];
-            float4 L = a.L[pix];
-            L.x += c.x; L.y += c.y; L.z += c.z;
-            a.L[pix] = L;
-        }
-    }
+    uint32_t slot_of = 0;
+    walk_pool<true, STATS>(
+        a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, a.lanes_log2,
+        [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
+            const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
+            o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
+            slot_of = __float_as_uint(r1.w);
+            return true;
+        },
+        [&](uint32_t, const HitState&, bool occluded) { if (occluded) reinterpret_cast<float*>(a.contrib + slot_of)[3] = 0.0f; },
+        nn, nt, wn, wt);
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
 }
 
@@ -2641,18 +2082,33 @@ __global__ void __launch_bounds__(1024) k_bin_scan(BinScanArgs a) {
     }
 }
 
-// packed tile-major -> linear frame (bottom row first); pixels of other ranks stay untouched.
-// sum[p] = (((sum[p] + L_0[p]) + L_1[p]) + ...): what n consecutive frames would have added, in their order, zero radiance skipped
-// as add_to_sum's callers skip it
-__global__ void __launch_bounds__(256) k_accumulate_samples(float* __restrict__ sum, const float4* __restrict__ l_final, uint32_t n_pixels, uint32_t n_samples) {
+// sum[p] = (((sum[p] + L_0[p]) + L_1[p]) + ...): what n consecutive frames would have added, in their order, zero radiance skipped as
+// add_to_sum's callers skip it.  L_k = l_final[k][p] as the path left it, or — a path that ended in a segment whose shadow rays are deferred
+// (bit 31 of the w word) — that prefix plus the path's contribution slots in segment order: L = L + C_b for every slot b of its mask whose
+// visibility word k_shadow_deferred left standing (the in-place form's `if (!occluded) L = L + C`, path_trace.fs:998, and its emitter adds).
+__global__ void __launch_bounds__(256) k_fold_paths(float* __restrict__ sum, const float4* __restrict__ l_final, const float4* __restrict__ contrib, uint32_t n_pixels,
+                                                    uint32_t n_samples, uint32_t first_slot_segment) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
+    const size_t n_paths = (size_t)n_samples * n_pixels;
     for (uint32_t smp = 0; smp < n_samples; ++smp) {
-        const float4 l = l_final[(size_t)smp * n_pixels + p];
-        if (l.x != 0.f || l.y != 0.f || l.z != 0.f) add_to_sum(sum, p, V3(l.x, l.y, l.z));
+        const size_t path = (size_t)smp * n_pixels + p;
+        const float4 l = l_final[path];
+        vec3 L = V3(l.x, l.y, l.z);
+        uint32_t m = __float_as_uint(l.w);
+        if (m & 0x80000000u) {
+            m = (m & 0xffffu) >> first_slot_segment;             // bit k = the slot of segment first_slot_segment + k
+            for (uint32_t k = 0; m != 0u; ++k, m >>= 1)
+                if (m & 1u) {
+                    const float4 c = contrib[(size_t)k * n_paths + path];
+                    if (c.w != 0.0f) L = L + V3(c.x, c.y, c.z);
+                }
+        }
+        if (L.x != 0.f || L.y != 0.f || L.z != 0.f) add_to_sum(sum, p, L);
     }
 }
 
+// packed tile-major -> linear frame (bottom row first); pixels of other ranks stay untouched.
 __global__ void __launch_bounds__(256) k_untile(FrameArgs f, const float* __restrict__ packed, float* __restrict__ linear) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < f.n_local_pixels; i += gridDim.x * blockDim.x) {
         uint32_t px, py;
@@ -2748,28 +2204,23 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
         else       launch(k_trace_bvh2<false, false>, g, b, lds, stream, a);
     }
 }
-// The first-segment kernels exist twice: compiled for 5 waves per SIMD (96 VGPRs) and for 6 (80 VGPRs, a few more scratch accesses
-// per wave).  A launch that fills the chip several times over runs faster with the sixth wave (CRT_SEG_OCC_FIRST); one that is
-// only as long as its longest waves — a shard, a small frame, the side-by-side sample form — runs those waves faster without the
-// extra scratch traffic (1/8 of a 1080p frame, 4 samples side by side: 0.0453 ms per frame at 5 waves, 0.0503 at 6).  The host
-// says which (SegmentArgs::wide_first); counting kernels keep the one form.
-#ifndef CRT_EXPERIMENTS
-// ---- default build: the variants that won their measurements, 24 instantiations of k_segment ----
+// The first-segment kernels exist twice: compiled for 5 waves per SIMD (96 VGPRs) and for 6 (80 VGPRs).  A launch that fills the chip several
+// times over runs faster with the sixth wave (CRT_SEG_OCC_FIRST); one that is only as long as its longest waves — a shard, a small frame,
+// the side-by-side sample form — runs those waves faster at 5 (1/8 of a 1080p frame, 4 samples side by side: 0.0453 ms per frame at 5 waves,
+// 0.0503 at 6).  The host says which (SegmentArgs::wide_first); counting kernels keep the one form.
 // Feature level of the shading code: PLAIN (Lambert, untextured: the reference's shipped scene), MAT (+ mirror / Disney), FULL (+ textured
-// albedo).  Counting kernels, the BVH2 frame mode and the shadow-queue form are not timed against anything and exist at the
-// highest level only (the extra branches are decided per material at run time: same arithmetic, same sums).  What lost every
-// measurement of rounds 1-2 — shadow-ray compaction across waves (COMPACT), bounce pools (PRETRACED + k_closest_queue), persistent
-// grids, 2- and 4-wave workgroups, triangle sharing in the first segment, batched BVH2 frames — is compiled only with
-// -DCRT_EXPERIMENTS (make EXPERIMENTS=1), where the GPU suite still checks it bit for bit.
-//               k_segment<FIRST, STATS, TEX, PRETRACED, INPLACE, BVH2, MAT, COMPACT, SHARE, BATCH, WIDE>
-#define CRT_K(F, S, T, Y, B2, M, SH, BA, WI) k_segment<F, S, T, false, Y, B2, M, false, SH, BA, WI>
-static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, bool bvh2, bool mat, bool stats, uint32_t grid, hipStream_t stream, int& wide_ran) {
+// albedo).  Counting kernels, the BVH2 frame mode, the deferred-shadow form and the shade-only (PRETRACED) form exist at the highest level
+// only (the extra branches are decided per material at run time: same arithmetic, same sums) — 33 instantiations of k_segment.
+//               k_segment<FIRST, STATS, TEX, PRETRACED, INPLACE, BVH2, MAT, BATCH, WIDE, ONE>
+#define CRT_K(F, S, T, P, Y, B2, M, BA, WI, ON) k_segment<F, S, T, P, Y, B2, M, BA, WI, ON>
+// returns bit 0: the launch ran the 6-waves-per-SIMD (WIDE) build of the first-segment kernel; bit 1: a one-pass (ONE) build (crt_debug_launch_info)
+int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
     const bool tex = a.textures != nullptr;
-    const bool share = !first && (a.tri_share & 3u) != 0u && a.tri_min != 0u && inplace && !bvh2;
     // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
     const size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
-    const dim3 g = grid_dim(grid, 1u), b = block_dim(1u);
-    const size_t lds = per_wave + (share ? 16 + (size_t)CRT_SHARE_BYTES : 0);
+    waves = fit_waves(waves, per_wave);
+    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
+    const size_t lds = waves * per_wave;
     const int feat = tex ? 2 : mat ? 1 : 0;
     if (first && a.n_samples > 1u) {
         // several samples per launch (crt_render_frames): CWBVH, shadow rays in place, no counting (crt_device.cpp batch_limit)
@@ -2778,180 +2229,75 @@ static void launch_segment_impl(const SegmentArgs& a, bool first, bool inplace, 
         const size_t lds4 = ws * per_wave + ws * 64 * sizeof(float4);
         SegmentArgs v = a;
         if (a.wave_samples && lds4 > 64u * 1024u) v.wave_samples = 0u;     // the sequential form, should the stacks and the result strip not fit
-        if (v.wave_samples == 2u && (a.n_samples & 3u)) v.wave_samples = 0u;   // samples in lanes come four at a time
+        if (v.wave_samples == 2u && ((a.n_samples & 3u) || waves != 1u)) v.wave_samples = 0u;   // samples in lanes come four at a time, on single-wave workgroups
         const bool side_by_side = v.wave_samples == 1u, in_lanes = v.wave_samples == 2u;
         // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups;
         // in the lanes of four single-wave workgroups per batch (one 4 x 4 pixel quadrant x 4 samples each): 16 * grid workgroups
-        const dim3 gg = side_by_side ? dim3(grid * 4u) : in_lanes ? dim3(grid * 16u) : g, bb = side_by_side ? dim3(ws * 64u) : b;
-        const size_t ll = side_by_side ? lds4 : lds;
-        const bool one_pass = in_lanes && a.n_samples == 4u && a.tri_min != 0u && a.lanes_log2 != 0u && CRT_ONE_PASS_KERNEL;      // four samples in the lanes of a wave: the builds without a sample loop
-        if (feat == 2 && one_pass)      launch(k_segment<true, false, true, false, true, false, true, false, false, true, false, true>, gg, bb, ll, stream, v);
-        else if (feat == 1 && one_pass) launch(k_segment<true, false, false, false, true, false, true, false, false, true, false, true>, gg, bb, ll, stream, v);
-        else if (feat == 2) launch(CRT_K(true, false, true, true, false, true, false, true, false), gg, bb, ll, stream, v);
-        else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, true, false), gg, bb, ll, stream, v);
-        else if (v.wide_first && one_pass) { wide_ran = 1; launch(k_segment<true, false, false, false, true, false, false, false, false, true, true, true>, gg, bb, ll, stream, v); }
-        else if (v.wide_first && !side_by_side) { wide_ran = 1; launch(CRT_K(true, false, false, true, false, false, false, true, true), gg, bb, ll, stream, v); }
-        else                launch(CRT_K(true, false, false, true, false, false, false, true, false), gg, bb, ll, stream, v);
-        return;
+        const dim3 gg = side_by_side ? dim3(grid * 4u) : in_lanes ? dim3(grid * 16u) : g, bb = side_by_side ? dim3(ws * 64u) : in_lanes ? dim3(64u) : b;
+        const size_t ll = side_by_side ? lds4 : in_lanes ? per_wave : lds;
+        const bool one_pass = in_lanes && a.n_samples == 4u && a.tri_min != 0u && a.lanes_log2 != 0u;      // four samples in the lanes of a wave: the builds without a sample loop
+        if (feat == 2 && one_pass)      { launch(CRT_K(true, false, true, false, true, false, true, true, false, true), gg, bb, ll, stream, v); return 2; }
+        else if (feat == 1 && one_pass) { launch(CRT_K(true, false, false, false, true, false, true, true, false, true), gg, bb, ll, stream, v); return 2; }
+        else if (feat == 2) launch(CRT_K(true, false, true, false, true, false, true, true, false, false), gg, bb, ll, stream, v);
+        else if (feat == 1) launch(CRT_K(true, false, false, false, true, false, true, true, false, false), gg, bb, ll, stream, v);
+        else if (v.wide_first && one_pass) { launch(CRT_K(true, false, false, false, true, false, false, true, true, true), gg, bb, ll, stream, v); return 3; }
+        else if (v.wide_first && !side_by_side) { launch(CRT_K(true, false, false, false, true, false, false, true, true, false), gg, bb, ll, stream, v); return 1; }
+        else                launch(CRT_K(true, false, false, false, true, false, false, true, false, false), gg, bb, ll, stream, v);
+        return 0;
     }
     if (bvh2) {                                          // the shipped shader's own walks as a frame renderer: Lambert (+ textures) only
-        if (first) { if (stats) launch(CRT_K(true, true, true, true, true, false, false, false, false), g, b, lds, stream, a);
-                     else       launch(CRT_K(true, false, true, true, true, false, false, false, false), g, b, lds, stream, a); }
-        else       { if (stats) launch(CRT_K(false, true, true, true, true, false, false, false, false), g, b, lds, stream, a);
-                     else       launch(CRT_K(false, false, true, true, true, false, false, false, false), g, b, lds, stream, a); }
-        return;
+        if (first) { if (stats) launch(CRT_K(true, true, true, false, true, true, false, false, false, false), g, b, lds, stream, a);
+                     else       launch(CRT_K(true, false, true, false, true, true, false, false, false, false), g, b, lds, stream, a); }
+        else       { if (stats) launch(CRT_K(false, true, true, false, true, true, false, false, false, false), g, b, lds, stream, a);
+                     else       launch(CRT_K(false, false, true, false, true, true, false, false, false, false), g, b, lds, stream, a); }
+        return 0;
     }
-    if (!inplace) {                                      // shadow queue + k_shadow (option "inplace_shadow" 0)
-        if (first) { if (stats) launch(CRT_K(true, true, true, false, false, true, false, false, false), g, b, lds, stream, a);
-                     else       launch(CRT_K(true, false, true, false, false, true, false, false, false), g, b, lds, stream, a); }
-        else       { if (stats) launch(CRT_K(false, true, true, false, false, true, false, false, false), g, b, lds, stream, a);
-                     else       launch(CRT_K(false, false, true, false, false, true, false, false, false), g, b, lds, stream, a); }
-        return;
+    if (pretraced) {                                     // shade-only pass behind k_closest_queue (option "bounce_refill")
+        if (inplace) { if (stats) launch(CRT_K(false, true, true, true, true, false, true, false, false, false), g, b, lds, stream, a);
+                       else       launch(CRT_K(false, false, true, true, true, false, true, false, false, false), g, b, lds, stream, a); }
+        else         { if (stats) launch(CRT_K(false, true, true, true, false, false, true, false, false, false), g, b, lds, stream, a);
+                       else       launch(CRT_K(false, false, true, true, false, false, true, false, false, false), g, b, lds, stream, a); }
+        return 0;
+    }
+    if (!inplace) {                                      // shadow rays deferred to k_shadow_deferred (option "inplace_shadow" 0 / 2)
+        if (first) { if (stats) launch(CRT_K(true, true, true, false, false, false, true, false, false, false), g, b, lds, stream, a);
+                     else       launch(CRT_K(true, false, true, false, false, false, true, false, false, false), g, b, lds, stream, a); }
+        else if (stats) launch(CRT_K(false, true, true, false, false, false, true, false, false, false), g, b, lds, stream, a);
+        else if (feat == 2) launch(CRT_K(false, false, true, false, false, false, true, false, false, false), g, b, lds, stream, a);
+        else if (feat == 1) launch(CRT_K(false, false, false, false, false, false, true, false, false, false), g, b, lds, stream, a);
+        else                launch(CRT_K(false, false, false, false, false, false, false, false, false, false), g, b, lds, stream, a);
+        return 0;
     }
     if (stats) {
-        if (first)      launch(CRT_K(true, true, true, true, false, true, false, false, false), g, b, lds, stream, a);
-        else if (share) launch(CRT_K(false, true, true, true, false, true, true, false, false), g, b, lds, stream, a);
-        else            launch(CRT_K(false, true, true, true, false, true, false, false, false), g, b, lds, stream, a);
-        return;
+        if (first) launch(CRT_K(true, true, true, false, true, false, true, false, false, false), g, b, lds, stream, a);
+        else       launch(CRT_K(false, true, true, false, true, false, true, false, false, false), g, b, lds, stream, a);
+        return 0;
     }
-    if (first) {
-        // one sample per launch (crt_render_frame): the builds with only the walks a default launch runs, where the launch is one
-#if CRT_LEAN_SINGLE      // measurement variant: 72 VGPRs (7 waves per SIMD) and SLOWER — 1 M triangles 13,452 against 14,719 Mray/s, 4K 15,748 against 17,186
-        if (a.tri_min != 0u && a.lanes_log2 != 0u && CRT_ONE_PASS_KERNEL) {
-            if (feat == 2)      launch(k_segment<true, false, true, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
-            else if (feat == 1) launch(k_segment<true, false, false, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
-            else                launch(k_segment<true, false, false, false, true, false, false, false, false, false, false, true>, g, b, lds, stream, a);
-            return;
-        }
-#endif
-        if (feat == 2)      launch(CRT_K(true, false, true, true, false, true, false, false, false), g, b, lds, stream, a);
-        else if (feat == 1) launch(CRT_K(true, false, false, true, false, true, false, false, false), g, b, lds, stream, a);
-        else                launch(CRT_K(true, false, false, true, false, false, false, false, false), g, b, lds, stream, a);
-        return;
-    }
-    if (share) {
-        if (feat == 2)      launch(CRT_K(false, false, true, true, false, true, true, false, false), g, b, lds, stream, a);
-        else if (feat == 1) launch(CRT_K(false, false, false, true, false, true, true, false, false), g, b, lds, stream, a);
-        else                launch(CRT_K(false, false, false, true, false, false, true, false, false), g, b, lds, stream, a);
-#if CRT_LEAN_BOUNCE      // measurement variant: bounce kernels that carry only the walks a default launch runs — the same 79 VGPRs, no faster (7,192 against 7,208 Mray/s on four segments)
-    } else if (a.tri_min != 0u && a.lanes_log2 != 0u && CRT_ONE_PASS_KERNEL) {
-        if (feat == 2)      launch(k_segment<false, false, true, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
-        else if (feat == 1) launch(k_segment<false, false, false, false, true, false, true, false, false, false, false, true>, g, b, lds, stream, a);
-        else                launch(k_segment<false, false, false, false, true, false, false, false, false, false, false, true>, g, b, lds, stream, a);
-#endif
-    } else {
-        if (feat == 2)      launch(CRT_K(false, false, true, true, false, true, false, false, false), g, b, lds, stream, a);
-        else if (feat == 1) launch(CRT_K(false, false, false, true, false, true, false, false, false), g, b, lds, stream, a);
-        else                launch(CRT_K(false, false, false, true, false, false, false, false, false), g, b, lds, stream, a);
-    }
+    if (feat == 2)      { if (first) launch(CRT_K(true, false, true, false, true, false, true, false, false, false), g, b, lds, stream, a);
+                          else       launch(CRT_K(false, false, true, false, true, false, true, false, false, false), g, b, lds, stream, a); }
+    else if (feat == 1) { if (first) launch(CRT_K(true, false, false, false, true, false, true, false, false, false), g, b, lds, stream, a);
+                          else       launch(CRT_K(false, false, false, false, true, false, true, false, false, false), g, b, lds, stream, a); }
+    else                { if (first) launch(CRT_K(true, false, false, false, true, false, false, false, false, false), g, b, lds, stream, a);
+                          else       launch(CRT_K(false, false, false, false, true, false, false, false, false, false), g, b, lds, stream, a); }
+    return 0;
 }
 #undef CRT_K
-// returns 1 when the launch ran the 6-waves-per-SIMD (WIDE) build of the first-segment kernel, else 0 (crt_debug_launch_info)
-int launch_segment(const SegmentArgs& a, bool first, bool /*pretraced*/, bool inplace, bool bvh2, bool mat, bool /*compact*/, bool stats, uint32_t grid, uint32_t /*waves*/,
-                   hipStream_t stream) {
-    int wide_ran = 0;
-    launch_segment_impl(a, first, inplace, bvh2, mat, stats, grid, stream, wide_ran);
-    return wide_ran;
+// grid: 8 x (pools a sub-queue can hold) single-wave workgroups; a pool beyond its sub-queue's count returns at once
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t pools_per_group, hipStream_t stream) {
+    const dim3 g(8u * pools_per_group), b(64u);
+    if (stats) launch(k_closest_queue<true>, g, b, stack_bytes(a.stack_entries), stream, a);
+    else       launch(k_closest_queue<false>, g, b, stack_bytes(a.stack_entries), stream, a);
 }
-#else   // CRT_EXPERIMENTS: every variant the kernel's template parameters describe
-#define CRT_KSEG(F, S, T, P, Y, B, M, C, SH, BA) \
-    (a.wide_first ? k_segment<F, S, T, P, Y, B, M, C, SH, BA, (F) && !(S)> : k_segment<F, S, T, P, Y, B, M, C, SH, BA, false>)
-// first: ray generation + traversal + shading.  !first && !pretraced: queue fetch + traversal + shading (lock-step).
-// !first && pretraced: queue fetch + shading of hits produced by launch_closest_queue.
-static void launch_segment_impl(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
-    const bool share = (a.tri_share & 3u) != 0u && a.tri_min != 0u && inplace && !pretraced && !bvh2 && !compact;
-    // one LDS region serves the CWBVH stack (8 B per level and lane) or the BVH2 stack (4 B)
-    size_t per_wave = std::max(stack_bytes(a.stack_entries), bvh2 ? (size_t)a.stack_entries2 * 64 * sizeof(int) : (size_t)0);
-    waves = fit_waves(waves, per_wave);
-    compact = compact && inplace && !pretraced && !bvh2 && waves > 1u;      // shadow-ray compaction needs partner waves
-    if (compact) per_wave = std::max(per_wave, stack_bytes(8u));             // 64 B of ray record per lane alias the stacks (k_segment's wave_stride)
-    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
-    const size_t lds = waves * per_wave + (compact || share ? 16 : 0) + (share ? (size_t)waves * CRT_SHARE_BYTES : 0);
-    const bool tex = a.textures != nullptr;
-    if (a.n_samples > 1u) {
-        // several samples per launch: first segment of a one-segment path, shadow rays in place, no counting, no shadow-ray compaction
-        // (crt_device.cpp batch_limit)
-        // as few passes as 4 waves allow, and no more waves than those passes need (5 samples: 2 passes of 3 waves)
-        const uint32_t ws_passes = (a.n_samples + 3u) / 4u, ws = (a.n_samples + ws_passes - 1u) / ws_passes;
-        const size_t lds4 = ws * per_wave + ws * 64 * sizeof(float4);
-        SegmentArgs seq = a;                         // the sequential form, should the stacks and the result strip not fit
-        seq.wave_samples = 0u;
-        if (a.wave_samples == 2u) {
-            // the samples in the lanes of four single-wave workgroups per batch; in this build with the plain batched kernels only
-            if ((a.n_samples & 3u) || bvh2 || share || waves != 1u) return launch_segment_impl(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
-            const dim3 g16(grid * 16u), b1(64u);
-#define CRT_LAUNCH_LS(T, M) launch(CRT_KSEG(true, false, T, false, true, false, M, false, false, true), g16, b1, per_wave, stream, a)
-            if (mat) { if (tex) CRT_LAUNCH_LS(true, true); else CRT_LAUNCH_LS(false, true); }
-            else     { if (tex) CRT_LAUNCH_LS(true, false); else CRT_LAUNCH_LS(false, false); }
-#undef CRT_LAUNCH_LS
-            return;
-        }
-        if (a.wave_samples && lds4 > 64u * 1024u) return launch_segment_impl(seq, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
-        if (a.wave_samples) {
-            // the samples on the 2 to 4 waves of a workgroup, one batch per workgroup: `grid` chunks of 4 batches = 4 * grid workgroups
-            const dim3 g4(grid * 4u), b4(ws * 64u);
-#define CRT_LAUNCH_WS(T, B2, M) launch(k_segment<true, false, T, false, true, B2, M, false, false, true>, g4, b4, lds4, stream, a)
-            if (bvh2) { if (tex) CRT_LAUNCH_WS(true, true, false); else CRT_LAUNCH_WS(false, true, false); }
-            else if (mat) { if (tex) CRT_LAUNCH_WS(true, false, true); else CRT_LAUNCH_WS(false, false, true); }
-            else { if (tex) CRT_LAUNCH_WS(true, false, false); else CRT_LAUNCH_WS(false, false, false); }
-#undef CRT_LAUNCH_WS
-            return;
-        }
-#define CRT_LAUNCH_BATCH(T, B2, M, SH) launch(CRT_KSEG(true, false, T, false, true, B2, M, false, SH, true), g, b, lds, stream, a)
-        if (bvh2) { if (tex) CRT_LAUNCH_BATCH(true, true, false, false); else CRT_LAUNCH_BATCH(false, true, false, false); }
-        else if (share) {
-            if (mat) { if (tex) CRT_LAUNCH_BATCH(true, false, true, true); else CRT_LAUNCH_BATCH(false, false, true, true); }
-            else     { if (tex) CRT_LAUNCH_BATCH(true, false, false, true); else CRT_LAUNCH_BATCH(false, false, false, true); }
-        } else {
-            if (mat) { if (tex) CRT_LAUNCH_BATCH(true, false, true, false); else CRT_LAUNCH_BATCH(false, false, true, false); }
-            else     { if (tex) CRT_LAUNCH_BATCH(true, false, false, false); else CRT_LAUNCH_BATCH(false, false, false, false); }
-        }
-#undef CRT_LAUNCH_BATCH
-        return;
-    }
-#define CRT_LAUNCH_SEG(F, S, T, P, Y, B) do { \
-        if (share) { if (mat) launch(CRT_KSEG(F, S, T, false, true, false, true, false, true, false), g, b, lds, stream, a); \
-                     else launch(CRT_KSEG(F, S, T, false, true, false, false, false, true, false), g, b, lds, stream, a); } \
-        else if (compact) { if (mat) launch(CRT_KSEG(F, S, T, false, true, false, true, true, false, false), g, b, lds, stream, a); \
-                       else launch(CRT_KSEG(F, S, T, false, true, false, false, true, false, false), g, b, lds, stream, a); } \
-        else if (mat && !(P) && !(B)) launch(CRT_KSEG(F, S, T, false, Y, false, true, false, false, false), g, b, lds, stream, a); \
-        else launch(CRT_KSEG(F, S, T, P, Y, B, false, false, false, false), g, b, lds, stream, a); } while (0)
-#define CRT_LAUNCH_SEG_T(F, S, P, Y, B) do { if (tex) CRT_LAUNCH_SEG(F, S, true, P, Y, B); else CRT_LAUNCH_SEG(F, S, false, P, Y, B); } while (0)
-#define CRT_LAUNCH_SEG_S(F, P, Y, B) do { if (stats) CRT_LAUNCH_SEG_T(F, true, P, Y, B); else CRT_LAUNCH_SEG_T(F, false, P, Y, B); } while (0)
-    if (pretraced) { if (inplace) CRT_LAUNCH_SEG_S(false, true, true, false); else CRT_LAUNCH_SEG_S(false, true, false, false); }   // shade (+ shadow walk)
-    else if (bvh2) { if (first) CRT_LAUNCH_SEG_S(true, false, true, true); else CRT_LAUNCH_SEG_S(false, false, true, true); }
-    else if (first) { if (inplace) CRT_LAUNCH_SEG_S(true, false, true, false); else CRT_LAUNCH_SEG_S(true, false, false, false); }
-    else            { if (inplace) CRT_LAUNCH_SEG_S(false, false, true, false); else CRT_LAUNCH_SEG_S(false, false, false, false); }
-#undef CRT_LAUNCH_SEG_S
-#undef CRT_LAUNCH_SEG_T
-#undef CRT_LAUNCH_SEG
-}
-int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
-    launch_segment_impl(a, first, pretraced, inplace, bvh2, mat, compact, stats, grid, waves, stream);
-    return (a.wide_first && first && !stats && (a.n_samples <= 1u || a.wave_samples == 2u)) ? 1 : 0;      // CRT_KSEG's choice; batched launches only in the lanes form
-}
-#endif  // CRT_EXPERIMENTS
-#ifdef CRT_EXPERIMENTS
-void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
-    waves = fit_waves(waves, stack_bytes(a.stack_entries));
-    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
-    const size_t lds = waves * stack_bytes(a.stack_entries);
-    if (stats) launch(k_closest_queue<true>, g, b, lds, stream, a);
-    else       launch(k_closest_queue<false>, g, b, lds, stream, a);
-}
-#endif
-void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream) {
-    waves = fit_waves(waves, stack_bytes(a.stack_entries));
-    const dim3 g = grid_dim(grid, waves), b = block_dim(waves);
-    const size_t lds = waves * stack_bytes(a.stack_entries);
-    if (stats) launch(k_shadow<true>, g, b, lds, stream, a);
-    else       launch(k_shadow<false>, g, b, lds, stream, a);
+void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t n_regions, hipStream_t stream) {
+    const dim3 g(8u * n_regions * a.pools_per_region), b(64u);
+    if (stats) launch(k_shadow_deferred<true>, g, b, stack_bytes(a.stack_entries), stream, a);
+    else       launch(k_shadow_deferred<false>, g, b, stack_bytes(a.stack_entries), stream, a);
 }
 void launch_bin_scan(const BinScanArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, a);
 }
-void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pixels, uint32_t n_samples, hipStream_t stream) {
-    hipLaunchKernelGGL(k_accumulate_samples, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, sum, l_final, n_pixels, n_samples);
+void launch_fold_paths(float* sum, const float4* l_final, const float4* contrib, uint32_t n_pixels, uint32_t n_samples, uint32_t first_slot_segment, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fold_paths, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, sum, l_final, contrib, n_pixels, n_samples, first_slot_segment);
 }
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_untile, dim3(grid), dim3(256), 0, stream, f, packed, linear);
@@ -2967,10 +2313,10 @@ int warm_rt_kernels() {
     hipError_t e;
     if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_trace<false, false>))) != hipSuccess) return (int)e;
     if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_trace<true, false>))) != hipSuccess) return (int)e;
-    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_shadow<false>))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_shadow_deferred<false>))) != hipSuccess) return (int)e;
     if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_untile))) != hipSuccess) return (int)e;
     if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_resolve))) != hipSuccess) return (int)e;
-    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_accumulate_samples))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_fold_paths))) != hipSuccess) return (int)e;
     return 0;
 }
 

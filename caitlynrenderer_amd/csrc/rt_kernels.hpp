@@ -9,7 +9,7 @@ namespace crt {
 // crt_scene_create refuses a CWBVH deeper than this; the launch uses min(this, depth of the tree).
 #define CRT_STACK_ENTRIES 16
 // Two more entries behind every lane's stack column: (u, v) and the original id of a closest-hit walk's best hit so far — written a few
-// times per ray, read once: LDS instead of three VGPRs across the traversal loop (rt_kernels.hip traverse_pool, walk_batch; the id's
+// times per ray, read once: LDS instead of three VGPRs across the traversal loop (rt_kernels.hip walk_pool, walk_batch; the id's
 // neighbour word is walk_batch's regroup scratch).
 #ifndef CRT_HIT_SLOTS
 #define CRT_HIT_SLOTS 2
@@ -35,8 +35,8 @@ struct TraceArgs {
     uint32_t n;
     uint32_t out_orig_id;      // 1: hit.tri = original triangle id, 0: CWBVH triangle index
     uint32_t stack_entries;
-    uint32_t refill_min;       // idle lanes that trigger a pool refill (traverse_pool)
-    uint32_t tri_min;          // vote ratio of traverse_pool: node step while node-ready lanes >= tri_min x triangle-waiting lanes
+    uint32_t refill_min;       // idle lanes that trigger a pool refill (walk_pool)
+    uint32_t tri_min;          // vote ratio of the walks: node step while node-ready lanes >= tri_min x triangle-waiting lanes
     uint32_t* overflow;        // += 1 per dropped stack push (never happens for a tree crt_scene_create accepted)
     uint32_t pool_split_log2;  // a wave's 256-ray slot of the index space is walked by 1 << this single-wave workgroups (pools of 256, 128, 64)
 };
@@ -119,14 +119,17 @@ struct SegmentArgs {
     int32_t tex_width, tex_height, n_textures;
     FrameArgs f;
     uint32_t sub_capacity;     // entries per sub-queue (8 sub-queues per queue)
-    uint32_t tri_min;          // vote ratio of traverse_pool; 0 = plain per-lane loop (tiny trees)
+    uint32_t tri_min;          // vote ratio of the walks; 0 = plain per-lane loop (tiny trees)
     uint32_t lanes_log2;       // walk_batch: a ray may spread over up to 1 << lanes_log2 lanes as its wave drains (0: one lane per ray throughout)
-    uint32_t tri_share;        // 0: one triangle per waiting lane and step; 1: pending triangles shared out to all lanes (closest hit); 2: + in-place shadow rays
     const float4* rays_in;     // segments >= 1: crt_ray with payload = local pixel
     const uint32_t* count_in;  // 8 counters, CRT_COUNTER_STRIDE apart
     const float4* hits_in;     // k_segment<PRETRACED>: (t, u, v, CWBVH triangle) per queue entry
     float4* rays_next;   uint32_t* count_next;
-    float4* shadow;      uint32_t* count_shadow;   // 3 x float4 per entry: (o,tmax) (d,pixel|final<<31) (C)
+    float4* shadow;      uint32_t* count_shadow;   // this segment's shadow rays: their count (8 counters) and, when they are DEFERRED (k_segment<!INPLACE>), this
+                                                   // segment's region of the NEE queue, 2 x float4 per entry: (o, tmax) (d, contribution slot)
+    float4* contrib;           // deferred: this segment's contribution slots, one per path: (C | T e, visibility word 1.0 / 0.0)
+    uint32_t slot_first;       // deferred: index of this segment's slot of path 0 in the frame's slot array (a queue entry names slot_first + path)
+    uint32_t slot_bit;         // deferred: this segment's bit in the path state's slot mask (1 << (8 + segment))
     PathBuffers pb;
     float* sum;                // packed tile-major RGB32F
     uint32_t last_segment;
@@ -139,7 +142,7 @@ struct SegmentArgs {
     uint32_t n_zero;
     uint32_t* overflow;        // += 1 per dropped stack push
     float4* l_final;           // crt_render_frames on paths of several segments: where a finished path leaves its radiance, indexed like
-                               // the path state by sample * n_local_pixels + pixel; k_accumulate_samples adds them to `sum` in sample order
+                               // the path state by sample * n_local_pixels + pixel; k_fold_paths adds them to `sum` in sample order
     uint32_t* tile_cost;       // FIRST, optional: += the clock ticks every wave spent on a tile's pixels, per local tile (feeds tile_order)
     uint32_t wide_first;       // FIRST: 1 = the 6-waves-per-SIMD build of the kernel (launches bound by throughput), 0 = the 5-wave one
     uint32_t wave_samples;     // BATCH: 2 = a wave renders a 4 x 4 pixel quadrant of a batch x 4 samples (lane = sample * 16 + pixel; n_samples a
@@ -165,21 +168,26 @@ struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-writ
     uint32_t sub_capacity;
     uint32_t refill_min;
     uint32_t tri_min;
+    uint32_t pool;             // rays per wave (walk_pool): 64 with refill_min 65 = one lock-step batch
+    uint32_t lanes_log2;       // != 0: the pool's last eight rays get eight lanes each
     unsigned long long* visit_totals;
     uint32_t* overflow;
 };
 
-struct ShadowArgs {
+struct ShadowArgs {            // k_shadow_deferred: the deferred NEE shadow rays of a frame, all segments in one launch
     const uint4* nodes;
     const float4* tris;
-    const float4* shadow;
-    const uint32_t* count;
-    float4* L;
-    float* sum;
+    const float4* shadow;      // the NEE queue: [region][8 sub-queues][sub_capacity] x 2 float4 (o, tmax) (d, contribution slot)
+    const uint32_t* count;     // region r, group g: count[r * count_stride + g * CRT_COUNTER_STRIDE]
+    float4* contrib;           // the frame's contribution slots; an occluded ray clears its slot's visibility word
+    uint32_t count_stride;
+    uint32_t pools_per_region; // pools a sub-queue can hold: ceil(sub_capacity / pool)
     uint32_t stack_entries;
     uint32_t sub_capacity;
     uint32_t refill_min;
     uint32_t tri_min;
+    uint32_t pool;
+    uint32_t lanes_log2;
     unsigned long long* visit_totals;
     uint32_t* overflow;
 };
@@ -187,16 +195,17 @@ struct ShadowArgs {
 // waves = waves per workgroup: 1 (every wave its own workgroup), 2 or 4 (256 threads); a per-scene setting
 void launch_trace(const TraceArgs& a, int mode, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
-// mat: the scene has Mirror / Disney materials (CWBVH lock-step segments only: not with pretraced or bvh2)
-// compact: gather the in-place shadow rays of a 2- or 4-wave workgroup into full waves before walking them
-// returns 1 when the launch ran the 6-waves-per-SIMD (WIDE) build of the first-segment kernel
-int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool compact, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
-void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
-void launch_shadow(const ShadowArgs& a, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+// mat: the scene has Mirror / Disney materials (CWBVH segments only: not with bvh2)
+// inplace_shadow: the NEE shadow rays are walked inside the kernel; false = deferred to the frame's k_shadow_deferred launch
+// returns bit 0: the launch ran the 6-waves-per-SIMD (WIDE) build of the first-segment kernel, bit 1: a one-pass (ONE) build
+int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t pools_per_group, hipStream_t stream);
+void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t n_regions, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 void launch_bin_scan(const BinScanArgs& a, hipStream_t stream);
-void launch_accumulate_samples(float* sum, const float4* l_final, uint32_t n_pixels, uint32_t n_samples, hipStream_t stream);
+// contrib may be null (no deferred segment); first_slot_segment = the segment slot 0 of the slot array belongs to
+void launch_fold_paths(float* sum, const float4* l_final, const float4* contrib, uint32_t n_pixels, uint32_t n_samples, uint32_t first_slot_segment, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 

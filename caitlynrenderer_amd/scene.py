@@ -184,11 +184,11 @@ class Scene:
 
     def debug_launch_info(self):
         """crt_debug_launch_info of the last first-segment launch: {"form": 0 | 1 | 2 (2 = four samples of a 4x4 pixel quadrant in the
-        lanes of a wave), "wide": the 6-waves-per-SIMD build ran, "samples": samples per pixel of the launch, "shards": tile shards
-        side by side (streams / devices)}"""
+        lanes of a wave), "wide": the 6-waves-per-SIMD build ran, "one_pass": a build without the sample loop ran (k_segment<..., ONE>),
+        "samples": samples per pixel of the launch, "shards": tile shards side by side (streams / devices)}"""
         info = (C.c_int32 * 4)()
         check(lib().crt_debug_launch_info(self._h, info))
-        return {"form": info[0], "wide": bool(info[1]), "samples": info[2], "shards": info[3]}
+        return {"form": info[0], "wide": bool(info[1] & 1), "one_pass": bool(info[1] & 2), "samples": info[2], "shards": info[3]}
 
     def debug_step_hist(self, stop=False):
         """crt_debug_step_hist: (closest[65], any[65]) node steps of the counting frames since the previous call by number of enabled lanes"""

@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 5   /* 5: crt_frame_stats.nodes_closest_uniform / nodes_any_uniform (the struct grew);
+#define CRT_ABI_VERSION 6   /* 6: options inplace_shadow 2 (deferred shadow rays), bounce_refill / refill_pool / shadow_pool / shadow_refill_min in every build,
+                              *    tri_share / compact_shadow gone; crt_debug_launch_info's build word carries the one-pass bit;
+                              * 5: crt_frame_stats.nodes_closest_uniform / nodes_any_uniform (the struct grew);
                               * 4: crt_warmup, crt_shard_tiles, crt_debug_launch_info, crt_debug_step_hist; options lanes_per_ray, ray_bins 4 / 5, tri_share bits;
                               * 3: crt_frame_stats.closest_hits, crt_set_devices (one process, several GPUs), crt_has_experiments;
                               * 2: crt_frame_stats.stack_overflows + wave_steps_*, crt_scene_desc.build_flags, crt_bvh_info build times */
@@ -177,15 +179,20 @@ int crt_sync(crt_scene* s);
  *     "timing_accumulate" n > 0: keep the spans of the next n launches instead of restarting every frame
  *                         (crt_frame_stats.ms_* are then sums over n_trace_launches launches); 0: per frame
  *   tuning
- *     "inplace_shadow"    1 = NEE shadow rays walked inside the segment kernel (default), 0 = shadow queue + k_shadow
+ *     "inplace_shadow"    the NEE shadow rays (path_trace.fs:968): 1 = walked inside the segment kernel (default); 2 = the first segment's in
+ *                         place, the bounce segments' DEFERRED: they wait in the frame's NEE queue with the index of a contribution
+ *                         slot (segment, path), ONE any-hit launch behind the last segment walks them all in full waves, an occluded
+ *                         ray clears its slot, and a last kernel adds every path's slots in segment order — the additions the in-place
+ *                         form makes, in the same order; 0 = every segment's deferred (frames then render one by one).  BVH2 frames
+ *                         ("accel") always walk in place.
+ *     "shadow_pool"       rays per wave of that launch: 64 (default; with "shadow_refill_min" 65 — the default — one lock-step batch),
+ *                         128, 256, 512: a lane whose ray has finished takes the pool's next ray once "shadow_refill_min" (1..64) lanes
+ *                         are idle; the pool's last eight rays get eight lanes each ("lanes_per_ray")
+ *     "bounce_refill"     segments >= 1: 0 = closest hit, shading and emission fused in one lock-step kernel (default); 1 = closest hits
+ *                         through pools of "refill_pool" (64 / 128 / 256 (default) / 512) rays per wave with lane refill at "refill_min"
+ *                         idle lanes (k_closest_queue), then a shade-only pass (k_segment<PRETRACED>)
  *     "tri_min"           vote ratio of the closest-hit traversal loop (default 2); 0 = plain per-lane loop, which
  *                         trees under 64 nodes get anyway
- *     "tri_share"         triangle steps of the traversal loops hand the waiting lanes' pending triangles (up to 3 each) to ALL lanes
- *                         of the wave.  Bits 0..1, through wave-private LDS strips (ray, result): 0 off (default), 1 the closest-hit
- *                         walks of the bounce segments, 2 = 3 also their in-place shadow walks (the strips cap a CU at 18 waves: -10 %
- *                         at 6 waves per SIMD).  + 4 / + 8 / + 16 (CRT_EXPERIMENTS builds): the in-place shadow walks of every / the
- *                         first / the bounce segments in a lean form — no strips, the owner's ray comes by ds_bpermute, one ballot
- *                         says which items hit (bounce segments +1.6 %, superseded by "lanes_per_ray"; first segment -2.6 %)
  *     "lanes_per_ray"     8 (default) or 1: a lock-step batch starts with one ray per lane and ends on its longest rays (1 M triangles,
  *                         bounce segments: 37 % of the closest-hit node steps run with at most 8 of the 64 lanes enabled, 41 % of
  *                         the any-hit ones).  In the bounce segments' closest-hit and in-place shadow walks, once at most 8 rays of a
@@ -224,20 +231,15 @@ int crt_sync(crt_scene* s);
  *     "trace_pool"        crt_trace / crt_trace_device: rays per wave, 64 (default: one lock-step batch per single-wave workgroup, the
  *                         finest grain for the dispatcher — 2.07 M primary rays of the 1 M-triangle scene 0.153 ms against 0.346),
  *                         128 or 256 (a pool: a lane whose ray has finished takes the pool's next ray once "refill_min" lanes
- *                         (default 8, 1..64) are idle; worth 4 % on incoherent bounce rays, tools/refill_probe.py)
+ *                         (default 8, 1..64; 65 = never while a lane is busy) are idle; worth 4 % on incoherent bounce rays, tools/refill_probe.py)
  *     "gather_transport"  scenes on several devices (crt_set_devices): 0 = RCCL send / recv (default when librccl.so loads and the
  *                         devices are distinct), 1 = hipMemcpyPeerAsync
  *   experimental (a library built with `make EXPERIMENTS=1`, crt_has_experiments() != 0; otherwise only the default value is
  *   accepted) — variants that lost every measurement and are kept for re-measurement, bit-identical like the rest:
- *     "bounce_refill"     segments >= 1: 0 = lock-step segment kernel (default), 1 = closest hits through lane-refill
- *                         pools (k_closest_queue) + shade-only pass
  *     "oversubscribe"     0 = one 64-ray batch per workgroup, the hardware dispatcher balances (default); k >= 1 =
  *                         persistent grid of k x the resident workgroups with a static schedule, then
  *                         "trace_occupancy" = workgroups per CU
- *     "waves_per_workgroup" 1 (default), 2 or 4, per scene
- *     "compact_shadow"    with 2 or 4 waves per workgroup and in-place shadows, the workgroup's NEE shadow rays are gathered
- *                         through LDS into full waves before they are walked
- *     also: "tri_share" 1 / 2 then share triangle steps in the first segment too, and BVH2 frames are batched */
+ *     "waves_per_workgroup" 1 (default), 2 or 4, per scene */
 int crt_set_option(crt_scene* s, const char* name, int value);
 /* replaces the camera-moved clear, Scene.h:1160-1172 */
 int crt_reset(crt_scene* s);
@@ -268,7 +270,7 @@ int crt_debug_time_graph(crt_scene* s, uint32_t n_frames, const float* rxy, uint
  * one after the other in each wave; 1 = side by side on the waves of a workgroup (option "wave_samples") */
 int crt_debug_launch_form(crt_scene* s, int32_t* form);
 /* test hook: the same launch in full: info[0] = form as above (2 = four samples of a 4 x 4 pixel quadrant in the lanes of a wave),
- * info[1] = 1 when the first segment ran its 6-waves-per-SIMD build (option "wide_first"), info[2] = samples per pixel of the launch,
+ * info[1] = bit 0: the first segment ran its 6-waves-per-SIMD build (option "wide_first"), bit 1: a one-pass build (no sample loop), info[2] = samples per pixel of the launch,
  * info[3] = tile shards rendering side by side (option "streams" / crt_set_devices) */
 int crt_debug_launch_info(crt_scene* s, int32_t info[4]);
 /* measurement aid: hist[130] receives, for the counting frames ("count_visits") rendered since the previous call, how many node steps ran

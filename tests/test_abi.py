@@ -44,7 +44,7 @@ def test_struct_sizes_match_reference_layouts(cr, survey):
 def test_abi_version_and_error_string(cr):
     from caitlynrenderer_amd import _lib
     L = _lib.lib()
-    assert L.crt_abi_version() == 5
+    assert L.crt_abi_version() == 6
     h = C.c_void_p()
     rc = L.crt_load_obj(b"/nonexistent/file.obj", None, C.byref(h))
     assert rc == _lib.CRT_ERR_IO and b"not found" in L.crt_last_error()

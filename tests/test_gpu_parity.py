@@ -19,7 +19,7 @@ class _Experiments:
 
 
 EXPERIMENTS = _Experiments()
-EXPERIMENTAL_OPTIONS = {"bounce_refill", "oversubscribe", "waves_per_workgroup", "compact_shadow", "trace_occupancy"}
+EXPERIMENTAL_OPTIONS = {"oversubscribe", "waves_per_workgroup", "trace_occupancy"}
 
 
 def _assert_hits_equal(got, want):
@@ -156,11 +156,12 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
     W, H = 233, 131
     rnd = cr.Rnd()
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(19)]                  # 19 = 8 + 8 + 3
-    for depth, opts, shard in ((1, {}, None), (1, {"tri_share": 0}, None), (1, {"accel": 1}, None), (1, {"inplace_shadow": 0}, None),
-                               (2, {}, None), (1, {"waves_per_workgroup": 4, "compact_shadow": 0}, (1, 3)), (4, {}, None), (3, {"tri_share": 1}, (0, 2)),
-                               (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None),
+    for depth, opts, shard in ((1, {}, None), (1, {"lanes_per_ray": 1}, None), (1, {"accel": 1}, None), (1, {"inplace_shadow": 0}, None),
+                               (2, {}, None), (1, {"waves_per_workgroup": 4}, (1, 3)), (4, {}, None), (3, {"inplace_shadow": 2}, (0, 2)),
+                               (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None), (4, {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}, None),
+                               (3, {"inplace_shadow": 0}, None), (3, {"bounce_refill": 1, "inplace_shadow": 2, "refill_pool": 128}, None), (1, {"inplace_shadow": 2}, None),
                                (1, {"wave_samples": 0}, None), (3, {"wave_samples": 0}, (1, 2)), (1, {"wave_samples": 1, "accel": 1}, (2, 3)),
-                               (4, {"wave_samples": 1, "tri_share": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2)),
+                               (4, {"wave_samples": 1, "inplace_shadow": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2)),
                                (1, {"wave_samples": 3}, None), (1, {"wave_samples": 3, "wide_first": 1}, (1, 2)), (3, {"wave_samples": 3}, None),
                                (3, {"ray_bins": 1}, None), (4, {"ray_bins": 1}, (1, 2)), (2, {"ray_bins": 3, "wave_samples": 0}, None)):
         if name in ("tess8_mat",) and opts.get("accel"):
@@ -181,12 +182,12 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
         assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)), (name, depth, opts)
         # the stats of a batched launch are its totals: 3 samples in the last launch of 19 = 8 + 8 + 3 where batching applies
         st_a, st_b = a.frame_stats(), b.frame_stats()
-        inplace = opts.get("inplace_shadow", 1) == 1 or opts.get("accel", 0) != 0
-        if opts.get("accel", 0) != 0 and not EXPERIMENTS:
-            inplace = False                                                   # the default build renders BVH2 frames one by one
+        # launches share samples unless the FIRST segment defers its shadow rays (the batched builds walk them in place) or the frame
+        # goes through the BVH2 walks (rendered one by one)
+        batched = opts.get("inplace_shadow", 1) != 0 and opts.get("accel", 0) == 0
         if depth == 1:
-            assert st_b["closest_rays"] == (3 if inplace else 1) * st_a["closest_rays"]
-        elif inplace and not opts.get("bounce_refill"):
+            assert st_b["closest_rays"] == (3 if batched else 1) * st_a["closest_rays"]
+        elif batched:
             # several segments: 4 samples per launch (19 = 4 x 4 + 3), each with its own path state; radiance added in frame order afterwards
             assert 2.5 * st_a["closest_rays"] < st_b["closest_rays"] < 3.5 * st_a["closest_rays"]
         else:
@@ -404,10 +405,10 @@ def test_full_resolution_mesh_frame_with_visit_counters(cr, ob, cornell, tess40)
 def test_async_frames_and_timing_options_do_not_change_results(cr, scenes, inplace):
     """Frames queued back to back (counter banks alternate, the kernels clear the next frame's bank) with the
     event spans reduced / accumulated give the same sum and ray counts as synchronous frames with full timing.
-    inplace = 1: one launch per path segment; inplace = 0: the shadow queue + k_shadow pipeline, two launches."""
+    inplace = 1: one launch per path segment; inplace = 0: the segments' shadow rays deferred to one more launch per frame."""
     _, _, data = scenes["tess8"]
     W, H, depth, frames = 320, 200, 3, 7
-    per_seg = 1 if inplace else 2
+    per_frame = depth + (0 if inplace else 1)      # launches that carry events (the fold kernel is not a traversal launch)
     rnd = cr.Rnd()
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(frames)]
     a = cr.Scene(data, W, H, depth)
@@ -420,7 +421,7 @@ def test_async_frames_and_timing_options_do_not_change_results(cr, scenes, inpla
     for rx, ry in rvs:
         a.render_frame(rx, ry)
     want, want_st = a.read_sum(), a.frame_stats()
-    assert want_st["n_trace_launches"] == per_seg * depth and want_st["ms_trace_closest"] > 0 and (want_st["ms_trace_any"] > 0) == (not inplace)
+    assert want_st["n_trace_launches"] == per_frame and want_st["ms_trace_closest"] > 0 and (want_st["ms_trace_any"] > 0) == (not inplace)
     a.close()
     for timing in (0, 1, 2):
         b = cr.Scene(data, W, H, depth)
@@ -433,12 +434,12 @@ def test_async_frames_and_timing_options_do_not_change_results(cr, scenes, inpla
         st = b.frame_stats()
         assert np.array_equal(b.read_sum().view(np.uint32), want.view(np.uint32)), timing
         assert (st["closest_rays"], st["any_rays"]) == (want_st["closest_rays"], want_st["any_rays"])
-        assert st["n_trace_launches"] == (0, frames * depth, per_seg * frames * depth)[timing]
+        assert st["n_trace_launches"] == (0, frames * depth, frames * per_frame)[timing]
         assert (st["ms_trace_closest"] > 0) == (timing > 0) and (st["ms_trace_any"] > 0) == (timing > 1 and not inplace)
         b.set_option("timing_accumulate", 0)
         b.set_option("timing", 2)
         b.render_frame(*rvs[0])
-        assert b.frame_stats()["n_trace_launches"] == per_seg * depth
+        assert b.frame_stats()["n_trace_launches"] == per_frame
         b.close()
 
 
@@ -474,18 +475,21 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
     else:
         # the default build carries none of the variants that lost their measurements: asking for one is an error, their defaults are accepted
         other = cr.Scene(data, 64, 64, 1)
-        for k, v in (("waves_per_workgroup", 4), ("oversubscribe", 1), ("bounce_refill", 1)):
+        for k, v in (("waves_per_workgroup", 4), ("oversubscribe", 1)):
             with pytest.raises(cr.CrtError, match="CRT_EXPERIMENTS"):
                 other.set_option(k, v)
-        for k, v in (("waves_per_workgroup", 1), ("oversubscribe", 0), ("bounce_refill", 0), ("compact_shadow", 1)):
+        for k, v in (("waves_per_workgroup", 1), ("oversubscribe", 0), ("bounce_refill", 0)):
             other.set_option(k, v)
         other.close()
-    for options in ({"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
-                    {"waves_per_workgroup": 4, "compact_shadow": 0}, {"tri_share": 0}, {"tri_share": 1}, {"lanes_per_ray": 1}, {"lanes_per_ray": 1, "tri_share": 0}, {"lanes_per_ray": 8, "tri_min": 1}, {"tri_share": 4}, {"tri_share": 11}, {"tri_share": 4, "tri_min": 1}, {"tri_share": 2, "waves_per_workgroup": 4},
-                    {"tri_share": 0, "waves_per_workgroup": 2}, {"tri_share": 2, "tri_min": 1}, {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
+    for options in ({"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"lanes_per_ray": 1}, {"lanes_per_ray": 8, "tri_min": 1},
+                    {"waves_per_workgroup": 2, "oversubscribe": 2}, {"waves_per_workgroup": 2, "tri_min": 0},
                     {"accel": 1, "waves_per_workgroup": 4, "_ref": {"accel": 1}}, {"oversubscribe": 1}, {"oversubscribe": 3, "waves_per_workgroup": 4},
-                    {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5}, {"ray_bins": 1}, {"ray_bins": 2}, {"ray_bins": 4}, {"ray_bins": 5, "tri_share": 1}, {"ray_bins": 3, "tri_share": 0}, {"ray_bins": 1, "inplace_shadow": 0},
-                    {"bounce_refill": 1}, {"bounce_refill": 1, "refill_min": 1}, {"bounce_refill": 1, "refill_min": 40}, {"inplace_shadow": 0},
+                    {"trace_occupancy": 2, "oversubscribe": 1}, {"tri_min": 0}, {"tri_min": 1}, {"tri_min": 5}, {"ray_bins": 1}, {"ray_bins": 2}, {"ray_bins": 4}, {"ray_bins": 5},
+                    {"ray_bins": 3, "lanes_per_ray": 1}, {"ray_bins": 1, "inplace_shadow": 0}, {"ray_bins": 4, "inplace_shadow": 2},
+                    {"bounce_refill": 1}, {"bounce_refill": 1, "refill_min": 1}, {"bounce_refill": 1, "refill_min": 40, "refill_pool": 128},
+                    {"bounce_refill": 1, "refill_min": 65, "refill_pool": 64}, {"bounce_refill": 1, "lanes_per_ray": 1, "refill_pool": 512}, {"inplace_shadow": 0},
+                    {"inplace_shadow": 2}, {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}, {"inplace_shadow": 2, "shadow_pool": 128, "shadow_refill_min": 64, "lanes_per_ray": 1},
+                    {"inplace_shadow": 0, "shadow_pool": 512, "shadow_refill_min": 1}, {"inplace_shadow": 2, "bounce_refill": 1},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
         if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):
             continue
@@ -497,11 +501,11 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
 
 
 @pytest.mark.parametrize("name,depth", [("tess8", 3), ("tess40", 4)])
-def test_shared_triangle_steps_keep_sums_and_counters(cr, ob, scenes, disney_scenes, name, depth):
-    """`tri_share`: triangle steps of the voting loop hand the waiting lanes' pending triangles to all lanes of the wave
-    (1: closest-hit walk, 2: also the in-place shadow rays).  Same tests with the same operands in the same order per ray:
-    radiance, ray counts and the per-block visit totals equal the default's and the oracle's; only the number of
-    wave-level triangle steps drops."""
+def test_deferred_shadow_rays_keep_sums_and_counters(cr, ob, scenes, disney_scenes, name, depth):
+    """`inplace_shadow` 2 / 0: the NEE shadow rays of the bounce segments / of every segment wait in the frame's NEE queue and are walked by ONE
+    any-hit launch behind the last segment (lock-step batches of 64, or pools with lane refill), an occluded ray clears its contribution
+    slot, and a last kernel adds every path's slots in segment order.  Same rays, same walks, the same additions in the same order: radiance,
+    ray counts and visit totals equal the in-place form's and the oracle's; what changes is how full the waves of the any-hit walks are."""
     _, _, data = scenes[name]
     W, H = 320, 184
     for d in (data, disney_scenes[0][name]):
@@ -513,25 +517,24 @@ def test_shared_triangle_steps_keep_sums_and_counters(cr, ob, scenes, disney_sce
         for rx, ry in rvs:
             _, cnt = orc.render_frame(rx, ry, ref, threads=8)
         steps = {}
-        for share in (0, 1, 2, 3, 4, 8, 7, 16, -1):  # + 4 / + 8 / + 16: the in-place shadow walk shares its triangle steps in the lean form (every segment / first / bounce only); -1: the defaults
+        for key, opts in (("inplace", {}), ("bounce", {"inplace_shadow": 2}), ("all", {"inplace_shadow": 0}),
+                          ("bounce_pool", {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}), ("bounce_one_lane", {"inplace_shadow": 2, "lanes_per_ray": 1}),
+                          ("refill", {"bounce_refill": 1}), ("wavefront", {"bounce_refill": 1, "inplace_shadow": 2, "refill_pool": 128, "shadow_pool": 128, "shadow_refill_min": 16})):
             s = cr.Scene(d, W, H, depth)
-            if share >= 0:
-                s.set_option("tri_share", share)
-                s.set_option("lanes_per_ray", 1)     # the sharing forms by themselves; the default (lanes per ray growing as the wave drains) is case -1
+            for k, v in opts.items():
+                s.set_option(k, v)
             s.set_option("count_visits", 1)
             for rx, ry in rvs:
                 s.render_frame(rx, ry)
             st = s.frame_stats()
-            assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["stack_overflows"] == 0, share
-            assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3], share
-            assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32)), share
-            steps[share] = (st["wave_steps_closest_tris"], st["wave_steps_any_tris"], st["tris_closest"], st["tris_any"])
+            assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and st["stack_overflows"] == 0, key
+            assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3], key
+            assert np.array_equal(s.read_sum().view(np.uint32), ref.view(np.uint32)), key
+            steps[key] = (st["wave_steps_any_nodes"], st["wave_steps_closest_nodes"], st["nodes_closest"], st["tris_closest"], st["nodes_any"], st["tris_any"])
             s.close()
-        assert steps[0][2:] == steps[1][2:] == steps[2][2:] == steps[3][2:] == steps[4][2:] == steps[8][2:] == steps[7][2:] == steps[16][2:] == steps[-1][2:]
-        assert steps[1][0] < steps[0][0] and steps[2][1] < steps[0][1]              # fewer wave-level triangle steps
-        if EXPERIMENTS:                                                                   # the lean shared shadow walk exists in an experiments build only
-            assert steps[4][1] < 0.7 * steps[0][1] and steps[16][1] < 0.7 * steps[0][1] and steps[8][1] < steps[0][1]
-        assert steps[-1][1] < steps[0][1]                                                 # four lanes per ray once the wave has drained: a leaf's triangles side by side
+        assert len({v[2:] for v in steps.values()}) == 1                                  # the same visits, block by block
+        assert steps["bounce"][0] < steps["inplace"][0] and steps["all"][0] < steps["inplace"][0]      # fuller waves: fewer wave-level any-hit node steps
+        assert steps["refill"][1] < steps["inplace"][1]                                   # and fewer closest-hit ones through the refilled pools
 
 
 @pytest.mark.parametrize("T", [16, 24])
@@ -912,7 +915,7 @@ def test_million_triangle_mesh_full_frame(cr, ob, mesh1m):
         assert 0.9 * W * H < st["nodes_closest_uniform"] < st["nodes_closest"] and 0 < st["nodes_any_uniform"] < st["nodes_any"]
         out = scene.read_sum()
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frame, float(np.abs(out - ref).max()))
-    # the same frame through the shadow queue + k_shadow pipeline (inplace_shadow = 0): same sum, and its queue feeds the
+    # the same frame with every segment's shadow rays deferred (inplace_shadow = 0): same sum, and the NEE queue feeds the
     # any-hit / closest-hit consistency check below
     scene.set_option("inplace_shadow", 0)
     scene.reset()
@@ -1130,7 +1133,7 @@ def test_the_launches_bench_times_equal_the_oracle_at_full_size(cr, ob, mesh1m):
             _bench_step(s, rvs[4 * k:4 * k + 4])
             s.sync()
             info = s.debug_launch_info()
-            assert info == {"form": 2, "wide": True, "samples": 4, "shards": 1}, (label, k, info)
+            assert info == {"form": 2, "wide": True, "one_pass": True, "samples": 4, "shards": 1}, (label, k, info)
         out = s.read_sum()
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (label, float(np.abs(out - ref).max()))
         assert s.frame_stats()["stack_overflows"] == 0
@@ -1296,7 +1299,7 @@ def test_special_materials_restrictions_and_options(cr, ob, disney_scenes):
         return out
 
     want = run({})
-    for options in ({"bounce_refill": 1}, {"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"waves_per_workgroup": 2, "compact_shadow": 0},
+    for options in ({"bounce_refill": 1}, {"waves_per_workgroup": 4}, {"waves_per_workgroup": 2}, {"inplace_shadow": 2},
                     {"oversubscribe": 2}, {"tri_min": 0}, {"inplace_shadow": 0, "tri_min": 3}):
         if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):
             continue
@@ -1900,7 +1903,7 @@ def test_bench_line_contract(tmp_path):
         for k, e in d["extras"].items():
             if e.get("counter_frac"):
                 assert e["frac"] <= e["counter_frac"] + 1e-3, (k, e["frac"], e["counter_frac"])
-    assert cfg["launch"] == {"form": 2, "wide": True, "samples": 4, "shards": 1} and d["sum_rows_match_oracle"] is True
+    assert cfg["launch"] == {"form": 2, "wide": True, "one_pass": True, "samples": 4, "shards": 1} and d["sum_rows_match_oracle"] is True
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mray/s" and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] > 1000 and abs(d["value"] - cfg["rays_per_step"] / d["ms_per_step"] / 1e3) / d["value"] < 0.01

@@ -49,10 +49,13 @@ for case in range(n_cases):
     opts = {"streams": int(rng.choice([1, 1, 1, 2, 2, 3]))}      # the frame on one stream, or its tile shards side by side on two or three
     opts["accel"] = accel
     if accel == 0:
-        opts.update(inplace_shadow=int(rng.random() < 0.7), tri_min=int(rng.choice([0, 1, 2, 2, 3])), tri_share=int(rng.choice([0, 1, 2, 3, 3, 4, 4, 7, 8, 11, 16, 16, 16])), lanes_per_ray=int(rng.choice([1, 8, 8])))
+        # shadow rays in place / deferred to one launch per frame (every segment's, or the bounce segments'), closest hits of the bounce
+        # segments fused or through refilled pools
+        opts.update(inplace_shadow=int(rng.choice([1, 1, 1, 2, 2, 0])), tri_min=int(rng.choice([0, 1, 2, 2, 3])), lanes_per_ray=int(rng.choice([1, 8, 8])),
+                    bounce_refill=int(rng.random() < 0.3), refill_pool=int(rng.choice([64, 128, 256, 512])), refill_min=int(rng.choice([1, 8, 8, 32, 65])),
+                    shadow_pool=int(rng.choice([64, 64, 128, 256])), shadow_refill_min=int(rng.choice([65, 65, 8, 32])))
         if EXPERIMENTS:          # variants of a `make EXPERIMENTS=1` library only
-            opts.update(bounce_refill=int(rng.random() < 0.3), oversubscribe=int(rng.choice([0, 0, 0, 1, 2])),
-                        waves_per_workgroup=int(rng.choice([1, 1, 2, 4])), compact_shadow=int(rng.random() < 0.5))
+            opts.update(oversubscribe=int(rng.choice([0, 0, 0, 1, 2])), waves_per_workgroup=int(rng.choice([1, 1, 2, 4])))
     opts["ray_bins"] = int(rng.choice([0, 0, 1, 1, 2, 3, 4, 4, 5]))     # bounce rays in emission order or binned by (octant, origin cell)
     opts["adaptive_tiles"] = int(rng.random() < 0.7)          # cost-sorted or centre-out tile order: the same pixels either way
     opts["wave_samples"] = int(rng.choice([0, 1, 2, 2, 3]))   # the samples of a launch in one wave, on the waves of a workgroup, or four in the lanes of a wave
@@ -75,8 +78,7 @@ for case in range(n_cases):
         scene.render_frames(rvs)
         tot = np.zeros(2, np.int64)
         last = np.zeros(2, np.int64)
-        per_launch = 8 if (((accel != 0 and EXPERIMENTS) or (accel == 0 and opts.get("inplace_shadow", 1) == 1)) and (depth == 1 or not opts.get("bounce_refill", 0))
-                           and not (opts.get("compact_shadow", 1) and (opts.get("tri_share", 0) & 3) == 0 and opts.get("waves_per_workgroup", 1) > 1)) else 1
+        per_launch = 8 if (accel == 0 and opts.get("inplace_shadow", 1) != 0) else 1       # crt_device.cpp batch_limit
         # the library's own split of a call into launches (crt_render_frames_async): up to per_launch frames each, and where four samples
         # can sit in the lanes of a wave (wave_samples >= 2, a tree of 64+ nodes, CWBVH) a launch of 5..7 frames goes as 4 + the rest
         fours = opts.get("wave_samples", 2) >= 2 and scene.bvh_info()["n_nodes8"] >= 64 and accel == 0
