@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CRT_LIB points the binding at another build of the same library (A/B measurements of kernel variants in one gpurun call)
 LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt.so")
 
-CRT_ABI_VERSION = 6
+CRT_ABI_VERSION = int(os.environ.get("CRT_LIB_ABI", "6"))      # CRT_LIB_ABI: with CRT_LIB, an older build of the library measured beside this one (tools/ab_run.sh)
 CRT_OK, CRT_ERR_INVALID, CRT_ERR_NO_DEVICE, CRT_ERR_HIP, CRT_ERR_IO, CRT_ERR_LIMIT, CRT_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 CRT_TRACE_CLOSEST, CRT_TRACE_ANY, CRT_TRACE_BVH2, CRT_TRACE_TIE_LOWEST_ID = 0, 1, 2, 4
 CRT_BUILD_LBVH_ON_DEVICE = 1

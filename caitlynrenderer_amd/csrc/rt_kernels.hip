@@ -1451,6 +1451,23 @@ __device__ __forceinline__ vec3 disney_sample(const Disney& m, vec3 n, vec3 wo, 
 }
 
 // ------------------------------------------------------------------ path segment -----
+// The kernel's argument block through the kernarg segment pointer, passed through an empty asm statement: a member read through the
+// result is a scalar load placed where it is written (the compiler cannot hoist it above the statement), not one of the loads the
+// by-value argument gets in the kernel's entry block.
+typedef const __attribute__((address_space(4))) SegmentArgs* KArgs;
+__device__ __forceinline__ RayBins load_bins(KArgs k) {
+    RayBins b;
+    b.count = k->bins_out.count; b.cap = k->bins_out.cap; b.off = k->bins_out.off; b.ovf_count = k->bins_out.ovf_count;
+    b.ovf_base = k->bins_out.ovf_base; b.per_lane = k->bins_out.per_lane;
+    for (int i = 0; i < 3; ++i) { b.origin[i] = k->bins_out.origin[i]; b.scale[i] = k->bins_out.scale[i]; }
+    return b;
+}
+__device__ __forceinline__ KArgs kernarg_here() {
+    KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 #ifndef CRT_SEG_OCC
 // Waves per SIMD the segment kernels are compiled for: 6 (80 VGPRs).  Until round 4 the bounce kernels needed 90-96 VGPRs and lost 20 % when
 // forced to 80 (spills); since the register diet (hit record in LDS, path state fetched after the walk, shadow walk after the bounce
@@ -1657,20 +1674,24 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                                                    nn, nt, wn, wt, V3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]), &nu, a.planes);
         }
 
+        // Everything the shading code reads from the argument block is fetched HERE, behind the closest-hit walk, through a laundered
+        // kernarg pointer: arguments used by value are all loaded in the kernel's first block and then live (or are spilled into VGPR lanes)
+        // across both walks — ~40 scalar registers of pointers and counts the loops never look at.
+        const KArgs ka = kernarg_here();
         if (!FIRST && active) {
             // Path state of a ray that came through the queue: radiance so far, throughput, RNG state, flags.  Fetched here, behind the
             // closest-hit walk, instead of where the ray is fetched: a dozen values the walk never looks at would otherwise sit in
             // VGPRs through its whole loop (the bounce kernels are the ones short of registers: 90-96 VGPRs at 5 waves per SIMD).
             asm volatile("" : "+v"(pix));                  // keeps the loads below the loop (they depend on this copy of the index)
-            if (a.l_final) {                               // a batched frame: the path belongs to sample pix / n_local_pixels, with that frame's randomVector
+            if (ka->l_final) {                               // a batched frame: the path belongs to sample pix / n_local_pixels, with that frame's randomVector
                 const uint32_t smp_of = pix / f.n_local_pixels;
-                rv = a.rv_s[0];
-                for (uint32_t k = 1; k < 8u; ++k) rv = smp_of == k ? a.rv_s[k] : rv;
+                rv = ka->rv_s[0];
+                for (uint32_t k = 1; k < 8u; ++k) rv = smp_of == k ? ka->rv_s[k] : rv;
             }
-            const float4 Tp = a.pb.T[pix];
-            const float2 sd = a.pb.seed[pix];
-            if (INPLACE) { const float4 Lp = a.pb.L[pix]; L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w; }
-            else prev_pdf = a.pb.L[pix].w;                 // a deferred segment adds nothing to L itself: the radiance so far is fetched when the path ends
+            const float4 Tp = ka->pb.T[pix];
+            const float2 sd = ka->pb.seed[pix];
+            if (INPLACE) { const float4 Lp = ka->pb.L[pix]; L = V3(Lp.x, Lp.y, Lp.z); prev_pdf = Lp.w; }
+            else prev_pdf = ka->pb.L[pix].w;                 // a deferred segment adds nothing to L itself: the radiance so far is fetched when the path ends
             T = V3(Tp.x, Tp.y, Tp.z);
             is_specular = (__float_as_uint(Tp.w) & 1u) != 0u;
             true_area = (__float_as_uint(Tp.w) & 2u) != 0u;
@@ -1681,7 +1702,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
         // segment order afterwards); slot_mask = the slots written so far, bit 8 + segment, kept in the path state's flag word
         auto contribute = [&](vec3 c) {
             if (INPLACE) L = L + c;
-            else { a.contrib[pix] = make_float4(c.x, c.y, c.z, 1.0f); slot_mask |= a.slot_bit; }
+            else { ka->contrib[pix] = make_float4(c.x, c.y, c.z, 1.0f); slot_mask |= ka->slot_bit; }
         };
         bool emit_shadow = false, emit_next = false, finished = active, pending = false;
         float pend_pdf = 0.f;
@@ -1693,19 +1714,19 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
             const size_t rec_rows = BVH2 ? 3u : (size_t)CRT_TRI_ROWS;            // the BVH2 walk's slot-ordered records stay packed
             const float4 tb = recs[rec_rows * (size_t)hit.tri + 1], tc = recs[rec_rows * (size_t)hit.tri + 2];
             const int slot = __float_as_int(tb.w), mtl = __float_as_int(tc.w);
-            const int4 vn = a.triangles[3 * (size_t)slot + 1];                    // path_trace.fs:440-454
+            const int4 vn = ka->triangles[3 * (size_t)slot + 1];                    // path_trace.fs:440-454
             vec3 n;
             if (vn.w == 0) n = V3((float)vn.x, (float)vn.y, (float)vn.z);
             else {
-                const float* N = a.normals;
+                const float* N = ka->normals;
                 const vec3 na = V3(N[3 * (size_t)vn.x], N[3 * (size_t)vn.x + 1], N[3 * (size_t)vn.x + 2]);
                 const vec3 nb = V3(N[3 * (size_t)vn.y], N[3 * (size_t)vn.y + 1], N[3 * (size_t)vn.y + 2]);
                 const vec3 nc = V3(N[3 * (size_t)vn.z], N[3 * (size_t)vn.z + 1], N[3 * (size_t)vn.z + 2]);
                 const float w = 1.0f - bu - bv;
                 n = (na * w + nb * bu) + nc * bv;
             }
-            const float4 m_albedo = a.materials[4 * (size_t)mtl], m_emission = a.materials[4 * (size_t)mtl + 1],
-                         m_specular = a.materials[4 * (size_t)mtl + 2];
+            const float4 m_albedo = ka->materials[4 * (size_t)mtl], m_emission = ka->materials[4 * (size_t)mtl + 1],
+                         m_specular = ka->materials[4 * (size_t)mtl + 2];
             const float cos_incident = dot(d, n);
             const vec3 original_n = n;
             if (cos_incident > 0) n = -n;
@@ -1719,7 +1740,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                     const float cos_light = -1.0f * dot(ld, n);
                     const float len2 = len * len;
                     const int li = (int)m_emission.w;
-                    const float* ap = a.lights + 18 * (size_t)li + 15;
+                    const float* ap = ka->lights + 18 * (size_t)li + 15;
                     float pdf_light = __fdiv_rn(len2, ap[0] * cos_light) * ap[1];
                     if (MAT && true_area) pdf_light = 2.0f * pdf_light;           // the previous vertex was a Disney one (below)
                     const float tt = prev_pdf * prev_pdf;                         // power_heuristic :214-218
@@ -1730,10 +1751,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                 const vec3 hit_point = (o + d * t) + n * 0.0002f;                 // path_trace.fs:930
                 vec3 albedo = V3(m_albedo.x, m_albedo.y, m_albedo.z);
                 if (TEX) {                                                        // path_trace.fs:471-483
-                    const float tex = a.materials[4 * (size_t)mtl + 3].x;
-                    if (tex != -1.0f && a.textures != nullptr) {
-                        const int4 vt = a.triangles[3 * (size_t)slot + 2];
-                        const float2 ta = a.texcoords[vt.x], tb2 = a.texcoords[vt.y], tc2 = a.texcoords[vt.z];
+                    const float tex = ka->materials[4 * (size_t)mtl + 3].x;
+                    if (tex != -1.0f && ka->textures != nullptr) {
+                        const int4 vt = ka->triangles[3 * (size_t)slot + 2];
+                        const float2 ta = ka->texcoords[vt.x], tb2 = ka->texcoords[vt.y], tc2 = ka->texcoords[vt.z];
                         const float w = 1.0f - bu - bv;
                         const float tu = (ta.x * w + tb2.x * bu) + tc2.x * bv;
                         const float tv = (ta.y * w + tb2.y * bu) + tc2.y * bv;
@@ -1750,11 +1771,11 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                     const vec3 ns = normalize(n);
                     const float dn = dot(d, ns);
                     T = T * albedo;
-                    if (!a.last_segment) {
+                    if (!ka->last_segment) {
                         const vec3 rdir = d - ns * (2.0f * dn);
-                        if (INPLACE || FIRST) a.pb.L[pix] = make_float4(L.x, L.y, L.z, prev_pdf);      // (a deferred bounce segment leaves (L, pdf) as they are)
-                        a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(1u | slot_mask));
-                        a.pb.seed[pix] = make_float2(sx, sy);
+                        if (INPLACE || FIRST) ka->pb.L[pix] = make_float4(L.x, L.y, L.z, prev_pdf);      // (a deferred bounce segment leaves (L, pdf) as they are)
+                        ka->pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float(1u | slot_mask));
+                        ka->pb.seed[pix] = make_float2(sx, sy);
                         emit_next = true;
                         finished = false;
                         nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
@@ -1767,12 +1788,12 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                     Disney dm;
                     if (disney) { ns = normalize(n); dm = disney_params(albedo, m_specular.x, m_specular.y); }
                     if (m_specular.w == 0.0f) {
-                        if (a.n_lights <= 0) {
+                        if (ka->n_lights <= 0) {
                             shader_rand(sx, sy, rv); shader_rand(sx, sy, rv); shader_rand(sx, sy, rv);
                         } else {
-                            int li = (int)(shader_rand(sx, sy, rv) * (float)(int)here((uint32_t)a.n_lights));
-                            if (li > a.n_lights - 1) li = a.n_lights - 1;
-                            const float* Lt = a.lights + 18 * (size_t)li;
+                            int li = (int)(shader_rand(sx, sy, rv) * (float)(int)here((uint32_t)ka->n_lights));
+                            if (li > ka->n_lights - 1) li = ka->n_lights - 1;
+                            const float* Lt = ka->lights + 18 * (size_t)li;
                             const float sq = sqrt_ieee(shader_rand(sx, sy, rv));    // :843-855
                             const float b0 = 1.0f - sq;
                             const float b1 = shader_rand(sx, sy, rv) * sq;
@@ -1817,11 +1838,11 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                                     contribute(c);
                                 }
                                 sh0 = make_float4(hit_point.x, hit_point.y, hit_point.z, len - CRT_EPS);
-                                sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(INPLACE ? pix : a.slot_first + pix));
+                                sh1 = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(INPLACE ? pix : ka->slot_first + pix));
                             }
                         }
                     }
-                    if (!a.last_segment) {
+                    if (!ka->last_segment) {
                         vec3 sdir;
                         float bsdf_pdf;
                         bool go_on = true;
@@ -1848,10 +1869,10 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                         }
                         if (go_on) {
                             if (INPLACE && pending) pend_pdf = bsdf_pdf;              // whoever walks the shadow ray writes L (+ C) and this pdf
-                            else if (INPLACE || FIRST) a.pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
-                            else reinterpret_cast<float*>(a.pb.L + pix)[3] = bsdf_pdf;      // deferred bounce segment: the radiance so far stays where it is
-                            a.pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float((disney ? 2u : 0u) | slot_mask));   // bit 0 is_specular, bit 1 true_area, bits 8.. slots written
-                            a.pb.seed[pix] = make_float2(sx, sy);
+                            else if (INPLACE || FIRST) ka->pb.L[pix] = make_float4(L.x, L.y, L.z, bsdf_pdf);
+                            else reinterpret_cast<float*>(ka->pb.L + pix)[3] = bsdf_pdf;      // deferred bounce segment: the radiance so far stays where it is
+                            ka->pb.T[pix] = make_float4(T.x, T.y, T.z, __uint_as_float((disney ? 2u : 0u) | slot_mask));   // bit 0 is_specular, bit 1 true_area, bits 8.. slots written
+                            ka->pb.seed[pix] = make_float2(sx, sy);
                             emit_next = true;
                             finished = false;
                             nx0 = make_float4(hit_point.x, hit_point.y, hit_point.z, CRT_INF);
@@ -1861,12 +1882,13 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                 }
             }
         }
-        if (a.bins_out.count) {
+        if (ka->bins_out.count) {
+            const RayBins bins_out = load_bins(ka);
             CRT_MARK("loop_begin bins");      // the optional bins are not part of the instruction model (tools/roofline.py): bracketed like a loop
             // the wave's own stack region is free between the walks: the LDS table of the ranked append (3 KB) lives there when it fits
             uint32_t* const tab = wave_stride * 8u >= 3072u ? reinterpret_cast<uint32_t*>(s_lds + (size_t)wid.lds_wave * wave_stride) : nullptr;
-            const uint32_t ni = bin_append(a.bins_out, emit_next, ray_bin_key(a.bins_out, nx0, nx1), tab);
-            if (emit_next) { a.rays_next[2 * (size_t)ni] = nx0; a.rays_next[2 * (size_t)ni + 1] = nx1; }
+            const uint32_t ni = bin_append(bins_out, emit_next, ray_bin_key(bins_out, nx0, nx1), tab);
+            if (emit_next) { ka->rays_next[2 * (size_t)ni] = nx0; ka->rays_next[2 * (size_t)ni + 1] = nx1; }
             CRT_MARK("loop_end");
         } else {
             const uint32_t ni = wave_append(emit_next, count_next);
@@ -1909,14 +1931,15 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
             }
             finished = false;
         }
+        const KArgs kb = kernarg_here();                   // what is read from here on is fetched now, not carried through the walk above
         // a path that ends here with nothing pending adds its radiance to the running sum now
         if (finished && !pending) {
             // several samples per launch on a path of several segments: the samples of a pixel finish in different launches, so each
             // leaves its radiance at its own place and k_fold_paths adds them in the order the frames would have come
-            if (a.l_final) a.l_final[pix] = make_float4(L.x, L.y, L.z, 0.f);
-            else if (!wave_samples && !lane_samples && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(a.sum, (FIRST && BATCH) ? e : pix, L);
+            if (kb->l_final) kb->l_final[pix] = make_float4(L.x, L.y, L.z, 0.f);
+            else if (!wave_samples && !lane_samples && (L.x != 0.f || L.y != 0.f || L.z != 0.f)) add_to_sum(kb->sum, (FIRST && BATCH) ? e : pix, L);
         }
-        if (lane_samples && !a.l_final) {
+        if (lane_samples && !kb->l_final) {
             // the four samples of a pixel sit in lanes j, j + 16, j + 32, j + 48: lane j adds them in sample order — what the frames one
             // after the other would add, zero radiance skipped as everywhere
             const bool mine = finished && !pending;
@@ -1932,7 +1955,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                 any_nz = any_nz || rx[k] != 0.f || ry[k] != 0.f || rz[k] != 0.f;
             }
             if (lane < 16u && e < n && any_nz) {
-                float* const sp3 = a.sum + 3 * (size_t)e;
+                float* const sp3 = kb->sum + 3 * (size_t)e;
                 float s0 = sp3[0], s1 = sp3[1], s2 = sp3[2];
 #pragma unroll
                 for (uint32_t k = 0; k < 4u; ++k)
@@ -1940,7 +1963,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
                 sp3[0] = s0; sp3[1] = s1; sp3[2] = s2;
             }
         }
-        if (wave_samples && !a.l_final) {
+        if (wave_samples && !kb->l_final) {
             // the waves' samples of this batch, added in sample order by wave 0 (what the frames one after the other would add)
             // behind the workgroup's stacks, whose size per wave is the larger of the two kinds of stack as in launch_segment
             const uint32_t stack_words = BVH2 && a.stack_entries2 * 64u > 2u * wave_stride ? a.stack_entries2 * 64u : 2u * wave_stride;
@@ -1949,9 +1972,9 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
             s_res[wid.lds_wave * 64u + lane] = mine ? make_float4(L.x, L.y, L.z, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
             if (wid.lds_wave == 0u && e < n) {
-                for (uint32_t k = 0; k < ws_waves && smp_it * ws_waves + k < a.n_samples; ++k) {
+                for (uint32_t k = 0; k < ws_waves && smp_it * ws_waves + k < kb->n_samples; ++k) {
                     const float4 r = s_res[k * 64u + lane];
-                    if (r.w != 0.f && (r.x != 0.f || r.y != 0.f || r.z != 0.f)) add_to_sum(a.sum, e, V3(r.x, r.y, r.z));
+                    if (r.w != 0.f && (r.x != 0.f || r.y != 0.f || r.z != 0.f)) add_to_sum(kb->sum, e, V3(r.x, r.y, r.z));
                 }
             }
             __syncthreads();                                       // persistent grids: the next pass reuses the strip

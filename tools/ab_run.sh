@@ -10,6 +10,7 @@ IFS=';' read -ra RUNS <<< "$AB_RUNS"
 for RUN in "${RUNS[@]}"; do
   RL=${RUN%%|*}; ARGS=${RUN#*|}
   for BL in "${LIBS[@]}"; do
+    unset CRT_LIB_ABI; [ -f "$R/variants/$BL/abi" ] && export CRT_LIB_ABI=$(cat "$R/variants/$BL/abi")
     if [ "$BL" = default ]; then unset CRT_LIB; else export CRT_LIB="$R/variants/$BL/libcrt.so"; [ -f "$CRT_LIB" ] || { echo "$BL: no such variant"; continue; }; fi
     timeout -k 10 ${AB_TIMEOUT:-240} python3 "$R/bench.py" --gpus 1 --no-cpu-baseline --no-live-pmc ${AB_CHECK:---no-oracle-check} --steps ${AB_STEPS:-30} --warmup 5 $ARGS > "$OUT/${BL}_$RL.json" 2> "$OUT/${BL}_$RL.log"
     python3 - "$BL" "$RL" "$OUT/${BL}_$RL.json" <<'PY' | tee -a "$OUT/table.txt"
@@ -22,4 +23,4 @@ except Exception as e:
 PY
   done
 done
-unset CRT_LIB
+unset CRT_LIB CRT_LIB_ABI

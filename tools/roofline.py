@@ -61,7 +61,7 @@ def demangle_args(name):
     return [int(x) for x in re.findall(r"Lb([01])E", m.group(1))] if m else None
 
 
-SEG_PARAMS = ["FIRST", "STATS", "TEX", "PRETRACED", "INPLACE", "BVH2", "MAT", "COMPACT", "SHARE", "BATCH", "WIDE", "ONE"]
+SEG_PARAMS = ["FIRST", "STATS", "TEX", "PRETRACED", "INPLACE", "BVH2", "MAT", "BATCH", "WIDE", "ONE"]
 
 
 def label_of(name):
@@ -188,10 +188,10 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
     remarks = remarks or os.path.join(csrc, "rt_kernels.remarks")
     k = parse_asm(asm)
     # the kernels the bench line is made of
-    want = {"first": [1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1],     # <FIRST, INPLACE, BATCH, WIDE, ONE>: 4 samples per launch in the lanes of a wave, Lambert
-            "first_single": [1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0],
-            "bounce": [0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0],    # <INPLACE, SHARE>
-            "bounce_plain": [0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0]}
+    want = {"first": [1, 0, 0, 0, 1, 0, 0, 1, 1, 1],     # <FIRST, INPLACE, BATCH, WIDE, ONE>: 4 samples per launch in the lanes of a wave, Lambert
+            "first_single": [1, 0, 0, 0, 1, 0, 0, 0, 0, 0],
+            "bounce_plain": [0, 0, 0, 0, 1, 0, 0, 0, 0, 0],   # <INPLACE>: closest hit + in-place shadow walk
+            "bounce_deferred": [0, 0, 0, 0, 0, 0, 0, 0, 0, 0]}    # <>: closest hit only, shadow rays left to k_shadow_deferred
     counts = {"source": "VALU instructions between the CRT_MARK lines of `make -C caitlynrenderer_amd/csrc asm` (rt_kernels.s, -DCRT_ISA_MARKS); "
                         "regions in order of appearance: closest-hit loop first, in-place any-hit loop second",
               "peak_gwave_instr_per_s": PEAK_GINSTR, "attainable_gwave_instr_per_s": round(ATTAINABLE_GINSTR, 1),

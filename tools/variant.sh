@@ -10,8 +10,12 @@ L=$1; EX=${2:-}; shift; shift || true
 W=$(mktemp -d /tmp/crt_variant_XXXXXX)
 trap 'rm -rf "$W"' EXIT
 mkdir -p "$W/caitlynrenderer_amd" "$W/include" "$R/variants/$L"
-cp -r "$R/caitlynrenderer_amd/csrc" "$W/caitlynrenderer_amd/csrc"
-cp "$R"/include/*.h "$W/include/"
+if [ -n "${VARIANT_REF:-}" ]; then      # VARIANT_REF=<commit>: that commit's sources instead of the working tree's
+  git -C "$R" archive "$VARIANT_REF" caitlynrenderer_amd/csrc include | tar -x -C "$W"
+else
+  cp -r "$R/caitlynrenderer_amd/csrc" "$W/caitlynrenderer_amd/csrc"
+  cp "$R"/include/*.h "$W/include/"
+fi
 find "$W" -name '*.o' -delete
 make -C "$W/caitlynrenderer_amd/csrc" -s -j4 EXTRA="$EX" "$@" > "$R/variants/$L/build.log" 2>&1 || { echo "variant $L: build FAILED"; tail -20 "$R/variants/$L/build.log"; exit 1; }
 cp "$W/caitlynrenderer_amd/libcrt.so" "$R/variants/$L/libcrt.so"
