@@ -38,8 +38,13 @@ namespace {
 constexpr int kMaxEvents = 8 + 8 * 16;
 constexpr uint32_t kCounterStride = 32;                        // == CRT_COUNTER_STRIDE in rt_kernels.hip (128 B)
 // kind 0 = rays into the segment, 1 = its shadow rays
-constexpr uint32_t kCounters = 2 * 17 * 8 * kCounterStride;    // (segment, kind, group) x stride
+constexpr uint32_t kQueueCounters = 2 * 17 * 8 * kCounterStride;    // (segment, kind, group) x stride
 inline uint32_t counter_index(uint32_t seg, uint32_t kind, uint32_t group) { return ((seg * 2 + kind) * 8 + group) * kCounterStride; }
+// behind them, in the same banks (cleared with them): the cursors of the persistent grids (rt_kernels.hip PoolStream) — one per sub-queue of
+// a segment's path-ray queue (k_closest_queue), one per (region, sub-queue) of the frame's NEE queue (k_shadow_deferred)
+inline uint32_t cursor_index_closest(uint32_t seg) { return kQueueCounters + seg * 8 * kCounterStride; }
+constexpr uint32_t kCursorShadow = kQueueCounters + 17 * 8 * kCounterStride;
+constexpr uint32_t kCounters = kCursorShadow + 17 * 8 * kCounterStride;
 
 struct EventSpan { hipEvent_t a = nullptr, b = nullptr; int kind = 0; };   // kind: 0 raygen 1 closest 2 any 3 shade/other
 
@@ -123,8 +128,14 @@ struct crt_scene {
     // segments >= 1: 0 = fused lock-step k_segment (default); 1 = closest hits through lane-refill pools (k_closest_queue) + shade-only pass
     uint32_t bounce_refill = 0;
     uint32_t refill_pool = 256;               // rays per wave of k_closest_queue (64 with refill_min 65: lock-step batches)
-    uint32_t shadow_pool = 64;                // rays per wave of k_shadow_deferred
-    uint32_t shadow_refill_min = 65;          // idle lanes that trigger a refill there (65: never — one lock-step batch per 64 rays of the pool)
+    // k_shadow_deferred: rays per pool / per chunk a wave reserves, and the idle lanes that trigger a refill (65: never — one lock-step
+    // batch per 64 rays of the pool).  1 M triangles, four segments: lock-step 64 7.34, static pools 128 / 16 7.42 (7.61 - 7.67 after the
+    // kernarg change), persistent 256 / 16 7.72 Gray/s
+    uint32_t shadow_pool = 256;
+    uint32_t shadow_refill_min = 16;
+    // the pool launches (k_shadow_deferred, k_closest_queue) as PERSISTENT grids: as many waves as the chip holds, each reserving chunks of
+    // `pool` rays through per-queue cursors until every queue is dry; 0 = one workgroup per pool
+    uint32_t persistent = 1;
     // crt_render_frames, how the samples of a launch sit on the hardware (include/crt.h, option "wave_samples"): 0 = one after the other in
     // each wave; 1 = side by side on the waves of a workgroup; 2 (default) = four samples of a 4 x 4 pixel quadrant in the lanes of a wave
     // where the launch allows it (a multiple of 4 samples, a tree of >= 64 nodes, CWBVH), otherwise 1 when the launch is bound by its longest
@@ -173,10 +184,10 @@ struct crt_scene {
     bool stats_from_frame = false;
     bool stats_counted = false;
     uint32_t tri_min = 2;                    // traverse_pool vote: node step while node-ready lanes >= tri_min x triangle-waiting lanes
-    // NEE shadow rays: 1 = walked inside k_segment, every segment (default); 0 = every segment's deferred to ONE any-hit launch behind the
-    // last segment (k_shadow_deferred) with the contributions folded per path in segment order (k_fold_paths); 2 = first segment in place,
-    // bounce segments deferred
-    uint32_t inplace_shadow = 1;
+    // NEE shadow rays: 1 = walked inside k_segment, every segment; 0 = every segment's deferred to ONE any-hit launch behind the last
+    // segment (k_shadow_deferred) with the contributions folded per path in segment order (k_fold_paths); 2 = first segment in place,
+    // bounce segments deferred; 3 (default) = 2 for trees of 64+ nodes (1 M triangles, four segments: 7.23 -> 7.72 Gray/s), else 1
+    uint32_t inplace_shadow = 3;
     uint32_t accel = 0;                      // frames: 0 CWBVH; 1 BVH2 walked as the shipped shader does (first visited wins); 2 BVH2, lowest id wins
     uint32_t refill_min = 8;                // walk_pool (crt_trace, k_closest_queue): idle lanes that trigger a refill
     // crt_trace: rays per wave (its refill pool): 64, 128 or 256.  64 = one lock-step batch per single-wave workgroup: four times the
@@ -275,6 +286,13 @@ struct crt_scene {
             g = std::min(g, ((uint64_t)n_cu * per_cu * oversubscribe + 7) / 8 * 8);
         }
         return (uint32_t)std::max<uint64_t>(g, 8);
+    }
+    // waves the chip holds at once of a kernel whose wave needs `lds` bytes (handed out in 1,280-byte units) and runs `per_simd` to a SIMD:
+    // the grid of a persistent launch (a multiple of 8: one slice per XCD group)
+    uint32_t resident_waves(size_t lds, uint32_t per_simd) const {
+        const uint64_t units = (lds + 1279) / 1280, by_lds = units ? (160u * 1024u / 1280u) / units : 32u;
+        const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(4ull * per_simd, by_lds));
+        return (uint32_t)((uint64_t)n_cu * per_cu / 8 * 8);
     }
     uint32_t flat_grid(uint64_t n) const {
         uint64_t blocks = (n + 255) / 256;
@@ -1000,6 +1018,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         (name[0] == 'r' ? s->refill_pool : s->shadow_pool) = (uint32_t)value;
     }
     else if (!std::strcmp(name, "shadow_refill_min")) s->shadow_refill_min = (uint32_t)std::min(65, std::max(1, value));
+    else if (!std::strcmp(name, "persistent")) s->persistent = value ? 1u : 0u;
 #ifdef CRT_EXPERIMENTS
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
@@ -1039,7 +1058,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         s->lanes_per_ray = (uint32_t)value;
     }
     else if (!std::strcmp(name, "inplace_shadow")) {
-        if (value < 0 || value > 2) return fail(CRT_ERR_INVALID, "crt_set_option: inplace_shadow is 1 (in place), 0 (every segment's shadow rays deferred) or 2 (bounce segments' deferred)");
+        if (value < 0 || value > 3) return fail(CRT_ERR_INVALID, "crt_set_option: inplace_shadow is 1 (in place), 0 (every segment's shadow rays deferred), 2 (bounce segments' deferred) or 3 (pick for me)");
         s->inplace_shadow = (uint32_t)value;
     }
     else if (!std::strcmp(name, "adaptive_tiles")) { s->adaptive_tiles = value ? 1u : 0u; if (value) s->tile_state = crt_scene::TILES_WANT; }
@@ -1096,8 +1115,9 @@ static bool uses_ray_bins(const crt_scene* s) {
 }
 // Segments [first, max_depth) defer their NEE shadow rays (option "inplace_shadow"); first = max_depth: none does.  BVH2 frames walk in place.
 static uint32_t first_deferred_segment(const crt_scene* s) {
-    if (s->accel != 0u || s->inplace_shadow == 1u) return s->max_depth;
-    return s->inplace_shadow == 0u ? 0u : std::min(1u, s->max_depth);
+    const uint32_t mode = s->inplace_shadow == 3u ? (s->info.n_nodes8 >= 64 ? 2u : 1u) : s->inplace_shadow;
+    if (s->accel != 0u || mode == 1u) return s->max_depth;
+    return mode == 0u ? 0u : std::min(1u, s->max_depth);
 }
 // d_lfinal for the samples the path buffers are sized for (frames that fold: several samples of multi-segment paths, deferred shadow rays)
 static int ensure_lfinal(crt_scene* s) {
@@ -1313,9 +1333,11 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
             qa.nodes = s->d_nodes; qa.tris = s->d_tris; qa.rays = sa.rays_in; qa.count = sa.count_in; qa.hits = s->d_qhits;
             qa.stack_entries = s->stack_entries; qa.sub_capacity = s->sub_capacity; qa.refill_min = s->refill_min; qa.tri_min = s->tri_min;
             qa.pool = s->refill_pool; qa.lanes_log2 = sa.lanes_log2;
+            qa.persistent = s->persistent; qa.cursors = cnt + cursor_index_closest(b);
             qa.visit_totals = s->d_visit_totals; qa.overflow = s->d_overflow;
             if (sp) crt::set_launch_events(sp->a, nullptr);                 // span = both launches of the segment
-            crt::launch_closest_queue(qa, s->count_visits, (s->sub_capacity + qa.pool - 1u) / qa.pool, s->stream);
+            const size_t lds_q = (size_t)(s->stack_entries + CRT_HIT_SLOTS) * 64 * sizeof(uint2);
+            crt::launch_closest_queue(qa, s->count_visits, s->persistent ? s->resident_waves(lds_q, 8) : 8u * ((s->sub_capacity + qa.pool - 1u) / qa.pool), s->stream);
             sa.hits_in = s->d_qhits;
             if (sp) crt::set_launch_events(nullptr, sp->b);
         } else if (sp) crt::set_launch_events(sp->a, sp->b);
@@ -1346,11 +1368,13 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sh.pool = s->shadow_pool; sh.refill_min = s->shadow_refill_min; sh.tri_min = s->tri_min ? s->tri_min : 1u;
         sh.lanes_log2 = s->lanes_per_ray >= 8u ? 3u : 0u;
         sh.pools_per_region = (s->sub_capacity + sh.pool - 1u) / sh.pool;
+        sh.persistent = s->persistent; sh.n_regions = s->max_depth - first_deferred; sh.cursors = cnt + kCursorShadow;
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sh.overflow = s->d_overflow;
         EventSpan* sp = s->new_span(2);
         if (sp) crt::set_launch_events(sp->a, sp->b);
-        crt::launch_shadow_deferred(sh, s->count_visits, s->max_depth - first_deferred, s->stream);
+        const size_t lds_q = (size_t)(s->stack_entries + CRT_HIT_SLOTS) * 64 * sizeof(uint2);
+        crt::launch_shadow_deferred(sh, s->count_visits, s->persistent ? s->resident_waves(lds_q, 8) : 8u * sh.n_regions * sh.pools_per_region, s->stream);
     }
     if (folds) crt::launch_fold_paths(s->d_sum, s->d_lfinal, any_deferred ? s->d_contrib : nullptr, P, n_samples, first_deferred, s->stream);
     if (s->count_visits)
@@ -1726,7 +1750,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
     r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
-    r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min;
+    r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min; r->persistent = src->persistent;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
     r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }

@@ -702,13 +702,55 @@ __device__ __forceinline__ void walk_batch(const uint4* __restrict__ nodes, cons
 // The best hit's (u, v) and original id live in the lane's hit slots (rt_kernels.hpp CRT_HIT_SLOTS), as in walk_batch.  `base` = the wave's
 // LDS region (lane 0's stack column); every lane of the wave calls this together.  Per-RAY counters (k_trace's stats) need max_kl = 0: a
 // regrouped ray's visits are counted by its group's first lane.
-template <bool ANY, bool STATS, typename Load, typename Done>
+#define CRT_COUNTER_STRIDE 32u   // uint32 slots between two per-group counters (128 B)
+// Where the rays of a walk_pool come from (all members wave-uniform).
+//   PoolStatic: the wave's own slice [next, end) of an index space.
+//   PoolStream (PERSISTENT THREADS, round 5): the wave draws from queues shared by the whole grid — `n_queues` sub-queues, queue k holding
+//   counts[(k >> 3) * count_stride + (k & 7) * CRT_COUNTER_STRIDE] rays at flat indices k * sub_capacity + e — through one cursor per queue
+//   (cursors[k * CRT_COUNTER_STRIDE], zero at launch; one returning atomic per refill, by one lane).  A wave starts on the queue of its own XCD
+//   group and moves on to the next queue when one runs dry, so no wave idles while any queue holds rays and the grid ends on ONE drain phase
+//   instead of one per pool: the launch is as many workgroups as the chip holds waves, each alive until every queue is empty.
+struct PoolStatic {
+    uint32_t next, end;
+    __device__ __forceinline__ bool more() const { return next < end; }
+    __device__ __forceinline__ uint32_t grab(uint32_t want, uint32_t& got) {
+        const uint32_t b = next;
+        got = end - next < want ? end - next : want;
+        next += got;
+        return b;
+    }
+};
+struct PoolStream {
+    const uint32_t* counts; uint32_t* cursors;
+    uint32_t count_stride, sub_capacity, n_queues, q, tried, chunk;
+    uint32_t next, end;          // what is left of the chunk this wave has reserved (flat indices)
+    __device__ __forceinline__ bool more() const { return next < end || tried < n_queues; }
+    __device__ __forceinline__ uint32_t grab(uint32_t want, uint32_t& got) {
+        // a refill hands out rays of the wave's reserved chunk; a new chunk costs one returning atomic (its round trip is on the wave's
+        // critical path: one per `chunk` rays, not one per refill — per-refill atomics lost 8 - 25 % on four segments of the 1 M-triangle scene)
+        while (next == end && tried < n_queues) {
+            const uint32_t n = counts[(size_t)(q >> 3) * count_stride + (q & 7u) * CRT_COUNTER_STRIDE];
+            const int leader = __builtin_ctzll(__ballot(true));
+            uint32_t b = 0;
+            if ((int)(threadIdx.x & 63u) == leader) b = atomicAdd(cursors + q * CRT_COUNTER_STRIDE, chunk);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)b, leader));
+            if (b < n) { next = q * sub_capacity + b; end = next + (n - b < chunk ? n - b : chunk); break; }
+            q = q + 1u == n_queues ? 0u : q + 1u;        // this queue is dry: on to the next
+            ++tried;
+        }
+        const uint32_t first = next;
+        got = end - next < want ? end - next : want;
+        next += got;
+        return first;
+    }
+};
+
+template <bool ANY, bool STATS, typename Source, typename Load, typename Done>
 __device__ __forceinline__ void walk_pool(const uint4* __restrict__ nodes, const float4* __restrict__ tris, uint2* base, int stack_entries, uint32_t* overflow,
-                                          uint32_t pool_begin, uint32_t pool_end, uint32_t refill_min, uint32_t tri_min, uint32_t max_kl, Load load, Done done,
+                                          Source src, uint32_t refill_min, uint32_t tri_min, uint32_t max_kl, Load load, Done done,
                                           uint32_t& n_nodes, uint32_t& n_tris, uint32_t& w_nodes, uint32_t& w_tris) {
     const uint32_t lane = threadIdx.x & 63u;
     uint2* const stk = base + lane;
-    uint32_t next = pool_begin;                     // wave-uniform
     uint32_t idx = 0;
     vec3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
     bool negx = false, negy = false, negz = false;
@@ -734,13 +776,15 @@ __device__ __forceinline__ void walk_pool(const uint4* __restrict__ nodes, const
         // no flag carried through the loop (see walk_batch): a lane has a ray exactly while it has a triangle group or inner hits pending; a
         // ray that is loaded without either (non-finite origin, empty slot) is finished by the end of the same iteration
         bool busy = tg.y != 0u || (cur.y & 0xff000000u) != 0u;
-        if (next < pool_end) {
+        if (src.more()) {
             const unsigned long long idle = __ballot(!busy);
             const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
             if (n_idle >= refill_min || n_idle == 64u) {
-                const uint32_t mine = next + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-                if (!busy && mine < pool_end) {
-                    idx = mine;
+                uint32_t got;
+                const uint32_t first = src.grab(n_idle, got);
+                const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+                if (!busy && rank < got) {
+                    idx = first + rank;
                     float tmax_in;
                     const bool has_ray = load(idx, o, d, tmax_in);
                     best_t = tmax_in; best_tri = -1;
@@ -755,14 +799,13 @@ __device__ __forceinline__ void walk_pool(const uint4* __restrict__ nodes, const
                     cur = (finite && has_ray) ? make_uint2(0u, 0x80000000u) : make_uint2(0u, 0u);
                     tg = make_uint2(0u, 0u);
                 }
-                next = next + n_idle < pool_end ? next + n_idle : pool_end;
             }
         }
         const unsigned long long m_busy = __ballot(busy);
         if (m_busy == 0ull) break;                  // pool drained and every lane finished
         // the pool has run dry and at most eight rays are left: they get eight lanes each (a just-loaded ray with nothing pending is
         // finished by this iteration first: the group phase wants rays that have something pending)
-        if (max_kl != 0u && next >= pool_end && (uint32_t)__builtin_popcountll(m_busy) <= (64u >> GROUP_KL) &&
+        if (max_kl != 0u && !src.more() && (uint32_t)__builtin_popcountll(m_busy) <= (64u >> GROUP_KL) &&
             __ballot(busy && tg.y == 0u && !(cur.y & 0xff000000u)) == 0ull) { regroup = true; break; }
 
         // ---- one step per iteration: either a node step (lanes with inner hits pending and no triangle group pending) or a triangle step
@@ -957,7 +1000,6 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
 #else
 #define CRT_CHUNK_LOOP(it) for (uint32_t it = 0; it < 1u; ++it)
 #endif
-#define CRT_COUNTER_STRIDE 32u   // uint32 slots between two per-group counters (128 B)
 #define CRT_NO_WORK 0xffffffffu
 
 __device__ __forceinline__ uint32_t dense_chunks_of_group(uint32_t n_items, uint32_t g) {
@@ -1091,7 +1133,7 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK) k_trace(TraceArgs a) {
                     a.stats[i] = ((dt > 65535u ? 65535u : dt) << 16) | (dn > 65535u ? 65535u : dn);
                 }
             };
-        walk_pool<ANY, STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, 0u, load, done, nn, nt, wn_unused, wt_unused);
+        walk_pool<ANY, STATS>(a.nodes, a.tris, stk - lane, (int)a.stack_entries, a.overflow, PoolStatic{first, last}, a.refill_min, a.tri_min, 0u, load, done, nn, nt, wn_unused, wt_unused);
         nn_total += nn; nt_total += nt;
     }
     (void)nn_total; (void)nt_total; (void)lane;
@@ -1990,60 +2032,69 @@ __global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_
     (void)stk; (void)stk2;
 }
 
-// Closest hit for a device-written path-ray queue (segments >= 1; option bounce_refill): per-wave pools of a.pool rays with lane refill
-// (walk_pool: a finished lane takes the pool's next ray, the pool's last eight rays get eight lanes each); hits go to a buffer parallel to
-// the queue and k_segment<PRETRACED> shades them.  One single-wave workgroup per pool.
+// Closest hit for a device-written path-ray queue (segments >= 1; option bounce_refill): lane refill (walk_pool: a finished lane takes the
+// next ray, the last eight rays get eight lanes each); hits go to a buffer parallel to the queue and k_segment<PRETRACED> shades them.
+// a.persistent: a grid of as many single-wave workgroups as the chip holds waves, every wave drawing rays from the eight sub-queues through
+// their cursors until all are dry (PoolStream); else one workgroup per pool of a.pool rays of a sub-queue (PoolStatic).
 template <bool STATS>
 __global__ void __launch_bounds__(64, CRT_SEG_OCC) k_closest_queue(QueueTraceArgs a) {
     extern __shared__ uint2 s_lds[];     // this wave's traversal stack [level][lane] + hit slots
     const uint32_t g = blockIdx.x & 7u, c = blockIdx.x >> 3;
-    const uint32_t n = a.count[g * CRT_COUNTER_STRIDE];
-    const uint32_t first = c * a.pool;
-    if (first >= n) return;
-    const uint32_t last = first + a.pool < n ? first + a.pool : n;
-    const float4* const rays = a.rays + 2 * (size_t)g * a.sub_capacity;
-    float4* const hits = a.hits + (size_t)g * a.sub_capacity;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
-    walk_pool<false, STATS>(
-        a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, a.lanes_log2,
-        [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
-            const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
-            o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
-            return true;
-        },
-        [&](uint32_t e, const HitState& best, bool hit) { hits[e] = make_float4(best.t, best.u, best.v, __int_as_float(hit ? best.tri : -1)); },
-        nn, nt, wn, wt);
+    auto load = [&](uint32_t e, vec3& o, vec3& d, float& tmax) {        // e: flat entry, sub-queue * sub_capacity + place
+        const float4 r0 = a.rays[2 * (size_t)e], r1 = a.rays[2 * (size_t)e + 1];
+        o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
+        return true;
+    };
+    auto done = [&](uint32_t e, const HitState& best, bool hit) { a.hits[e] = make_float4(best.t, best.u, best.v, __int_as_float(hit ? best.tri : -1)); };
+    if (a.persistent) {
+        walk_pool<false, STATS>(a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, PoolStream{a.count, a.cursors, 0u, a.sub_capacity, 8u, g, 0u, a.pool, 0u, 0u}, a.refill_min, a.tri_min,
+                                a.lanes_log2, load, done, nn, nt, wn, wt);
+    } else {
+        const uint32_t n = a.count[g * CRT_COUNTER_STRIDE];
+        const uint32_t first = c * a.pool;
+        if (first >= n) return;
+        const uint32_t last = first + a.pool < n ? first + a.pool : n;
+        walk_pool<false, STATS>(a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, PoolStatic{g * a.sub_capacity + first, g * a.sub_capacity + last}, a.refill_min, a.tri_min,
+                                a.lanes_log2, load, done, nn, nt, wn, wt);
+    }
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
 }
 
 // The deferred NEE occlusion tests (path_trace.fs:968) of a frame, all segments in ONE launch: region r of the queue holds the shadow rays
-// segment r (of those that defer) emitted, 8 sub-queues each; every single-wave workgroup takes a pool of a.pool rays of one sub-queue
-// (a.pool = 64 and refill_min = 65: one lock-step batch) and walks them with walk_pool — full waves from the first step, the last eight rays
-// of a pool on eight lanes each.  An OCCLUDED ray clears the visibility word of its contribution slot (queue entry: (o, tmax) (d, slot));
-// k_fold_paths then adds what is left, in segment order.  Same rays, same walks as the in-place form: occlusion and visit totals keep the
-// oracle's values.
+// segment r (of those that defer) emitted, 8 sub-queues each.  Walked by walk_pool — full waves from the first step, a pool's last eight rays
+// on eight lanes each — either as a persistent grid drawing from all n_regions x 8 sub-queues (a.persistent, PoolStream) or one single-wave
+// workgroup per pool of a.pool rays (a.pool = 64 and refill_min = 65: one lock-step batch).  An OCCLUDED ray clears the visibility word of
+// its contribution slot (queue entry: (o, tmax) (d, slot)); k_fold_paths then adds what is left, in segment order.  Same rays, same walks as
+// the in-place form: occlusion and visit totals keep the oracle's values.
 template <bool STATS>
 __global__ void __launch_bounds__(64, CRT_SEG_OCC) k_shadow_deferred(ShadowArgs a) {
     extern __shared__ uint2 s_lds[];
     const uint32_t g = blockIdx.x & 7u, q = blockIdx.x >> 3;
-    const uint32_t r = q / a.pools_per_region, c = q - r * a.pools_per_region;     // region (segment), pool within the group's sub-queue
-    const uint32_t n = a.count[(size_t)r * a.count_stride + g * CRT_COUNTER_STRIDE];
-    const uint32_t first = c * a.pool;
-    if (first >= n) return;
-    const uint32_t last = first + a.pool < n ? first + a.pool : n;
-    const float4* const rays = a.shadow + 2 * ((size_t)r * 8u + g) * a.sub_capacity;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
     uint32_t slot_of = 0;
-    walk_pool<true, STATS>(
-        a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, first, last, a.refill_min, a.tri_min, a.lanes_log2,
-        [&](uint32_t e, vec3& o, vec3& d, float& tmax) {
-            const float4 r0 = rays[2 * (size_t)e], r1 = rays[2 * (size_t)e + 1];
-            o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
-            slot_of = __float_as_uint(r1.w);
-            return true;
-        },
-        [&](uint32_t, const HitState&, bool occluded) { if (occluded) reinterpret_cast<float*>(a.contrib + slot_of)[3] = 0.0f; },
-        nn, nt, wn, wt);
+    auto load = [&](uint32_t e, vec3& o, vec3& d, float& tmax) {        // e: flat entry, (region * 8 + sub-queue) * sub_capacity + place
+        const float4 r0 = a.shadow[2 * (size_t)e], r1 = a.shadow[2 * (size_t)e + 1];
+        o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
+        slot_of = __float_as_uint(r1.w);
+        return true;
+    };
+    auto done = [&](uint32_t, const HitState&, bool occluded) { if (occluded) reinterpret_cast<float*>(a.contrib + slot_of)[3] = 0.0f; };
+    if (a.persistent) {
+        // the wave starts on its own XCD group's sub-queue of region (q mod n_regions)
+        const uint32_t q0 = (q % a.n_regions) * 8u + g;
+        walk_pool<true, STATS>(a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, PoolStream{a.count, a.cursors, a.count_stride, a.sub_capacity, a.n_regions * 8u, q0, 0u, a.pool, 0u, 0u},
+                               a.refill_min, a.tri_min, a.lanes_log2, load, done, nn, nt, wn, wt);
+    } else {
+        const uint32_t r = q / a.pools_per_region, c = q - r * a.pools_per_region;     // region (segment), pool within the group's sub-queue
+        const uint32_t n = a.count[(size_t)r * a.count_stride + g * CRT_COUNTER_STRIDE];
+        const uint32_t first = c * a.pool;
+        if (first >= n) return;
+        const uint32_t last = first + a.pool < n ? first + a.pool : n;
+        const uint32_t qb = (r * 8u + g) * a.sub_capacity;
+        walk_pool<true, STATS>(a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, PoolStatic{qb + first, qb + last}, a.refill_min, a.tri_min, a.lanes_log2, load, done,
+                               nn, nt, wn, wt);
+    }
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
 }
 
@@ -2305,14 +2356,15 @@ int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplac
     return 0;
 }
 #undef CRT_K
-// grid: 8 x (pools a sub-queue can hold) single-wave workgroups; a pool beyond its sub-queue's count returns at once
-void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t pools_per_group, hipStream_t stream) {
-    const dim3 g(8u * pools_per_group), b(64u);
+// grid: 8 x (pools a sub-queue can hold) single-wave workgroups, a pool beyond its sub-queue's count returns at once; persistent: `grid_waves`
+// workgroups (a multiple of 8), as many as the chip holds
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid_waves, hipStream_t stream) {
+    const dim3 g(grid_waves), b(64u);
     if (stats) launch(k_closest_queue<true>, g, b, stack_bytes(a.stack_entries), stream, a);
     else       launch(k_closest_queue<false>, g, b, stack_bytes(a.stack_entries), stream, a);
 }
-void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t n_regions, hipStream_t stream) {
-    const dim3 g(8u * n_regions * a.pools_per_region), b(64u);
+void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t grid_waves, hipStream_t stream) {
+    const dim3 g(grid_waves), b(64u);
     if (stats) launch(k_shadow_deferred<true>, g, b, stack_bytes(a.stack_entries), stream, a);
     else       launch(k_shadow_deferred<false>, g, b, stack_bytes(a.stack_entries), stream, a);
 }

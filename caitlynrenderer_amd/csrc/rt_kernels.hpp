@@ -170,6 +170,8 @@ struct QueueTraceArgs {        // k_closest_queue: closest hit for a device-writ
     uint32_t tri_min;
     uint32_t pool;             // rays per wave (walk_pool): 64 with refill_min 65 = one lock-step batch
     uint32_t lanes_log2;       // != 0: the pool's last eight rays get eight lanes each
+    uint32_t persistent;       // 1: a grid of resident waves that draw rays from the sub-queues through `cursors` until all are dry
+    uint32_t* cursors;         // persistent: one per sub-queue, CRT_COUNTER_STRIDE apart, zero at launch
     unsigned long long* visit_totals;
     uint32_t* overflow;
 };
@@ -188,6 +190,9 @@ struct ShadowArgs {            // k_shadow_deferred: the deferred NEE shadow ray
     uint32_t tri_min;
     uint32_t pool;
     uint32_t lanes_log2;
+    uint32_t persistent;       // 1: a grid of resident waves drawing from all n_regions x 8 sub-queues through `cursors`
+    uint32_t n_regions;
+    uint32_t* cursors;         // persistent: one per (region, sub-queue), CRT_COUNTER_STRIDE apart, zero at launch
     unsigned long long* visit_totals;
     uint32_t* overflow;
 };
@@ -199,8 +204,8 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 // inplace_shadow: the NEE shadow rays are walked inside the kernel; false = deferred to the frame's k_shadow_deferred launch
 // returns bit 0: the launch ran the 6-waves-per-SIMD (WIDE) build of the first-segment kernel, bit 1: a one-pass (ONE) build
 int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
-void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t pools_per_group, hipStream_t stream);
-void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t n_regions, hipStream_t stream);
+void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid_waves, hipStream_t stream);
+void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t grid_waves, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 void launch_bin_scan(const BinScanArgs& a, hipStream_t stream);

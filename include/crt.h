@@ -179,15 +179,19 @@ int crt_sync(crt_scene* s);
  *     "timing_accumulate" n > 0: keep the spans of the next n launches instead of restarting every frame
  *                         (crt_frame_stats.ms_* are then sums over n_trace_launches launches); 0: per frame
  *   tuning
- *     "inplace_shadow"    the NEE shadow rays (path_trace.fs:968): 1 = walked inside the segment kernel (default); 2 = the first segment's in
+ *     "inplace_shadow"    the NEE shadow rays (path_trace.fs:968): 1 = walked inside the segment kernel; 2 = the first segment's in
  *                         place, the bounce segments' DEFERRED: they wait in the frame's NEE queue with the index of a contribution
  *                         slot (segment, path), ONE any-hit launch behind the last segment walks them all in full waves, an occluded
  *                         ray clears its slot, and a last kernel adds every path's slots in segment order — the additions the in-place
- *                         form makes, in the same order; 0 = every segment's deferred (frames then render one by one).  BVH2 frames
- *                         ("accel") always walk in place.
- *     "shadow_pool"       rays per wave of that launch: 64 (default; with "shadow_refill_min" 65 — the default — one lock-step batch),
- *                         128, 256, 512: a lane whose ray has finished takes the pool's next ray once "shadow_refill_min" (1..64) lanes
- *                         are idle; the pool's last eight rays get eight lanes each ("lanes_per_ray")
+ *                         form makes, in the same order; 0 = every segment's deferred (frames then render one by one); 3 (default) = 2
+ *                         for trees of 64+ nodes, else 1.  BVH2 frames ("accel") always walk in place.
+ *     "shadow_pool"       rays per pool of that launch: 64, 128, 256 (default), 512: a lane whose ray has finished takes the pool's next
+ *                         ray once "shadow_refill_min" (1..64, default 16; 65 = never: lock-step batches of 64) lanes are idle; the
+ *                         pool's last eight rays get eight lanes each ("lanes_per_ray")
+ *     "persistent"        1 (default): the pool launches (k_shadow_deferred, k_closest_queue) are PERSISTENT grids — as many single-wave
+ *                         workgroups as the chip holds waves, each reserving chunks of "shadow_pool" / "refill_pool" rays from the
+ *                         sub-queues through one cursor per queue until all are dry (one returning atomic per chunk), so the launch
+ *                         ends on one drain phase instead of one per pool; 0: one workgroup per pool
  *     "bounce_refill"     segments >= 1: 0 = closest hit, shading and emission fused in one lock-step kernel (default); 1 = closest hits
  *                         through pools of "refill_pool" (64 / 128 / 256 (default) / 512) rays per wave with lane refill at "refill_min"
  *                         idle lanes (k_closest_queue), then a shade-only pass (k_segment<PRETRACED>)

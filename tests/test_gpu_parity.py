@@ -160,6 +160,7 @@ def test_render_frames_equals_the_same_frames_one_by_one(cr, ob, cornell, tess8,
                                (2, {}, None), (1, {"waves_per_workgroup": 4}, (1, 3)), (4, {}, None), (3, {"inplace_shadow": 2}, (0, 2)),
                                (3, {"bounce_refill": 1}, None), (2, {"accel": 2}, None), (4, {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}, None),
                                (3, {"inplace_shadow": 0}, None), (3, {"bounce_refill": 1, "inplace_shadow": 2, "refill_pool": 128}, None), (1, {"inplace_shadow": 2}, None),
+                               (4, {"bounce_refill": 1, "inplace_shadow": 2, "persistent": 1, "refill_min": 16, "shadow_refill_min": 16}, None), (3, {"inplace_shadow": 2, "persistent": 1, "shadow_refill_min": 8}, (1, 2)),
                                (1, {"wave_samples": 0}, None), (3, {"wave_samples": 0}, (1, 2)), (1, {"wave_samples": 1, "accel": 1}, (2, 3)),
                                (4, {"wave_samples": 1, "inplace_shadow": 2}, None), (1, {"wide_first": 1}, None), (2, {"wide_first": 0, "wave_samples": 0}, (0, 2)),
                                (1, {"wave_samples": 3}, None), (1, {"wave_samples": 3, "wide_first": 1}, (1, 2)), (3, {"wave_samples": 3}, None),
@@ -490,6 +491,8 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
                     {"bounce_refill": 1, "refill_min": 65, "refill_pool": 64}, {"bounce_refill": 1, "lanes_per_ray": 1, "refill_pool": 512}, {"inplace_shadow": 0},
                     {"inplace_shadow": 2}, {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}, {"inplace_shadow": 2, "shadow_pool": 128, "shadow_refill_min": 64, "lanes_per_ray": 1},
                     {"inplace_shadow": 0, "shadow_pool": 512, "shadow_refill_min": 1}, {"inplace_shadow": 2, "bounce_refill": 1},
+                    {"inplace_shadow": 2, "persistent": 1, "shadow_refill_min": 16}, {"bounce_refill": 1, "persistent": 1, "refill_min": 24}, {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 0, "refill_min": 1, "shadow_refill_min": 64},
+                    {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 2, "lanes_per_ray": 1, "shadow_refill_min": 8},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
         if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):
             continue
@@ -517,9 +520,10 @@ def test_deferred_shadow_rays_keep_sums_and_counters(cr, ob, scenes, disney_scen
         for rx, ry in rvs:
             _, cnt = orc.render_frame(rx, ry, ref, threads=8)
         steps = {}
-        for key, opts in (("inplace", {}), ("bounce", {"inplace_shadow": 2}), ("all", {"inplace_shadow": 0}),
-                          ("bounce_pool", {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}), ("bounce_one_lane", {"inplace_shadow": 2, "lanes_per_ray": 1}),
-                          ("refill", {"bounce_refill": 1}), ("wavefront", {"bounce_refill": 1, "inplace_shadow": 2, "refill_pool": 128, "shadow_pool": 128, "shadow_refill_min": 16})):
+        for key, opts in (("default", {}), ("inplace", {"inplace_shadow": 1}), ("bounce", {"inplace_shadow": 2, "persistent": 0, "shadow_pool": 64, "shadow_refill_min": 65}), ("all", {"inplace_shadow": 0, "persistent": 0}),
+                          ("bounce_pool", {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8, "persistent": 0}), ("bounce_one_lane", {"inplace_shadow": 2, "lanes_per_ray": 1}),
+                          ("refill", {"bounce_refill": 1, "persistent": 0, "inplace_shadow": 1}), ("wavefront", {"bounce_refill": 1, "inplace_shadow": 2, "refill_pool": 128, "shadow_pool": 128, "shadow_refill_min": 16, "persistent": 0}),
+                          ("persistent", {"bounce_refill": 1, "inplace_shadow": 2, "persistent": 1, "refill_min": 16, "shadow_refill_min": 16})):
             s = cr.Scene(d, W, H, depth)
             for k, v in opts.items():
                 s.set_option(k, v)
@@ -535,6 +539,8 @@ def test_deferred_shadow_rays_keep_sums_and_counters(cr, ob, scenes, disney_scen
         assert len({v[2:] for v in steps.values()}) == 1                                  # the same visits, block by block
         assert steps["bounce"][0] < steps["inplace"][0] and steps["all"][0] < steps["inplace"][0]      # fuller waves: fewer wave-level any-hit node steps
         assert steps["refill"][1] < steps["inplace"][1]                                   # and fewer closest-hit ones through the refilled pools
+        if name == "tess40":                                                              # (a persistent grid spreads a small frame's rays over more waves than it has batches)
+            assert steps["persistent"][1] < steps["inplace"][1] and steps["persistent"][0] < steps["inplace"][0]
 
 
 @pytest.mark.parametrize("T", [16, 24])
