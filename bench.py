@@ -32,7 +32,7 @@ Workloads (BASELINE.json `configs`, made concrete in SURVEY.md §8d):
 forwards rank 0's JSON line and exits with the children's status; launched under torch.distributed.run by someone else it
 simply is one of the ranks.
 
-Prints ONE JSON line (< 6 KB) on rank 0 with the driver's keys plus
+Prints ONE JSON line (< 8 KB) on rank 0 with the driver's keys plus
   "roofline": the dominant kernel (the fused segment kernel) against the roof that binds it — VECTOR-INSTRUCTION ISSUE, not HBM (every
       BASELINE scene is cache-resident: SURVEY 8d's algorithmic bytes / time exceeds the HBM peak and is reported as `algorithmic_gbps`,
       never as a fraction).  achieved = TRAVERSAL wave-instructions of a launch — (node visits x I_node + triangle tests x I_tri) / 64,
@@ -81,9 +81,10 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = one fixed frame split over the ranks (configs[4], default); weak = the frame grows with N")
     ap.add_argument("--tile", type=int, default=16, help="tile edge in pixels (multiple of 8): unit of the ranks' shards and of the cost-sorted launch order")
-    ap.add_argument("--builder", default="sbvh",
-                    help="sbvh = the reference's split-BVH on the host (default); lbvh = GPU linear BVH (crt_lbvh_build); "
-                         "ploc / ploc<radius> = GPU parallel locally-ordered clustering")
+    ap.add_argument("--builder", default="auto",
+                    help="auto (default) = the reference's split-BVH on the host at N = 1, the binned-SAH tree crt_scene_create builds on each rank's GPU "
+                         "at N > 1 (9.5 ms instead of every rank building the SBVH on the shared host cores; 17.19 against 17.21 Gray/s); "
+                         "sbvh = the host SBVH everywhere; lbvh = GPU linear BVH (crt_lbvh_build); ploc / ploc<radius> = GPU parallel locally-ordered clustering")
     ap.add_argument("--convert", default="host", choices=["host", "device"],
                     help="BVH2 -> CWBVH conversion on the host (default) or on the GPU (crt_cwbvh_convert_device, same bytes)")
     ap.add_argument("--accel", default="cwbvh", choices=["cwbvh", "bvh2"],
@@ -152,8 +153,8 @@ def self_launch(args):
 _SCENE_CACHE = {}
 
 
-def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
-    key = (name, builder, convert, materials)
+def build_workload(name, builder="sbvh", convert="host", materials="lambert", sbvh_flags=0):
+    key = (name, builder, convert, materials) if not sbvh_flags else (name, builder, convert, materials, sbvh_flags)
     if key in _SCENE_CACHE:
         return _SCENE_CACHE[key]
     import copy
@@ -185,7 +186,9 @@ def build_workload(name, builder="sbvh", convert="host", materials="lambert"):
     if materials == "disney":
         label += ", mirror tall box + GGX/Disney-diffuse short box and floor (oracle-defined materials)"
     t0 = time.time()
-    data = cr.SceneData.build(mesh, cam, builder=builder, convert=convert)
+    data = cr.SceneData.build(mesh, cam, builder=builder, convert=convert, sbvh_flags=sbvh_flags) if sbvh_flags else cr.SceneData.build(mesh, cam, builder=builder, convert=convert)
+    if sbvh_flags:
+        label += " over the SAH BVH (exact-sweep object splits only, sbvh.h:338-378)"
     if builder == "lbvh":
         label += " over a GPU-built LBVH"
     elif builder.startswith("ploc"):
@@ -353,7 +356,7 @@ def live_pmc(workloads, budget_s=330.0):
         shutil.rmtree(top, ignore_errors=True)
 
 
-def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials=None, device_built=None):
+def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials=None, device_built=None, accel=None, sbvh_flags=0):
     """Measure one workload: returns the dict of the bench line for it (rank 0) or None (other ranks).
     device_built = "lbvh" | "ploc<r>" | "sah": the scene is built by crt_scene_create itself from the source-order arrays
     (BVH2, CWBVH and records produced in HBM) instead of from host-built trees."""
@@ -361,6 +364,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
     import caitlynrenderer_amd as cr
     from caitlynrenderer_amd import tiles
     args, torch = ctx.args, ctx.torch
+    accel = accel or args.accel
     rank, world = (ctx.rank, ctx.world) if sharded else (0, 1)
     takes_part = sharded or ctx.rank == 0
     use_dist = ctx.use_dist and sharded
@@ -383,7 +387,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
                 + f", CWBVH over a BVH2 built on the GPU ({device_built}), everything assembled in HBM by crt_scene_create"
             build_s = build_info["scene_create_wall_ms"] / 1e3
         else:
-            data, cam, label, build_s = build_workload(name, args.builder, args.convert, materials or args.materials)
+            data, cam, label, build_s = build_workload(name, "sbvh" if args.builder == "auto" else args.builder, args.convert, materials or args.materials, sbvh_flags)
             scene = cr.Scene(data, W, H, depth)
         one_proc = ctx.one_proc_ids if sharded else None     # N devices behind this one handle (crt_set_devices) instead of N ranks
         if one_proc:
@@ -397,13 +401,13 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         # ... and a frame of a few-node scene (the 32-triangle Cornell box: 58 us per launch) is bound by the gaps between launches: three
         # tile shards on three streams keep the GPU busy through them (+13 %; four streams are bound by the host's launch rate)
         streams = 1
-        if not one_proc and args.accel == "cwbvh":
+        if not one_proc and accel == "cwbvh":
             scene.set_option("streams", args.streams)            # 0 (the default here): the library's own pick, as described above
             streams = len(scene.devices()["devices"])
         for kv in args.option:
             k, v = kv.split("=")
             scene.set_option(k, int(v))
-        if args.accel == "bvh2":
+        if accel == "bvh2":
             scene.set_option("accel", 1)
             label = label.replace("CWBVH", "BVH2 walked as the shipped shader does")
         info = scene.bvh_info()
@@ -413,10 +417,21 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         rnd = cr.Rnd()
         rvs = [(rnd.randf2(), rnd.randf2()) for _ in range((Wu + K) * spp + 1)]
 
-        # ---- untimed: algorithmic bytes of one frame (visit counters from the counting kernels) ----
-        scene.set_option("count_visits", 1)
-        scene.render_frame(*rvs[0])
-        cs = scene.frame_stats()
+        # ---- untimed: the visit counters of ONE STEP (all its samples and segments), from counting kernels in the form the timed launches
+        # have (count_visits 2: four samples in the lanes of a wave where the timed step runs so; the uniform node steps depend on which
+        # rays share a wave).  A step of k launches is counted launch by launch.
+        scene.set_option("count_visits", 2)
+        cs = None
+        first = rvs[1 + Wu * spp:1 + (Wu + 1) * spp]            # the frames of the first timed step
+        parts = [first[i:i + 4] for i in range(0, spp, 4)] if spp % 4 == 0 else [[r] for r in first]
+        for part in parts:
+            if len(part) == 4:
+                scene.render_frames(part)        # one counting launch per segment in the lanes form, or four single frames where that form does not apply
+            else:
+                scene.render_frame(*part[0])
+            st_c = scene.frame_stats()
+            keys = ("closest_rays", "any_rays", "closest_hits", "nodes_closest", "tris_closest", "nodes_any", "tris_any", "nodes_closest_uniform", "nodes_any_uniform")
+            cs = {k: int(st_c.get(k, 0)) + (cs[k] if cs else 0) for k in keys}
         scene.set_option("count_visits", 0)
         scene.reset()
 
@@ -468,7 +483,7 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         if streams == 1:
             # HIP events on every segment launch of the timed region, on the scene's own stream (attached to the dispatch:
             # they take the kernel's own start/stop timestamps)
-            scene.set_option("timing_accumulate", K * spp * max(1, depth))
+            scene.set_option("timing_accumulate", K * (spp * max(1, depth) + 2))
         else:
             # several streams: the launch time of the roofline is the step's wall time / launches (below), and an event-carrying dispatch
             # would only keep its neighbours on the other streams from overlapping it
@@ -502,9 +517,24 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         launch_info = scene.debug_launch_info()          # how the timed steps' first-segment launches ran (form, build, samples, shards)
         st = scene.frame_stats()
         n_timed_launches = st["n_trace_launches"] if streams == 1 else launches_per_step * K
-        launch_ms_timed = st["ms_trace_closest"] / max(1, n_timed_launches)
+        n_segment_launches = K * launches_per_step if streams == 1 else n_timed_launches      # without the deferred any-hit launches (event kind 2)
+        launch_ms_timed = (st["ms_trace_closest"] + st["ms_trace_any"]) / max(1, n_segment_launches)
+        # spread of the timed steps: device time of each step = the sum of its launches' own durations (one stream), else of wall-clock
+        # steps rendered one by one after the clock has stopped (several streams carry no events: they would keep the shards from overlapping)
+        if streams == 1 and depth == 1:
+            lt = scene.launch_times()
+            per = max(1, len(lt) // K)
+            step_ms = [float(lt[i * per:(i + 1) * per].sum()) for i in range(K)] if len(lt) >= K else []
+            spread_src = "device time of each timed step (its launches' events)"
+        else:
+            step_ms = []
+            for k in range(min(K, 20)):
+                t1 = time.perf_counter(); step(Wu + k); scene.sync(); step_ms.append((time.perf_counter() - t1) * 1e3)
+            spread_src = f"wall time of {len(step_ms)} steps rendered one by one after the timed region"
+        spread = ({"min": round(min(step_ms), 4), "median": round(float(np.median(step_ms)), 4), "max": round(max(step_ms), 4), "n": len(step_ms), "what": spread_src}
+                  if step_ms else None)
         # samples per pixel one launch rendered: 1, or the step's spp where crt_render_frames batched them
-        samples_per_launch = max(1, round(K * spp * max(1, depth) / max(1, n_timed_launches)))
+        samples_per_launch = max(1, round(K * spp * max(1, depth) / max(1, n_segment_launches)))
         scene.set_option("timing_accumulate", 0)
         scene.set_option("timing", 2)
         any_ms, total_ms = [], []
@@ -521,50 +551,51 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         rank_ms = ctx.gather_floats(render_s / K * 1e3) if use_dist else [render_s / K * 1e3]
 
     if takes_part and ctx.rank == 0:
-        launches = max(1, depth)
-        node_bytes = 96 if args.accel == "bvh2" else NODE_BYTES      # own 2 texels + 4 child texels per BVH2 visit
-        # the segment kernel walks the NEE shadow rays in place (no k_shadow launch): their visits are this launch's work too
-        fused_shadow = st["any_rays"] > 0 and float(np.median(any_ms)) == 0.0
-        nodes = cs["nodes_closest"] + (cs["nodes_any"] if fused_shadow else 0)
-        tris = cs["tris_closest"] + (cs["tris_any"] if fused_shadow else 0)
-        alg_bytes = (node_bytes * nodes + TRI_BYTES * tris) / launches * samples_per_launch
+        launches = max(1, depth)                                      # segment launches per step and sample batch
+        node_bytes = 96 if accel == "bvh2" else NODE_BYTES      # own 2 texels + 4 child texels per BVH2 visit
+        rl = roofline_module()
+        # the counters describe this rank's share of ONE step (spp samples, every segment; deferred shadow rays are that step's work too)
+        counters = dict(cs, primary_rays=int(n_primary) * spp)
+        launches_per_step = launches * max(1, spp // samples_per_launch)      # segment launches one step is made of
+        alg_bytes = rl.algorithmic_bytes(counters, node_bytes) / launches_per_step
         t_launch = launch_ms_timed * 1e-3
-        if streams > 1:
+        if streams > 1 or depth > 1:
             # the shards' launches run side by side: a segment of the WHOLE frame takes the step's wall time / its launches per shard (a
-            # single launch's own duration would count the time it shares the GPU with the other shards' launches more than once)
-            t_launch = dt / max(1.0, K * spp * max(1, depth) / samples_per_launch)
+            # single launch's own duration would count the time it shares the GPU with the other shards' launches more than once); and a
+            # multi-segment step is more than its segment launches (the deferred shadow rays' launch, the fold): the step's wall time / segments
+            t_launch = dt / max(1.0, K * launches_per_step)
         # counter passes exist per (workload, depth) at 1920x1080 on the host-built tree with the reference's materials
         pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and (not device_built or name == HBM_RESIDENT) and materials in (None, "lambert")) else {}
         traffic = pmc.get("l2_fabric_bytes_per_launch")
         if traffic is not None:      # a pass that rendered fewer samples per launch than this block's launches: scaled to the same unit
             traffic = int(traffic * samples_per_launch / max(1, pmc.get("samples_per_launch", 1)))
-        counters = {"primary_rays": int(n_primary), "closest_rays": int(cs["closest_rays"]), "any_rays": int(cs["any_rays"]),
-                    "closest_hits": int(cs["closest_hits"]), "nodes_closest": int(cs["nodes_closest"]), "tris_closest": int(cs["tris_closest"]),
-                    "nodes_any": int(cs["nodes_any"]), "tris_any": int(cs["tris_any"]),
-                    "nodes_closest_uniform": int(cs.get("nodes_closest_uniform", 0)), "nodes_any_uniform": int(cs.get("nodes_any_uniform", 0))}
-        roofline = valu_roofline(counters, t_launch, launches, samples_per_launch, args.accel, pmc)
+        roofline = valu_roofline(counters, t_launch, launches_per_step, samples_per_launch, accel, pmc)
         if one_proc and len(set(one_proc)) < len(one_proc):
             # virtual devices share one GPU: a launch's duration there says nothing about the kernel (the number this mode prints is not a
             # scaling figure either)
             roofline["achieved"] = roofline["frac"] = None
         traffic_gbps = round(traffic / t_launch / 1e9, 1) if traffic and t_launch > 0 else None
+        alg_gbps = round(alg_bytes / t_launch / 1e9, 1) if t_launch > 0 else None
         roofline.update({
             "traffic": traffic, "traffic_source": pmc.get("source"),
             # bytes crossing L2 <-> fabric per second; for a scene larger than the 256 MiB Infinity Cache (the hbm_resident blocks) this is
             # HBM bandwidth, for the cache-resident BASELINE scenes mostly MALL hits
             "traffic_gbps": traffic_gbps,
             "hbm_frac": round(traffic_gbps / HBM_PEAK_GBS, 4) if traffic_gbps else None,      # L2<->fabric bytes / s over the HBM peak: HBM traffic proper only when the scene exceeds the Infinity Cache
-            "algorithmic_gbps": round(alg_bytes / t_launch / 1e9, 1) if t_launch > 0 else None,
+            "algorithmic_gbps": alg_gbps,
+            "algorithmic_over_peak": round(alg_gbps / HBM_PEAK_GBS, 4) if alg_gbps else None,  # SURVEY 8d's bytes / s over the HBM peak: above 1 on every cache-resident scene
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "l2_hit_rate": pmc.get("l2_hit_rate"),
-            "launch_ms": round(t_launch * 1e3, 4), "launches_timed": int(n_timed_launches), "samples_per_launch": int(samples_per_launch),
+            "launch_ms": round(t_launch * 1e3, 4), "launches_timed": int(n_segment_launches), "samples_per_launch": int(samples_per_launch),
             "path_segments": depth, "frame_device_ms": round(float(np.median(total_ms)), 4),
             "nodes_per_ray": round(cs["nodes_closest"] / max(1, cs["closest_rays"]), 3), "tris_per_ray": round(cs["tris_closest"] / max(1, cs["closest_rays"]), 3),
             "any_hit_nodes_per_ray": round(cs["nodes_any"] / max(1, cs["any_rays"]), 3), "any_hit_tris_per_ray": round(cs["tris_any"] / max(1, cs["any_rays"]), 3),
             "counters": counters,
         })
+        if accel == "bvh2":
+            roofline["accel"] = "bvh2"
         out = {
-            "value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(dt / K * 1e3, 4), "scaling": scaling,
+            "value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(dt / K * 1e3, 4), "step_ms_spread": spread, "scaling": scaling,
             "config": {"workload": label, "resolution": f"{W}x{H}", "spp_per_step": spp, "path_segments": depth,
                        "rays_per_step": int(rays_all) * spp, "tile": tile, "parallelism": f"tiles/{world}",
                        "n_nodes8": int(info["n_nodes8"]), "n_tris8": int(info["n_tris8"]), "stack_overflows": int(st["stack_overflows"]), "streams": int(streams),
@@ -586,18 +617,18 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
         if build_info:
             out["config"]["device_build"] = build_info
         out["config"]["launch"] = launch_info
-        if not args.no_oracle_check and args.accel == "cwbvh" and (world == 1 or one_proc):
+        if not args.no_oracle_check and (world == 1 or one_proc):
             # after the clock has stopped: ONE more step, exactly as the timed region ran it, on a cleared sum, and 16 rows of the result
             # against the CPU oracle on the same frames (the checker, never the thing measured)
-            out["sum_rows_match_oracle"] = rows_match_oracle(scene, step, Wu, spp, rvs, data, name, device_built, materials or args.materials, cam, W, H, depth)
-        if cpu_base and not args.no_cpu_baseline and args.accel == "cwbvh":
-            out["cpu_baseline"] = cpu_baseline(data, cam, W, H, depth, rvs[0], cs)
+            out["sum_rows_match_oracle"] = rows_match_oracle(scene, step, Wu, spp, rvs, data, name, device_built, materials or args.materials, cam, W, H, depth, accel)
+        if cpu_base and not args.no_cpu_baseline and accel == "cwbvh":
+            out["cpu_baseline"] = cpu_baseline(data, cam, W, H, depth, rvs[1 + Wu * spp:1 + (Wu + 1) * spp], cs)
     if takes_part:
         scene.close()
     return out
 
 
-def rows_match_oracle(scene, step, Wu, spp, rvs, data, name, device_built, materials, cam, W, H, depth):
+def rows_match_oracle(scene, step, Wu, spp, rvs, data, name, device_built, materials, cam, W, H, depth, accel="cwbvh"):
     """True / False: the sum buffer after one step of the timed form equals the oracle's on 16 pixel rows through the image centre, bit
     for bit.  A scene crt_scene_create built on the GPU is checked against the oracle walking the same builder's tree (downloaded through
     the host-array entry points).  None when the check could not run."""
@@ -620,8 +651,9 @@ def rows_match_oracle(scene, step, Wu, spp, rvs, data, name, device_built, mater
         y0 = (H // 2 - 8) // 8 * 8
         orc = ob.Oracle(data, W, H, depth, cam)
         rows = np.zeros((H, W, 3), np.float32)
+        o_accel, o_tie = (ob.BVH2, ob.TIE_FIRST_VISITED) if accel == "bvh2" else (ob.BVH8, ob.TIE_LOWEST_ID)
         for rx, ry in rvs[1 + Wu * spp:1 + (Wu + 1) * spp]:
-            orc.render_rows(rx, ry, y0, y0 + 16, rows)
+            orc.render_rows(rx, ry, y0, y0 + 16, rows, accel=o_accel, tie=o_tie)
         return bool(np.array_equal(got[y0:y0 + 16].view(np.uint32), rows[y0:y0 + 16].view(np.uint32)) and rows[y0:y0 + 16].max() > 0)
     except Exception as e:                             # the check must never take the measurement down with it
         log(f"[bench] oracle row check did not run: {e!r}")
@@ -642,29 +674,35 @@ def roofline_module():
     return _RL
 
 
+ROOFLINE_NOTE = ("the scene is cache-resident, so the HBM roof does not bind (algorithmic_over_peak > 1: cache-served bytes; hbm_frac: measured "
+                 "L2<->fabric bytes / 8 TB/s); frac = algorithmic traversal wave-instr (every node visit at the general 8-wide test) / time / peak; "
+                 "frac_executed prices uniform node steps at their executed cost and is <= issue_busy x lane_util")
+
+
 def valu_roofline(c, t_launch, launches, samples_per_launch, accel="cwbvh", pmc=None):
     """The roof that binds the segment kernel: vector-instruction issue (tools/roofline.py has the definition and recomputes it).
-    achieved = traversal wave-instructions per launch / launch time; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction;
-    with counters (pmc): issue_busy, lane_util, counter_frac = their product (>= frac by construction), non_traversal_share."""
+    c = the counters of one step, launches = segment launches that step is made of, t_launch = mean duration of one of them;
+    peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; with counters (pmc): issue_busy, lane_util, counter_frac = their
+    product (>= frac_executed), non_traversal_share."""
     global _ISA
     if _ISA is None:
         try:
             _ISA = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
         except Exception:
             _ISA = {}
-    r = {"bound": "valu_issue", "kernel": "k_segment (ray generation / queue fetch + CWBVH closest hit + shading + in-place NEE any-hit walk), mean over the path's segments",
-         "achieved": None, "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Gwave-instr/s", "frac": None}
+    r = {"bound": "valu_issue", "kernel": "k_segment (raygen / queue fetch + CWBVH closest hit + shading + NEE any-hit walk), mean over the step's segment launches",
+         "achieved": None, "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Gwave-instr/s", "frac": None, "note": ROOFLINE_NOTE}
     if _ISA.get("I_node") and accel == "cwbvh" and t_launch > 0:
-        got = roofline_module().roofline_block(c, _ISA, t_launch * 1e3, launches, samples_per_launch, pmc)
-        r.update({k: got[k] for k in ("achieved", "frac", "frac_at_general_step", "attainable", "traversal_wave_instr_per_launch", "shell_static_wave_instr_per_launch",
+        got = roofline_module().roofline_block(c, _ISA, t_launch * 1e3, launches, pmc, samples_per_launch)
+        r.update({k: got[k] for k in ("achieved", "frac", "frac_executed", "traversal_wave_instr_per_launch", "executed_traversal_wave_instr_per_launch",
                                       "issue_busy", "lane_util", "counter_frac", "non_traversal_share") if k in got})
     return r
 
 
-def cpu_baseline(data, cam, W, H, depth, rv, cs):
-    """The CPU oracle (a scalar port of the same algorithm on the same CWBVH) on a bounded sample of
-    the same workload: whole frames for small scenes, a band of pixel rows when a frame would take
-    too long; all host cores.  Also cross-checks the GPU visit counters on that sample."""
+def cpu_baseline(data, cam, W, H, depth, rvs, cs):
+    """The CPU oracle (a scalar port of the same algorithm on the same CWBVH) on a bounded sample of the same workload: the frames of one
+    step, whole for small scenes, a band of pixel rows when that would take too long; all host cores.  Also cross-checks the GPU visit
+    counters of that step (cs) when the sample is the whole step."""
     import numpy as np
     from oracle import binding as ob
     orc = ob.Oracle(data, W, H, depth, cam)
@@ -672,25 +710,28 @@ def cpu_baseline(data, cam, W, H, depth, rv, cs):
     y0, y1 = 0, H
     t0 = time.perf_counter()
     probe = np.zeros((H, W, 3), np.float32)
-    cnt = orc.render_rows(rv[0], rv[1], H // 2 - 4, H // 2 + 4, probe)
+    cnt = orc.render_rows(rvs[0][0], rvs[0][1], H // 2 - 4, H // 2 + 4, probe)
     rate = (cnt[0] + cnt[1]) / (time.perf_counter() - t0)              # rays/s, one thread
     est_full = (cs["closest_rays"] + cs["any_rays"]) / (rate * threads)
     if est_full > 12.0:                                                  # keep the sample near 10 s
         rows = max(8, int(H * 10.0 / est_full) // 8 * 8)
         y0 = (H - rows) // 2 // 8 * 8
         y1 = y0 + rows
-    times, rays = [], 0
+    times, rays, c = [], 0, [0, 0, 0, 0]
     for rep in range(3 if est_full < 4 else 1):
         buf = np.zeros((H, W, 3), np.float32)
+        c = [0, 0, 0, 0]
         t0 = time.perf_counter()
-        if (y0, y1) == (0, H):
-            _, c = orc.render_frame(rv[0], rv[1], buf, threads=threads)
-        else:
-            import concurrent.futures as cf
-            bands = [(a, min(a + 8, y1)) for a in range(y0, y1, 8)]
-            with cf.ThreadPoolExecutor(threads) as ex:
-                cs_ = list(ex.map(lambda b: orc.render_rows(rv[0], rv[1], b[0], b[1], buf), bands))
-            c = [sum(x[k] for x in cs_) for k in range(4)]
+        for rx, ry in rvs:
+            if (y0, y1) == (0, H):
+                _, c1 = orc.render_frame(rx, ry, buf, threads=threads)
+            else:
+                import concurrent.futures as cf
+                bands = [(a, min(a + 8, y1)) for a in range(y0, y1, 8)]
+                with cf.ThreadPoolExecutor(threads) as ex:
+                    cs_ = list(ex.map(lambda b: orc.render_rows(rx, ry, b[0], b[1], buf), bands))
+                c1 = [sum(x[k] for x in cs_) for k in range(4)]
+            c = [c[k] + c1[k] for k in range(4)]
         times.append(time.perf_counter() - t0)
         rays = c[0] + c[1]
     check = None
@@ -699,8 +740,76 @@ def cpu_baseline(data, cam, W, H, depth, rv, cs):
                      c[2] == cs["nodes_closest"] + cs["nodes_any"] and c[3] == cs["tris_closest"] + cs["tris_any"])
     return {"value": round(rays / float(np.median(times)) / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
             "single_thread_value": round(rate / 1e6, 3),          # one thread, 8 pixel rows through the image centre
-            "sample": f"rows {y0}..{y1} of {H} ({rays} rays, same frame and CWBVH as the GPU step)",
+            "sample": f"rows {y0}..{y1} of {H}, the {len(rvs)} frames of one step ({rays} rays, same frames and CWBVH as the GPU step)",
             "visit_counters_match_gpu": check}
+
+
+def frame_loop_block(ctx, name, W, H, frames=60):
+    """What INTEGRATION.md section 3 prescribes per DISPLAYED frame in place of Scene::Render's three passes (Scene.h:1208-1230: one sample,
+    a copy pass, the output pass): crt_render_frame (one sample per pixel) + the tone-mapped RGBA8 image — left in device memory
+    (crt_resolve_device: where the reference's output pass leaves it, the default framebuffer) or copied into host memory (crt_resolve).
+    ms per iteration and its parts; the bytes of the last image against the oracle's resolve of the oracle's sum on 16 rows."""
+    import numpy as np
+    import caitlynrenderer_amd as cr
+    args = ctx.args
+    data, cam, label, _ = build_workload(name, "sbvh" if args.builder == "auto" else args.builder, args.convert, "lambert")
+    scene = cr.Scene(data, W, H, 1)
+    scene.set_shard(0, 1, args.tile)
+    rnd = cr.Rnd()
+    rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(2 * frames + 8)]
+    for r in rvs[:8]:                                   # warm: tile order measured, code objects loaded, staging buffers allocated
+        scene.render_frame(*r, sync=False)
+    scene.resolve(1.0 / 8)
+    scene.reset()
+    # (a) the image stays in HBM: render + resolve enqueued frame after frame, one wait at the end
+    t0 = time.perf_counter()
+    for i in range(frames):
+        scene.render_frame(*rvs[8 + i], sync=False)
+        scene.resolve_device(1.0 / (i + 1), sync=False)
+    scene.sync()
+    dev_ms = (time.perf_counter() - t0) / frames * 1e3
+    # (b) the image in host memory every frame (the D2H copy and its wait are on the loop's critical path)
+    t0 = time.perf_counter()
+    img = None
+    for i in range(frames):
+        scene.render_frame(*rvs[8 + frames + i], sync=False)
+        img = scene.resolve(1.0 / (frames + i + 1))
+    host_ms = (time.perf_counter() - t0) / frames * 1e3
+    # parts: the segment launch by its own events, the resolve pass as what is left of (a)
+    scene.set_option("timing", 1)
+    scene.set_option("timing_accumulate", 16)
+    for r in rvs[:16]:
+        scene.render_frame(*r, sync=False)
+    scene.sync()
+    lt = scene.launch_times()
+    launch_ms = float(np.median(lt)) if len(lt) else None
+    scene.set_option("timing_accumulate", 0)
+    scene.set_option("timing", 0)
+    out = {"workload": label.split(",")[0].replace("procedural tessellated Cornell ", "") + f" {W}x{H}: crt_render_frame + resolve per displayed frame",
+           "ms_per_frame_image_in_hbm": round(dev_ms, 4), "ms_per_frame_image_in_host_memory": round(host_ms, 4),
+           "segment_launch_ms": round(launch_ms, 4) if launch_ms else None,
+           "untile_resolve_ms": round(dev_ms - launch_ms, 4) if launch_ms else None, "d2h_and_wait_ms": round(host_ms - dev_ms, 4),
+           "fps_image_in_hbm": round(1e3 / dev_ms, 1)}
+    if not args.no_oracle_check:
+        try:
+            from oracle import binding as ob
+            n_total = 16 + 2 * frames         # frames in the sum the last image shows: 16 (parts) were rendered after it — so render the check apart
+            scene.reset()
+            for r in rvs[:2]:
+                scene.render_frame(*r, sync=False)
+            got = scene.resolve(0.5)
+            y0 = (H // 2 - 8) // 8 * 8
+            orc = ob.Oracle(data, W, H, 1, cam)
+            rows = np.zeros((H, W, 3), np.float32)
+            for rx, ry in rvs[:2]:
+                orc.render_rows(rx, ry, y0, y0 + 16, rows)
+            want = ob.resolve(rows[y0:y0 + 16], 0.5)
+            out["rgba_rows_match_oracle"] = bool(np.array_equal(got[y0:y0 + 16], want) and want[..., :3].max() > 0)
+        except Exception as e:
+            log(f"[bench] frame-loop oracle check did not run: {e!r}")
+            out["rgba_rows_match_oracle"] = None
+    scene.close()
+    return out
 
 
 def dry_block(ctx, W, H, spp, scaling):
@@ -782,6 +891,8 @@ def main():
         head = dry_block(ctx, W, H, spp, scaling)
         extra = {}
     else:
+        if N > 1 and args.builder == "auto" and not args.device_built and name != "cornell":
+            args.device_built = "sah"          # every rank's crt_scene_create builds the tree on its own GPU: no host SBVH build in the N > 1 path
         head = run_block(ctx, name, W, H, args.depth, spp, True, N == 1 and not args.device_built, scaling, device_built=args.device_built)
         extra = {}
         if auto and not args.no_extra and args.accel == "cwbvh":
@@ -792,6 +903,14 @@ def main():
                 extra["incoherent"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak")
                 extra["incoherent_disney"] = run_block(ctx, "mesh1m", 1920, 1080, 4, 4, True, False, "weak", materials="disney")
                 extra["scale_base"] = run_block(ctx, "mesh1m", 3840, 2160, 1, 4, True, False, "strong")
+                # the reference's own published claims (README.md:21-22), measured on this GPU: "CWBVH 2 to 4 times faster than SBVH" = the same
+                # frames through the shipped shader's BVH2 walk (accel bvh2) over the SBVH; "SBVH 20-30 % faster than SAH BVH" = that walk
+                # over the SAH-only tree (object splits, no spatial splits)
+                extra["bvh2_cornell"] = run_block(ctx, "cornell", 1920, 1080, 1, 1, True, False, "weak", accel="bvh2")
+                extra["bvh2_mesh1m"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, False, "weak", accel="bvh2")
+                extra["bvh2_mesh1m_sah"] = run_block(ctx, "mesh1m", 1920, 1080, 1, 4, True, False, "weak", accel="bvh2", sbvh_flags=1)
+                extra["frame_loop_cornell"] = frame_loop_block(ctx, "cornell", 1920, 1080)
+                extra["frame_loop_mesh1m"] = frame_loop_block(ctx, "mesh1m", 1920, 1080)
                 if not args.no_hbm_resident:
                     # > 256 MiB of nodes + records: the one block whose `traffic` is HBM traffic.  Built on the GPU (binned SAH): the
                     # reference's host builder would take minutes at this size.
@@ -802,14 +921,14 @@ def main():
                     args.steps = saved
             elif args.scaling == "strong":
                 ctx.barrier()
-                extra["n1_same_workload"] = run_block(ctx, name, W, H, args.depth, spp, False, False, "strong")
+                extra["n1_same_workload"] = run_block(ctx, name, W, H, args.depth, spp, False, False, "strong", device_built=args.device_built)      # on the same tree
                 ctx.barrier()
 
     if ctx.rank == 0:
         out = {"metric": METRIC.replace("1920x1080", f"{W}x{H}"), "value": head["value"], "unit": head["unit"], "n_gpus": N, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": head["config"], "roofline": head["roofline"]}
-        for k in ("cpu_baseline", "gather_ms", "rank_device_ms_per_step", "sum_rows_match_oracle", "collective"):
+        for k in ("step_ms_spread", "cpu_baseline", "gather_ms", "rank_device_ms_per_step", "sum_rows_match_oracle", "collective"):
             if k in head:
                 out[k] = head[k]
         if head.get("dry_run"):
@@ -819,7 +938,17 @@ def main():
             # the same frame rendered by rank 0 alone in this job: what N ranks are measured against
             out["n1_same_workload"] = {"value": n1["value"], "ms_per_step": n1["ms_per_step"]}
             out["scaling_efficiency"] = round(head["value"] / (N * n1["value"]), 4)
-        ex = {k: compact(v) for k, v in extra.items() if v is not None}
+        ex = {k: (compact(v) if "roofline" in v else v) for k, v in extra.items() if v is not None}
+        if ex.get("bvh2_mesh1m") and ex.get("bvh2_cornell"):
+            # README.md:21-22 next to this GPU's numbers (throughput ratios on the same frames; the reference quotes none of its own hardware)
+            claims = {"readme": "README.md:21-22: 'SBVH 20-30 % faster than SAH BVH', 'CWBVH 2 to 4 times faster than SBVH'",
+                      "cwbvh_over_bvh2_mesh1m": round(head["value"] / ex["bvh2_mesh1m"]["value"], 3),
+                      "cwbvh_over_bvh2_cornell": round(ex["cornell"]["value"] / ex["bvh2_cornell"]["value"], 3) if ex.get("cornell") else None}
+            if ex.get("bvh2_mesh1m_sah"):
+                claims["sbvh_over_sah_bvh2_walk"] = round(ex["bvh2_mesh1m"]["value"] / ex["bvh2_mesh1m_sah"]["value"], 3)
+                a, b = extra["bvh2_mesh1m"]["roofline"]["counters"], extra["bvh2_mesh1m_sah"]["roofline"]["counters"]
+                claims["sah_over_sbvh_node_visits"] = round((b["nodes_closest"] + b["nodes_any"]) / max(1, a["nodes_closest"] + a["nodes_any"]), 3)
+            out["reference_claims"] = claims
         if ex:
             out["extras"] = ex
         sys.stdout.flush()
@@ -834,10 +963,13 @@ def compact(b):
     """An extra block of the line: what it is, its throughput and its roofline figures, nothing else (README.md explains the fields)."""
     r, c = b["roofline"], b["config"]
     e = {"workload": c["workload"].split(",")[0].replace("procedural tessellated Cornell ", "") + f" {c['resolution']} d{c['path_segments']} spp{c['spp_per_step']}"
-                     + (" disney" if "Disney" in c["workload"] else "") + (" gpu-built" if "device_build" in c else ""),
+                     + (" disney" if "Disney" in c["workload"] else "") + (" gpu-built" if "device_build" in c else "") + (" bvh2" if r.get("accel") == "bvh2" else "")
+         + (" sah-only" if "SAH BVH" in c["workload"] else ""),
          "value": b["value"], "ms_per_step": b["ms_per_step"], "launch_ms": r["launch_ms"], "samples_per_launch": r["samples_per_launch"],
-         "frac": r["frac"], "achieved": r["achieved"], "algorithmic_gbps": r["algorithmic_gbps"]}
-    for k in ("traffic", "traffic_gbps", "hbm_frac", "issue_busy", "lane_util", "counter_frac", "non_traversal_share", "l2_hit_rate"):
+         "frac": r["frac"]}
+    if b.get("step_ms_spread"):
+        e["step_ms"] = [b["step_ms_spread"]["min"], b["step_ms_spread"]["median"], b["step_ms_spread"]["max"]]      # min, median, max (README.md: how they are measured)
+    for k in ("frac_executed", "traffic", "traffic_gbps", "hbm_frac", "issue_busy", "lane_util", "counter_frac", "non_traversal_share", "l2_hit_rate"):
         if r.get(k) is not None:
             e[k] = r[k]
     if b.get("sum_rows_match_oracle") is not None:

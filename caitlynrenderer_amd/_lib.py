@@ -81,6 +81,8 @@ SYMBOLS = {
     "crt_sum_device": (_I, [_P, C.POINTER(_P)]),
     "crt_trace": (_I, [_P, _P, _SZ, _P, _I, _P]),
     "crt_trace_device": (_I, [_P, _P, _SZ, _P, _I, _P, _I]),
+    "crt_resolve_device": (_I, [_P, C.c_float, C.POINTER(C.c_void_p), _I]),
+    "crt_get_launch_times": (_I, [_P, _P, _SZ, C.POINTER(_SZ)]),
     "crt_debug_read_queue": (_I, [_P, _I, _U32, _P, _SZ, C.POINTER(_SZ)]),
     "crt_debug_time_graph": (_I, [_P, _U32, _P, _U32, C.POINTER(_F), C.POINTER(_F)]),
     "crt_debug_launch_form": (_I, [_P, C.POINTER(C.c_int32)]),

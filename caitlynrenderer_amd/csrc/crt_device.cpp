@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -22,6 +23,7 @@
 #include "crt_error.hpp"
 #include "device_build.hpp"
 #include "host/cwbvh.hpp"
+#include "host/flatnode_link.hpp"
 #include "rt_kernels.hpp"
 
 using crt::fail;
@@ -116,6 +118,8 @@ struct crt_scene {
     float* d_sum = nullptr;
     float* d_linear = nullptr;
     uint8_t* d_rgba = nullptr;
+    uint8_t* h_rgba = nullptr;           // pinned staging buffer of crt_resolve
+    float* d_gamma = nullptr;            // the 256 thresholds of the pinned gamma (resolve kernels)
     float4* d_rays[2] = {nullptr, nullptr};   // path-ray queues, only for max_depth > 1
     // DEFERRED NEE shadow rays (option "inplace_shadow" 0 / 2, rt_kernels.hip k_segment<!INPLACE>): the frame's NEE queue — one region per
     // deferring segment, 8 sub-queues each, 2 x float4 per ray: (o, tmax) (d, contribution slot) — and the contribution slots, one per
@@ -170,6 +174,7 @@ struct crt_scene {
     bool have_camera = false;
     uint32_t jitter = 1;
     bool count_visits = false;
+    bool count_batched = false;               // option count_visits 2: counting frames may share a launch in the timed form (four samples in the lanes of a wave)
     unsigned long long* d_visit_totals = nullptr;   // [0..3] lane visits: closest nodes/tris, any nodes/tris; [4..7] wave-level steps of the same blocks; [8] closest-hit rays that hit; [10], [11] closest / any-hit node visits of uniform node steps
     unsigned long long* h_visit_totals = nullptr;   // pinned
 
@@ -256,7 +261,7 @@ struct crt_scene {
         if (stream) hipStreamSynchronize(stream);
         if (shares_scene)                    // borrowed from the primary, which frees them
             for (const auto& b : scene_bufs) *reinterpret_cast<void**>(reinterpret_cast<char*>(this) + b.first) = nullptr;
-        void* ptrs[] = {d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_planes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
+        void* ptrs[] = {d_gamma, d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_planes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
                         d_rays[0], d_rays[1], d_nee, d_contrib, d_qhits, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal, d_bins};
         for (void* p : ptrs) if (p) hipFree(p);
@@ -265,6 +270,7 @@ struct crt_scene {
         if (ev_tile_cost) hipEventDestroy(ev_tile_cost);
         if (ev_tile_order) hipEventDestroy(ev_tile_order);
         if (h_counts) hipHostFree(h_counts);
+        if (h_rgba) hipHostFree(h_rgba);
         if (h_visit_totals) hipHostFree(h_visit_totals);
         for (EventSpan& s : spans) { if (s.a) hipEventDestroy(s.a); if (s.b) hipEventDestroy(s.b); }
         if (stream) hipStreamDestroy(stream);
@@ -551,8 +557,8 @@ namespace {
 struct Warmer {
     std::mutex m;
     std::thread t;
-    bool started[64] = {};                         // per HIP device
-    int rc = 0;
+    std::vector<int> started;                      // HIP devices whose code objects are loaded or loading
+    std::atomic<int> rc{0};                        // first failure of a background load (crt_warmup reports it; a first use then loads again and fails loudly itself)
     static int load_all() {
         int e;
         if ((e = crt::warm_rt_kernels()) || (e = crt::warm_lbvh_kernels()) || (e = crt::warm_cwbvh_kernels()) || (e = crt::warm_scene_build_kernels())) return e;
@@ -560,16 +566,22 @@ struct Warmer {
     }
     void start(int device) {                       // returns at once
         std::lock_guard<std::mutex> g(m);
-        if (device < 0 || device >= 64 || started[device]) return;
-        started[device] = true;
+        if (device < 0 || std::find(started.begin(), started.end(), device) != started.end()) return;
         if (t.joinable()) t.join();
         try {
-            t = std::thread([this, device] { if (hipSetDevice(device) == hipSuccess) rc = load_all(); });
+            started.push_back(device);
+            t = std::thread([this, device] {
+                int e = (int)hipSetDevice(device);
+                if (!e) e = load_all();
+                int none = 0;
+                if (e) rc.compare_exchange_strong(none, e);
+            });
         } catch (const std::exception&) { /* no thread: the code objects load at first use, as before */ }
     }
-    void wait() {
+    int wait() {                                   // joins the background load; its result (0 = fine)
         std::lock_guard<std::mutex> g(m);
         if (t.joinable()) t.join();
+        return rc.load();
     }
     ~Warmer() { if (t.joinable()) t.join(); }
 };
@@ -585,7 +597,8 @@ int crt_warmup(void) {
     HIPCHK(hipFree(nullptr));                          // creates the context
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
-    g_warmer.wait();
+    const int bg = g_warmer.wait();
+    if (bg) return fail(CRT_ERR_HIP, std::string("crt_warmup: a background load of a code object had failed: ") + hipGetErrorString((hipError_t)bg));
     const int e = Warmer::load_all();
     if (e) return fail(CRT_ERR_HIP, std::string("crt_warmup: loading a code object failed: ") + hipGetErrorString((hipError_t)e));
     hipStream_t st = nullptr;
@@ -849,7 +862,8 @@ static int scene_create_impl(const crt_scene_desc* d, crt_scene** out) {
 // of FlatNodes over PCIe twice at 1 M triangles).  Temporaries of both builders come from one arena allocation.
 static int scene_create_device_built(const crt_scene_desc* d, crt_scene** out) {
     const auto t_begin = std::chrono::steady_clock::now();
-    if (d->n_triangles >= (1u << 23)) return fail(CRT_ERR_LIMIT, "crt_scene_create: more than 2^23 triangles (the 2 n - 1 FlatNode links are floats, exact below 2^24)");
+    // (the FlatNode array of a scene built here never leaves the device: links of 2^24 or more are kept as bit patterns, host/flatnode_link.hpp)
+    if (2ull * d->n_triangles >= crt::kMaxLinkBits) return fail(CRT_ERR_LIMIT, "crt_scene_create: more than 2^29 triangles");
     const bool have_tex = d->albedo_textures && d->n_textures > 0;
     std::unique_ptr<crt_scene> owner(new (std::nothrow) crt_scene);
     crt_scene* s = owner.get();
@@ -1011,7 +1025,7 @@ int crt_reset(crt_scene* s) {
 int crt_set_option(crt_scene* s, const char* name, int value) {
     if (!s || !name) return fail(CRT_ERR_INVALID, "crt_set_option: null argument");
     if (!std::strcmp(name, "jitter")) s->jitter = value ? 1u : 0u;
-    else if (!std::strcmp(name, "count_visits")) s->count_visits = value != 0;
+    else if (!std::strcmp(name, "count_visits")) { s->count_visits = value != 0; s->count_batched = value == 2; }
     else if (!std::strcmp(name, "bounce_refill")) s->bounce_refill = value ? 1u : 0u;
     else if (!std::strcmp(name, "refill_pool") || !std::strcmp(name, "shadow_pool")) {
         if (value != 64 && value != 128 && value != 256 && value != 512) return fail(CRT_ERR_INVALID, std::string("crt_set_option: ") + name + " is 64, 128, 256 or 512");
@@ -1434,8 +1448,14 @@ static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
 // rays walked in place) — bounce queues and the shadow queue hold one entry per pixel
 static uint32_t batch_limit(const crt_scene* s) {
     // the batched builds of the first segment walk its shadow rays in place; counting frames run one by one
-    if (first_deferred_segment(s) == 0u || s->count_visits) return 1u;
+    if (first_deferred_segment(s) == 0u || (s->count_visits && !s->count_batched)) return 1u;
     if (s->accel != 0u) return 1u;                                     // the BVH2 frame mode (a comparison aid) has no batched build
+    if (s->count_visits) {
+        // counting in the timed form: exactly the launch of four samples in the lanes of a wave has a counting build (launch_segment)
+        const bool lanes_form = s->wave_samples >= 2u && s->info.n_nodes8 >= 64 && s->tri_min != 0u && s->lanes_per_ray >= 8u;
+        const uint64_t fit4 = s->n_local_pixels ? 0x7fffffffull / s->n_local_pixels : 4ull;
+        return lanes_form && fit4 >= 4ull ? 4u : 1u;
+    }
     if (s->max_depth == 1u) return 8u;
     // several segments: every sample keeps its own path state and queue entries (ensure_batch_buffers) and the samples' radiance is
     // added in frame order by k_fold_paths
@@ -1473,6 +1493,7 @@ int crt_render_frames_async(crt_scene* s, uint32_t n, const float* rx, const flo
     for (uint32_t i = 0; i < n;) {
         uint32_t k = std::min(lim, n - i);
         if (fours && k > 4u && (k & 3u)) k &= ~3u;                       // 7 frames = 4 + 3, not 7 one after the other
+        if (s->count_visits && k != 4u) k = 1u;                          // counting launches: four samples in the lanes form, or one
         const int rc = render_batch_all(s, k, rx + i, ry + i);
         if (rc) return rc;
         i += k;
@@ -1667,6 +1688,61 @@ int crt_sum_device(crt_scene* s, const float** d_rgb) {
     return CRT_OK;
 }
 
+// The pinned gamma of the resolve kernels: thr[j] (j = 1..255) = the smallest float x >= 0 whose reference byte
+// (uint8)(clamp01((float)pow((double)x, 1 / 2.2)) * 255 + 0.5) is >= j — pow in double, rounded once.  The byte of any x is then the number of
+// thresholds it has reached, whatever the device's own powf does in its last bits.  (oracle/oracle.c builds the same table by itself.)
+static const float* gamma_thresholds() {
+    static float thr[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto ref_byte = [](float x) {
+            float v = (float)std::pow((double)x, (double)(1.0f / 2.2f));
+            v = v < 0.f ? 0.f : v > 1.f ? 1.f : v;
+            return (uint32_t)(uint8_t)(v * 255.0f + 0.5f);
+        };
+        thr[0] = 0.f;
+        for (uint32_t j = 1; j < 256u; ++j) {
+            uint32_t lo = 0u, hi = 0x7f800000u;              // bit patterns of the non-negative floats, ordered like their values; ref_byte(+inf) = 255
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2u;
+                float x; std::memcpy(&x, &mid, 4);
+                if (ref_byte(x) >= j) hi = mid; else lo = mid + 1u;
+            }
+            std::memcpy(&thr[j], &lo, 4);
+        }
+    });
+    return thr;
+}
+
+// tone-mapped RGBA8 of the frame in s->d_rgba (this device), straight from the packed tile buffers: this scene's, and its peers' as gathered
+static int resolve_to_device(crt_scene* s, float inv_count) {
+    const size_t npx = (size_t)s->width * s->height;
+    int rc;
+    if (!s->d_rgba) { if ((rc = dev_alloc(&s->d_rgba, 4 * npx))) return rc; }
+    if (!s->d_gamma) {
+        if ((rc = dev_alloc(&s->d_gamma, 256))) return rc;
+        HIPCHK(hipMemcpy(s->d_gamma, gamma_thresholds(), 256 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // a shard of a frame (crt_set_shard with world > 1) leaves the other ranks' pixels at 0
+    if (s->shard_world > 1u) HIPCHK(hipMemsetAsync(s->d_rgba, 0, 4 * npx, s->stream));
+    if (s->n_local_pixels) {
+        const crt::FrameArgs f = frame_args(s, 0.f, 0.f);
+        crt::launch_resolve_packed(f, s->d_sum, inv_count, s->d_gamma, s->d_rgba, s->flat_grid(s->n_local_pixels), s->stream);
+    }
+    if (!s->peers.empty()) {
+        if ((rc = gather_peers(s))) return rc;
+        for (size_t k = 0; k < s->peers.size(); ++k) {
+            const crt_scene* p = s->peers[k];
+            if (!p->n_local_pixels) continue;
+            crt::FrameArgs f = frame_args(p, 0.f, 0.f);
+            f.tile_xy = s->d_peer_tiles[k];
+            f.tile_order = nullptr;
+            crt::launch_resolve_packed(f, s->d_gather[k], inv_count, s->d_gamma, s->d_rgba, s->flat_grid(p->n_local_pixels), s->stream);
+        }
+    }
+    return CRT_OK;
+}
+
 int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
     if (!s || !rgba) return fail(CRT_ERR_INVALID, "crt_resolve: null argument");
     const size_t npx = (size_t)s->width * s->height;
@@ -1674,11 +1750,39 @@ int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes) {
     HIPCHK(hipSetDevice(s->device));
     int rc = ensure_frame(s);
     if (rc) return rc;
-    if ((rc = untile_to_linear(s))) return rc;
-    if (!s->d_rgba) { if ((rc = dev_alloc(&s->d_rgba, 4 * npx))) return rc; }
-    crt::launch_resolve(s->d_linear, (uint32_t)npx, inv_count, s->d_rgba, s->flat_grid(npx), s->stream);
-    HIPCHK(hipMemcpyAsync(rgba, s->d_rgba, n_bytes, hipMemcpyDeviceToHost, s->stream));
+    if ((rc = resolve_to_device(s, inv_count))) return rc;
+    // through a pinned staging buffer: a copy into pageable memory is staged by the runtime in small pieces (8.3 MB: ~2.5 ms against 0.4)
+    if (!s->h_rgba) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_rgba), 4 * npx));
+    HIPCHK(hipMemcpyAsync(s->h_rgba, s->d_rgba, n_bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    std::memcpy(rgba, s->h_rgba, n_bytes);
+    return CRT_OK;
+}
+
+int crt_resolve_device(crt_scene* s, float inv_count, const uint8_t** d_rgba, int sync) {
+    if (!s || !d_rgba) return fail(CRT_ERR_INVALID, "crt_resolve_device: null argument");
+    *d_rgba = nullptr;
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_frame(s);
+    if (rc) return rc;
+    if ((rc = resolve_to_device(s, inv_count))) return rc;
+    if (sync) HIPCHK(hipStreamSynchronize(s->stream));
+    *d_rgba = s->d_rgba;
+    return CRT_OK;
+}
+
+int crt_get_launch_times(crt_scene* s, float* ms, size_t cap, size_t* n_out) {
+    if (!s || !n_out) return fail(CRT_ERR_INVALID, "crt_get_launch_times: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    size_t n = 0;
+    for (int i = 0; i < s->n_spans; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, s->spans[i].a, s->spans[i].b) != hipSuccess) continue;
+        if (ms && n < cap) ms[n] = t;
+        ++n;
+    }
+    *n_out = n;
     return CRT_OK;
 }
 
@@ -1749,6 +1853,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->info = src->info; r->bvh2_stack = src->bvh2_stack; r->stack_entries = src->stack_entries; r->special_materials = src->special_materials;
     r->cam = src->cam; r->have_camera = src->have_camera; r->jitter = src->jitter;
     r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
+    r->count_batched = src->count_batched;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
     r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min; r->persistent = src->persistent;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
@@ -1907,15 +2012,12 @@ static int gather_peers(crt_scene* s) {
         if (nr == 0) nr = ne;
         (void)hipSetDevice(s->device);
         if (nr != 0) {
-            // a first run on real hardware must not end here: the peer copies below do the same job (the slices are disjoint buffers;
-            // whatever part of the grouped send / recv was enqueued wrote the same bytes to the same places)
-            (void)fail(CRT_OK, std::string("crt_read_sum: RCCL gather failed (") + (g_rccl.err ? g_rccl.err(nr) : "?") + "), gathering with hipMemcpyPeerAsync from now on");
-            std::fprintf(stderr, "[crt] %s\n", crt_last_error());
+            // This read fails and the NEXT one gathers with peer copies.  Nothing is waited for here: a failed group can leave unmatched
+            // send / recv kernels on the devices' streams, and a synchronise behind them may never return.  (The multi-device path has run
+            // on virtual devices and at world size 1 only: DESIGN.md section 7.)
             s->gather_transport = 1;
-            for (crt_scene* p : s->peers) { (void)hipSetDevice(p->device); (void)hipStreamSynchronize(p->stream); }
-            (void)hipSetDevice(s->device);
-            (void)hipStreamSynchronize(s->stream);
-            (void)hipGetLastError();
+            return fail(CRT_ERR_HIP, std::string("RCCL gather failed (") + (g_rccl.err ? g_rccl.err(nr) : "?") +
+                                     "); this read-back is lost, the next one gathers with hipMemcpyPeerAsync (option gather_transport 1)");
         }
     }
     if (s->gather_transport != 0 || s->rccl_comms.empty()) {

@@ -45,7 +45,7 @@ __global__ void k_parents(const crt_flatnode* __restrict__ bvh2, uint32_t n2, in
     if (i >= n2) return;
     const crt_flatnode fn = bvh2[i];
     if (is_leaf(fn)) return;
-    const int left = (int)fn.bmin[3];
+    const int left = crt::link_of(fn.bmin[3]);
     if (left <= (int)i || (uint32_t)left + 1u >= n2) { atomicOr(flags, ERR_LINK); return; }   // children follow parents (BFS order)
     parent[left] = (int32_t)i;
     parent[left + 1] = (int32_t)i;
@@ -78,12 +78,12 @@ __global__ void k_costs_level(const crt_flatnode* __restrict__ bvh2, uint32_t be
     int np;
     if (is_leaf(fn)) {
         np = (int)fn.bmax[3];
-        const int start = (int)fn.bmin[3];
+        const int start = crt::link_of(fn.bmin[3]);
         if (np < 1 || np > 3) { atomicOr(flags, ERR_LEAF_SIZE); return; }
         if (start < 0 || (uint32_t)(start + np) > n_slots) { atomicOr(flags, ERR_LEAF_RANGE); return; }
         leaf_decisions(half_area(fn), np, d);
     } else {
-        const int left = (int)fn.bmin[3];
+        const int left = crt::link_of(fn.bmin[3]);
         // the host bails out on ERR_LINK before the first cost pass; this check keeps the kernel in bounds on its own
         if (left <= (int)i || (uint32_t)left + 1u >= n2) { atomicOr(flags, ERR_LINK); return; }
         np = nprims[left] + nprims[left + 1];

@@ -37,14 +37,14 @@ struct Converter {
             const float area = cw::half_area(fn);
             if (is_leaf(fn)) {
                 const int np = (int)fn.bmax[3];
-                const int start = (int)fn.bmin[3];
+                const int start = link_of(fn.bmin[3]);
                 if (np < 1 || np > 3) { out->error = "BVH2 leaf with more than 3 triangles cannot be encoded"; return false; }
                 if (start < 0 || (size_t)(start + np) > n_slots) { out->error = "BVH2 leaf range outside the triangle array"; return false; }
                 nprims[node] = np;
                 cw::leaf_decisions(area, np, &D((int)node, 0));
                 continue;
             }
-            const int left = (int)fn.bmin[3], right = left + 1;
+            const int left = link_of(fn.bmin[3]), right = left + 1;
             if (left <= node || (size_t)right >= n2) { out->error = "BVH2 child link out of order"; return false; }
             const int np = nprims[left] + nprims[right];
             nprims[node] = np;

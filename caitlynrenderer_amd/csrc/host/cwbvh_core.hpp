@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../../include/crt.h"
+#include "flatnode_link.hpp"
 
 #if defined(__HIPCC__)
 #define CRT_HD __host__ __device__ inline
@@ -78,7 +79,7 @@ CRT_HD int get_children(const crt_flatnode* bvh2, const Decision* dec, int node,
         const crt_flatnode& fn = bvh2[n];
         if (is_leaf(fn)) { children[count++] = n; continue; }
         const Decision& d = dec[(size_t)n * 7 + i];
-        const int left = (int)fn.bmin[3], right = left + 1;
+        const int left = link_of(fn.bmin[3]), right = left + 1;
         // push right first so that the left subtree is expanded (and emitted) first
         if (dec[(size_t)right * 7 + d.dr].type == DISTRIBUTE) { st_node[sp] = right; st_i[sp] = d.dr; }
         else                                                  { st_node[sp] = right; st_i[sp] = -1; }
@@ -195,10 +196,10 @@ CRT_HD int collect_slots(const crt_flatnode* bvh2, int node, int32_t out[3]) {
     while (sp > 0) {
         const crt_flatnode& fn = bvh2[st[--sp]];
         if (is_leaf(fn)) {
-            const int start = (int)fn.bmin[3], range = (int)fn.bmax[3];
+            const int start = link_of(fn.bmin[3]), range = (int)fn.bmax[3];
             for (int i = 0; i < range && n < 3; ++i) out[n++] = start + i;
         } else {
-            const int left = (int)fn.bmin[3];
+            const int left = link_of(fn.bmin[3]);
             if (sp + 2 <= 4) { st[sp++] = left + 1; st[sp++] = left; }
         }
     }

@@ -20,6 +20,7 @@
 #include "crt_error.hpp"
 #include "crt_handles.hpp"
 #include "device_build.hpp"
+#include "host/flatnode_link.hpp"
 
 using crt::fail;
 
@@ -181,14 +182,14 @@ __global__ void k_flatten(const uint32_t* __restrict__ order, const uint32_t* __
         const float* bx = leaf_box + 6 * (size_t)(uint32_t)(sorted[leaf] & 0xffffffffull);
         f.bmin[0] = bx[0]; f.bmin[1] = bx[1]; f.bmin[2] = bx[2];
         f.bmax[0] = bx[3]; f.bmax[1] = bx[4]; f.bmax[2] = bx[5];
-        f.bmin[3] = (float)leaf;                        // leaf slot = position in Morton order
+        f.bmin[3] = crt::link_enc((uint32_t)leaf);                        // leaf slot = position in Morton order
         f.bmax[3] = 1.0f;
     } else {
         const int2 c = child[id];
         const uint32_t l = pos[c.x], r = pos[c.y];
         if (r != l + 1u || l <= p) atomicOr(bad, 1u);   // children adjacent and after their parent
         f.bmin[0] = f.bmin[1] = f.bmin[2] = 0.f; f.bmax[0] = f.bmax[1] = f.bmax[2] = 0.f;   // set by k_refit_level
-        f.bmin[3] = (float)l;
+        f.bmin[3] = crt::link_enc(l);
         f.bmax[3] = 0.0f;
     }
     flat[p] = f;
@@ -210,7 +211,7 @@ __global__ void k_refit_level(crt_flatnode* __restrict__ flat, uint32_t begin, u
     if (p >= end) return;
     crt_flatnode f = flat[p];
     if (f.bmax[3] != 0.0f) return;                      // leaf
-    const uint32_t l = (uint32_t)f.bmin[3];
+    const uint32_t l = (uint32_t)crt::link_of(f.bmin[3]);
     const crt_flatnode a = flat[l], b = flat[l + 1];
     for (int k = 0; k < 3; ++k) { f.bmin[k] = fminf(a.bmin[k], b.bmin[k]); f.bmax[k] = fmaxf(a.bmax[k], b.bmax[k]); }
     flat[p] = f;
@@ -446,12 +447,12 @@ __global__ void k_ploc_flatten(const uint32_t* __restrict__ order, const uint32_
     f.bmax[0] = hi.x; f.bmax[1] = hi.y; f.bmax[2] = hi.z;
     const int left = __float_as_int(lo.w);
     if (left < 0) {
-        f.bmin[3] = (float)__float_as_int(hi.w);        // leaf slot = position in Morton order
+        f.bmin[3] = crt::link_enc((uint32_t)__float_as_int(hi.w));        // leaf slot = position in Morton order
         f.bmax[3] = 1.0f;
     } else {
         const uint32_t l = pos[left], r = pos[__float_as_int(hi.w)];
         if (r != l + 1u || l <= p) atomicOr(bad, 1u);
-        f.bmin[3] = (float)l;
+        f.bmin[3] = crt::link_enc(l);
         f.bmax[3] = 0.0f;
     }
     flat[p] = f;
@@ -943,13 +944,13 @@ __global__ void k_sah_flatten(const uint32_t* __restrict__ order, const uint32_t
         const float* bx = leaf_box + 6 * (size_t)tri_order[right];
         f.bmin[0] = bx[0]; f.bmin[1] = bx[1]; f.bmin[2] = bx[2];
         f.bmax[0] = bx[3]; f.bmax[1] = bx[4]; f.bmax[2] = bx[5];
-        f.bmin[3] = (float)right;
+        f.bmin[3] = crt::link_enc((uint32_t)right);
         f.bmax[3] = 1.0f;
     } else {
         const uint32_t l = pos[left], r = pos[right];
         if (r != l + 1u || l <= p) atomicOr(bad, 1u);
         f.bmin[0] = f.bmin[1] = f.bmin[2] = 0.f; f.bmax[0] = f.bmax[1] = f.bmax[2] = 0.f;   // set by k_refit_level
-        f.bmin[3] = (float)l;
+        f.bmin[3] = crt::link_enc(l);
         f.bmax[3] = 0.0f;
     }
     flat[p] = f;

@@ -16,6 +16,7 @@
 
 #include "rt_kernels.hpp"
 #include "rt_math.hpp"
+#include "host/flatnode_link.hpp"
 
 namespace crt {
 
@@ -1170,7 +1171,7 @@ __device__ __forceinline__ bool traverse_bvh2(const float4* __restrict__ nodes, 
     while (ind > -1) {
         const float4 bmin = nodes[2 * (size_t)ind], bmax = nodes[2 * (size_t)ind + 1];
         if (STATS) ++nn;
-        const int left = (int)bmin.w;
+        const int left = link_of(bmin.w);            // an index as a float, or its bit pattern from 2^24 on (host/flatnode_link.hpp)
         if (bmax.w == 0.0f) {
             const float4 amin = nodes[2 * (size_t)left], amax = nodes[2 * (size_t)left + 1];
             const float4 cmin = nodes[2 * (size_t)left + 2], cmax = nodes[2 * (size_t)left + 3];
@@ -2194,26 +2195,42 @@ __global__ void __launch_bounds__(256) k_untile(FrameArgs f, const float* __rest
     }
 }
 
-// Shader/output.fs:9-20 on the linear sum buffer.
-__global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linear, uint32_t n_pixels, float inv_count,
-                                                 uint8_t* __restrict__ rgba) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x) {
-        const float c0 = linear[3 * (size_t)i] * inv_count, c1 = linear[3 * (size_t)i + 1] * inv_count,
-                    c2 = linear[3 * (size_t)i + 2] * inv_count;
-        const float lum = 0.3f * c0 + 0.6f * c1 + 0.1f * c2;
-        const float k = rcp_ieee(1.0f + __fdiv_rn(lum, 2.0f));
-        const float cc[3] = {c0, c1, c2};
-        uchar4 out;
-        uint8_t* o8 = reinterpret_cast<uint8_t*>(&out);
+// Shader/output.fs:9-20: c = S / frames; c *= 1 / (1 + lum(c) / 2); pow(c, 1 / 2.2); 8-bit UNORM write.  The power is PINNED: pow's last
+// bits differ between libm and the device, and the byte only depends on which of 255 thresholds the argument has reached — thr[j] = the
+// smallest float x whose reference byte (double-precision pow, rounded once) is >= j, a table the host computes (crt_device.cpp
+// gamma_thresholds; the oracle has its own) — so the byte is a count of thresholds: eight compares, and exact on both sides.
+__device__ __forceinline__ uchar4 resolve_pixel(float s0, float s1, float s2, float inv_count, const float* __restrict__ thr) {
+    const float c0 = s0 * inv_count, c1 = s1 * inv_count, c2 = s2 * inv_count;
+    const float lum = 0.3f * c0 + 0.6f * c1 + 0.1f * c2;
+    const float k = rcp_ieee(1.0f + __fdiv_rn(lum, 2.0f));
+    const float cc[3] = {c0, c1, c2};
+    uchar4 out;
+    uint8_t* o8 = reinterpret_cast<uint8_t*>(&out);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float v = powf(cc[ch] * 1.0f * k, 1.0f / 2.2f);
-            v = v < 0.f ? 0.f : v > 1.f ? 1.f : v;
-            if (v != v) v = 0.f;
-            o8[ch] = (uint8_t)(v * 255.0f + 0.5f);
-        }
-        o8[3] = 255;
-        reinterpret_cast<uchar4*>(rgba)[i] = out;
+    for (int ch = 0; ch < 3; ++ch) {
+        const float x = cc[ch] * 1.0f * k;
+        uint32_t lo = 0u;                                  // thr[1..255] ascending; byte = the largest j with x >= thr[j] (0: none; NaN and negatives: none)
+#pragma unroll
+        for (uint32_t step = 128u; step != 0u; step >>= 1)
+            if (x >= thr[lo + step]) lo += step;
+        o8[ch] = (uint8_t)lo;
+    }
+    o8[3] = 255;
+    return out;
+}
+__global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ linear, uint32_t n_pixels, float inv_count, const float* __restrict__ thr,
+                                                 uint8_t* __restrict__ rgba) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x)
+        reinterpret_cast<uchar4*>(rgba)[i] = resolve_pixel(linear[3 * (size_t)i], linear[3 * (size_t)i + 1], linear[3 * (size_t)i + 2], inv_count, thr);
+}
+// The same straight from a packed tile-major sum buffer (this device's own, or a peer's slice as gathered): un-tile and resolve in one pass —
+// what the drop-in frame loop runs per displayed frame (Scene.h:1226-1230), 12 B read + 4 B written per pixel.
+__global__ void __launch_bounds__(256) k_resolve_packed(FrameArgs f, const float* __restrict__ packed, float inv_count, const float* __restrict__ thr,
+                                                        uint8_t* __restrict__ rgba) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < f.n_local_pixels; i += gridDim.x * blockDim.x) {
+        uint32_t px, py;
+        if (!pixel_of(f, i, px, py)) continue;
+        reinterpret_cast<uchar4*>(rgba)[(size_t)py * f.width + px] = resolve_pixel(packed[3 * (size_t)i], packed[3 * (size_t)i + 1], packed[3 * (size_t)i + 2], inv_count, thr);
     }
 }
 
@@ -2310,6 +2327,8 @@ int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplac
         const dim3 gg = side_by_side ? dim3(grid * 4u) : in_lanes ? dim3(grid * 16u) : g, bb = side_by_side ? dim3(ws * 64u) : in_lanes ? dim3(64u) : b;
         const size_t ll = side_by_side ? lds4 : in_lanes ? per_wave : lds;
         const bool one_pass = in_lanes && a.n_samples == 4u && a.tri_min != 0u && a.lanes_log2 != 0u;      // four samples in the lanes of a wave: the builds without a sample loop
+        // counting in the TIMED form (option count_visits 2): what the uniform node steps see depends on which rays share a wave
+        if (stats && one_pass) { launch(CRT_K(true, true, true, false, true, false, true, true, false, true), gg, bb, ll, stream, v); return 2; }
         if (feat == 2 && one_pass)      { launch(CRT_K(true, false, true, false, true, false, true, true, false, true), gg, bb, ll, stream, v); return 2; }
         else if (feat == 1 && one_pass) { launch(CRT_K(true, false, false, false, true, false, true, true, false, true), gg, bb, ll, stream, v); return 2; }
         else if (feat == 2) launch(CRT_K(true, false, true, false, true, false, true, true, false, false), gg, bb, ll, stream, v);
@@ -2377,8 +2396,11 @@ void launch_fold_paths(float* sum, const float4* l_final, const float4* contrib,
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_untile, dim3(grid), dim3(256), 0, stream, f, packed, linear);
 }
-void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, stream, linear, n_pixels, inv_count, rgba);
+void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, const float* thr, uint8_t* rgba, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, stream, linear, n_pixels, inv_count, thr, rgba);
+}
+void launch_resolve_packed(const FrameArgs& f, const float* packed, float inv_count, const float* thr, uint8_t* rgba, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve_packed, dim3(grid), dim3(256), 0, stream, f, packed, inv_count, thr, rgba);
 }
 
 // crt_warmup: load this translation unit's code object on the current device (asking for a kernel's attributes does that without

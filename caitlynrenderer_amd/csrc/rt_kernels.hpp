@@ -212,7 +212,9 @@ void launch_bin_scan(const BinScanArgs& a, hipStream_t stream);
 // contrib may be null (no deferred segment); first_slot_segment = the segment slot 0 of the slot array belongs to
 void launch_fold_paths(float* sum, const float4* l_final, const float4* contrib, uint32_t n_pixels, uint32_t n_samples, uint32_t first_slot_segment, hipStream_t stream);
 void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint32_t grid, hipStream_t stream);
-void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, uint8_t* rgba, uint32_t grid, hipStream_t stream);
+// thr: the 256 thresholds of the pinned gamma (thr[j] = smallest x whose byte is >= j; thr[0] unused), in device memory
+void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, const float* thr, uint8_t* rgba, uint32_t grid, hipStream_t stream);
+void launch_resolve_packed(const FrameArgs& f, const float* packed, float inv_count, const float* thr, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 
 void set_step_hist(unsigned long long* d_hist);      // measurement aid: [2][65] node-step histogram of the counting kernels, null = off
 int warm_rt_kernels();      // crt_warmup: loads this unit's code object on the current device

@@ -19,8 +19,12 @@ __device__ __forceinline__ float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y *
 __device__ __forceinline__ vec3 cross(vec3 a, vec3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-#ifndef CRT_FAST_RCP
+// The short forms of 1 / x and sqrt(x) below give the IEEE bits only because of THIS chip's 1-ulp v_rcp_f32 / v_rsq_f32 (checked on every
+// float by tools/ubench/*_exhaustive.hip, run by the GPU suite): any other target takes the compiler's correctly rounded expansions.
+#if defined(__gfx950__)
 #define CRT_FAST_RCP 1
+#else
+#define CRT_FAST_RCP 0
 #endif
 // IEEE correctly rounded square root.  NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS the HIP
 // headers map that to __ocml_native_sqrt_f32 (bare v_sqrt_f32, 1 ulp).  sqrtf lowers to llvm.sqrt.f32,

@@ -116,6 +116,7 @@ int warm_scene_build_kernels() {
     if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_gather_slots))) != hipSuccess) return (int)e;
     if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_gather_records))) != hipSuccess) return (int)e;
     if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_restride))) != hipSuccess) return (int)e;
+    if ((e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_expand_planes))) != hipSuccess) return (int)e;
     return 0;
 }
 

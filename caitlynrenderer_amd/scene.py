@@ -156,6 +156,24 @@ class Scene:
         check(lib().crt_resolve(self._h, float(np.float32(inv_count)), _ptr(out), out.size))
         return out
 
+    def resolve_device(self, inv_count=None, sync=True):
+        """crt_resolve_device: the tone-mapped RGBA8 frame left in device memory (what the reference's output pass leaves in the default
+        framebuffer); returns the device pointer"""
+        if inv_count is None:
+            inv_count = 1.0 / max(self.frame_count, 1)
+        p = C.c_void_p()
+        check(lib().crt_resolve_device(self._h, float(np.float32(inv_count)), C.byref(p), 1 if sync else 0))
+        return p.value
+
+    def launch_times(self):
+        """crt_get_launch_times: ms of every event-carrying launch since the spans were restarted (options timing / timing_accumulate)"""
+        n = C.c_size_t()
+        check(lib().crt_get_launch_times(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        if n.value:
+            check(lib().crt_get_launch_times(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
+
     def trace(self, rays, mode=CRT_TRACE_CLOSEST, stats=False):
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)
         hits = np.empty(rays.shape[0], HIT_DT)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 6   /* 6: options inplace_shadow 2 (deferred shadow rays), bounce_refill / refill_pool / shadow_pool / shadow_refill_min in every build,
+#define CRT_ABI_VERSION 6   /* 6: crt_resolve_device, crt_get_launch_times, count_visits 2; options inplace_shadow 2 (deferred shadow rays), bounce_refill / refill_pool / shadow_pool / shadow_refill_min in every build,
                               *    tri_share / compact_shadow gone; crt_debug_launch_info's build word carries the one-pass bit;
                               * 5: crt_frame_stats.nodes_closest_uniform / nodes_any_uniform (the struct grew);
                               * 4: crt_warmup, crt_shard_tiles, crt_debug_launch_info, crt_debug_step_hist; options lanes_per_ray, ray_bins 4 / 5, tri_share bits;
@@ -169,7 +169,9 @@ int crt_sync(crt_scene* s);
  *                         shader walks it (path_trace.fs:511-819, first visited triangle wins a tie); 2 = the BVH2 with
  *                         the lowest-id tie rule; 1 and 2 need desc.bvh
  *   telemetry
- *     "count_visits"      0/1: traversal launches also count node fetches / triangle tests (crt_frame_stats)
+ *     "count_visits"      0/1: traversal launches also count node fetches / triangle tests (crt_frame_stats), frame by frame; 2: counting
+ *                         frames may share a launch in the form the timed launches have (crt_render_frames of four frames: four samples
+ *                         of a 4x4 pixel quadrant in the lanes of a wave) — what the uniform node steps see depends on which rays share a wave
  *     "adaptive_tiles"    1 (default): the order in which the tiles of the frame (16x16 pixels unless crt_set_shard says otherwise) are handed to the GPU follows their
  *                         measured cost, most expensive first (one frame per new view is timed, tile by tile); 0: centre-out
  *                         order only.  Which pixel lands where — in the image and in the sum buffer — does not depend on it.
@@ -257,6 +259,12 @@ int crt_sum_device(crt_scene* s, const float** d_rgb);
 /* replaces the output pass, Shader/output.fs:9-20 + Scene.h:1226-1230:
  * rgba8 = pow(tonemap(sum*inv_count), 1/2.2), alpha 255; n_bytes = width*height*4 */
 int crt_resolve(crt_scene* s, float inv_count, uint8_t* rgba, size_t n_bytes);
+/* the same image left where the reference's output pass leaves it — in device memory (the default framebuffer, Scene.h:1226-1230): RGBA8,
+ * width*height*4 bytes, bottom row first, on the scene's (first) device; un-tile and tone map in one pass over the packed tile buffers, no
+ * copy to the host.  sync = 0: enqueued on the scene's stream (crt_sync waits for it).  The pointer stays valid until the next resolve.
+ * The gamma is pinned (the byte = how many of 255 precomputed thresholds the tone-mapped value has reached), so the bytes of
+ * crt_resolve / crt_resolve_device equal the CPU oracle's exactly. */
+int crt_resolve_device(crt_scene* s, float inv_count, const uint8_t** d_rgba, int sync);
 /* closest-/any-hit over an explicit HOST ray buffer (test/bench entry).
  * stats may be NULL.  For CRT_TRACE_ANY, hit.tri >= 0 iff occluded (t,u,v = 0). */
 int crt_trace(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits, int mode, crt_ray_stats* stats);
@@ -264,6 +272,9 @@ int crt_trace(crt_scene* s, const crt_ray* rays, size_t n, crt_hit* hits, int mo
  * on the scene's stream unless sync != 0. */
 int crt_trace_device(crt_scene* s, const void* d_rays, size_t n, void* d_hits, int mode, void* d_stats, int sync);
 
+/* the duration in ms of every launch that carried events since the spans were last restarted (options "timing", "timing_accumulate"),
+ * in launch order; ms may be NULL to query the count */
+int crt_get_launch_times(crt_scene* s, float* ms, size_t cap, size_t* n_out);
 /* test hook: read back a ray queue of the last rendered frame (which: 0 = path rays entering
  * `segment`, 2 = that segment's shadow rays).  dst may be NULL to query the count. */
 int crt_debug_read_queue(crt_scene* s, int which, uint32_t segment, crt_ray* dst, size_t cap, size_t* n_out);

@@ -915,17 +915,51 @@ void orc_render_frame(const orc_scene* s, int accel, int tie, float rx, float ry
             for (int k = 0; k < 4; ++k) counters[k] += jobs[t].counters[k];
 }
 
-/* Shader/output.fs:9-20: c = S*inv; c *= 1/(1 + lum/2); pow(c, 1/2.2); 8-bit UNORM write. */
+/* Shader/output.fs:9-20: c = S*inv; c *= 1/(1 + lum/2); pow(c, 1/2.2); 8-bit UNORM write.
+ * The power is PINNED (pow's last bits are the implementation's): the byte of x is the number of thresholds thr[1..255] it has reached,
+ * thr[j] = the smallest float x >= 0 with (uint8)(clamp01((float)pow((double)x, 1/2.2)) * 255 + 0.5) >= j.  NaN and negatives reach none. */
+static unsigned ref_gamma_byte(float x) {
+    float v = (float)pow((double)x, (double)(1.0f / 2.2f));
+    v = v < 0.f ? 0.f : v > 1.f ? 1.f : v;
+    return (unsigned)(uint8_t)(v * 255.0f + 0.5f);
+}
+static const float* gamma_table(void) {
+    static float thr[256];
+    static int ready = 0;
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&mu);
+    if (!ready) {
+        thr[0] = 0.f;
+        for (unsigned j = 1; j < 256; ++j) {
+            uint32_t lo = 0u, hi = 0x7f800000u;            /* the non-negative floats by bit pattern */
+            while (lo < hi) {
+                uint32_t mid = lo + (hi - lo) / 2u;
+                float x;
+                memcpy(&x, &mid, 4);
+                if (ref_gamma_byte(x) >= j) hi = mid; else lo = mid + 1u;
+            }
+            memcpy(&thr[j], &lo, 4);
+        }
+        ready = 1;
+    }
+    pthread_mutex_unlock(&mu);
+    return thr;
+}
 void orc_resolve(const float* sum, size_t n_pixels, float inv_count, uint8_t* rgba) {
+    const float* thr = gamma_table();
     for (size_t i = 0; i < n_pixels; ++i) {
         float c[3] = {sum[3 * i] * inv_count, sum[3 * i + 1] * inv_count, sum[3 * i + 2] * inv_count};
         float lum = 0.3f * c[0] + 0.6f * c[1] + 0.1f * c[2];
         float k = 1.0f / (1.0f + lum / 2.0f);
         for (int ch = 0; ch < 3; ++ch) {
-            float v = powf(c[ch] * 1.0f * k, 1.0f / 2.2f);
-            v = v < 0.f ? 0.f : v > 1.f ? 1.f : v;
-            if (v != v) v = 0.f;
-            rgba[4 * i + ch] = (uint8_t)(v * 255.0f + 0.5f);
+            float x = c[ch] * 1.0f * k;
+            /* number of thresholds reached = first j in [1, 256) with !(x >= thr[j]), minus one (thr ascends; a NaN reaches none) */
+            unsigned lo = 1, hi = 256;
+            while (lo < hi) {
+                unsigned mid = (lo + hi) / 2;
+                if (x >= thr[mid]) lo = mid + 1; else hi = mid;
+            }
+            rgba[4 * i + ch] = (uint8_t)(lo - 1);
         }
         rgba[4 * i + 3] = 255;
     }

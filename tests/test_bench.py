@@ -38,6 +38,26 @@ def test_plain_command_launches_its_own_ranks(n, tmp_path):
         assert cfg["parallelism"] == f"tiles/{n}" and cfg["gather_floats_per_rank"] == -(-32400 // n) * 16 * 16 * 3
 
 
+def test_the_gather_of_the_eight_rank_dry_run_is_sized_by_the_librarys_own_shards(tmp_path):
+    """configs[4] at N = 8: the packed-tile buffer every rank contributes to the gather (`gather_floats_per_rank`, padded to the largest
+    shard) is what crt_shard_tiles — the tile dealing libcrt.so itself uses for crt_set_shard — hands the ranks for 3840x2160 / tile 16;
+    the shards cover the frame exactly once."""
+    from caitlynrenderer_amd import tiles
+    run = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"], cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-3000:]
+    d = json.loads([l for l in run.stdout.splitlines() if l.strip()][0])
+    shards = [tiles.shard_tiles_of_library(3840, 2160, 16, rank=r, world=8) for r in range(8)]
+    counts = [len(x) for x in shards]
+    assert sum(counts) == 240 * 135 == d["config"]["tiles"] and max(counts) - min(counts) <= 1
+    assert d["config"]["gather_floats_per_rank"] == max(counts) * 16 * 16 * 3
+    seen = set()
+    for x in shards:
+        seen |= {(int(a), int(b)) for a, b in x}
+    assert len(seen) == 240 * 135
+    for r in range(8):                                   # the python launcher's bookkeeping and the library's deal are the same lists
+        assert [tuple(map(int, t)) for t in tiles.local_tiles(3840, 2160, 16, r, 8)] == [tuple(map(int, t)) for t in shards[r]]
+
+
 def test_weak_scaling_option_keeps_per_rank_pixels(tmp_path):
     run = _run(["--gpus", "4", "--scaling", "weak", "--dry-run"], cwd=str(tmp_path))
     assert run.returncode == 0, run.stderr[-3000:]

@@ -17,7 +17,7 @@ def _load(name):
 
 
 ASM = """
-_ZN3crt9k_segmentILb1ELb0ELb0ELb0ELb1ELb0ELb0ELb0ELb0ELb0ELb0EEEvNS_11SegmentArgsE:
+_ZN3crt9k_segmentILb1ELb0ELb0ELb0ELb1ELb0ELb0ELb0ELb0ELb0EEEvNS_11SegmentArgsE:
 	s_load_dwordx2 s[0:1], s[4:5], 0x0
 	v_mov_b32_e32 v0, 0
 	v_add_f32_e32 v1, v0, v0
@@ -62,7 +62,7 @@ def test_isa_regions_are_counted_between_the_guarding_branch_and_its_join_label(
     p.write_text(ASM)
     k = r.parse_asm(str(p))
     (name, e), = k.items()
-    assert r.demangle_args(name) == [1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0] and r.label_of(name) == "k_segment<FIRST,INPLACE>"
+    assert r.demangle_args(name) == [1, 0, 0, 0, 1, 0, 0, 0, 0, 0] and r.label_of(name) == "k_segment<FIRST,INPLACE>"
     regs = {kind: n for kind, _, n in e["regions"]}
     assert regs["node"] == 3 and regs["tri"] == 2 and regs["shade"] == 3            # vector instructions under each block's lane mask
     assert regs["loop"] == 7                                                          # 2 compares + 3 + 2 inside the loop
@@ -70,59 +70,79 @@ def test_isa_regions_are_counted_between_the_guarding_branch_and_its_join_label(
 
 
 def test_the_committed_bench_line_is_recomputable_and_below_its_counter_bound():
-    """profiles/r04_bench_default.json (the line bench.py printed on the MI355X box): the headline's frac follows from its own counters
-    and profiles/isa_counts.json, and on EVERY block that carries hardware counters frac <= issue_busy x lane_util — useful work cannot
-    exceed executed work (the static shell count had frac above that bound on the headline and 1.9x above it on Cornell)."""
+    """profiles/r05_bench_default.json (the line bench.py printed on the MI355X box): EVERY derived figure of the headline's roofline object
+    follows from the line's own counters, launch time and profiles/isa_counts.json — frac (algorithmic), frac_executed, the algorithmic
+    bytes with SURVEY 8d's 24 B per pixel-sample, their rate and its ratio to the HBM peak, hbm_frac, counter_frac — and on every block
+    that carries hardware counters frac_executed <= issue_busy x lane_util: useful work cannot exceed executed work."""
     import pytest
     r = _load("roofline")
     isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
-    path = os.path.join(ROOT, "profiles", "r04_bench_default.json")
+    path = os.path.join(ROOT, "profiles", "r05_bench_default.json")
     if not os.path.exists(path):
-        pytest.skip("no round-4 bench line committed yet")
+        pytest.skip("no round-5 bench line committed yet")
     line = [l for l in open(path) if l.startswith("{")][-1]
-    assert len(line) < 6000
+    assert len(line) < 9000
     d = json.loads(line)
     ro = d["roofline"]
-    got = r.roofline_block(ro["counters"], isa, ro["launch_ms"], ro["path_segments"], ro["samples_per_launch"])
-    assert abs(got["frac"] - ro["frac"]) < 2e-3 and ro["bound"] == "valu_issue" and ro["peak"] == r.PEAK_GINSTR
+    got = r.recompute_line_block(ro, isa)
+    for k, v in got.items():
+        assert ro.get(k) is not None and abs(v - ro[k]) <= 2e-3 * max(1.0, abs(v)), (k, v, ro.get(k))
+    cs = ro["counters"]
+    assert ro["algorithmic_bytes_per_launch"] == 80 * (cs["nodes_closest"] + cs["nodes_any"]) + 52 * (cs["tris_closest"] + cs["tris_any"]) + 24 * cs["primary_rays"]
+    assert cs["primary_rays"] == 4 * 1920 * 1080 and ro["bound"] == "valu_issue" and ro["peak"] == r.PEAK_GINSTR and "HBM roof does not bind" in ro["note"]
+    assert ro["algorithmic_over_peak"] > 1.0 > ro["hbm_frac"] > 0                      # the bytes come from the caches
+    assert ro["frac_executed"] <= ro["frac"] and ro["frac_executed"] <= ro["counter_frac"] + 1e-3
     assert "1004672 tris" in d["config"]["workload"] and d["config"]["spp_per_step"] == 4
-    assert d["config"]["launch"] == {"form": 2, "wide": True, "samples": 4, "shards": 1} and d["sum_rows_match_oracle"] is True
+    assert d["config"]["launch"] == {"form": 2, "wide": True, "one_pass": True, "samples": 4, "shards": 1} and d["sum_rows_match_oracle"] is True
+    sp = d["step_ms_spread"]
+    assert sp["n"] == d["steps"] and sp["min"] <= sp["median"] <= sp["max"] and abs(sp["median"] - d["ms_per_step"]) < 0.1 * d["ms_per_step"]
     with_counters = 0
-    for name, e in [("headline", ro)] + list(d["extras"].items()):
+    for name, e in [("headline", ro)] + [(k, v) for k, v in d["extras"].items() if "frac" in v]:
+        if e["frac"] is None:
+            continue                                                                  # the BVH2 walk has no instruction model
         assert 0 < e["frac"] <= 1.0, name                                             # no block above its roof
         if e.get("issue_busy") and e.get("lane_util"):
             with_counters += 1
             assert abs(e["counter_frac"] - e["issue_busy"] * e["lane_util"]) < 2e-3, name
-            assert e["frac"] <= e["counter_frac"] + 1e-3, (name, e["frac"], e["counter_frac"])
+            assert e["frac_executed"] <= e["counter_frac"] + 1e-3, (name, e["frac_executed"], e["counter_frac"])
             assert 0 <= e["non_traversal_share"] < 1, name
         if e.get("traffic_gbps"):
             assert abs(e["hbm_frac"] - e["traffic_gbps"] / 8000.0) < 1e-3, name
     assert with_counters >= 3
     for name, e in d["extras"].items():
-        assert e.get("sum_rows_match_oracle") in (True, None), name
-    assert d["extras"]["cornell"]["frac"] < 0.6                                       # the static shell count said 0.82
+        assert e.get("sum_rows_match_oracle", e.get("rgba_rows_match_oracle")) in (True, None), name
     assert d["extras"]["hbm_resident"]["scene_mb"] > 256 * 1.048576 and 0 < d["extras"]["hbm_resident_d4"]["hbm_frac"] < 1
+    cl = d["reference_claims"]
+    assert cl["cwbvh_over_bvh2_mesh1m"] > 1.0 and cl["sbvh_over_sah_bvh2_walk"] > 0.9 and "README.md:21-22" in cl["readme"]
+    fl = d["extras"]["frame_loop_mesh1m"]
+    assert fl["ms_per_frame_image_in_hbm"] <= fl["ms_per_frame_image_in_host_memory"] and fl["segment_launch_ms"] > 0
 
 
 def test_roofline_model_is_traversal_only_and_monotone():
     r = _load("roofline")
-    isa = {"I_node": 230, "I_tri": 80, "I_ray_first": 800, "I_ray_bounce": 700, "I_shade": 480}
-    cs = {"primary_rays": 1000, "closest_rays": 1500, "closest_hits": 900, "nodes_closest": 30000, "tris_closest": 4000, "nodes_any": 9000, "tris_any": 1000}
-    w = r.traversal_wave_instr(cs, isa, depth=2, samples=4)
-    assert w == ((39000 * 230 + 5000 * 80) / 64.0 / 2 * 4)
-    pmc = {"valu_issue": {"busy": 0.6, "lane_util": 0.5, "valu_instructions_per_launch": 4 * w}, "samples_per_launch": 4}
-    b = r.roofline_block(cs, isa, 1.0, 2, 4, pmc)
+    isa = {"I_node": 230, "I_node_uniform": 130, "I_node_uniform_any": 120, "I_tri": 80, "I_ray_first": 800, "I_ray_bounce": 700, "I_shade": 480}
+    cs = {"primary_rays": 1000, "closest_rays": 1500, "closest_hits": 900, "nodes_closest": 30000, "tris_closest": 4000, "nodes_any": 9000, "tris_any": 1000,
+          "nodes_closest_uniform": 10000, "nodes_any_uniform": 2000}
+    w = r.traversal_wave_instr(cs, isa)
+    assert w == (39000 * 230 + 5000 * 80) / 64.0                                       # algorithmic: every visit at the general step
+    we = r.traversal_wave_instr(cs, isa, executed=True)
+    assert we == ((39000 - 12000) * 230 + 10000 * 130 + 2000 * 120 + 5000 * 80) / 64.0 and we < w
+    assert r.algorithmic_bytes(cs) == 80 * 39000 + 52 * 5000 + 24 * 1000
+    pmc = {"valu_issue": {"busy": 0.6, "lane_util": 0.5, "valu_instructions_per_launch": 2 * we}, "samples_per_launch": 4}
+    b = r.roofline_block(cs, isa, 0.001, 2, pmc, 4)
     assert b["counter_frac"] == 0.3 and abs(b["non_traversal_share"] - 0.5) < 1e-3       # half of the executed lane-work is node / triangle tests
-    assert b["traversal_wave_instr_per_launch"] == int(w) and b["shell_static_wave_instr_per_launch"] > 0
-    assert "counter_frac" not in r.roofline_block(cs, isa, 1.0, 2, 4, None)
+    assert b["traversal_wave_instr_per_launch"] == int(w / 2) and b["shell_static_wave_instr_per_launch"] > 0 and b["frac_executed"] < b["frac"]
+    faster = r.roofline_block(cs, isa, 0.0005, 2, pmc, 4)
+    assert faster["frac"] > b["frac"]                                                  # a faster launch never prints a lower fraction
+    assert "counter_frac" not in r.roofline_block(cs, isa, 0.001, 2, None)
 
 
 def test_counter_summary_leaves_the_single_sample_tail_out(tmp_path):
     """bench.py ends a run with single-sample frames (full event timing); under rocprofv3 --pmc those dispatches — a quarter of the
     work, partly the same kernels — must not be averaged with the steps' 4-sample launches."""
     pt = _load("pmc_traffic")
-    seg = "void crt::k_segment<true, false, false, false, true, false, false, false, false, true, true>(crt::SegmentArgs)"
-    stats = "void crt::k_segment<true, true, true, false, true, false, true, false, false, false, false>(crt::SegmentArgs)"
+    seg = "void crt::k_segment<true, false, false, false, true, false, false, true, true, true>(crt::SegmentArgs)"
+    stats = "void crt::k_segment<true, true, true, false, true, false, true, false, false, false>(crt::SegmentArgs)"
     cols = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
 
     def write(kind, counters):
@@ -148,3 +168,26 @@ def test_counter_summary_leaves_the_single_sample_tail_out(tmp_path):
     assert steps["l2_hit_rate"] == 0.75 and abs(steps["valu_issue"]["lane_util"] - 0.5) < 1e-9
     # issue_busy = 2 x wave-instructions / (SIMDs x shader cycles), bounded by 1 by construction
     assert abs(steps["valu_issue"]["busy"] - 2 * 400e3 / (1024 * 400 * 8000.0 / 8)) < 1e-3
+
+
+def test_isa_counts_file_matches_the_kernels_as_compiled(tmp_path):
+    """profiles/isa_counts.json prices the roofline's node visits and triangle tests: its I_node / I_node_uniform / I_node_uniform_any / I_tri must be
+    what the CURRENT rt_kernels.hip compiles to (the marker build of `make asm`), or frac_executed <= counter_frac would hold by accident."""
+    import shutil
+    import subprocess
+    import pytest
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    r = _load("roofline")
+    csrc = os.path.join(ROOT, "caitlynrenderer_amd", "csrc")
+    out = tmp_path / "k.s"
+    subprocess.run([hipcc, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "--offload-arch=gfx950", "-DCRT_ISA_MARKS",
+                    "-S", "--cuda-device-only", "-o", str(out), os.path.join(csrc, "rt_kernels.hip")], check=True, capture_output=True, timeout=600)
+    k = r.parse_asm(str(out))
+    name = next(n for n in k if r.demangle_args(n) == [1, 0, 0, 0, 1, 0, 0, 1, 1, 1])          # <FIRST, INPLACE, BATCH, WIDE, ONE>: the headline's launch
+    regs = k[name]["regions"]
+    isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+    uni = [x[2] for x in regs if x[0] == "uninode"]
+    assert isa["I_node"] == next(x[2] for x in regs if x[0] == "node") and isa["I_tri"] == next(x[2] for x in regs if x[0] == "tri")
+    assert isa["I_node_uniform"] == uni[0] and isa["I_node_uniform_any"] == uni[-1] and len(uni) == 2

@@ -27,10 +27,17 @@ def per_kernel(dirname, tail=0):
     def is_seg(r):
         n = r["Kernel_Name"].split("(")[0]
         return n.startswith("void crt::k_segment<") and n.split(",")[1].strip() == "false"
+
+    def is_frame_end(r):      # one dispatch per multi-segment frame: the deferred shadow rays' launch, the fold
+        n = r["Kernel_Name"].split("(")[0]
+        return n.startswith("void crt::k_shadow_deferred<false>") or n.startswith("crt::k_fold_paths")
     if tail:
         ids = sorted({int(r["Dispatch_Id"]) for r in rows if is_seg(r)})
         drop = set(ids[-tail:])
-        rows = [r for r in rows if not (is_seg(r) and int(r["Dispatch_Id"]) in drop)]
+        if drop:
+            # ... and what those tail frames launched behind their segments
+            drop |= {int(r["Dispatch_Id"]) for r in rows if is_frame_end(r) and int(r["Dispatch_Id"]) > min(drop)}
+        rows = [r for r in rows if not ((is_seg(r) or is_frame_end(r)) and int(r["Dispatch_Id"]) in drop)]
     agg = collections.defaultdict(list)
     for r in rows:
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -47,9 +54,13 @@ def entry_from_dirs(dirs, wl, tail=0):
     if not names:
         return None
 
-    def total(c):       # summed over the segment kernels (first + bounce), per launch
+    extra = sorted({k for k, _ in agg if k.startswith("void crt::k_shadow_deferred<false>") or k.startswith("crt::k_fold_paths")})
+
+    def total(c):       # summed over the segment kernels (first + bounce) and what a multi-segment frame launches behind them (the deferred
+        # shadow rays' walk, the fold), per SEGMENT launch — the unit bench.py's launch time of such a step is in (step time / segments)
         vals = [v for k in names for v in agg.get((k, c), [])]
-        return sum(vals), len(vals)
+        more = [v for k in extra for v in agg.get((k, c), [])]
+        return sum(vals) + sum(more), len(vals)
     fetch, n_l = total("FETCH_SIZE")
     write, n_w = total("WRITE_SIZE")
     hit, _ = total("TCC_HIT_sum")

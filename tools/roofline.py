@@ -221,6 +221,7 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
         # a uniform node step (every enabled lane fetches the same node: scalar loads, scalar decode): what such a visit executes instead
         if f.get("uniform_node_steps"):
             counts["I_node_uniform"] = f["uniform_node_steps"][0]
+            counts["I_node_uniform_any"] = f["uniform_node_steps"][-1]        # the in-place shadow walk's (the plain per-lane loop)
         # a ray's shell: what every ray runs (ray generation or queue fetch, loop set-up, queue emission) and what only a ray that
         # hit something runs (shading, NEE set-up, bounce sampling)
         counts["I_shade"] = f["shade"][0] if f["shade"] else 0
@@ -243,23 +244,34 @@ def cmd_isa(asm=None, remarks=None, tag="r03"):
         print("wrote", path)
 
 
-def traversal_wave_instr(cs, isa, depth=1, samples=1):
-    """Traversal wave-instructions of ONE launch (node visits and triangle tests only, 64-lane equivalents): the frame's total over its
-    `depth` segment launches / depth, x samples per launch.  cs: totals of one counting frame."""
-    # node visits of uniform node steps (the node through the scalar cache, its decode on the scalar unit) execute I_node_uniform
-    # vector instructions, the others I_node: executed counts, so that the figure cannot exceed what the counters saw
-    n_uni = cs.get("nodes_closest_uniform", 0) + cs.get("nodes_any_uniform", 0)
-    n_nodes = cs["nodes_closest"] + cs["nodes_any"]
-    lane_instr = (n_nodes - n_uni) * isa["I_node"] + n_uni * isa.get("I_node_uniform", isa["I_node"]) + (cs["tris_closest"] + cs["tris_any"]) * isa["I_tri"]
-    return lane_instr / 64.0 / max(1, depth) * samples
+NODE_BYTES, TRI_BYTES, FB_BYTES = 80, 52, 24        # bytes per node fetch, per triangle test, per pixel-sample (sum read + write)
 
 
-def shell_static_wave_instr(cs, isa, depth=1, samples=1):
+def traversal_wave_instr(cs, isa, executed=False):
+    """Traversal wave-instructions (node visits and triangle tests only, 64-lane equivalents) of the work the counters `cs` describe
+    (bench.py: ONE STEP — every sample and segment of it — counted in the form the timed launches have).
+    executed = False: the ALGORITHMIC count — every node visit priced at the general 8-wide test, I_node (what SURVEY 8d's bytes stand for);
+    executed = True: uniform node steps at what they really execute (I_node_uniform in closest-hit walks, I_node_uniform_any in shadow
+    walks): the figure the hardware counters bound from above."""
+    n_c, n_a = cs["nodes_closest"], cs["nodes_any"]
+    u_c, u_a = (cs.get("nodes_closest_uniform", 0), cs.get("nodes_any_uniform", 0)) if executed else (0, 0)
+    i_n = isa["I_node"]
+    lane_instr = (n_c - u_c + n_a - u_a) * i_n + u_c * isa.get("I_node_uniform", i_n) + u_a * isa.get("I_node_uniform_any", isa.get("I_node_uniform", i_n)) \
+        + (cs["tris_closest"] + cs["tris_any"]) * isa["I_tri"]
+    return lane_instr / 64.0
+
+
+def algorithmic_bytes(cs, node_bytes=NODE_BYTES):
+    """80 B per node fetch + 52 B per triangle test + 24 B of sum-buffer traffic per pixel-sample, over the work `cs` describes"""
+    return node_bytes * (cs["nodes_closest"] + cs["nodes_any"]) + TRI_BYTES * (cs["tris_closest"] + cs["tris_any"]) + FB_BYTES * cs["primary_rays"]
+
+
+def shell_static_wave_instr(cs, isa):
     """The per-ray shell as a STATIC instruction count (both sides of every branch): an upper bound of what it executes, for reference only."""
     n_first = cs["primary_rays"]
     n_bounce = cs["closest_rays"] - n_first
     lane_instr = n_first * isa["I_ray_first"] + n_bounce * isa.get("I_ray_bounce", isa["I_ray_first"]) + cs["closest_hits"] * isa["I_shade"]
-    return lane_instr / 64.0 / max(1, depth) * samples
+    return lane_instr / 64.0
 
 
 def counter_figures(pmc, samples_per_launch):
@@ -273,50 +285,65 @@ def counter_figures(pmc, samples_per_launch):
             "valu_instr_per_launch": int(vi.get("valu_instructions_per_launch", 0) * scale)}
 
 
-def roofline_block(cs, isa, launch_ms, depth, samples, pmc=None):
-    w = traversal_wave_instr(cs, isa, depth, samples)
-    achieved = w / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    # the same visits priced at the GENERAL node step (what the walk would execute without the uniform steps): the uniform steps lower
-    # the executed instructions per visit, so `frac` (executed) falls while the rays per second rise; this figure moves with the speed
-    cs_general = dict(cs, nodes_closest_uniform=0, nodes_any_uniform=0)
-    w_general = traversal_wave_instr(cs_general, isa, depth, samples)
+def roofline_block(cs, isa, launch_ms, launches, pmc=None, samples_per_launch=1):
+    """The VALU-issue roofline of a block.  cs: counters of one STEP; launches: segment launches the step is made of (its path segments);
+    launch_ms: mean duration of one of them.  frac = algorithmic traversal wave-instructions per launch / launch time / peak — moves with
+    the speed; frac_executed = the same with uniform node steps at their executed cost — bounded by the counters' issue_busy x lane_util."""
+    launches = max(1, launches)
+    t = launch_ms * 1e-3
+    w_alg = traversal_wave_instr(cs, isa) / launches
+    w_exe = traversal_wave_instr(cs, isa, executed=True) / launches
+    achieved = w_alg / t / 1e9 if t > 0 else 0.0
     r = {"achieved": round(achieved, 1), "peak": PEAK_GINSTR, "frac": round(achieved / PEAK_GINSTR, 4),
-         "frac_at_general_step": round(w_general / (launch_ms * 1e-3) / 1e9 / PEAK_GINSTR, 4) if launch_ms > 0 else 0.0,
-         "attainable": round(ATTAINABLE_GINSTR, 1), "frac_of_attainable": round(achieved / ATTAINABLE_GINSTR, 4),
-         "traversal_wave_instr_per_launch": int(w), "shell_static_wave_instr_per_launch": int(shell_static_wave_instr(cs, isa, depth, samples))}
-    c = counter_figures(pmc, samples)
+         "frac_executed": round(w_exe / t / 1e9 / PEAK_GINSTR, 4) if t > 0 else 0.0,
+         "attainable": round(ATTAINABLE_GINSTR, 1),
+         "traversal_wave_instr_per_launch": int(w_alg), "executed_traversal_wave_instr_per_launch": int(w_exe),
+         "shell_static_wave_instr_per_launch": int(shell_static_wave_instr(cs, isa) / launches)}
+    c = counter_figures(pmc, samples_per_launch)
     if c:
         r.update({"issue_busy": c["issue_busy"], "lane_util": c["lane_util"], "counter_frac": c["counter_frac"]})
         if c["valu_instr_per_launch"]:
             # executed lane-full wave-instructions of the launch (everything the lanes did) against the traversal's share of them
-            r["non_traversal_share"] = round(1.0 - w / (c["valu_instr_per_launch"] * c["lane_util"]), 4)
+            r["non_traversal_share"] = round(1.0 - w_exe / (c["valu_instr_per_launch"] * c["lane_util"]), 4)
     return r
+
+
+def recompute_line_block(r, isa):
+    """Every derived figure of a bench-line block's `roofline` object from its own counters, launch time and isa_counts.json:
+    {"frac", "frac_executed", "achieved", "algorithmic_bytes_per_launch", "algorithmic_gbps", "algorithmic_over_peak", "hbm_frac", "counter_frac"}"""
+    cs, launches, t = r["counters"], max(1, r.get("path_segments", 1)), r["launch_ms"] * 1e-3
+    got = roofline_block(cs, isa, r["launch_ms"], launches)
+    out = {"frac": got["frac"], "frac_executed": got["frac_executed"], "achieved": got["achieved"]}
+    nb = 96 if r.get("accel") == "bvh2" else NODE_BYTES
+    out["algorithmic_bytes_per_launch"] = int(algorithmic_bytes(cs, nb) / launches)
+    out["algorithmic_gbps"] = round(out["algorithmic_bytes_per_launch"] / t / 1e9, 1)
+    out["algorithmic_over_peak"] = round(out["algorithmic_gbps"] / 8000.0, 4)
+    if r.get("traffic"):
+        out["hbm_frac"] = round(r["traffic"] / t / 1e9 / 8000.0, 4)
+    if r.get("issue_busy") and r.get("lane_util"):
+        out["counter_frac"] = round(r["issue_busy"] * r["lane_util"], 4)
+    return out
 
 
 def cmd_frac(bench_json, stats_csv=None):
     isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
     line = [l for l in open(bench_json) if l.startswith("{")][-1]
     d = json.loads(line)
-    blocks = {"top": d}
-    blocks.update({k: v for k, v in d.items() if isinstance(v, dict) and "roofline" in v})
     avg_us = {}
     if stats_csv:
         for r in csv.DictReader(open(stats_csv)):
             avg_us[r["Name"]] = float(r["AverageNs"]) / 1e3
-    for name, b in blocks.items():
-        r = b.get("roofline") or {}
-        cs = r.get("counters")
-        if not cs:
-            continue
-        pmc = {"valu_issue": {"busy": r.get("issue_busy"), "lane_util": r.get("lane_util")}} if r.get("issue_busy") else None
-        got = roofline_block(cs, isa, r["launch_ms"], r.get("path_segments", 1), r.get("samples_per_launch", 1), pmc)
-        bound = got.get("counter_frac")
-        print(f"{name:22s} launch {r['launch_ms']:.4f} ms  frac {got['frac']:.4f} (line says {r.get('frac')})"
-              + (f"  <= issue_busy x lane_util {bound:.4f}: {'ok' if got['frac'] <= bound else 'VIOLATED'}" if bound else "  (no counters on this block)")
-              + f"  achieved {got['achieved']} G wave-instr/s  algorithmic GB/s {r.get('algorithmic_gbps')}")
-    if avg_us:
-        for n, us in sorted(avg_us.items(), key=lambda kv: -kv[1])[:6]:
-            print(f"  rocprofv3 average {us:10.1f} us  {n[:110]}")
+    r = d.get("roofline") or {}
+    if r.get("counters"):
+        got = recompute_line_block(r, isa)
+        for k, v in got.items():
+            print(f"  {k:32s} recomputed {v}   line says {r.get(k)}")
+        if "counter_frac" in got:
+            print(f"  frac_executed <= issue_busy x lane_util: {'ok' if got['frac_executed'] <= got['counter_frac'] + 1e-3 else 'VIOLATED'}")
+    for name, e in (d.get("extras") or {}).items():
+        print(f"  {name:22s} {e.get('value')} Mray/s  launch {e.get('launch_ms')} ms  frac {e.get('frac')}  frac_executed {e.get('frac_executed')}  counter_frac {e.get('counter_frac')}")
+    for n, us in sorted(avg_us.items(), key=lambda kv: -kv[1])[:6]:
+        print(f"  rocprofv3 average {us:10.1f} us  {n[:110]}")
 
 
 if __name__ == "__main__":
