@@ -126,6 +126,11 @@ struct crt_scene {
     // (deferring segment, path): (C | T e, visibility word)
     float4* d_nee = nullptr;
     float4* d_contrib = nullptr;
+    // option "sort_shadow": the frame's deferred shadow rays walked in the order of the cell they start in (rt_kernels.hip k_nee_*):
+    // perm[place] = queue entry, 4096-bin histogram + cursors + the eight parts' lengths
+    uint32_t* d_nee_perm = nullptr;
+    uint32_t* d_nee_bins = nullptr;           // hist [4096] | cursor [4096] | meta [9 x stride]
+    uint32_t sort_shadow = 0;                 // (1 M triangles, four segments: 7.18 against 7.59 Gray/s unsorted — the sort costs more than the 4 % fewer any-hit node steps return)
     uint32_t defer_cap = 0, defer_regions = 0, defer_sub_capacity = 0;   // what the two were sized for
     uint32_t lfinal_cap = 0;                  // samples d_lfinal is sized for
     float4* d_qhits = nullptr;                // closest hits of the path-ray queue (max_depth > 1, option bounce_refill)
@@ -262,7 +267,7 @@ struct crt_scene {
         if (shares_scene)                    // borrowed from the primary, which frees them
             for (const auto& b : scene_bufs) *reinterpret_cast<void**>(reinterpret_cast<char*>(this) + b.first) = nullptr;
         void* ptrs[] = {d_gamma, d_texcoords, d_textures, d_bvh2, d_tris2, d_nodes, d_planes, d_tris, d_triangles, d_normals, d_materials, d_lights, d_tile_xy, d_sum, d_linear, d_rgba,
-                        d_rays[0], d_rays[1], d_nee, d_contrib, d_qhits, pb.L, pb.T, pb.seed, d_counts,
+                        d_rays[0], d_rays[1], d_nee, d_contrib, d_nee_perm, d_nee_bins, d_qhits, pb.L, pb.T, pb.seed, d_counts,
                         d_t_rays, d_t_hits, d_t_stats, d_visit_totals, d_overflow, d_tile_order, d_tile_cost, d_lfinal, d_bins};
         for (void* p : ptrs) if (p) hipFree(p);
         if (h_tile_cost) hipHostFree(h_tile_cost);
@@ -367,7 +372,7 @@ int build_shard(crt_scene* s) {
 
 void free_frame_buffers(crt_scene* s) {
     void** ptrs[] = {(void**)&s->d_tile_xy, (void**)&s->d_tile_order, (void**)&s->d_tile_cost, (void**)&s->d_sum, (void**)&s->d_linear, (void**)&s->d_rgba, (void**)&s->d_rays[0],
-                     (void**)&s->d_rays[1], (void**)&s->d_nee, (void**)&s->d_contrib, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed,
+                     (void**)&s->d_rays[1], (void**)&s->d_nee, (void**)&s->d_contrib, (void**)&s->d_nee_perm, (void**)&s->d_qhits, (void**)&s->pb.L, (void**)&s->pb.T, (void**)&s->pb.seed,
                      (void**)&s->d_lfinal};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     s->batch_cap = 1;
@@ -1033,6 +1038,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     }
     else if (!std::strcmp(name, "shadow_refill_min")) s->shadow_refill_min = (uint32_t)std::min(65, std::max(1, value));
     else if (!std::strcmp(name, "persistent")) s->persistent = value ? 1u : 0u;
+    else if (!std::strcmp(name, "sort_shadow")) s->sort_shadow = value ? 1u : 0u;
 #ifdef CRT_EXPERIMENTS
     else if (!std::strcmp(name, "trace_occupancy")) s->trace_occupancy = (uint32_t)std::max(1, value);
     else if (!std::strcmp(name, "oversubscribe")) s->oversubscribe = (uint32_t)std::max(0, value);
@@ -1151,12 +1157,18 @@ static int ensure_defer_buffers(crt_scene* s) {
     if (regions == 0u) return CRT_OK;
     if (s->d_nee && s->defer_cap == s->batch_cap && s->defer_regions >= regions && s->defer_sub_capacity == s->sub_capacity) return CRT_OK;
     HIPCHK(hipStreamSynchronize(s->stream));
-    for (void** p : {(void**)&s->d_nee, (void**)&s->d_contrib}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {(void**)&s->d_nee, (void**)&s->d_contrib, (void**)&s->d_nee_perm}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     s->defer_cap = s->defer_regions = 0;
     const uint64_t slots = (uint64_t)regions * s->n_local_pixels * s->batch_cap;
     if (slots >= (1ull << 32)) return fail(CRT_ERR_LIMIT, "deferred shadow rays: more than 2^32 contribution slots (segments x pixels x samples per launch); use inplace_shadow 1");
     int rc;
     if ((rc = dev_alloc(&s->d_nee, 2 * 8 * (size_t)s->sub_capacity * regions)) || (rc = dev_alloc(&s->d_contrib, (size_t)slots))) return rc;
+    if ((uint64_t)8 * s->sub_capacity * regions >= (1ull << 32)) return fail(CRT_ERR_LIMIT, "deferred shadow rays: more than 2^32 queue entries; use inplace_shadow 1");
+    if ((rc = dev_alloc(&s->d_nee_perm, 8 * (size_t)s->sub_capacity * regions))) return rc;
+    if (!s->d_nee_bins) {
+        if ((rc = dev_alloc(&s->d_nee_bins, 2 * 4096 + 9 * kCounterStride))) return rc;
+        HIPCHK(hipMemset(s->d_nee_bins, 0, (2 * 4096 + 9 * kCounterStride) * sizeof(uint32_t)));
+    }
     s->defer_cap = s->batch_cap; s->defer_regions = regions; s->defer_sub_capacity = s->sub_capacity;
     return CRT_OK;
 }
@@ -1383,12 +1395,25 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         sh.lanes_log2 = s->lanes_per_ray >= 8u ? 3u : 0u;
         sh.pools_per_region = (s->sub_capacity + sh.pool - 1u) / sh.pool;
         sh.persistent = s->persistent; sh.n_regions = s->max_depth - first_deferred; sh.cursors = cnt + kCursorShadow;
+        if (s->sort_shadow && s->info.n_nodes8 >= 64) {
+            // sorted by the cell the rays start in: three small launches (histogram, scan, scatter), then a persistent grid over the sorted order
+            crt::NeeSortArgs na{};
+            na.shadow = s->d_nee; na.count = sh.count; na.count_stride = sh.count_stride; na.sub_capacity = s->sub_capacity; na.n_queues = sh.n_regions * 8u;
+            for (int k = 0; k < 3; ++k) {
+                const float ext = s->bounds_hi[k] - s->bounds_lo[k];
+                na.origin[k] = s->bounds_lo[k];
+                na.scale[k] = ext > 0.f ? 16.0f / ext : 0.f;
+            }
+            na.hist = s->d_nee_bins; na.cursor = s->d_nee_bins + 4096; na.perm = s->d_nee_perm; na.meta = s->d_nee_bins + 2 * 4096;
+            crt::launch_nee_sort(na, (uint32_t)s->n_cu * 2u, s->stream);
+            sh.perm = s->d_nee_perm; sh.sort_meta = na.meta; sh.persistent = 1u;
+        }
         sh.visit_totals = s->d_visit_totals ? s->d_visit_totals + 2 : nullptr;
         sh.overflow = s->d_overflow;
         EventSpan* sp = s->new_span(2);
         if (sp) crt::set_launch_events(sp->a, sp->b);
         const size_t lds_q = (size_t)(s->stack_entries + CRT_HIT_SLOTS) * 64 * sizeof(uint2);
-        crt::launch_shadow_deferred(sh, s->count_visits, s->persistent ? s->resident_waves(lds_q, 8) : 8u * sh.n_regions * sh.pools_per_region, s->stream);
+        crt::launch_shadow_deferred(sh, s->count_visits, sh.persistent ? s->resident_waves(lds_q, 8) : 8u * sh.n_regions * sh.pools_per_region, s->stream);
     }
     if (folds) crt::launch_fold_paths(s->d_sum, s->d_lfinal, any_deferred ? s->d_contrib : nullptr, P, n_samples, first_deferred, s->stream);
     if (s->count_visits)
@@ -1414,7 +1439,7 @@ static int ensure_batch_buffers(crt_scene* s, uint32_t cap) {
     HIPCHK(hipStreamSynchronize(s->stream));
     // The lazily allocated hit buffer and the deferred shadow rays' buffers follow the per-group capacity: dropped now (null pointers the
     // next frame re-allocates at the size then in force), whatever happens below.
-    for (void** p : {(void**)&s->d_nee, (void**)&s->d_contrib, (void**)&s->d_qhits}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {(void**)&s->d_nee, (void**)&s->d_contrib, (void**)&s->d_nee_perm, (void**)&s->d_qhits}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     s->defer_cap = s->defer_regions = 0;
     // Everything else is allocated at the new size FIRST and swapped in only when all of it exists: a failed growth (~250 B per
     // pixel and sample: 16 GB for a 4K frame at 8 samples) leaves the scene exactly as it was, able to render frame by frame.
@@ -1855,7 +1880,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
     r->count_batched = src->count_batched;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
-    r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min; r->persistent = src->persistent;
+    r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min; r->persistent = src->persistent; r->sort_shadow = src->sort_shadow;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
     r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }

@@ -242,7 +242,7 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     return hit_mask;
 }
 // Build switches that remain (make EXTRA="-D<name>=<value>"; tools/variant.sh builds a variant library beside the product one):
-//   CRT_SEG_OCC, CRT_SEG_OCC_FIRST, CRT_SEG_OCC_BATCH   waves per SIMD the segment kernels are compiled for (6 / 6 / 5)
+//   CRT_SEG_OCC, CRT_SEG_OCC_FIRST, CRT_SEG_OCC_BATCH, CRT_SEG_OCC_DEFERRED   waves per SIMD the segment kernels are compiled for (6 / 6 / 5 / 8)
 //   CRT_HIT_SLOTS, CRT_NODE_ROWS, CRT_TRI_ROWS           LDS hit-record slots per lane; device row strides (rt_kernels.hpp)
 //   CRT_ISA_MARKS                                        `make asm`: marker comments tools/roofline.py counts between
 //   CRT_EXPERIMENTS                                      persistent grids and 2- / 4-wave workgroups (make EXPERIMENTS=1)
@@ -723,7 +723,7 @@ struct PoolStatic {
 };
 struct PoolStream {
     const uint32_t* counts; uint32_t* cursors;
-    uint32_t count_stride, sub_capacity, n_queues, q, tried, chunk;
+    uint32_t count_stride, sub_capacity, n_queues, q, tried, chunk;      // sub_capacity: flat-index distance between two queues
     uint32_t next, end;          // what is left of the chunk this wave has reserved (flat indices)
     __device__ __forceinline__ bool more() const { return next < end || tried < n_queues; }
     __device__ __forceinline__ uint32_t grab(uint32_t want, uint32_t& got) {
@@ -1263,85 +1263,7 @@ __device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
     return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
 }
 
-// ---- bounce-ray bins (rt_kernels.hpp RayBins) ----
-__device__ __forceinline__ uint32_t ray_bin_key(const RayBins& b, float4 o, float4 d) {
-    // NaN coordinates fall into cell 0 (v_max ignores a NaN operand); the key only decides where the ray waits, never what it hits
-    const float cx = __builtin_fminf(__builtin_fmaxf((o.x - b.origin[0]) * b.scale[0], 0.0f), 7.0f);
-    const float cy = __builtin_fminf(__builtin_fmaxf((o.y - b.origin[1]) * b.scale[1], 0.0f), 7.0f);
-    const float cz = __builtin_fminf(__builtin_fmaxf((o.z - b.origin[2]) * b.scale[2], 0.0f), 7.0f);
-    const uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-    return (oct << 9) | ((uint32_t)cz << 6) | ((uint32_t)cy << 3) | (uint32_t)cx;      // octant-major: neighbouring bins share the octant
-}
-// Queue entry for this lane's ray (meaningless where !want).  The lanes of a wave that share a key are found with one ballot per
-// distinct key (a bounce off one 8 x 8 pixel patch spreads over a handful of cells and 4 - 8 octants), each such set takes its places
-// with ONE atomic (all sets' atomics issue together), and what does not fit its bin takes a place in the overflow region.
-// `tab`: 768 words of wave-private LDS that nothing else uses right now (the wave's traversal stack: both walks are over when a
-// segment emits its rays), or null.
-__device__ __forceinline__ uint32_t bin_append(const RayBins& b, bool want, uint32_t key, uint32_t* tab = nullptr) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t idx = 0;
-    if (b.per_lane == 2u && tab != nullptr) {
-        // Ranking through LDS: a 256-slot wave-private table hashed by the key.  The first ray to reach a slot owns
-        // it and publishes its key; the rays that share that key then rank themselves with one ds_add_rtn each and take their places in
-        // the bin with ONE global atomic for all of them.  A ray whose key collides with another key's slot (a wave of bounce rays holds
-        // ~50 keys in 256 slots: a few rays per wave) takes its place with an atomic of its own, as per_lane = 1 does for every ray.
-        // ~45 instructions per emitting wave where the ballot loop below needs ~12 per distinct key (~600 on a wave of bounce rays).
-        uint32_t* const t_cnt = tab; uint32_t* const t_key = tab + 256; uint32_t* const t_base = tab + 512;
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) t_cnt[lane + 64u * k] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t h = (key ^ (key >> 8)) & 255u;               // cell bits and octant bits folded together
-        const bool first = want && atomicAdd(&t_cnt[h], 1u) == 0u;   // ds_add_rtn_u32: who got here first owns the slot
-        if (first) t_key[h] = key;
-        __builtin_amdgcn_wave_barrier();
-        const bool same = want && t_key[h] == key;                    // this ray shares the owner's key
-        __builtin_amdgcn_wave_barrier();
-        if (first) t_cnt[h] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        uint32_t rank = 0;
-        if (same) rank = atomicAdd(&t_cnt[h], 1u);                    // consecutive ranks among the rays of that key
-        __builtin_amdgcn_wave_barrier();
-        if (same && rank == 0u) t_base[h] = atomicAdd(b.count + key, t_cnt[h]);
-        __builtin_amdgcn_wave_barrier();
-        if (same) idx = t_base[h] + rank;
-        else if (want) idx = atomicAdd(b.count + key, 1u);            // a collided key: its own place
-        __builtin_amdgcn_wave_barrier();                              // the table is the traversal stack again after this
-    } else if (b.per_lane) {
-        // a wave of bounce rays holds about as many keys as rays (its rays left one cell in one octant and landed all over the
-        // scene): finding the few lanes that share one costs more than their atomics
-        if (want) idx = atomicAdd(b.count + key, 1u);
-    } else {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        unsigned long long todo = __ballot(want);
-        uint32_t rank = 0, n_same = 0, leader = lane;
-        while (todo) {                                               // wave-uniform: one pass per distinct key
-            const int l = __builtin_ctzll(todo);
-            const uint32_t k = __builtin_amdgcn_readlane(key, l);
-            const unsigned long long m = __ballot(want && key == k);
-            if (want && key == k) { rank = (uint32_t)__builtin_popcountll(m & below); n_same = (uint32_t)__builtin_popcountll(m); leader = (uint32_t)l; }
-            todo &= ~m;
-        }
-        uint32_t base = 0;
-        if (want && lane == leader) base = atomicAdd(b.count + key, n_same);
-        base = __shfl(base, (int)leader);
-        idx = base + rank;
-    }
-    const uint32_t cap = want ? b.cap[key] : 0u;
-    const bool fits = want && idx < cap;
-    const uint32_t ov = wave_append(want && !fits, b.ovf_count);
-    return fits ? b.off[key] + idx : b.ovf_base + ov;
-}
-// consumer index -> queue entry: the bin whose range [start[b], start[b + 1]) holds e (binary search, 12 steps), or the overflow region
-__device__ __forceinline__ uint32_t binned_entry(const uint32_t* __restrict__ start, const uint32_t* __restrict__ off, uint32_t ovf_base, uint32_t e) {
-    const uint32_t in_bins = start[CRT_RAY_BINS];
-    if (e >= in_bins) return ovf_base + (e - in_bins);
-    uint32_t lo = 0u, hi = CRT_RAY_BINS;                             // invariant: start[lo] <= e < start[hi]
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (start[mid] <= e) lo = mid; else hi = mid;
-    }
-    return off[lo] + (e - start[lo]);
-}
+#include "rt_sort.hpp"      // regrouping rays between launches: bounce-ray bins (option ray_bins), the deferred shadow rays sorted by origin cell (sort_shadow)
 
 // local pixel index -> frame pixel.  Pixels are laid out tile-major; inside a tile, 8x8 blocks
 // row-major, so one 64-lane wave covers an 8x8 pixel block (coherent primary rays).
@@ -1518,6 +1440,11 @@ __device__ __forceinline__ KArgs kernarg_here() {
 // +6 % on the Cornell box; a seventh (72 VGPRs) +0.8 % / -1.8 % (profiles/r04_occupancy_ab.txt).
 #define CRT_SEG_OCC 6
 #endif
+#ifndef CRT_SEG_OCC_DEFERRED
+// The bounce kernels that leave their shadow rays to k_shadow_deferred carry one walk, not two: they fit 64 VGPRs without a spill, and the eighth
+// wave hides more of the L2-miss latency these segments wait on (issue_busy 0.48): four segments +1.5 %, two +1.7 %, Disney +1.7 % (profiles/r05_experiments.md)
+#define CRT_SEG_OCC_DEFERRED 8
+#endif
 #ifndef CRT_SEG_OCC_FIRST
 // The batched first-segment kernel <FIRST, INPLACE, BATCH, WIDE> (the headline's launch): 6 as well; round 3, same box, three runs each,
 // 5 / 6 / 7 / 8 waves: 1 M triangles 1080p 12,205 / 12,384 / 12,032 / 10,875 Mray/s, 4K 13,980 / 14,267 / 13,979 / 12,759.
@@ -1555,7 +1482,7 @@ __device__ __forceinline__ KArgs kernarg_here() {
 // on the FlatNode array — the live path of the reference as a frame renderer.
 // BATCH (FIRST + INPLACE): a.n_samples samples per pixel in one launch (crt_render_frames), see the sample loop.  WIDE / ONE: see below.
 template <bool FIRST, bool STATS, bool TEX, bool PRETRACED, bool INPLACE, bool BVH2 = false, bool MAT = false, bool BATCH = false, bool WIDE = false, bool ONE = false>
-__global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
+__global__ void __launch_bounds__(CRT_TRACE_BLOCK, ((WIDE || ONE) ? CRT_SEG_OCC_FIRST : (BATCH || STATS) ? CRT_SEG_OCC_BATCH : (!FIRST && !INPLACE && !PRETRACED) ? CRT_SEG_OCC_DEFERRED : CRT_SEG_OCC)) k_segment(SegmentArgs a) {
     extern __shared__ uint2 s_lds[];     // traversal stacks [wave][level][lane]
     // Uniform node steps are compiled into every first-segment kernel.  (In the single-sample kernel they lost while the uniform step still
     // converted bytes and the loops carried their flags — 8 x 8-pixel waves agree less than the 4 x 4-pixel waves of a batched launch, and the
@@ -2075,13 +2002,19 @@ __global__ void __launch_bounds__(64, CRT_SEG_OCC) k_shadow_deferred(ShadowArgs 
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;
     uint32_t slot_of = 0;
     auto load = [&](uint32_t e, vec3& o, vec3& d, float& tmax) {        // e: flat entry, (region * 8 + sub-queue) * sub_capacity + place
+        if (a.perm) e = a.perm[e];                                        // sorted: e was a place in the sorted order
         const float4 r0 = a.shadow[2 * (size_t)e], r1 = a.shadow[2 * (size_t)e + 1];
         o = V3(r0.x, r0.y, r0.z); d = V3(r1.x, r1.y, r1.z); tmax = r0.w;
         slot_of = __float_as_uint(r1.w);
         return true;
     };
     auto done = [&](uint32_t, const HitState&, bool occluded) { if (occluded) reinterpret_cast<float*>(a.contrib + slot_of)[3] = 0.0f; };
-    if (a.persistent) {
+    if (a.perm) {
+        // sorted by origin cell: the sorted array in eight equal parts, one per XCD group (k_nee_scan wrote their lengths), a persistent grid
+        const uint32_t eighth = a.sort_meta[8u * CRT_COUNTER_STRIDE];
+        walk_pool<true, STATS>(a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, PoolStream{a.sort_meta, a.cursors, 0u, eighth, 8u, g, 0u, a.pool, 0u, 0u},
+                               a.refill_min, a.tri_min, a.lanes_log2, load, done, nn, nt, wn, wt);
+    } else if (a.persistent) {
         // the wave starts on its own XCD group's sub-queue of region (q mod n_regions)
         const uint32_t q0 = (q % a.n_regions) * 8u + g;
         walk_pool<true, STATS>(a.nodes, a.tris, s_lds, (int)a.stack_entries, a.overflow, PoolStream{a.count, a.cursors, a.count_stride, a.sub_capacity, a.n_regions * 8u, q0, 0u, a.pool, 0u, 0u},
@@ -2097,64 +2030,6 @@ __global__ void __launch_bounds__(64, CRT_SEG_OCC) k_shadow_deferred(ShadowArgs 
                                nn, nt, wn, wt);
     }
     if (STATS) flush_visit_totals(a.visit_totals, nn, nt, wn, wt);
-}
-
-// Between the launch that fills the bins of a segment and the launch that walks them (RayBins in rt_kernels.hpp): fill counts ->
-// consumer index space, ray count of the consuming launch, next frame's capacities and offsets, counters back to zero.
-__global__ void __launch_bounds__(1024) k_bin_scan(BinScanArgs a) {
-    __shared__ uint32_t s_wave[2][16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t PER = CRT_RAY_BINS / 1024u;
-    uint32_t filled[PER], want[PER], f_sum = 0, w_sum = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t b = tid * PER + k, c = a.count[b], cap = a.cap[b];
-        filled[k] = c < cap ? c : cap;
-        want[k] = c + (c >> 3) + 16u;                    // what the bin received, an eighth more, and room for a bin that was empty
-        f_sum += filled[k]; w_sum += want[k];
-        a.count[b] = 0u;
-    }
-    // exclusive prefix of (f_sum, w_sum) over the 1024 threads: inside the wave by shuffles, across waves through LDS
-    uint32_t f_inc = f_sum, w_inc = w_sum;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t fu = __shfl_up(f_inc, d), wu = __shfl_up(w_inc, d);
-        if ((int)lane >= d) { f_inc += fu; w_inc += wu; }
-    }
-    if (lane == 63u) { s_wave[0][wave] = f_inc; s_wave[1][wave] = w_inc; }
-    __syncthreads();
-    uint32_t f_base = 0, w_base = 0, f_all = 0, w_all = 0;
-    for (uint32_t w = 0; w < 16u; ++w) {
-        if (w < wave) { f_base += s_wave[0][w]; w_base += s_wave[1][w]; }
-        f_all += s_wave[0][w]; w_all += s_wave[1][w];
-    }
-    uint32_t f_at = f_base + f_inc - f_sum, w_at = w_base + w_inc - w_sum;
-    // the capacities asked for may exceed the bins' share of the queue (a launch of more samples than the last one): scaled down
-    const float shrink = w_all > a.queue_entries ? (float)a.queue_entries / (float)w_all : 1.0f;
-    if (shrink < 1.0f) {
-        // rescale and redo the offsets' prefix on the scaled values
-        uint32_t s_sum = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) { want[k] = (uint32_t)((float)want[k] * shrink); s_sum += want[k]; }
-        uint32_t s_inc = s_sum;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(s_inc, d); if ((int)lane >= d) s_inc += u; }
-        __syncthreads();
-        if (lane == 63u) s_wave[1][wave] = s_inc;
-        __syncthreads();
-        w_base = 0;
-        for (uint32_t w = 0; w < wave; ++w) w_base += s_wave[1][w];
-        w_at = w_base + s_inc - s_sum;
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t b = tid * PER + k;
-        a.start[b] = f_at; f_at += filled[k];
-        a.cap_next[b] = want[k]; a.off_next[b] = w_at; w_at += want[k];
-    }
-    if (tid == 0u) {
-        a.start[CRT_RAY_BINS] = f_all;
-        *a.n_in = f_all + *a.ovf_count;
-        *a.ovf_count = 0u;
-    }
 }
 
 // sum[p] = (((sum[p] + L_0[p]) + L_1[p]) + ...): what n consecutive frames would have added, in their order, zero radiance skipped as
@@ -2381,6 +2256,11 @@ void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid_wav
     const dim3 g(grid_waves), b(64u);
     if (stats) launch(k_closest_queue<true>, g, b, stack_bytes(a.stack_entries), stream, a);
     else       launch(k_closest_queue<false>, g, b, stack_bytes(a.stack_entries), stream, a);
+}
+void launch_nee_sort(const NeeSortArgs& a, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_nee_hist, dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_nee_scan, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(k_nee_scatter, dim3(blocks), dim3(256), 0, stream, a);
 }
 void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t grid_waves, hipStream_t stream) {
     const dim3 g(grid_waves), b(64u);

@@ -193,8 +193,21 @@ struct ShadowArgs {            // k_shadow_deferred: the deferred NEE shadow ray
     uint32_t persistent;       // 1: a grid of resident waves drawing from all n_regions x 8 sub-queues through `cursors`
     uint32_t n_regions;
     uint32_t* cursors;         // persistent: one per (region, sub-queue), CRT_COUNTER_STRIDE apart, zero at launch
+    const uint32_t* perm;      // sorted (option sort_shadow): place in the sorted order -> queue entry; null = emission order
+    const uint32_t* sort_meta; // sorted: rays in each eighth of the sorted array [k * CRT_COUNTER_STRIDE], length of an eighth [8 * CRT_COUNTER_STRIDE]
     unsigned long long* visit_totals;
     uint32_t* overflow;
+};
+
+struct NeeSortArgs {           // k_nee_hist / k_nee_scan / k_nee_scatter: the frame's deferred shadow rays sorted by the cell they start in
+    const float4* shadow;      // the NEE queue (ShadowArgs::shadow)
+    const uint32_t* count;     // its counters, as ShadowArgs::count / count_stride
+    uint32_t count_stride, sub_capacity, n_queues;      // n_queues = regions x 8
+    float origin[3], scale[3]; // cell coordinate = clamp((p - origin) * scale, 0, 15)
+    uint32_t* hist;            // [4096] zero between frames
+    uint32_t* cursor;          // [4096] scratch
+    uint32_t* perm;            // out: [total] queue entries in sorted order
+    uint32_t* meta;            // out: see ShadowArgs::sort_meta
 };
 
 // waves = waves per workgroup: 1 (every wave its own workgroup), 2 or 4 (256 threads); a per-scene setting
@@ -206,6 +219,7 @@ void launch_trace_bvh2(const Bvh2Args& a, int any, bool stats, uint32_t grid, ui
 int launch_segment(const SegmentArgs& a, bool first, bool pretraced, bool inplace_shadow, bool bvh2, bool mat, bool stats, uint32_t grid, uint32_t waves, hipStream_t stream);
 void launch_closest_queue(const QueueTraceArgs& a, bool stats, uint32_t grid_waves, hipStream_t stream);
 void launch_shadow_deferred(const ShadowArgs& a, bool stats, uint32_t grid_waves, hipStream_t stream);
+void launch_nee_sort(const NeeSortArgs& a, uint32_t blocks, hipStream_t stream);
 // start/stop events for the NEXT traversal-kernel launch of this thread (either may be null); consumed by it
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 void launch_bin_scan(const BinScanArgs& a, hipStream_t stream);

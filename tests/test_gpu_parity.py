@@ -499,7 +499,7 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
                     {"bounce_refill": 1, "refill_min": 65, "refill_pool": 64}, {"bounce_refill": 1, "lanes_per_ray": 1, "refill_pool": 512}, {"inplace_shadow": 0},
                     {"inplace_shadow": 2}, {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}, {"inplace_shadow": 2, "shadow_pool": 128, "shadow_refill_min": 64, "lanes_per_ray": 1},
                     {"inplace_shadow": 0, "shadow_pool": 512, "shadow_refill_min": 1}, {"inplace_shadow": 2, "bounce_refill": 1},
-                    {"inplace_shadow": 2, "persistent": 1, "shadow_refill_min": 16}, {"bounce_refill": 1, "persistent": 1, "refill_min": 24}, {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 0, "refill_min": 1, "shadow_refill_min": 64},
+                    {"inplace_shadow": 2, "persistent": 1, "shadow_refill_min": 16}, {"sort_shadow": 1}, {"sort_shadow": 1, "persistent": 0}, {"inplace_shadow": 0, "sort_shadow": 1, "shadow_pool": 64}, {"bounce_refill": 1, "persistent": 1, "refill_min": 24}, {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 0, "refill_min": 1, "shadow_refill_min": 64},
                     {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 2, "lanes_per_ray": 1, "shadow_refill_min": 8},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
         if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):
@@ -528,7 +528,7 @@ def test_deferred_shadow_rays_keep_sums_and_counters(cr, ob, scenes, disney_scen
         for rx, ry in rvs:
             _, cnt = orc.render_frame(rx, ry, ref, threads=8)
         steps = {}
-        for key, opts in (("default", {}), ("inplace", {"inplace_shadow": 1}), ("bounce", {"inplace_shadow": 2, "persistent": 0, "shadow_pool": 64, "shadow_refill_min": 65}), ("all", {"inplace_shadow": 0, "persistent": 0}),
+        for key, opts in (("default", {}), ("inplace", {"inplace_shadow": 1}), ("bounce", {"inplace_shadow": 2, "persistent": 0, "shadow_pool": 64, "shadow_refill_min": 65, "sort_shadow": 0}), ("sorted", {"sort_shadow": 1}), ("all", {"inplace_shadow": 0, "persistent": 0, "sort_shadow": 0}),
                           ("bounce_pool", {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8, "persistent": 0}), ("bounce_one_lane", {"inplace_shadow": 2, "lanes_per_ray": 1}),
                           ("refill", {"bounce_refill": 1, "persistent": 0, "inplace_shadow": 1}), ("wavefront", {"bounce_refill": 1, "inplace_shadow": 2, "refill_pool": 128, "shadow_pool": 128, "shadow_refill_min": 16, "persistent": 0}),
                           ("persistent", {"bounce_refill": 1, "inplace_shadow": 2, "persistent": 1, "refill_min": 16, "shadow_refill_min": 16})):
@@ -546,6 +546,7 @@ def test_deferred_shadow_rays_keep_sums_and_counters(cr, ob, scenes, disney_scen
             s.close()
         assert len({v[2:] for v in steps.values()}) == 1                                  # the same visits, block by block
         assert steps["bounce"][0] < steps["inplace"][0] and steps["all"][0] < steps["inplace"][0]      # fuller waves: fewer wave-level any-hit node steps
+        assert steps["sorted"][0] < steps["default"][0]                                   # rays that start together walk together: fewer still once sorted by origin cell
         assert steps["refill"][1] < steps["inplace"][1]                                   # and fewer closest-hit ones through the refilled pools
         if name == "tess40":                                                              # (a persistent grid spreads a small frame's rays over more waves than it has batches)
             assert steps["persistent"][1] < steps["inplace"][1] and steps["persistent"][0] < steps["inplace"][0]

@@ -1,0 +1,5 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5w
+CRT_LIB=$GRAFT_REPO_ROOT/variants/exp/libcrt.so timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --deselect tests/test_gpu_parity.py::test_native_library_is_the_one_running --deselect tests/test_gpu_parity.py::test_bench_line_contract --deselect tests/test_gpu_parity.py::test_bench_self_launch_under_rccl_on_one_gpu --deselect tests/test_gpu_parity.py::test_bench_one_process_several_devices > gpurun_out/r5w/pytest_experiments.log 2>&1; echo "experiments pytest rc=$?"; tail -3 gpurun_out/r5w/pytest_experiments.log
+timeout -k 10 800 python tools/soak.py 6000 777 2>&1 | grep -v amdgpu.ids > gpurun_out/r5w/soak.txt; tail -3 gpurun_out/r5w/soak.txt; grep -c MISMATCH gpurun_out/r5w/soak.txt

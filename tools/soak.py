@@ -53,7 +53,7 @@ for case in range(n_cases):
         # segments fused or through refilled pools
         opts.update(inplace_shadow=int(rng.choice([1, 1, 1, 2, 2, 0])), tri_min=int(rng.choice([0, 1, 2, 2, 3])), lanes_per_ray=int(rng.choice([1, 8, 8])),
                     bounce_refill=int(rng.random() < 0.3), refill_pool=int(rng.choice([64, 128, 256, 512])), refill_min=int(rng.choice([1, 8, 8, 32, 65])),
-                    shadow_pool=int(rng.choice([64, 64, 128, 256])), shadow_refill_min=int(rng.choice([65, 65, 8, 32])), persistent=int(rng.random() < 0.4))
+                    shadow_pool=int(rng.choice([64, 64, 128, 256])), shadow_refill_min=int(rng.choice([65, 65, 8, 32])), persistent=int(rng.random() < 0.4), sort_shadow=int(rng.random() < 0.6))
         if EXPERIMENTS:          # variants of a `make EXPERIMENTS=1` library only
             opts.update(oversubscribe=int(rng.choice([0, 0, 0, 1, 2])), waves_per_workgroup=int(rng.choice([1, 1, 2, 4])))
     opts["ray_bins"] = int(rng.choice([0, 0, 1, 1, 2, 3, 4, 4, 5]))     # bounce rays in emission order or binned by (octant, origin cell)
