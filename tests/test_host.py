@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, REFERENCE, have_reference
+from conftest import GOLDEN, REFERENCE, ROOT, have_reference
 
 
 def test_host_rng_known_answers(cr, ob, survey):
@@ -410,3 +410,26 @@ def test_cpp_example_builds_and_reports_usage(cr):
     assert os.path.exists(exe)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_flatnode_link_word_round_trips_in_both_of_its_forms(tmp_path):
+    """host/flatnode_link.hpp: a FlatNode link below 2^24 is the reference's float (FlatNode.h:34-40, exact), one of 2^24 or more its bit pattern,
+    and a reader tells them apart by the value (floats written from integers are >= 1.0; slot 0 is 0.0f either way).  Compiled for the host here;
+    the device builders and walks include the same header."""
+    import subprocess
+    src = tmp_path / "link.cpp"
+    src.write_text('#include <cstdio>\n#include <cstring>\n#include "host/flatnode_link.hpp"\n'
+                   'int main() {\n'
+                   '  const unsigned probe[] = {0u, 1u, 2u, 77u, (1u << 23) - 1u, (1u << 23), (1u << 24) - 1u, (1u << 24), (1u << 24) + 1u, 33554431u, 123456789u, crt::kMaxLinkBits - 1u};\n'
+                   '  for (unsigned i : probe) {\n'
+                   '    const float w = crt::link_enc(i);\n'
+                   '    if ((unsigned)crt::link_of(w) != i) { std::printf("round trip of %u failed\\n", i); return 1; }\n'
+                   '    if (i < (1u << 24) && w != (float)i) { std::printf("%u is not the float form\\n", i); return 1; }\n'
+                   '    if (i >= (1u << 24) && !(w < 1.0f)) { std::printf("%u reads as a float\\n", i); return 1; }\n'
+                   '  }\n'
+                   '  for (unsigned i = 1; i < (1u << 24); i += 9973u) if (crt::link_of((float)i) != (int)i) return 2;   // every float-valued link a caller can hand in\n'
+                   '  std::puts("ok");\n  return 0;\n}\n')
+    exe = tmp_path / "link"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "caitlynrenderer_amd", "csrc"), "-o", str(exe), str(src)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout

@@ -2,7 +2,7 @@
 """Copies what tools/profile_round.sh left under gpurun_out/round_<tag>/ into profiles/ (tracked): bench lines, rocprofv3 kernel stats,
 the per-dispatch PMC CSVs, the derived summaries.   usage: tools/profile_collect.py r03"""
 import glob, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(ROOT, "gpurun_out", f"round_{tag}"), os.path.join(ROOT, "profiles")
 

@@ -5,7 +5,7 @@
 #   2. the --pmc passes per workload (three separate passes: FETCH_SIZE + GRBM, WRITE_SIZE, SQ), summarised by tools/pmc_traffic.py
 #   3. the default bench line, the one-process multi-device rehearsal, lane utilisation, the VALU issue microbenchmark
 # usage (on the box): bash tools/profile_round.sh rNN
-TAG=${1:-r04}
+TAG=${1:-r05}
 # PART=1: kernel stats + counter passes; PART=2: bench lines, probes; unset: everything (may not fit one 20-minute gpurun call)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round_$TAG; [ "$PART" != "2" ] && rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -34,7 +34,7 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.log
 echo "bench default done"
 python bench.py --gpus 1 --one-process --virtual-devices 8 --no-cpu-baseline --no-live-pmc > $O/bench_one_process_virtual8.json 2> $O/bench_one_process_virtual8.log
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --workload mesh1m --resolution 3840x2160 --no-cpu-baseline > $O/bench_config5_world1.json 2> $O/bench_config5_world1.log
-for A in "mesh1m 1" "mesh1m 4" "mesh1m 4 lanes_per_ray=1" "cornell 1"; do python tools/lane_util.py $A; done > $O/lane_util.txt 2>&1
+for A in "mesh1m 1" "mesh1m 1 lanes" "mesh1m 4" "mesh1m 4 lanes" "mesh1m 4 inplace_shadow=1" "mesh1m 4 lanes_per_ray=1" "cornell 1"; do python tools/lane_util.py $A; done > $O/lane_util.txt 2>&1
 for A in "mesh1m 1" "mesh1m 4"; do python tools/lane_hist.py $A; done > $O/lane_hist.txt 2>&1
 python tools/build_probe.py > $O/build_probe.txt 2>&1
 ./tools/ubench/valu_issue_cycles > $O/valu_issue_cycles.txt 2>&1
