@@ -565,7 +565,8 @@ def run_block(ctx, name, W, H, depth, spp, sharded, cpu_base, scaling, materials
             # multi-segment step is more than its segment launches (the deferred shadow rays' launch, the fold): the step's wall time / segments
             t_launch = dt / max(1.0, K * launches_per_step)
         # counter passes exist per (workload, depth) at 1920x1080 on the host-built tree with the reference's materials
-        pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and (not device_built or name == HBM_RESIDENT) and materials in (None, "lambert")) else {}
+        pmc = pmc_entry(name, depth) if ((W, H) == (1920, 1080) and accel == "cwbvh" and not sbvh_flags and (not device_built or name == HBM_RESIDENT)
+                                         and materials in (None, "lambert")) else {}
         traffic = pmc.get("l2_fabric_bytes_per_launch")
         if traffic is not None:      # a pass that rendered fewer samples per launch than this block's launches: scaled to the same unit
             traffic = int(traffic * samples_per_launch / max(1, pmc.get("samples_per_launch", 1)))
