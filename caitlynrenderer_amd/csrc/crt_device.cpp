@@ -81,7 +81,7 @@ struct crt_scene {
 
     // scene (replicated on every rank)
     uint4* d_nodes = nullptr;
-    float4* d_planes = nullptr;          // the nodes' child planes as floats, 12 rows per node (uniform node steps; built by finish_scene_setup on every device)
+    float4* d_planes = nullptr;          // the nodes' child planes as floats, 12 rows per node (uniform node steps; built by ensure_planes at the first CWBVH frame)
     float4* d_tris = nullptr;
     int4* d_triangles = nullptr;
     float* d_normals = nullptr;
@@ -524,6 +524,19 @@ static int pad_rows(crt_scene* s, T** buf, uint32_t rows_in, uint32_t rows_out, 
     return CRT_OK;
 }
 
+// The nodes' child planes as floats (uniform node steps, rt_kernels.hip node8_intersect_planes): 192 B per node, 2.4 x the node array — built
+// when a frame first walks the CWBVH, so a scene that only ever renders through its BVH2 (option accel 1 / 2) or only serves crt_trace never
+// holds them.  In stream order before the frame's kernels: no host wait.  A replica made later gets its copy with the other scene buffers.
+static int ensure_planes(crt_scene* s) {
+    if (s->d_planes || !s->d_nodes || !s->info.n_nodes8) return CRT_OK;
+    int rc;
+    if ((rc = dev_alloc(&s->d_planes, (size_t)s->info.n_nodes8 * 12))) return rc;
+    note_buf(s, &s->d_planes, (size_t)s->info.n_nodes8 * 12 * sizeof(float4));
+    crt::launch_expand_planes(s->d_nodes, (uint32_t)CRT_NODE_ROWS, s->d_planes, s->info.n_nodes8, s->stream);
+    if (hipGetLastError() != hipSuccess) return fail(CRT_ERR_HIP, "plane expansion failed");
+    return CRT_OK;
+}
+
 static int finish_scene_setup(crt_scene* s) {
     int rc;
     if (!s->rows_padded) {           // a replica's buffers arrive padded (crt_set_devices copies them as they are)
@@ -531,12 +544,7 @@ static int finish_scene_setup(crt_scene* s) {
         if ((rc = pad_rows(s, &s->d_tris, 3u, (uint32_t)CRT_TRI_ROWS, (size_t)s->info.n_tris8))) return rc;
         s->rows_padded = true;
     }
-    if (s->d_nodes && s->info.n_nodes8 && !s->d_planes) {      // a replica got its copy (or the primary's own array) with the other scene buffers
-        if ((rc = dev_alloc(&s->d_planes, (size_t)s->info.n_nodes8 * 12))) return rc;
-        note_buf(s, &s->d_planes, (size_t)s->info.n_nodes8 * 12 * sizeof(float4));
-        crt::launch_expand_planes(s->d_nodes, (uint32_t)CRT_NODE_ROWS, s->d_planes, s->info.n_nodes8, s->stream);
-        if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail(CRT_ERR_HIP, "crt_scene_create: plane expansion failed");
-    }
+    // (the float planes of the uniform node steps: ensure_planes, at the first frame that walks the CWBVH)
     if ((rc = dev_alloc(&s->d_overflow, 1))) return rc;
     if (hipMemset(s->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) return fail(CRT_ERR_HIP, "hipMemset failed");
     if ((rc = dev_alloc(&s->d_counts, 2 * kCounters))) return rc;
@@ -1276,6 +1284,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         }
     }
     s->bank ^= 1u;
+    if (s->accel == 0u) { const int prc = ensure_planes(s); if (prc) return prc; }
     if (!s->counts_clean) HIPCHK(hipMemsetAsync(s->d_counts, 0, 2 * kCounters * sizeof(uint32_t), s->stream));
     s->counts_clean = false;
     uint32_t* const cnt = s->counts();
@@ -1929,6 +1938,7 @@ static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n
         for (uint32_t j = 0; j < k; ++j) distinct = distinct && devices[j] != devices[k];
     }
     HIPCHK(hipSetDevice(s->device));
+    if (n_devices > 1u) { const int prc = ensure_planes(s); if (prc) return prc; }      // replicas copy (or share) the planes: none builds its own
     HIPCHK(hipStreamSynchronize(s->stream));
     s->drop_peers();
     s->streams = 1;

@@ -947,56 +947,6 @@ __device__ __forceinline__ bool traverse_any_then_groups(const uint4* __restrict
                 }
                 CRT_MARK("node_end");
             }
-#ifdef CRT_ANY_SHARE
-        }
-        {
-            // VERDICT r4 item 4, measured and not adopted (profiles/r05_experiments.md §6): when at most CRT_ANY_SHARE (<= 16) lanes have a leaf
-            // pending and one of them more than one triangle, the wave tests them side by side — four lanes per owner, lane j of a quad the bit
-            // position top - j of the owner's pending mask (the window of group_tri_step); what is left goes through the plain loop below.
-            const bool has_leaf = tg.y != 0u;
-            const unsigned long long m_leaf = __ballot(has_leaf);
-            const uint32_t n_leaf = (uint32_t)__builtin_popcountll(m_leaf);
-            if (n_leaf != 0u && n_leaf <= (uint32_t)(CRT_ANY_SHARE) && __ballot((tg.y & (tg.y - 1u)) != 0u) != 0ull) {
-                uint2* const slot_it = base + (stack_entries + 1) * 64;
-                const uint32_t rank = (uint32_t)__builtin_popcountll(m_leaf & ((1ull << lane) - 1ull));
-                if (has_leaf) slot_it[rank].y = lane;
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t q = lane >> 2, j = lane & 3u;
-                const bool act = q < n_leaf;
-                const int src = act ? (int)slot_it[q].y : (int)lane;
-                const vec3 so = V3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src)), sd = V3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
-                const float st = __shfl(tmax, src);
-                const uint32_t sx = (uint32_t)__shfl((int)tg.x, src), sy = (uint32_t)__shfl((int)tg.y, src);
-                __builtin_amdgcn_wave_barrier();
-                bool hit = false;
-                if (act && sy != 0u) {
-                    const uint32_t top = 31u - (uint32_t)__builtin_clz(sy);
-                    if (j <= top && ((sy >> (top - j)) & 1u) != 0u) {
-                        const float4* tp = tri_rows(tris, sx + (top - j));
-                        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                        float u, v, t;
-                        hit = mt_test(ta, tb, tc, so, sd, u, v, t) && t < st;
-                    }
-                }
-                const unsigned long long hm = __ballot(hit);
-                if (STATS) count_wave_step(w_tris);
-                if (has_leaf) {
-                    const uint32_t mine4 = (uint32_t)(hm >> (rank * 4u)) & 0xfu;        // bit j: the triangle at position top - j is hit
-                    const uint32_t top = 31u - (uint32_t)__builtin_clz(tg.y);
-                    const uint32_t lo = top >= 3u ? top - 3u : 0u;
-                    if (mine4) {
-                        const uint32_t first = top - (uint32_t)__builtin_ctz(mine4);  // the first hit in the plain loop's order
-                        if (STATS) n_tris += (uint32_t)__builtin_popcount(tg.y >> first);
-                        hit_tri = (int)(tg.x + first); tg.y = 0u; cur.y = 0u; sp = 0;
-                    } else {
-                        if (STATS) n_tris += (uint32_t)__builtin_popcount(tg.y >> lo);
-                        tg.y &= ~(0xffffffffu << lo);
-                    }
-                }
-            }
-        }
-        {
-#endif
             while (tg.y) {
                 CRT_MARK("tri_begin");
                 const int b = 31 - __builtin_clz(tg.y);
