@@ -142,6 +142,8 @@ struct crt_scene {
     // kernarg change), persistent 256 / 16 7.72 Gray/s
     uint32_t shadow_pool = 256;
     uint32_t shadow_refill_min = 16;
+    uint32_t shadow_waves = 6;               // waves per SIMD the persistent any-hit grid of the deferred shadow rays is sized for (the kernel fits 8; two shards'
+                                             // grids share the chip: 4 / 5 / 6 / 7 / 8 = 7,723 / 7,767 / 7,776 / 7,750 / 7,721 on four segments, 10,540 / 10,450 / 10,338 at 5 / 6 / 8 on two)
     // the pool launches (k_shadow_deferred, k_closest_queue) as PERSISTENT grids: as many waves as the chip holds, each reserving chunks of
     // `pool` rays through per-queue cursors until every queue is dry; 0 = one workgroup per pool
     uint32_t persistent = 1;
@@ -1045,6 +1047,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
         (name[0] == 'r' ? s->refill_pool : s->shadow_pool) = (uint32_t)value;
     }
     else if (!std::strcmp(name, "shadow_refill_min")) s->shadow_refill_min = (uint32_t)std::min(65, std::max(1, value));
+    else if (!std::strcmp(name, "shadow_waves")) s->shadow_waves = (uint32_t)std::min(8, std::max(1, value));
     else if (!std::strcmp(name, "persistent")) s->persistent = value ? 1u : 0u;
     else if (!std::strcmp(name, "sort_shadow")) s->sort_shadow = value ? 1u : 0u;
 #ifdef CRT_EXPERIMENTS
@@ -1422,7 +1425,7 @@ static int render_batch_async(crt_scene* s, uint32_t n_samples, const float* rxs
         EventSpan* sp = s->new_span(2);
         if (sp) crt::set_launch_events(sp->a, sp->b);
         const size_t lds_q = (size_t)(s->stack_entries + CRT_HIT_SLOTS) * 64 * sizeof(uint2);
-        crt::launch_shadow_deferred(sh, s->count_visits, sh.persistent ? s->resident_waves(lds_q, 8) : 8u * sh.n_regions * sh.pools_per_region, s->stream);
+        crt::launch_shadow_deferred(sh, s->count_visits, sh.persistent ? s->resident_waves(lds_q, s->shadow_waves) : 8u * sh.n_regions * sh.pools_per_region, s->stream);
     }
     if (folds) crt::launch_fold_paths(s->d_sum, s->d_lfinal, any_deferred ? s->d_contrib : nullptr, P, n_samples, first_deferred, s->stream);
     if (s->count_visits)
@@ -1889,7 +1892,7 @@ static int replicate_scene(const crt_scene* src, int device, crt_scene** out) {
     r->tri_min = src->tri_min; r->inplace_shadow = src->inplace_shadow; r->accel = src->accel; r->refill_min = src->refill_min; r->trace_pool = src->trace_pool; r->count_visits = src->count_visits;
     r->count_batched = src->count_batched;
     r->trace_occupancy = src->trace_occupancy; r->oversubscribe = src->oversubscribe; r->waves_per_workgroup = src->waves_per_workgroup;
-    r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min; r->persistent = src->persistent; r->sort_shadow = src->sort_shadow;
+    r->lanes_per_ray = src->lanes_per_ray; r->bounce_refill = src->bounce_refill; r->refill_pool = src->refill_pool; r->shadow_pool = src->shadow_pool; r->shadow_refill_min = src->shadow_refill_min; r->shadow_waves = src->shadow_waves; r->persistent = src->persistent; r->sort_shadow = src->sort_shadow;
     r->wave_samples = src->wave_samples; r->wide_first = src->wide_first; r->adaptive_tiles = src->adaptive_tiles; r->timing = src->timing;
     r->ray_bins = src->ray_bins; r->rows_padded = src->rows_padded;
     for (int k = 0; k < 3; ++k) { r->bounds_lo[k] = src->bounds_lo[k]; r->bounds_hi[k] = src->bounds_hi[k]; }

@@ -242,7 +242,7 @@ __device__ __forceinline__ uint32_t node8_intersect_planes(uint4& n0, uint4& n1,
     return hit_mask;
 }
 // Build switches that remain (make EXTRA="-D<name>=<value>"; tools/variant.sh builds a variant library beside the product one):
-//   CRT_SEG_OCC, CRT_SEG_OCC_FIRST, CRT_SEG_OCC_BATCH, CRT_SEG_OCC_DEFERRED   waves per SIMD the segment kernels are compiled for (6 / 6 / 5 / 8)
+//   CRT_SEG_OCC, CRT_SEG_OCC_FIRST, CRT_SEG_OCC_BATCH, CRT_SEG_OCC_DEFERRED, CRT_SHADOW_OCC   waves per SIMD the segment kernels / k_shadow_deferred are compiled for (6 / 6 / 5 / 8 / 8)
 //   CRT_HIT_SLOTS, CRT_NODE_ROWS, CRT_TRI_ROWS           LDS hit-record slots per lane; device row strides (rt_kernels.hpp)
 //   CRT_ISA_MARKS                                        `make asm`: marker comments tools/roofline.py counts between
 //   CRT_EXPERIMENTS                                      persistent grids and 2- / 4-wave workgroups (make EXPERIMENTS=1)
@@ -1995,8 +1995,11 @@ __global__ void __launch_bounds__(64, CRT_SEG_OCC) k_closest_queue(QueueTraceArg
 // workgroup per pool of a.pool rays (a.pool = 64 and refill_min = 65: one lock-step batch).  An OCCLUDED ray clears the visibility word of
 // its contribution slot (queue entry: (o, tmax) (d, slot)); k_fold_paths then adds what is left, in segment order.  Same rays, same walks as
 // the in-place form: occlusion and visit totals keep the oracle's values.
+#ifndef CRT_SHADOW_OCC
+#define CRT_SHADOW_OCC 8      // 64 VGPRs, no vector spill: d4 +0.8 .. 1.2 %, d2 +1.5 .. 2.1 % against the 76 registers of six waves (profiles/r05_experiments.md §8)
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(64, CRT_SEG_OCC) k_shadow_deferred(ShadowArgs a) {
+__global__ void __launch_bounds__(64, CRT_SHADOW_OCC) k_shadow_deferred(ShadowArgs a) {
     extern __shared__ uint2 s_lds[];
     const uint32_t g = blockIdx.x & 7u, q = blockIdx.x >> 3;
     uint32_t nn = 0, nt = 0, wn = 0, wt = 0;

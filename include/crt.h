@@ -193,7 +193,9 @@ int crt_sync(crt_scene* s);
  *     "persistent"        1 (default): the pool launches (k_shadow_deferred, k_closest_queue) are PERSISTENT grids — as many single-wave
  *                         workgroups as the chip holds waves, each reserving chunks of "shadow_pool" / "refill_pool" rays from the
  *                         sub-queues through one cursor per queue until all are dry (one returning atomic per chunk), so the launch
- *                         ends on one drain phase instead of one per pool; 0: one workgroup per pool
+ *                         ends on one drain phase instead of one per pool; 0: one workgroup per pool.  "shadow_waves" (1..8,
+ *                         default 6): waves per SIMD k_shadow_deferred's grid is sized for (the kernel fits 8; the grids of the
+ *                         shards on "streams" share the chip)
  *     "bounce_refill"     segments >= 1: 0 = closest hit, shading and emission fused in one lock-step kernel (default); 1 = closest hits
  *                         through pools of "refill_pool" (64 / 128 / 256 (default) / 512) rays per wave with lane refill at "refill_min"
  *                         idle lanes (k_closest_queue), then a shade-only pass (k_segment<PRETRACED>)

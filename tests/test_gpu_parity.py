@@ -499,7 +499,7 @@ def test_scheduling_and_loop_variants_give_identical_frames(cr, scenes, name):
                     {"bounce_refill": 1, "refill_min": 65, "refill_pool": 64}, {"bounce_refill": 1, "lanes_per_ray": 1, "refill_pool": 512}, {"inplace_shadow": 0},
                     {"inplace_shadow": 2}, {"inplace_shadow": 2, "shadow_pool": 256, "shadow_refill_min": 8}, {"inplace_shadow": 2, "shadow_pool": 128, "shadow_refill_min": 64, "lanes_per_ray": 1},
                     {"inplace_shadow": 0, "shadow_pool": 512, "shadow_refill_min": 1}, {"inplace_shadow": 2, "bounce_refill": 1},
-                    {"inplace_shadow": 2, "persistent": 1, "shadow_refill_min": 16}, {"sort_shadow": 1}, {"sort_shadow": 1, "persistent": 0}, {"inplace_shadow": 0, "sort_shadow": 1, "shadow_pool": 64}, {"bounce_refill": 1, "persistent": 1, "refill_min": 24}, {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 0, "refill_min": 1, "shadow_refill_min": 64},
+                    {"inplace_shadow": 2, "persistent": 1, "shadow_refill_min": 16}, {"shadow_waves": 8}, {"shadow_waves": 1, "shadow_pool": 64}, {"sort_shadow": 1}, {"sort_shadow": 1, "persistent": 0}, {"inplace_shadow": 0, "sort_shadow": 1, "shadow_pool": 64}, {"bounce_refill": 1, "persistent": 1, "refill_min": 24}, {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 0, "refill_min": 1, "shadow_refill_min": 64},
                     {"bounce_refill": 1, "persistent": 1, "inplace_shadow": 2, "lanes_per_ray": 1, "shadow_refill_min": 8},
                     {"inplace_shadow": 0, "bounce_refill": 1}, {"inplace_shadow": 0, "tri_min": 0}, {"inplace_shadow": 0, "oversubscribe": 2}):
         if not EXPERIMENTS and EXPERIMENTAL_OPTIONS & set(options):

@@ -2,23 +2,24 @@
 """Per kernel: every counter of the passes tools/pmc_anatomy.sh made, as the mean per dispatch and — for cycle counters — as a share of the
 dispatch's shader cycles (GRBM_GUI_ACTIVE / 8 XCDs) times the number of units that count (256 TA / TCP / TD, 1024 SIMDs for SQ wave-cycle
 counters is NOT applied: SQ cycle counters are reported per SQ_WAVE_CYCLES or per SQ_BUSY where the pass has it).
-usage: tools/pmc_anatomy.py DIR"""
+usage: tools/pmc_anatomy.py DIR [TAIL]"""
 import collections, csv, glob, os, sys
 
 UNITS = {"TA_": 256, "TCP_": 256, "TD_": 256}
 
 
-def main(d):
+def main(d, tail=0):
+    """tail: how many of the LAST segment-kernel dispatches of each pass to leave out (bench.py ends a run with min(10, steps x spp)
+    single-sample frames, `depth` segment launches each: a quarter of the work of a 4-sample launch, some by the same kernel)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pmc_traffic
     per = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> values
     for p in sorted(glob.glob(os.path.join(d, "pass*"))):
         if not os.path.isdir(p):
             continue
-        for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0]
-                if not k.startswith(("void crt::", "crt::")):
-                    continue
-                per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for (k, c), v in pmc_traffic.per_kernel(p, tail).items():
+            if k.startswith(("void crt::", "crt::")):
+                per[k][c] += v
     for k, cs in sorted(per.items()):
         gui = cs.get("GRBM_GUI_ACTIVE")
         if not gui or sum(gui) / len(gui) < 8e4:
@@ -53,4 +54,4 @@ def main(d):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)

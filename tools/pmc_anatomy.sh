@@ -1,7 +1,8 @@
 #!/bin/bash
 # Where a kernel's idle issue slots go: small --pmc passes (at most 2-4 counters of one block per pass, each under its own timeout) of one
 # bench.py workload, summarised per kernel by tools/pmc_anatomy.py.
-#   usage (on the box): bash tools/pmc_anatomy.sh OUTDIR "bench.py arguments"
+#   usage (on the box): bash tools/pmc_anatomy.sh OUTDIR "bench.py arguments" [TAIL]
+# TAIL = segment launches of the run's closing single-sample frames to leave out: min(10, steps x spp) x depth (10 for one segment, 40 for four)
 R=$GRAFT_REPO_ROOT; O=$1; ARGS="--no-cpu-baseline --no-live-pmc --no-oracle-check --settle-ms 0 --steps 5 --warmup 2 --streams 1 $2"
 mkdir -p $O; cd /tmp && export TMPDIR=/tmp
 i=0
@@ -24,4 +25,4 @@ GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACT
 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU
 GRBM_GUI_ACTIVE SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_TC_STALL
 PASSES
-python3 $R/tools/pmc_anatomy.py $O | tee $O/anatomy.txt
+python3 $R/tools/pmc_anatomy.py $O ${3:-0} | tee $O/anatomy.txt
