@@ -170,6 +170,34 @@ def test_counter_summary_leaves_the_single_sample_tail_out(tmp_path):
     assert abs(steps["valu_issue"]["busy"] - 2 * 400e3 / (1024 * 400 * 8000.0 / 8)) < 1e-3
 
 
+def test_counter_anatomy_reports_unit_shares_without_the_single_sample_tail(tmp_path, capsys):
+    """tools/pmc_anatomy.py: cycle counters of the per-CU units as a share of 256 x the dispatch's shader cycles (GRBM_GUI_ACTIVE / 8 XCDs),
+    SQ wave-cycle counters as a share of SQ_WAVE_CYCLES, the run's closing single-sample dispatches left out."""
+    pa = _load("pmc_anatomy")
+    seg = "void crt::k_segment<false, false, false, false, false, false, false, false, false, false>(crt::SegmentArgs)"
+    cols = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
+    passes = [{"GRBM_GUI_ACTIVE": 8e6, "TA_TA_BUSY_sum": 128e6, "TA_TOTAL_WAVEFRONTS_sum": 8e6},
+              {"GRBM_GUI_ACTIVE": 8e6, "SQ_WAVE_CYCLES": 1000.0, "SQ_WAIT_ANY": 400.0, "SQ_ACTIVE_INST_ANY": 200.0, "SQ_WAIT_INST_ANY": 400.0},
+              {"GRBM_GUI_ACTIVE": 8e6, "TCP_TCC_READ_REQ_sum": 1e6, "TCP_TCC_READ_REQ_LATENCY_sum": 424e6}]
+    for i, counters in enumerate(passes, 1):
+        d = tmp_path / f"pass{i}" / "run"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.DictWriter(f, cols)
+            w.writeheader()
+            for disp in range(1, 8):                    # 4 step launches at full size, 3 tail launches at a quarter
+                scale = 1.0 if disp <= 4 else 0.25
+                for c, v in counters.items():
+                    w.writerow({"Dispatch_Id": disp, "Kernel_Name": seg, "Counter_Name": c, "Counter_Value": v * scale})
+    pa.main(str(tmp_path), tail=3)
+    out = capsys.readouterr().out
+    assert "dispatches per pass 4, shader cycles per dispatch 1,000,000" in out           # 8e6 / 8 XCDs, the tail left out
+    assert "TA_TA_BUSY_sum" in out and "0.500 of 256 units x cycles" in out               # 128e6 / (256 x 1e6)
+    assert "SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.400" in out and "L1->L2 read latency 424 cycles per request" in out
+    pa.main(str(tmp_path))
+    assert "dispatches per pass 7" in capsys.readouterr().out                             # without the tail argument everything is averaged
+
+
 def test_isa_counts_file_matches_the_kernels_as_compiled(tmp_path):
     """profiles/isa_counts.json prices the roofline's node visits and triangle tests: its I_node / I_node_uniform / I_node_uniform_any / I_tri must be
     what the CURRENT rt_kernels.hip compiles to (the marker build of `make asm`), or frac_executed <= counter_frac would hold by accident."""
