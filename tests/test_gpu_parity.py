@@ -1092,8 +1092,17 @@ def test_config4_with_mirror_and_disney_materials_at_full_size(cr, ob, mesh1m, c
     batched = cr.Scene(data, W, H, depth)
     batched.render_frame(RX1, RY1)
     batched.render_frames(rvs)
-    assert np.array_equal(batched.read_sum().view(np.uint32), want.view(np.uint32))
+    got = batched.read_sum()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     batched.close()
+    # ... and the batched step against the ORACLE on the same five frames (a band of rows through the boxes; the whole frame five times over
+    # would take the CPU minutes): what the step adds per frame — not only its first frame — keeps the oracle's bits
+    y0 = (H // 2 - 16) // 8 * 8
+    rows = np.zeros((H, W, 3), np.float32)
+    for rx, ry in [(RX1, RY1)] + rvs:
+        orc.render_rows(rx, ry, y0, y0 + 32, rows)
+    assert rows[y0:y0 + 32].max() > 0
+    assert np.array_equal(got[y0:y0 + 32].view(np.uint32), rows[y0:y0 + 32].view(np.uint32))
 
 
 def test_wide_first_segment_build_on_the_whole_million_triangle_frame(cr, ob, mesh1m):
@@ -1236,7 +1245,7 @@ def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
     records + 73 MB of nodes, more than the 256 MiB Infinity Cache, so its fetches are HBM fetches — built by the GPU SAH builder
     (16.2 M BVH2 nodes: the largest tree whose float links are still exact).  Parity at that size: 100,000 sampled rays (primary
     rays of frame 1 and random rays inside the box) bit-exact against the oracle on ids, t, u, v; any-hit agrees with closest-hit on
-    every one of them; 16 rows of the 1080p frame equal the oracle's; and the scene crt_scene_create builds by itself from the
+    every one of them; the whole two-segment 1080p frame equals the oracle's (sum, ray counts, visit totals); and the scene crt_scene_create builds by itself from the
     source-order arrays (what the bench block renders) gives the same frame as the one uploaded from the host arrays."""
     from caitlynrenderer_amd.meshgen import tessellated_cornell
     base, cam = cornell
@@ -1268,13 +1277,17 @@ def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
     cut["tmax"] = (rng.random(100000) * 8).astype(np.float32)
     occ = scene.trace(cut, cr.CRT_TRACE_ANY)["tri"] >= 0
     assert np.array_equal(occ, (got["tri"] >= 0) & (got["t"] < cut["tmax"]))
-    # 16 rows of the two-segment frame against the oracle; the whole frame against the device-built scene of the same builder
+    # the WHOLE two-segment frame against the oracle (sum, ray counts, visit totals); then against the device-built scene of the same builder
+    scene.set_option("count_visits", 1)
     scene.render_frame(RX1, RY1)
     out = scene.read_sum()
-    rows = np.zeros((H, W, 3), np.float32)
-    orc.render_rows(RX1, RY1, 536, 552, rows)
-    assert np.array_equal(out[536:552].view(np.uint32), rows[536:552].view(np.uint32)) and rows[536:552].max() > 0
-    assert scene.frame_stats()["stack_overflows"] == 0
+    st = scene.frame_stats()
+    ref, cnt = orc.render_frame(RX1, RY1, threads=16)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)) and ref.max() > 0, float(np.abs(out - ref).max())
+    assert (st["closest_rays"], st["any_rays"]) == (cnt[0], cnt[1]) and cnt[0] > 2_500_000
+    assert st["nodes_closest"] + st["nodes_any"] == cnt[2] and st["tris_closest"] + st["tris_any"] == cnt[3]
+    assert st["stack_overflows"] == 0
+    scene.set_option("count_visits", 0)
     scene.close()
     dev = cr.Scene(cr.SceneData.for_device_build(mesh, cam, builder="sah"), W, H, 2)
     assert dev.bvh_info()["n_nodes8"] == info["n_nodes8"]
