@@ -1295,14 +1295,18 @@ def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
     assert np.array_equal(dev.read_sum().view(np.uint32), out.view(np.uint32))
     dev.close()
     # the launches bench.py's hbm_resident blocks time: the device-built scene, a step = 4 frames through one crt_render_frames call with
-    # default options, at one segment (lanes form on the 6-wave build) and at four (two streams); 16 rows against the oracle
+    # default options, at one segment (lanes form on the 6-wave build: the whole frame against the oracle) and at four (two streams: 80 rows)
     rnd = cr.Rnd()
     rvs = [(rnd.randf2(), rnd.randf2()) for _ in range(4)]
     for depth, shards in ((1, 1), (4, 2)):
         orc_d = ob.Oracle(data, W, H, depth, cam)
         rows = np.zeros((H, W, 3), np.float32)
+        y_lo, y_hi = (0, H) if depth == 1 else (504, 584)      # one segment: the whole frame, four frames over; four segments: 80 rows through the boxes
         for r in rvs:
-            orc_d.render_rows(r[0], r[1], 536, 552, rows)
+            if depth == 1:
+                orc_d.render_frame(r[0], r[1], rows, threads=16)
+            else:
+                orc_d.render_rows(r[0], r[1], y_lo, y_hi, rows)
         dev = cr.Scene(cr.SceneData.for_device_build(mesh, cam, builder="sah"), W, H, depth)
         dev.set_option("streams", 0)
         _bench_step(dev, rvs)
@@ -1310,7 +1314,7 @@ def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
         li = dev.debug_launch_info()
         assert li["form"] == 2 and li["samples"] == 4 and li["shards"] == shards and (li["wide"] or depth > 1), li
         got = dev.read_sum()
-        assert np.array_equal(got[536:552].view(np.uint32), rows[536:552].view(np.uint32)) and rows[536:552].max() > 0, depth
+        assert np.array_equal(got[y_lo:y_hi].view(np.uint32), rows[y_lo:y_hi].view(np.uint32)) and rows[y_lo:y_hi].max() > 0, depth
         assert dev.frame_stats()["stack_overflows"] == 0
         dev.close()
 
