@@ -142,6 +142,7 @@ struct crt_scene {
     // kernarg change), persistent 256 / 16 7.72 Gray/s
     uint32_t shadow_pool = 256;
     uint32_t shadow_refill_min = 16;
+    uint32_t step_hist_mode = 0;             // crt_debug_step_hist: 0 = node steps by enabled lanes, 1 = by distinct (node, octant) keys in the wave
     uint32_t shadow_waves = 6;               // waves per SIMD the persistent any-hit grid of the deferred shadow rays is sized for (the kernel fits 8; two shards'
                                              // grids share the chip: 4 / 5 / 6 / 7 / 8 = 7,723 / 7,767 / 7,776 / 7,750 / 7,721 on four segments, 10,540 / 10,450 / 10,338 at 5 / 6 / 8 on two)
     // the pool launches (k_shadow_deferred, k_closest_queue) as PERSISTENT grids: as many waves as the chip holds, each reserving chunks of
@@ -1048,6 +1049,7 @@ int crt_set_option(crt_scene* s, const char* name, int value) {
     }
     else if (!std::strcmp(name, "shadow_refill_min")) s->shadow_refill_min = (uint32_t)std::min(65, std::max(1, value));
     else if (!std::strcmp(name, "shadow_waves")) s->shadow_waves = (uint32_t)std::min(8, std::max(1, value));
+    else if (!std::strcmp(name, "step_hist_mode")) s->step_hist_mode = value ? 1u : 0u;
     else if (!std::strcmp(name, "persistent")) s->persistent = value ? 1u : 0u;
     else if (!std::strcmp(name, "sort_shadow")) s->sort_shadow = value ? 1u : 0u;
 #ifdef CRT_EXPERIMENTS
@@ -2099,7 +2101,7 @@ int crt_debug_step_hist(crt_scene* s, unsigned long long* hist) {
     }
     HIPCHK(hipMemcpy(hist, d_hist, 130 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(d_hist, 0, 130 * sizeof(unsigned long long)));
-    crt::set_step_hist(d_hist);
+    crt::set_step_hist(d_hist, s->step_hist_mode);
     return CRT_OK;
 }
 

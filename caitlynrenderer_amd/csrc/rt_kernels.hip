@@ -115,13 +115,28 @@ __device__ __forceinline__ void count_wave_step(uint32_t& c) {
 // Measurement aid (crt_debug_step_hist): how many lanes were enabled at each node step of the counting kernels, per walk kind — the
 // distribution behind the lane-utilisation figures (how much of the idle time is "fewer than half of the lanes still have a ray").
 __device__ unsigned long long* g_step_hist = nullptr;       // [2][65]: closest-hit walks, any-hit walks; null = off
+__device__ uint32_t g_step_hist_mode = 0u;                 // 0: by enabled lanes; 1: by DISTINCT (node, octant) keys among the enabled lanes (1 = a uniform step)
 __device__ __forceinline__ void hist_node_step(bool any, uint32_t nidx = 0u, uint32_t oct = 0u) {
     unsigned long long* const h = g_step_hist;
     if (h == nullptr) return;
     const unsigned long long m = __ballot(true);
-    if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) atomicAdd(&h[(any ? 65 : 0) + __builtin_popcountll(m)], 1ull);
+    uint32_t n = (uint32_t)__builtin_popcountll(m);
+    if (g_step_hist_mode) {                                 // what a packet walk (one scalar-unit step per distinct node of the wave) would have to execute
+        const uint32_t key = (nidx << 3) | (oct & 7u);
+        unsigned long long left = m;
+        n = 0u;
+        while (left) {
+            const uint32_t k0 = (uint32_t)__shfl((int)key, __builtin_ctzll(left));
+            left &= ~__ballot(key == k0);
+            ++n;
+        }
+    }
+    if ((int)(threadIdx.x & 63u) == __builtin_ctzll(m)) atomicAdd(&h[(any ? 65 : 0) + n], 1ull);
 }
-void set_step_hist(unsigned long long* d_hist) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist), &d_hist, sizeof d_hist); }
+void set_step_hist(unsigned long long* d_hist, uint32_t mode) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist), &d_hist, sizeof d_hist);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_hist_mode), &mode, sizeof mode);
+}
 
 struct HitState {
     float t, u, v;
@@ -835,7 +850,7 @@ __device__ __forceinline__ void walk_pool(const uint4* __restrict__ nodes, const
                 const uint32_t nidx = nbase + (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
                 const uint4* np = node_rows(nodes, nidx);
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY); }
+                if (STATS) { ++n_nodes; count_wave_step(w_nodes); hist_node_step(ANY, nidx, oct4); }
                 const uint32_t hitmask = node8_intersect(n0, n1, n2, n3, n4, o, inv, negx, negy, negz, oct4, best_t);
                 cur.x = n1.x;
                 tg.x = n1.y;

@@ -230,7 +230,7 @@ void launch_untile(const FrameArgs& f, const float* packed, float* linear, uint3
 void launch_resolve(const float* linear, uint32_t n_pixels, float inv_count, const float* thr, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 void launch_resolve_packed(const FrameArgs& f, const float* packed, float inv_count, const float* thr, uint8_t* rgba, uint32_t grid, hipStream_t stream);
 
-void set_step_hist(unsigned long long* d_hist);      // measurement aid: [2][65] node-step histogram of the counting kernels, null = off
+void set_step_hist(unsigned long long* d_hist, uint32_t mode = 0u);      // measurement aid: [2][65] node-step histogram of the counting kernels (mode 0: by enabled lanes, 1: by distinct nodes), null = off
 int warm_rt_kernels();      // crt_warmup: loads this unit's code object on the current device
 
 }  // namespace crt

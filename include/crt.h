@@ -292,7 +292,9 @@ int crt_debug_launch_form(crt_scene* s, int32_t* form);
 int crt_debug_launch_info(crt_scene* s, int32_t info[4]);
 /* measurement aid: hist[130] receives, for the counting frames ("count_visits") rendered since the previous call, how many node steps ran
  * with k of the wave's 64 lanes enabled — closest-hit walks in hist[k], any-hit walks in hist[65 + k] — and the collection (re)starts;
- * hist = NULL stops it.  Process-wide; tools/lane_hist.py prints the distribution behind the lane-utilisation figures. */
+ * hist = NULL stops it.  Process-wide; tools/lane_hist.py prints the distribution behind the lane-utilisation figures.  With option
+ * "step_hist_mode" 1 (set before the call that starts the collection) the index is the number of DISTINCT (node, octant) keys among the
+ * step's enabled lanes instead — 1 = a uniform step — i.e. the steps a packet walk would need. */
 int crt_debug_step_hist(crt_scene* s, unsigned long long* hist);
 
 /* Multi-GPU tile sharding (no reference counterpart).  The framebuffer is

@@ -1319,6 +1319,42 @@ def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
         dev.close()
 
 
+@pytest.mark.gpu
+def test_node_step_histograms_add_up_to_the_wave_step_counters(cr, scenes):
+    """crt_debug_step_hist (measurement aid): node steps of the counting kernels by enabled lanes (mode 0) or by distinct (node, octant) keys
+    among the enabled lanes (option step_hist_mode 1).  Either way a frame's histogram holds exactly the frame's wave-level node steps, the
+    lane-weighted sum of mode 0 is the visit count, and a step never has more distinct nodes than enabled lanes."""
+    data = scenes["tess40"][2]
+    W, H = 256, 192
+    for depth in (1, 3):
+        per_mode = []
+        for mode in (0, 1):
+            scene = cr.Scene(data, W, H, depth)
+            scene.set_option("count_visits", 1)
+            scene.set_option("lanes_per_ray", 1)          # the histogram covers the one-lane-per-ray loops (a group phase's steps are not in it)
+            scene.set_option("step_hist_mode", mode)
+            scene.debug_step_hist()                 # start
+            scene.render_frame(RX1, RY1)
+            st = scene.frame_stats()
+            closest, anyh = scene.debug_step_hist()
+            scene.debug_step_hist(stop=True)
+            scene.close()
+            assert int(closest.sum()) == st["wave_steps_closest_nodes"] > 0 and int(anyh.sum()) == st["wave_steps_any_nodes"] > 0, (depth, mode)
+            assert closest[0] == 0 and anyh[0] == 0
+            k = np.arange(65, dtype=np.uint64)
+            if mode == 0:
+                assert int((closest * k).sum()) == st["nodes_closest"] and int((anyh * k).sum()) == st["nodes_any"]
+            else:
+                assert int((closest * k).sum()) <= st["nodes_closest"] and int((anyh * k).sum()) <= st["nodes_any"]
+                assert closest[1] > 0                  # the root step of a primary wave is a single node
+            per_mode.append((closest, anyh))
+        # one segment: the same waves take the same steps in both runs (bounce rays come in the order their producers finished), and the distinct-node
+        # count of a step is at most its lane count, so the cumulative distributions are ordered
+        if depth == 1:
+            for a, b in zip(per_mode[0], per_mode[1]):
+                assert a.sum() == b.sum() and np.all(np.cumsum(b) >= np.cumsum(a))
+
+
 @pytest.fixture(scope="module")
 def disney_scenes(cr, cornell):
     """Cornell box with a mirror tall box, a brushed-metal short box and a glossy floor (meshgen.with_disney_materials),
