@@ -533,6 +533,16 @@ static int pad_rows(crt_scene* s, T** buf, uint32_t rows_in, uint32_t rows_out, 
 static int ensure_planes(crt_scene* s) {
     if (s->d_planes || !s->d_nodes || !s->info.n_nodes8) return CRT_OK;
     int rc;
+    if (s->primary && s->shares_scene) {
+        // a replica on its primary's own device that was made before any CWBVH frame (the scene rendered through its BVH2 until now): it borrows
+        // the primary's planes like every other scene buffer.  Rare path: one host wait for the primary's stream.
+        crt_scene* const p = s->primary;
+        if ((rc = ensure_planes(p))) return rc;
+        HIPCHK(hipStreamSynchronize(p->stream));
+        s->d_planes = p->d_planes;
+        note_buf(s, &s->d_planes, (size_t)s->info.n_nodes8 * 12 * sizeof(float4));      // borrowed: the destructor lets go of it
+        return CRT_OK;
+    }
     if ((rc = dev_alloc(&s->d_planes, (size_t)s->info.n_nodes8 * 12))) return rc;
     note_buf(s, &s->d_planes, (size_t)s->info.n_nodes8 * 12 * sizeof(float4));
     crt::launch_expand_planes(s->d_nodes, (uint32_t)CRT_NODE_ROWS, s->d_planes, s->info.n_nodes8, s->stream);
@@ -1943,7 +1953,7 @@ static int set_devices_of_shard(crt_scene* s, const int32_t* devices, uint32_t n
         for (uint32_t j = 0; j < k; ++j) distinct = distinct && devices[j] != devices[k];
     }
     HIPCHK(hipSetDevice(s->device));
-    if (n_devices > 1u) { const int prc = ensure_planes(s); if (prc) return prc; }      // replicas copy (or share) the planes: none builds its own
+    if (n_devices > 1u && s->accel == 0u) { const int prc = ensure_planes(s); if (prc) return prc; }      // replicas copy (or share) the planes (a scene on its BVH2: ensure_planes, later)
     HIPCHK(hipStreamSynchronize(s->stream));
     s->drop_peers();
     s->streams = 1;

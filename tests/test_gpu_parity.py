@@ -1320,6 +1320,32 @@ def test_scene_larger_than_the_infinity_cache(cr, ob, cornell):
 
 
 @pytest.mark.gpu
+def test_float_planes_are_built_when_a_frame_first_walks_the_cwbvh(cr, scenes):
+    """The float copy of the nodes' planes (uniform node steps) is built by the first CWBVH frame, not by crt_scene_create: a scene that
+    rendered through its BVH2 first — alone, and with tile shards on two streams made BEFORE any CWBVH frame (the shard on the same GPU borrows
+    the planes its primary then builds) — gives the frames of a scene that walked the CWBVH from the start."""
+    data = scenes["tess40"][2]
+    W, H, depth = 320, 200, 3
+    ref = cr.Scene(data, W, H, depth)
+    ref.render_frame(RX1, RY1)
+    ref.render_frame(RX2, RY2)
+    want = ref.read_sum()
+    ref.close()
+    for streams in (1, 2):
+        s = cr.Scene(data, W, H, depth)
+        s.set_option("accel", 1)
+        if streams > 1:
+            s.set_option("streams", streams)
+        s.render_frame(RX1, RY1)                # BVH2 walk: no planes yet
+        s.reset()
+        s.set_option("accel", 0)
+        s.render_frame(RX1, RY1)
+        s.render_frame(RX2, RY2)
+        assert np.array_equal(s.read_sum().view(np.uint32), want.view(np.uint32)), streams
+        s.close()
+
+
+@pytest.mark.gpu
 def test_node_step_histograms_add_up_to_the_wave_step_counters(cr, scenes):
     """crt_debug_step_hist (measurement aid): node steps of the counting kernels by enabled lanes (mode 0) or by distinct (node, octant) keys
     among the enabled lanes (option step_hist_mode 1).  Either way a frame's histogram holds exactly the frame's wave-level node steps, the
