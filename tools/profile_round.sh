@@ -37,7 +37,7 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 for A in "mesh1m 1" "mesh1m 1 lanes" "mesh1m 4" "mesh1m 4 lanes" "mesh1m 4 inplace_shadow=1" "mesh1m 4 lanes_per_ray=1" "cornell 1"; do python tools/lane_util.py $A; done > $O/lane_util.txt 2>&1
 for A in "mesh1m 1" "mesh1m 4"; do python tools/lane_hist.py $A; done > $O/lane_hist.txt 2>&1
 python tools/build_probe.py > $O/build_probe.txt 2>&1
-./tools/ubench/valu_issue_cycles > $O/valu_issue_cycles.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_issue_cycles tools/ubench/valu_issue_cycles.hip > $O/valu_issue_cycles.build.log 2>&1 && /tmp/valu_issue_cycles > $O/valu_issue_cycles.txt 2>&1
 python tools/shard_times.py 3840x2160 1 4 > $O/shard_times_4k.txt 2>&1
 python tools/roofline.py frac $O/bench_default.json > $O/roofline_frac.txt 2>&1
 cat $O/bench_default.json | head -c 3000; echo
